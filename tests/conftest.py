@@ -1,0 +1,40 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
+    return {k: z[k] for k in z.files}
+
+
+def sub_state(g, prefix):
+    """{'sd0/encoder/downscaler.x': arr} -> {'encoder.downscaler.x': tensor}"""
+    out = {}
+    for k, v in g.items():
+        if k.startswith(prefix + '/'):
+            out[k[len(prefix) + 1:].replace('/', '.')] = torch.from_numpy(np.array(v))
+    return out
+
+
+@pytest.fixture(scope='session')
+def golden():
+    return load_golden
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a).double()
+    b = torch.as_tensor(b).double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))

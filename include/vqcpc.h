@@ -1,0 +1,178 @@
+/* vqcpc.h -- C ABI of libvqcpc_hip.so: the MI355X (gfx950) kernels of the VQ-CPC encoder training step.
+ *
+ * The reference (SonyCSLParis/vqcpc-bach) is pure Python/PyTorch and has NO plugin / FFI interface; its "boundary" for
+ * this path is the Python class surface.  Each entry point below therefore names the reference
+ * tensor expression it replaces (file:line relative to /root/reference).  A maintainer binds them with ctypes
+ * (see INTEGRATION.md); vqcpc_bach_amd/hip.py is exactly that binding.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative VQCPC_E* code and never throws; vqcpc_last_error() gives the
+ *     thread-local message of the last failure;
+ *   - all pointers are DEVICE pointers to caller-owned memory (fp32 / int64 / int32 as declared), 16-byte aligned,
+ *     row-major; `ld*` arguments are row strides in ELEMENTS; nothing is allocated inside: kernels that need scratch take
+ *     a caller-provided workspace whose size comes from the matching *_workspace() query (a pure host function);
+ *   - work is enqueued asynchronously on `stream` (a hipStream_t passed as void*; NULL = default stream); no hidden
+ *     synchronisation; functions are stateless and re-entrant;
+ *   - activations are "block-major": row = block * L + token, i.e. the reference's time-first (L, N, E) tensors
+ *     transposed to (N, L, E) and flattened.
+ */
+#ifndef VQCPC_H
+#define VQCPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VQCPC_ABI_VERSION 1
+
+#define VQCPC_OK 0
+#define VQCPC_EINVAL (-1)    /* bad argument (shape, alignment, null pointer) */
+#define VQCPC_ELAUNCH (-2)   /* HIP launch / runtime error */
+#define VQCPC_EWORKSPACE (-3) /* workspace too small */
+
+int vqcpc_abi_version(void);
+const char* vqcpc_last_error(void);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Dropout RNG shared by all kernels: keep(seed, i) = (u24(splitmix64(seed + i * 0x9E3779B97F4A7C15)) >= p * 2^24).
+ * vqcpc_dropout_mask writes that keep-mask (1.0f / 0.0f) for i in [0, n) so that tests can reproduce every
+ * in-kernel mask (element index conventions are documented per kernel).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused per-voice embedding + input projection + positional concatenation.
+ * Replaces BachCPCDataProcessor.embed (VQCPCB/data_processor/bach_cpc_data_processor.py:42-68) followed by
+ * input_linear and the two positional concatenations of RelativeTransformerDownscaler.forward
+ * (VQCPCB/downscalers/relative_transformer_downscaler.py:104-115).
+ *   table  [n_voices][vmax][dlin] : host-side product  E_v . W_in^T + b_in  (so lookup == embed + linear)
+ *   chan   [n_voices][pos], event [tokens_per_block / n_voices][pos]
+ *   out    [n_rows][d], d = dlin + 2*pos :  out[r] = [ table[v][tokens[r]] | chan[v] | event[e] ],
+ *          p = r % tokens_per_block, v = p % n_voices, e = p / n_voices.
+ * bwd accumulates d_table / d_chan / d_event (overwritten, deterministic two-stage reduction).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_embed_pos_fwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, const float* table,
+                        int vmax, int dlin, const float* chan, const float* event, int pos, float* out, void* stream);
+int64_t vqcpc_embed_pos_bwd_workspace(int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin, int pos);
+int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin,
+                        int pos, const float* g_out, float* d_table, float* d_chan, float* d_event, void* workspace,
+                        int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32).  Replace every F.linear / nn.Linear on the path:
+ * multihead_attention_custom.py:171,346 (in_proj / out_proj), transformer_custom.py:285 (linear1/linear2),
+ * relative_transformer_downscaler.py:132 (output_linear), mlp_upscaler.py:21-34 and their autograd backward.
+ *
+ * vqcpc_gemm_nt:  C[M,N] = epilogue( A[M,K] . B[N,K]^T )      (forward: B = weight; dgrad: B = weight^T)
+ *   epilogue order:  + bias[N] (nullable) -> ReLU (act==1) -> dropout(p, seed; element index m*N+n, scaled 1/(1-p))
+ *                    -> * (gate[m,n] > 0 ? gate_scale : 0) (nullable) -> + add[m,n] (nullable) -> store.
+ * vqcpc_gemm_tn:  dW[N,K] (+)= A[M,N]^T . B[M,K],  db[N] (+)= column sums of A (db nullable)
+ *   split over M into partials in `workspace`, then reduced deterministically; accumulate!=0 adds to dW/db.
+ * K % 4 == 0, lda/ldb % 4 == 0 required (16-byte vector loads).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                  const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
+                  float gate_scale, const float* add, int64_t ldadd, void* stream);
+int64_t vqcpc_gemm_tn_workspace(int64_t M, int N, int K);
+int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
+                  int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* out[C][R] = in[R][C]^T (weight transposes for the dgrad form of vqcpc_gemm_nt) */
+int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused small-L self-attention with learned relative bias (L = 16 or 4, whole block in one wavefront).
+ * Replaces MultiheadAttentionCustom.forward :247-343 and SubsampledRelativeAttention.forward
+ * (VQCPCB/transformer/subsampled_relative_attention.py:30-122) through its closed form
+ *   bias[h,i,j] = q[h,i].e1[h, L-1-(i-j)] (j <= i) | q[h,i].e2[h, j-i] (j > i).
+ *   qkv [n_blocks*L][ldq]: q | k | v at column offsets 0, d, 2d; head h = columns [h*hd, (h+1)*hd); q is UNSCALED
+ *   e1, e2 [H*L][hd];  ctx [n_blocks*L][ldo] (heads merged);  probs [n_blocks][H][L][L] = softmax BEFORE dropout
+ *   dropout element index = ((block*H + h)*L + i)*L + j.
+ * bwd: d_qkv [n_blocks*L][ldg] (all 3d columns written), d_e1/d_e2 overwritten (deterministic partials in workspace).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
+                      float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* stream);
+int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd);
+int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
+                      const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
+                      int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused residual + dropout + LayerNorm:  y = LN(x + dropout(r)) * gamma + beta   (eps inside the sqrt, biased var).
+ * Replaces transformer_custom.py:282-283 and :288-289.  x has row stride ldx (the [::4] subsample of
+ * relative_transformer_downscaler.py:125 is a stride, not a copy); r, y contiguous [M][d].
+ * dropout element index = m*d + c.   mean/rstd [M] are saved for the backward.
+ * bwd: d_s [M][d] = gradient w.r.t. (x + dropout(r)) = gradient of the x path; d_r = d_s * mask / (1-p) (may alias d_s
+ * when p == 0; pass NULL then); d_gamma / d_beta overwritten.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
+                            float* mean, float* rstd, int64_t M, int d, float eps, float drop_p, uint64_t seed,
+                            void* stream);
+int64_t vqcpc_add_layernorm_bwd_workspace(int64_t M, int d);
+int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
+                            const float* mean, const float* rstd, float* d_s, float* d_r, float* d_gamma, float* d_beta,
+                            int64_t M, int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes,
+                            void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Product vector quantiser: nearest code per sub-vector + straight-through output + commitment/codebook loss.
+ * Replaces ProductVectorQuantizer.forward distances/argmin/one-hot matmul/_loss/STE
+ * (VQCPCB/quantizer/vector_quantizer.py:105-148, :72-83) without the (rows, K, D) intermediate.
+ *   z [R][D], codebooks [ncb][K][dsub] (D = ncb*dsub), idx [R][ncb] int64, zq_sg [R][D] = z + (q - z), loss [R].
+ * Distance order is canonical: d = 0; for t ascending d = d + (z_t - e_t)^2 with separately rounded sub/mul/add;
+ * k ascending, strict '<' (first index wins ties) -- bit-identical to oracle/vqcpc_oracle.py:vq_distances_canonical.
+ * squared != 0: loss = (1 + beta) * sum (q - z)^2 computed as q_latent + beta * e_latent;
+ * squared == 0: loss = (1 + beta) * || (q - z) + 1e-5 ||_2.
+ * bwd: d_z = g_zq + g_loss * d(loss)/dz ; d_codebooks [ncb][K][dsub] = segment-sum of g_loss * d(loss)/dq
+ * (this is the slot the north_star calls "codebook update": the reference trains codebooks by Adam, not EMA).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_vq_fwd(const float* z, const float* codebooks, int64_t R, int ncb, int K, int dsub, float beta, int squared,
+                 int64_t* idx, float* zq_sg, float* loss, void* stream);
+int64_t vqcpc_vq_bwd_workspace(int64_t R, int ncb, int K, int dsub);
+int vqcpc_vq_bwd(const float* z, const float* codebooks, const int64_t* idx, const float* g_zq, const float* g_loss,
+                 int64_t R, int ncb, int K, int dsub, float beta, int squared, float* d_z, float* d_codebooks,
+                 void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * MlpUpscaler middle: h' = SELU(dropout(h))  (VQCPCB/upscalers/mlp_upscaler.py:21-34); element index = flat index.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_dropout_selu_fwd(const float* h, float* out, int64_t n, float drop_p, uint64_t seed, void* stream);
+int vqcpc_dropout_selu_bwd(const float* h, const float* g_out, float* g_h, int64_t n, float drop_p, uint64_t seed,
+                           void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Fused bilinear scores + InfoNCE + accuracy.  Replaces FksModule.forward (VQCPCB/vqcpc_helper.py:86-98) on the
+ * positive and the N negative sets, the reshuffling of vqcpc_encoder_trainer.py:240-263, nce_loss
+ * (vqcpc_helper.py:5-29) and the score matrix (:269).
+ *   c [B][cdim], W [zdim][cdim][K], z_pos [B][K][zdim], z_neg [B][N][K][zdim]
+ *   f_pos [B][K], f_neg [B][K][N] (saved for bwd), loss_b [B] = -sum_k (pos - logsumexp([neg, pos])),
+ *   hits [B][K] = (pos > max_n neg) as 0/1.   loss = mean_b loss_b, accuracy[k] = mean_b hits.
+ * bwd (g = dLoss/d(mean loss), a device scalar): d_c, d_W (deterministic two-stage), d_z_pos, d_z_neg.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_nce_fwd(const float* c, const float* W, const float* z_pos, const float* z_neg, int B, int K, int N, int zdim,
+                  int cdim, float* f_pos, float* f_neg, float* loss_b, float* hits, void* stream);
+int64_t vqcpc_nce_bwd_workspace(int B, int K, int N, int zdim, int cdim);
+int vqcpc_nce_bwd(const float* c, const float* W, const float* z_pos, const float* z_neg, const float* f_pos,
+                  const float* f_neg, const float* g, int B, int K, int N, int zdim, int cdim, float* d_c, float* d_W,
+                  float* d_z_pos, float* d_z_neg, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Optimiser on one flat fp32 buffer (all parameters of the trainer are views into it; so are the gradients, which is
+ * also the RCCL all-reduce bucket).  Replaces nn.utils.clip_grad_norm_(., 5) + torch.optim.Adam.step
+ * (VQCPCB/vqcpc_encoder_trainer.py:92,313-314).
+ *   vqcpc_sumsq:   out[0] = sum g^2 (double accumulation, deterministic; workspace from vqcpc_sumsq_workspace)
+ *   vqcpc_adam_step: coef = min(1, max_norm / (sqrt(sumsq[0]) + 1e-6)) read ON DEVICE (no host sync); g *= coef;
+ *                  m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).
+ *   grad_scale multiplies g first (1/world_size for a summed all-reduce).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int64_t vqcpc_sumsq_workspace(int64_t n);
+int vqcpc_sumsq(const float* g, int64_t n, float grad_scale, double* out, void* workspace, int64_t workspace_bytes,
+                void* stream);
+int vqcpc_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step, float grad_scale, float max_norm, const double* sumsq, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VQCPC_H */

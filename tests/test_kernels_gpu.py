@@ -1,0 +1,356 @@
+"""Per-kernel parity: every libvqcpc_hip.so entry point (called through the C ABI via ctypes) against the CPU oracle on
+seeded inputs, and against the reference-generated golden vectors.  Integer outputs are bit-exact; fp32 tolerances are
+written next to each assert (relative to the reference tensor's max magnitude)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, sub_state
+from oracle import vqcpc_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+FWD_TOL = 3e-5
+GRAD_TOL = 3e-4
+T = torch.from_numpy
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'GPU tests need an MI355X'
+    from vqcpc_bach_amd import hip, ops as _ops
+    hip.load()
+    return _ops
+
+
+def dev(t):
+    return t.detach().to('cuda').contiguous()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# VQ
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('name', ['vq_ncb1', 'vq_ncb2', 'vq_ncb2_d32', 'vq_wide_d64', 'vq_ties', 'vq_l2norm'])
+def test_vq_golden(ops, name):
+    g = load_golden(name)
+    z = T(g['z'])
+    shape = z.shape
+    D = shape[-1]
+    cb = T(g['codebooks'])
+    zd = dev(z.reshape(-1, D)).requires_grad_(True)
+    cbd = dev(cb).requires_grad_(True)
+    zq, idx, loss = ops.VQFn.apply(zd, cbd, float(g['beta']), bool(g['squared']))
+    assert idx.dtype == torch.int64
+    assert torch.equal(idx.cpu().reshape(g['idx'].shape), T(g['idx'])), 'index assignment must be bit-exact'
+    assert torch.equal(zq.detach().cpu().reshape(shape), T(g['zq'])), 'z + (q - z) is exact fp32 arithmetic'
+    assert rel_err(loss.detach().cpu().reshape(g['loss'].shape), g['loss']) < FWD_TOL
+    gz, gl = dev(T(g['g_zq']).reshape(-1, D)), dev(T(g['g_loss']).reshape(-1))
+    ((zq * gz).sum() + (loss * gl).sum()).backward()
+    assert rel_err(zd.grad.cpu().reshape(shape), g['dz']) < GRAD_TOL
+    assert rel_err(cbd.grad.cpu(), g['dE']) < GRAD_TOL
+
+
+@pytest.mark.parametrize('R,ncb,K,dsub', [(5000, 2, 512, 16), (3001, 1, 64, 16), (777, 4, 1024, 16), (1500, 1, 32, 3),
+                                          (1024, 2, 100, 5), (34816, 2, 512, 16)])
+def test_vq_index_bit_exact_vs_oracle(ops, R, ncb, K, dsub):
+    gen = torch.Generator().manual_seed(R + K)
+    D = ncb * dsub
+    z = torch.randn(R, D, generator=gen)
+    cb = torch.randn(ncb, K, dsub, generator=gen)
+    cb[:, K // 2] = cb[:, K // 3]                      # an exact tie inside every codebook
+    z[: K // 4, :dsub] = cb[0, : K // 4]               # inputs sitting exactly on codes
+    zq, idx, loss = ops.VQFn.apply(dev(z), dev(cb), 0.25, True)
+    ref_idx = O.vq_assign(z, list(cb))
+    assert torch.equal(idx.cpu(), ref_idx)
+    zq_ref, _, loss_ref = O.vq_forward(z, list(cb), 0.25, True, idx=ref_idx)
+    assert torch.equal(zq.cpu(), zq_ref)
+    assert rel_err(loss.cpu(), loss_ref) < FWD_TOL
+
+
+def test_vq_backward_vs_oracle(ops):
+    gen = torch.Generator().manual_seed(3)
+    R, ncb, K, dsub = 2000, 2, 128, 16
+    z = torch.randn(R, ncb * dsub, generator=gen)
+    cb = torch.randn(ncb, K, dsub, generator=gen)
+    gz, gl = torch.randn(R, ncb * dsub, generator=gen), torch.randn(R, generator=gen)
+    zc = z.clone().requires_grad_(True)
+    cbs = [c.clone().requires_grad_(True) for c in cb]
+    zq, _, loss = O.vq_forward(zc, cbs, 0.25, True)
+    ((zq * gz).sum() + (loss * gl).sum()).backward()
+    zd, cbd = dev(z).requires_grad_(True), dev(cb).requires_grad_(True)
+    zq2, _, loss2 = ops.VQFn.apply(zd, cbd, 0.25, True)
+    ((zq2 * dev(gz)).sum() + (loss2 * dev(gl)).sum()).backward()
+    assert rel_err(zd.grad.cpu(), zc.grad) < GRAD_TOL
+    assert rel_err(cbd.grad.cpu(), torch.stack([c.grad for c in cbs])) < GRAD_TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# GEMMs
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(256, 128, 64), (1000, 96, 32), (130, 33, 36), (4096, 768, 256), (64, 1024, 256),
+                                   (513, 256, 1024), (7, 5, 4)])
+def test_gemm_nt_plain(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    out = ops.gemm_nt(dev(a), dev(b), bias=dev(bias))
+    ref = (a.double() @ b.double().t() + bias.double())
+    assert rel_err(out.cpu(), ref) < 2e-6 * max(1, K ** 0.5)
+
+
+def test_gemm_nt_is_transpose_detecting(ops):
+    # A = I with an ASYMMETRIC B catches a swapped C-write
+    n = 128
+    b = torch.arange(n * n, dtype=torch.float32).reshape(n, n) / 7.0
+    out = ops.gemm_nt(dev(torch.eye(n)), dev(b))
+    assert torch.equal(out.cpu(), b.t().contiguous())
+
+
+def test_gemm_nt_strided_rows_and_epilogue(ops):
+    gen = torch.Generator().manual_seed(5)
+    M, N, K = 300, 200, 64
+    big = torch.randn(4 * M, K, generator=gen)
+    a = big[::4]                                    # the [::4] subsample as a row stride
+    b, bias = torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    gate, add = torch.randn(M, N, generator=gen), torch.randn(M, N, generator=gen)
+    bigd = dev(big)
+    out = ops.gemm_nt(bigd[::4], dev(b), bias=dev(bias), act=1, gate=dev(gate), gate_scale=1.25, add=dev(add))
+    ref = torch.relu(a.double() @ b.double().t() + bias.double()) * (gate.double() > 0) * 1.25 + add.double()
+    assert rel_err(out.cpu(), ref) < 1e-5
+    # write into a strided destination
+    dst = torch.zeros(4 * M, N, device='cuda')
+    ops.gemm_nt(bigd[::4], dev(b), out=dst[::4])
+    assert rel_err(dst[::4].cpu(), a.double() @ b.double().t()) < 1e-5
+    assert float(dst[1::4].abs().max()) == 0.0
+
+
+def test_gemm_nt_dropout_epilogue(ops):
+    gen = torch.Generator().manual_seed(6)
+    M, N, K, p, seed = 257, 130, 32, 0.3, 12345
+    a, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen)
+    out = ops.gemm_nt(dev(a), dev(b), act=1, drop_p=p, seed=seed)
+    mask = ops.dropout_mask(M * N, p, seed, 'cuda').cpu().reshape(M, N)
+    assert 0.25 < 1 - float(mask.mean()) < 0.35
+    ref = torch.relu(a.double() @ b.double().t()) * mask.double() / (1 - p)
+    assert rel_err(out.cpu(), ref) < 1e-5
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 128, 128), (4097, 96, 36), (50000, 768, 256), (333, 4, 256), (20000, 32, 512)])
+def test_gemm_tn(ops, M, N, K):
+    gen = torch.Generator().manual_seed(M + N)
+    a, b = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+    dw, db = ops.gemm_tn(dev(a), dev(b))
+    assert rel_err(dw.cpu(), a.double().t() @ b.double()) < 2e-6 * max(1, M ** 0.5)
+    assert rel_err(db.cpu(), a.double().sum(0)) < 2e-6 * max(1, M ** 0.5)
+
+
+def test_gemm_tn_strided_b(ops):
+    gen = torch.Generator().manual_seed(9)
+    M, N, K = 2000, 64, 32
+    a, big = torch.randn(M, N, generator=gen), torch.randn(4 * M, K, generator=gen)
+    dw, _ = ops.gemm_tn(dev(a), dev(big)[::4])
+    assert rel_err(dw.cpu(), a.double().t() @ big[::4].double()) < 1e-4
+
+
+def test_transpose(ops):
+    w = torch.randn(100, 37)
+    assert torch.equal(ops.transpose(dev(w)).cpu(), w.t().contiguous())
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# LayerNorm, embedding
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,d,p', [(1000, 256, 0.0), (77, 32, 0.0), (513, 512, 0.0), (400, 128, 0.2), (64, 1024, 0.0)])
+def test_add_layernorm(ops, M, d, p):
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + d)
+    big = torch.randn(4 * M, d, generator=gen)
+    x, r = big[::4], torch.randn(M, d, generator=gen)
+    gamma, beta, dy = torch.randn(d, generator=gen), torch.randn(d, generator=gen), torch.randn(M, d, generator=gen)
+    seed = 99
+    mask = ops.dropout_mask(M * d, p, seed, 'cuda').cpu().reshape(M, d) / (1 - p)
+    xc, rc, gc, bc = (t.clone().requires_grad_(True) for t in (x, r, gamma, beta))
+    y_ref = O.layer_norm(xc + rc * mask, gc, bc)
+    (y_ref * dy).sum().backward()
+
+    bigd = dev(big)
+    y = torch.empty(M, d, device='cuda')
+    mean, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    hip.call('vqcpc_add_layernorm_fwd', bigd[::4], 4 * d, dev(r), dev(gamma), dev(beta), y, mean, rstd, M, d, 1e-5, p, seed)
+    assert rel_err(y.cpu(), y_ref.detach()) < FWD_TOL
+    ds, dr = torch.empty(M, d, device='cuda'), torch.empty(M, d, device='cuda')
+    dg, db = torch.empty(d, device='cuda'), torch.empty(d, device='cuda')
+    nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', M, d)
+    ws = hip.workspace(nbytes, 'cuda')
+    hip.call('vqcpc_add_layernorm_bwd', dev(dy), bigd[::4], 4 * d, dev(r), dev(gamma), mean, rstd, ds, dr, dg, db, M, d, p,
+             seed, ws, nbytes)
+    assert rel_err(ds.cpu(), xc.grad) < GRAD_TOL
+    assert rel_err(dr.cpu(), rc.grad) < GRAD_TOL
+    assert rel_err(dg.cpu(), gc.grad) < GRAD_TOL
+    assert rel_err(db.cpu(), bc.grad) < GRAD_TOL
+
+
+@pytest.mark.parametrize('nblk,d,V', [(300, 256, 57), (17, 32, 12), (1000, 128, 57)])
+def test_embed_pos(ops, nblk, d, V):
+    gen = torch.Generator().manual_seed(nblk)
+    pos, nv, tpb = 8, 4, 16
+    dlin = d - 2 * pos
+    tokens = torch.randint(0, V, (nblk * tpb,), generator=gen)
+    table = torch.randn(nv, V, dlin, generator=gen)
+    chan, event = torch.randn(nv, pos, generator=gen), torch.randn(tpb // nv, pos, generator=gen)
+    gout = torch.randn(nblk * tpb, d, generator=gen)
+    tc, cc, ec = (t.clone().requires_grad_(True) for t in (table, chan, event))
+    p = torch.arange(nblk * tpb) % tpb
+    ref = torch.cat([tc[p % nv, tokens], cc[p % nv], ec[p // nv]], dim=1)
+    (ref * gout).sum().backward()
+    td, cd, ed = (dev(t).requires_grad_(True) for t in (table, chan, event))
+    out = ops.EmbedPosFn.apply(dev(tokens), td, cd, ed, tpb)
+    assert torch.equal(out.detach().cpu(), ref.detach())
+    (out * dev(gout)).sum().backward()
+    assert rel_err(td.grad.cpu(), tc.grad) < GRAD_TOL
+    assert rel_err(cd.grad.cpu(), cc.grad) < GRAD_TOL
+    assert rel_err(ed.grad.cpu(), ec.grad) < GRAD_TOL
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# relative attention
+# ----------------------------------------------------------------------------------------------------------------
+def _attn_ref(qkv, e1, e2, L, H, hd, mask=None):
+    """Oracle attention core on an (n*L, 3d) qkv matrix -> ctx (n*L, d), probs (n, H, L, L)."""
+    d = H * hd
+    n = qkv.shape[0] // L
+    q, k, v = qkv.reshape(n, L, 3 * d).split(d, dim=-1)
+    q = q * (float(hd) ** -0.5)
+    q, k, v = (t.reshape(n, L, H, hd).transpose(1, 2) for t in (q, k, v))
+    scores = q @ k.transpose(-1, -2) + O.relative_bias(q, e1, e2)
+    probs = torch.softmax(scores, dim=-1)
+    pd = probs if mask is None else probs * mask
+    return (pd @ v).transpose(1, 2).reshape(n * L, d), probs
+
+
+@pytest.mark.parametrize('n,L,H,hd,p', [(37, 16, 2, 16, 0.0), (64, 16, 8, 32, 0.0), (129, 4, 8, 32, 0.0), (40, 16, 8, 64, 0.0),
+                                        (33, 4, 4, 16, 0.0), (50, 16, 4, 32, 0.15), (70, 4, 2, 16, 0.15), (3000, 16, 8, 32, 0.0)])
+def test_relattn(ops, n, L, H, hd, p):
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(n + L + H)
+    d = H * hd
+    qkv = torch.randn(n * L, 3 * d, generator=gen)
+    e1, e2 = torch.randn(H * L, hd, generator=gen), torch.randn(H * L, hd, generator=gen)
+    dctx = torch.randn(n * L, d, generator=gen)
+    seed = 4242
+    mask = None
+    if p > 0:
+        mask = ops.dropout_mask(n * H * L * L, p, seed, 'cuda').cpu().reshape(n, H, L, L) / (1 - p)
+    qc, e1c, e2c = (t.clone().requires_grad_(True) for t in (qkv, e1, e2))
+    ctx_ref, probs_ref = _attn_ref(qc, e1c, e2c, L, H, hd, mask)
+    (ctx_ref * dctx).sum().backward()
+
+    qd, e1d, e2d = dev(qkv), dev(e1), dev(e2)
+    ctx = torch.empty(n * L, d, device='cuda')
+    probs = torch.empty(n, H, L, L, device='cuda')
+    hip.call('vqcpc_relattn_fwd', qd, 3 * d, e1d, e2d, ctx, d, probs, n, L, H, hd, p, seed)
+    assert rel_err(probs.cpu(), probs_ref.detach()) < FWD_TOL
+    assert rel_err(ctx.cpu(), ctx_ref.detach()) < FWD_TOL
+    dqkv = torch.empty(n * L, 3 * d, device='cuda')
+    de1, de2 = torch.empty_like(e1d), torch.empty_like(e2d)
+    nbytes = hip.query('vqcpc_relattn_bwd_workspace', n, L, H, hd)
+    ws = hip.workspace(nbytes, 'cuda')
+    hip.call('vqcpc_relattn_bwd', dev(dctx), d, qd, 3 * d, probs, e1d, e2d, dqkv, 3 * d, de1, de2, n, L, H, hd, p, seed, ws,
+             nbytes)
+    assert rel_err(dqkv.cpu(), qc.grad) < GRAD_TOL
+    assert rel_err(de1.cpu(), e1c.grad) < GRAD_TOL
+    assert rel_err(de2.cpu(), e2c.grad) < GRAD_TOL
+    assert float(de2.cpu().reshape(H, L, hd)[:, 0].abs().max()) == 0.0   # e2 row 0 is never used (j > i strictly)
+
+
+@pytest.mark.parametrize('name,L', [('layer_L16', 16), ('layer_L4', 4)])
+def test_encoder_layer_golden(ops, name, L):
+    """One TransformerEncoderLayerCustom forward/backward against the reference's own output."""
+    g = load_golden(name)
+    H = int(g['H'])
+    sd = sub_state(g, 'sd')
+    order = ['self_attn.in_proj_weight', 'self_attn.in_proj_bias', 'self_attn.out_proj.weight', 'self_attn.out_proj.bias',
+             'self_attn.attn_bias.e1', 'self_attn.attn_bias.e2', 'linear1.weight', 'linear1.bias', 'linear2.weight',
+             'linear2.bias', 'norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias']
+    params = [dev(sd[k]).requires_grad_(True) for k in order]
+    x = T(g['x']).transpose(0, 1).contiguous()                   # (n, L, d) block-major
+    n, _, d = x.shape
+    xd = dev(x.reshape(n * L, d)).requires_grad_(True)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, *params)
+    y_ref = T(g['y']).transpose(0, 1).reshape(n * L, d)
+    assert rel_err(y.detach().cpu(), y_ref) < FWD_TOL
+    assert rel_err(probs.cpu(), g['attn']) < FWD_TOL
+    gy = T(g['g']).transpose(0, 1).reshape(n * L, d)
+    (y * dev(gy)).sum().backward()
+    assert rel_err(xd.grad.cpu(), T(g['dx']).transpose(0, 1).reshape(n * L, d)) < GRAD_TOL
+    for k, prm in zip(order, params):
+        assert rel_err(prm.grad.cpu(), g['grad/' + k]) < GRAD_TOL, k
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPC heads, upscaler activation, optimiser
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('B,K,N,zdim,cdim', [(5, 4, 6, 8, 6), (256, 8, 15, 32, 32), (33, 16, 15, 32, 32)])
+def test_nce(ops, B, K, N, zdim, cdim):
+    gen = torch.Generator().manual_seed(B + K)
+    c, W = torch.randn(B, cdim, generator=gen), torch.randn(zdim, cdim, K, generator=gen) * 0.3
+    zp, zn = torch.randn(B, K, zdim, generator=gen), torch.randn(B, N, K, zdim, generator=gen)
+    ref_in = [t.clone().requires_grad_(True) for t in (c, W, zp, zn)]
+    f_pos, f_neg = O.fks_scores(*ref_in)
+    loss_ref = O.nce_loss(f_pos, f_neg)
+    loss_ref.backward()
+    din = [dev(t).requires_grad_(True) for t in (c, W, zp, zn)]
+    loss_b, hits, fp, fn = ops.NCEFn.apply(*din)
+    loss = loss_b.mean()
+    loss.backward()
+    assert rel_err(fp.cpu(), f_pos.detach()) < FWD_TOL and rel_err(fn.cpu(), f_neg.detach()) < FWD_TOL
+    assert abs(float(loss) - float(loss_ref)) < FWD_TOL * abs(float(loss_ref))
+    assert torch.equal(hits.cpu(), (f_pos > f_neg.max(2)[0]).float())
+    for a, b in zip(din, ref_in):
+        assert rel_err(a.grad.cpu(), b.grad) < GRAD_TOL
+
+
+def test_nce_golden(ops):
+    g = load_golden('cpc_heads')
+    c, W, zr, zn = (dev(T(g[k])) for k in ('c', 'fks_module/W', 'z_right', 'z_neg'))
+    loss_b, hits, fp, fn = ops.NCEFn.apply(c, W, zr, zn)
+    assert rel_err(fp.cpu(), g['f_pos']) < FWD_TOL and rel_err(fn.cpu(), g['f_neg']) < FWD_TOL
+    assert abs(float(loss_b.mean()) - float(g['loss'])) < FWD_TOL * abs(float(g['loss']))
+    assert torch.equal(hits.mean(0).cpu(), T(g['acc']))
+
+
+@pytest.mark.parametrize('p', [0.0, 0.25])
+def test_dropout_selu(ops, p):
+    gen = torch.Generator().manual_seed(11)
+    h, g = torch.randn(5000, generator=gen) * 2, torch.randn(5000, generator=gen)
+    seed = 31337
+    mask = ops.dropout_mask(5000, p, seed, 'cuda').cpu() / (1 - p)
+    hc = h.clone().requires_grad_(True)
+    ref = O.selu(hc * mask)
+    (ref * g).sum().backward()
+    hd_ = dev(h).requires_grad_(True)
+    out = ops.DropoutSeluFn.apply(hd_, p, seed)
+    (out * dev(g)).sum().backward()
+    assert rel_err(out.detach().cpu(), ref.detach()) < FWD_TOL
+    assert rel_err(hd_.grad.cpu(), hc.grad) < GRAD_TOL
+
+
+@pytest.mark.parametrize('scale', [1.0, 300.0])
+def test_flat_adam_with_clip(ops, scale):
+    gen = torch.Generator().manual_seed(12)
+    n = 100003
+    p0, g0 = torch.randn(n, generator=gen), torch.randn(n, generator=gen) * scale / (n ** 0.5)
+    P = {'w': p0.clone()}
+    grads = {'w': g0.clone()}
+    state = {}
+    for _ in range(3):
+        gg = {'w': grads['w'].clone()}
+        total = O.clip_grad_norm(list(gg.values()), 5.0)
+        O.adam_step(P, gg, state, 1e-3)
+    pd, gd = dev(p0), dev(g0)
+    opt = ops.FlatAdam(pd, gd, lr=1e-3)
+    for _ in range(3):
+        gd.copy_(dev(g0))
+        opt.step()
+    assert abs(opt.grad_norm() - float(total)) < 1e-5 * float(total)
+    assert (scale > 100) == (float(total) > 5.0)
+    assert rel_err(pd.cpu(), P['w']) < 1e-6

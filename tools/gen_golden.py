@@ -297,7 +297,7 @@ if __name__ == '__main__':
     gen_relbias('relbias_L16', n=3, H=2, L=16, hd=8, seed=10)
     gen_relbias('relbias_L4', n=5, H=4, L=4, hd=4, seed=11)
     gen_layer('layer_L16', n=6, H=2, L=16, d=32, ff=64, seed=20)
-    gen_layer('layer_L4', n=6, H=4, L=4, d=32, ff=48, seed=21)
+    gen_layer('layer_L4', n=6, H=2, L=4, d=32, ff=48, seed=21)   # hd = 16
     gen_cpc_heads('cpc_heads', B=5, Kl=3, Kr=4, N=6, zdim=8, cdim=6, hidden=12, seed=30)
     tiny = dict(emb=8, vocab=[11, 11, 11, 11], d=32, H=2, layers=[2, 1], ff=64, D=4, K=8, ncb=1, zdim=8, up_hidden=16,
                 cdim=8, gru_hidden=16, B=6, N=3, Kl=2, Kr=2)

@@ -1,0 +1,70 @@
+// Shared device/host helpers for libvqcpc_hip.so (gfx950 only, wave64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/vqcpc.h"
+
+namespace vq {
+
+void set_error(const char* fmt, ...);
+
+#define VQ_REQUIRE(cond, ...)                   \
+    do {                                        \
+        if (!(cond)) {                          \
+            vq::set_error(__VA_ARGS__);         \
+            return VQCPC_EINVAL;                \
+        }                                       \
+    } while (0)
+
+#define VQ_CHECK_LAUNCH(name)                                                        \
+    do {                                                                             \
+        hipError_t e_ = hipGetLastError();                                           \
+        if (e_ != hipSuccess) {                                                      \
+            vq::set_error("%s: launch failed: %s", name, hipGetErrorString(e_));     \
+            return VQCPC_ELAUNCH;                                                    \
+        }                                                                            \
+    } while (0)
+
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int64_t round_up(int64_t a, int64_t b) { return (a + b - 1) / b * b; }
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+constexpr int kWave = 64;
+constexpr int kNumCU = 256;   // MI355X
+
+// ---- dropout RNG: stateless, one 64-bit mix per element (splitmix64 finaliser) -----------------------------------
+__host__ __device__ __forceinline__ uint32_t rng_u24(uint64_t seed, uint64_t idx) {
+    uint64_t x = seed + idx * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return static_cast<uint32_t>(x >> 40);   // top 24 bits
+}
+__host__ __device__ __forceinline__ uint32_t drop_threshold(float p) { return static_cast<uint32_t>(p * 16777216.0f); }
+// keep-mask value: 0 or 1/(1-p).  thr == 0 (p == 0) keeps everything with scale 1.
+__device__ __forceinline__ float drop_scale(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+    if (thr == 0) return 1.0f;
+    return rng_u24(seed, idx) >= thr ? inv_keep : 0.0f;
+}
+
+// ---- wave64 reductions ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// deterministic reduction of `nsplit` partial arrays: out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*stride + i]
+int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
+                         hipStream_t stream);
+
+}  // namespace vq

@@ -1,0 +1,386 @@
+// Wavefront-primitive kernels: fused embedding-table gather + positional concat, fused residual + dropout + LayerNorm.
+#include "common.h"
+
+namespace vq {
+
+// =====================================================================================================================
+// embedding + positional (forward): one float4 per lane, grid-stride over [n_rows][d/4]
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __restrict__ tokens, int64_t n_rows, int tpb,
+                                                            int nv, const float* __restrict__ table, int vmax, int dlin,
+                                                            const float* __restrict__ chan, const float* __restrict__ ev,
+                                                            int pos, float* __restrict__ out) {
+    const int d = dlin + 2 * pos;
+    const int d4 = d >> 2;
+    const int64_t total = n_rows * d4;
+    int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; e < total; e += step) {
+        const int64_t row = e / d4;
+        const int col = (int)(e - row * d4) << 2;
+        const int p = (int)(row % tpb);
+        const int v = p % nv, evt = p / nv;
+        float4 val;
+        if (col < dlin) {
+            const int64_t tok = tokens[row];
+            val = *reinterpret_cast<const float4*>(table + ((int64_t)v * vmax + tok) * dlin + col);
+        } else if (col < dlin + pos) {
+            val = *reinterpret_cast<const float4*>(chan + v * pos + (col - dlin));
+        } else {
+            val = *reinterpret_cast<const float4*>(ev + evt * pos + (col - dlin - pos));
+        }
+        *reinterpret_cast<float4*>(out + row * d + col) = val;
+    }
+}
+
+// =====================================================================================================================
+// embedding backward, stage 1.  grid = (nchunks, n_voices).  Workgroup (chunk, v) walks the rows of voice v in its chunk;
+// lane `c` owns column c of an LDS table [vmax][d] (+ one row of positional sums), so the read-modify-write needs no
+// atomics and is deterministic.  Partials: ws[chunk][v][vmax + 1][d]  (row vmax = sums of the chan|event columns,
+// event sums are further split per event in a second small array).
+// =====================================================================================================================
+constexpr int kEmbRowsPerChunk = 2048;   // rows of ALL voices per chunk
+
+__global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __restrict__ tokens, int64_t n_rows, int tpb,
+                                                            int nv, int vmax, int dlin, int pos,
+                                                            const float* __restrict__ g, float* __restrict__ ws) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int d = dlin + 2 * pos;
+    const int nev = tpb / nv;
+    // LDS: tab [vmax][dlin] | chan_sum [pos] | ev_sum [nev][pos]
+    float* tab = lds;
+    float* csum = tab + vmax * dlin;
+    float* esum = csum + pos;
+    const int lds_floats = vmax * dlin + pos + nev * pos;
+    for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) lds[i] = 0.0f;
+    __syncthreads();
+    const int v = blockIdx.y;
+    const int64_t row0 = (int64_t)blockIdx.x * kEmbRowsPerChunk;
+    const int64_t row1 = min(row0 + kEmbRowsPerChunk, n_rows);
+    // rows of this voice: row % tpb % nv == v.  kEmbRowsPerChunk is a multiple of tpb (checked on the host).
+    for (int col = threadIdx.x; col < d; col += blockDim.x) {
+        // 8 rows in flight per lane: issue the loads first, then the (ordered) LDS read-modify-writes
+        for (int64_t base = row0 + v; base < row1; base += (int64_t)nv * 8) {
+            float gv[8];
+            int tk[8], evi[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int64_t row = base + (int64_t)u * nv;
+                const bool ok = row < row1;
+                gv[u] = ok ? g[row * d + col] : 0.0f;
+                tk[u] = (ok && col < dlin) ? (int)tokens[row] : 0;
+                evi[u] = ok ? (int)(row % tpb) / nv : 0;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                if (col < dlin) tab[tk[u] * dlin + col] += gv[u];
+                else if (col < dlin + pos) csum[col - dlin] += gv[u];
+                else esum[evi[u] * pos + (col - dlin - pos)] += gv[u];
+            }
+        }
+    }
+    __syncthreads();
+    float* dst = ws + ((int64_t)blockIdx.x * nv + v) * lds_floats;
+    for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) dst[i] = lds[i];
+}
+
+// stage 2: sum partials over chunks (and over voices for the event table)
+__global__ __launch_bounds__(256) void embed_pos_bwd_reduce(const float* __restrict__ ws, int nchunks, int nv, int vmax,
+                                                            int dlin, int pos, int nev, float* __restrict__ d_table,
+                                                            float* __restrict__ d_chan, float* __restrict__ d_event) {
+    const int lds_floats = vmax * dlin + pos + nev * pos;
+    const int n_tab = nv * vmax * dlin, n_chan = nv * pos, n_ev = nev * pos;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o < n_tab) {
+        const int v = o / (vmax * dlin), i = o % (vmax * dlin);
+        float acc = 0.0f;
+        for (int ch = 0; ch < nchunks; ++ch) acc += ws[((int64_t)ch * nv + v) * lds_floats + i];
+        d_table[o] = acc;
+    } else if (o < n_tab + n_chan) {
+        const int q = o - n_tab, v = q / pos, i = q % pos;
+        float acc = 0.0f;
+        for (int ch = 0; ch < nchunks; ++ch) acc += ws[((int64_t)ch * nv + v) * lds_floats + vmax * dlin + i];
+        d_chan[q] = acc;
+    } else if (o < n_tab + n_chan + n_ev) {
+        const int q = o - n_tab - n_chan;
+        float acc = 0.0f;
+        for (int ch = 0; ch < nchunks; ++ch)
+            for (int v = 0; v < nv; ++v) acc += ws[((int64_t)ch * nv + v) * lds_floats + vmax * dlin + pos + q];
+        d_event[q] = acc;
+    }
+}
+
+// =====================================================================================================================
+// residual + dropout + LayerNorm.  One wavefront per row, 4 rows per workgroup, lane owns columns lane*4 + 256*it.
+// =====================================================================================================================
+constexpr int kLnMaxIt = 4;   // d <= 1024
+
+template <bool HAS_R>
+__global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
+                                                         const float* __restrict__ r, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, float* __restrict__ y,
+                                                         float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
+                                                         int d, float eps, uint32_t thr, float inv_keep, uint64_t seed) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nit = (d + 255) >> 8;
+    const float inv_d = 1.0f / (float)d;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        float4 s[kLnMaxIt];
+        float sum = 0.0f;
+#pragma unroll
+        for (int it = 0; it < kLnMaxIt; ++it) {
+            const int col = lane * 4 + it * 256;
+            if (it < nit && col < d) {
+                float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + col);
+                if (HAS_R) {
+                    const float4 rv = *reinterpret_cast<const float4*>(r + row * d + col);
+                    const uint64_t e = (uint64_t)row * d + col;
+                    xv.x += rv.x * drop_scale(seed, e + 0, thr, inv_keep);
+                    xv.y += rv.y * drop_scale(seed, e + 1, thr, inv_keep);
+                    xv.z += rv.z * drop_scale(seed, e + 2, thr, inv_keep);
+                    xv.w += rv.w * drop_scale(seed, e + 3, thr, inv_keep);
+                }
+                s[it] = xv;
+                sum += (xv.x + xv.y) + (xv.z + xv.w);
+            } else {
+                s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+        const float mu = wave_sum(sum) * inv_d;
+        float sq = 0.0f;
+#pragma unroll
+        for (int it = 0; it < kLnMaxIt; ++it) {
+            const int col = lane * 4 + it * 256;
+            if (it < nit && col < d) {
+                const float a = s[it].x - mu, b = s[it].y - mu, c = s[it].z - mu, e = s[it].w - mu;
+                sq += (a * a + b * b) + (c * c + e * e);
+            }
+        }
+        const float rs = 1.0f / sqrtf(wave_sum(sq) * inv_d + eps);
+#pragma unroll
+        for (int it = 0; it < kLnMaxIt; ++it) {
+            const int col = lane * 4 + it * 256;
+            if (it < nit && col < d) {
+                const float4 gm = *reinterpret_cast<const float4*>(gamma + col);
+                const float4 bt = *reinterpret_cast<const float4*>(beta + col);
+                float4 o;
+                o.x = (s[it].x - mu) * rs * gm.x + bt.x;
+                o.y = (s[it].y - mu) * rs * gm.y + bt.y;
+                o.z = (s[it].z - mu) * rs * gm.z + bt.z;
+                o.w = (s[it].w - mu) * rs * gm.w + bt.w;
+                *reinterpret_cast<float4*>(y + row * d + col) = o;
+            }
+        }
+        if (lane == 0) {
+            mean[row] = mu;
+            rstd[row] = rs;
+        }
+    }
+}
+
+// backward: d_s, d_r and per-workgroup partial d_gamma / d_beta (ws[block][2][d])
+template <bool HAS_R>
+__global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         int64_t ldx, const float* __restrict__ r,
+                                                         const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ d_s,
+                                                         float* __restrict__ d_r, float* __restrict__ ws, int64_t M, int d,
+                                                         uint32_t thr, float inv_keep, uint64_t seed) {
+    __shared__ float red[4 * 2 * 1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nit = (d + 255) >> 8;
+    const float inv_d = 1.0f / (float)d;
+    float4 dg[kLnMaxIt], db[kLnMaxIt], gm[kLnMaxIt];
+#pragma unroll
+    for (int it = 0; it < kLnMaxIt; ++it) {
+        dg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        db[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        const int col = lane * 4 + it * 256;
+        gm[it] = (it < nit && col < d) ? *reinterpret_cast<const float4*>(gamma + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
+        const float mu = mean[row], rs = rstd[row];
+        float4 xh[kLnMaxIt], gy[kLnMaxIt], msk[kLnMaxIt];
+        float s1 = 0.0f, s2 = 0.0f;   // sum(g), sum(g * xhat) with g = dy * gamma
+#pragma unroll
+        for (int it = 0; it < kLnMaxIt; ++it) {
+            const int col = lane * 4 + it * 256;
+            if (it < nit && col < d) {
+                float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + col);
+                msk[it] = make_float4(1.f, 1.f, 1.f, 1.f);
+                if (HAS_R) {
+                    const float4 rv = *reinterpret_cast<const float4*>(r + row * d + col);
+                    const uint64_t e = (uint64_t)row * d + col;
+                    msk[it].x = drop_scale(seed, e + 0, thr, inv_keep);
+                    msk[it].y = drop_scale(seed, e + 1, thr, inv_keep);
+                    msk[it].z = drop_scale(seed, e + 2, thr, inv_keep);
+                    msk[it].w = drop_scale(seed, e + 3, thr, inv_keep);
+                    xv.x += rv.x * msk[it].x;
+                    xv.y += rv.y * msk[it].y;
+                    xv.z += rv.z * msk[it].z;
+                    xv.w += rv.w * msk[it].w;
+                }
+                const float4 dv = *reinterpret_cast<const float4*>(dy + row * d + col);
+                xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
+                gy[it] = make_float4(dv.x * gm[it].x, dv.y * gm[it].y, dv.z * gm[it].z, dv.w * gm[it].w);
+                s1 += (gy[it].x + gy[it].y) + (gy[it].z + gy[it].w);
+                s2 += (gy[it].x * xh[it].x + gy[it].y * xh[it].y) + (gy[it].z * xh[it].z + gy[it].w * xh[it].w);
+                dg[it].x += dv.x * xh[it].x;
+                dg[it].y += dv.y * xh[it].y;
+                dg[it].z += dv.z * xh[it].z;
+                dg[it].w += dv.w * xh[it].w;
+                db[it].x += dv.x;
+                db[it].y += dv.y;
+                db[it].z += dv.z;
+                db[it].w += dv.w;
+            }
+        }
+        const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
+#pragma unroll
+        for (int it = 0; it < kLnMaxIt; ++it) {
+            const int col = lane * 4 + it * 256;
+            if (it < nit && col < d) {
+                float4 o;
+                o.x = rs * (gy[it].x - m1 - xh[it].x * m2);
+                o.y = rs * (gy[it].y - m1 - xh[it].y * m2);
+                o.z = rs * (gy[it].z - m1 - xh[it].z * m2);
+                o.w = rs * (gy[it].w - m1 - xh[it].w * m2);
+                *reinterpret_cast<float4*>(d_s + row * d + col) = o;
+                if (HAS_R && d_r != nullptr) {
+                    o.x *= msk[it].x;
+                    o.y *= msk[it].y;
+                    o.z *= msk[it].z;
+                    o.w *= msk[it].w;
+                    *reinterpret_cast<float4*>(d_r + row * d + col) = o;
+                }
+            }
+        }
+    }
+    // reduce the 4 waves' column partials through LDS, then one partial per workgroup
+#pragma unroll
+    for (int it = 0; it < kLnMaxIt; ++it) {
+        const int col = lane * 4 + it * 256;
+        if (it < nit && col < d) {
+            *reinterpret_cast<float4*>(&red[(wave * 2 + 0) * 1024 + col]) = dg[it];
+            *reinterpret_cast<float4*>(&red[(wave * 2 + 1) * 1024 + col]) = db[it];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * d; i += 256) {
+        const int which = i / d, col = i % d;
+        float acc = 0.0f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) acc += red[(w * 2 + which) * 1024 + col];
+        ws[(int64_t)blockIdx.x * 2 * d + i] = acc;
+    }
+}
+
+static int ln_blocks(int64_t M) { return (int)std::min<int64_t>(ceil_div(M, 4), 2048); }
+
+}  // namespace vq
+
+using namespace vq;
+
+extern "C" {
+
+int vqcpc_embed_pos_fwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, const float* table,
+                        int vmax, int dlin, const float* chan, const float* event, int pos, float* out, void* stream) {
+    VQ_REQUIRE(tokens && table && chan && event && out, "embed_pos_fwd: null pointer");
+    VQ_REQUIRE(n_rows >= 0 && tokens_per_block > 0 && n_voices > 0 && tokens_per_block % n_voices == 0 && vmax > 0,
+               "embed_pos_fwd: bad shape");
+    VQ_REQUIRE(dlin % 4 == 0 && pos % 4 == 0 && dlin > 0, "embed_pos_fwd: dlin and pos must be multiples of 4");
+    VQ_REQUIRE(n_rows % tokens_per_block == 0, "embed_pos_fwd: n_rows must be a whole number of blocks");
+    if (n_rows == 0) return VQCPC_OK;
+    const int64_t total = n_rows * ((dlin + 2 * pos) / 4);
+    const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 8192);
+    hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tokens, n_rows,
+                       tokens_per_block, n_voices, table, vmax, dlin, chan, event, pos, out);
+    VQ_CHECK_LAUNCH("embed_pos_fwd");
+    return VQCPC_OK;
+}
+
+int64_t vqcpc_embed_pos_bwd_workspace(int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin, int pos) {
+    const int64_t nchunks = ceil_div(std::max<int64_t>(n_rows, 1), kEmbRowsPerChunk);
+    const int64_t per = (int64_t)vmax * dlin + pos + (int64_t)(tokens_per_block / n_voices) * pos;
+    return nchunks * n_voices * per * (int64_t)sizeof(float);
+}
+
+int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin,
+                        int pos, const float* g_out, float* d_table, float* d_chan, float* d_event, void* workspace,
+                        int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(tokens && g_out && d_table && d_chan && d_event && workspace, "embed_pos_bwd: null pointer");
+    VQ_REQUIRE(n_rows > 0 && tokens_per_block > 0 && n_voices > 0 && tokens_per_block % n_voices == 0 &&
+                   kEmbRowsPerChunk % tokens_per_block == 0 && n_rows % tokens_per_block == 0,
+               "embed_pos_bwd: bad shape");
+    const int nev = tokens_per_block / n_voices;
+    const size_t lds = ((size_t)vmax * dlin + pos + (size_t)nev * pos) * sizeof(float);
+    VQ_REQUIRE(lds <= 160 * 1024, "embed_pos_bwd: table of %d x %d floats does not fit the LDS", vmax, dlin);
+    if (workspace_bytes < vqcpc_embed_pos_bwd_workspace(n_rows, tokens_per_block, n_voices, vmax, dlin, pos)) {
+        set_error("embed_pos_bwd: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    const int nchunks = (int)ceil_div(n_rows, kEmbRowsPerChunk);
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)embed_pos_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(nchunks, n_voices), dim3(256), lds, s, tokens, n_rows,
+                       tokens_per_block, n_voices, vmax, dlin, pos, g_out, (float*)workspace);
+    VQ_CHECK_LAUNCH("embed_pos_bwd");
+    const int total = n_voices * vmax * dlin + n_voices * pos + nev * pos;
+    hipLaunchKernelGGL(embed_pos_bwd_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)workspace,
+                       nchunks, n_voices, vmax, dlin, pos, nev, d_table, d_chan, d_event);
+    VQ_CHECK_LAUNCH("embed_pos_bwd_reduce");
+    return VQCPC_OK;
+}
+
+int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
+                            float* mean, float* rstd, int64_t M, int d, float eps, float drop_p, uint64_t seed,
+                            void* stream) {
+    VQ_REQUIRE(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
+    VQ_REQUIRE(M >= 0 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_fwd: bad shape");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "add_layernorm_fwd: bad dropout probability");
+    if (M == 0) return VQCPC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t thr = drop_threshold(drop_p);
+    const float ik = 1.0f / (1.0f - drop_p);
+    if (r)
+        hipLaunchKernelGGL(add_ln_fwd_kernel<true>, dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean,
+                           rstd, M, d, eps, thr, ik, seed);
+    else
+        hipLaunchKernelGGL(add_ln_fwd_kernel<false>, dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean,
+                           rstd, M, d, eps, thr, ik, seed);
+    VQ_CHECK_LAUNCH("add_layernorm_fwd");
+    return VQCPC_OK;
+}
+
+int64_t vqcpc_add_layernorm_bwd_workspace(int64_t M, int d) {
+    return (int64_t)ln_blocks(std::max<int64_t>(M, 1)) * 2 * d * (int64_t)sizeof(float);
+}
+
+int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
+                            const float* mean, const float* rstd, float* d_s, float* d_r, float* d_gamma, float* d_beta,
+                            int64_t M, int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes,
+                            void* stream) {
+    VQ_REQUIRE(dy && x && gamma && mean && rstd && d_s && d_gamma && d_beta && workspace, "add_layernorm_bwd: null pointer");
+    VQ_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_bwd: bad shape");
+    if (workspace_bytes < vqcpc_add_layernorm_bwd_workspace(M, d)) {
+        set_error("add_layernorm_bwd: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const uint32_t thr = drop_threshold(drop_p);
+    const float ik = 1.0f / (1.0f - drop_p);
+    const int blocks = ln_blocks(M);
+    if (r)
+        hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
+                           d_r, (float*)workspace, M, d, thr, ik, seed);
+    else
+        hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
+                           d_r, (float*)workspace, M, d, thr, ik, seed);
+    VQ_CHECK_LAUNCH("add_layernorm_bwd");
+    int rc = launch_reduce_splits((const float*)workspace, (int64_t)2 * d, blocks, d_gamma, d, 0, s);
+    if (rc) return rc;
+    return launch_reduce_splits((const float*)workspace + d, (int64_t)2 * d, blocks, d_beta, d, 0, s);
+}
+
+}  // extern "C"

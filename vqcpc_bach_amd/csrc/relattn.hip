@@ -1,0 +1,430 @@
+// Fused small-L self-attention with the closed-form learned relative bias (L = 16 or 4).
+//
+// A "problem" is one (block n, head h): q, k, v are L x hd.  4*L lanes work on one problem, so a wavefront holds
+// PPW = 64 / (4L) problems (1 for L = 16, 4 for L = 4) and the whole score tile lives in registers:
+//   lane (i = sl >> 2, jg = sl & 3) owns scores S[i][jj*4 + jg], jj < L/4 and output columns [jg*hd/4, (jg+1)*hd/4).
+// S[i][j] = q_i . (k_j + Erel[j - i + L - 1]),  Erel[r] = e1[h][r] (r < L: j <= i) | e2[h][r - L + 1] (r >= L: j > i)
+// which is SubsampledRelativeAttention.forward (subsampled_relative_attention.py:30-122) without its pad / view / mask
+// tensors, added to q.k^T as in MultiheadAttentionCustom.forward (multihead_attention_custom.py:314-343).
+// f32 MFMA runs at the f32 VALU rate on gfx950, and the tile is 16x16x32, so this kernel is plain VALU + LDS and is
+// bound by HBM traffic (q, k, v in; ctx, probs out).
+#include "common.h"
+
+namespace vq {
+
+constexpr int kAttThreads = 256;
+constexpr int kPad = 4;
+
+template <int L, int HD>
+struct AttCfg {
+    static constexpr int LPP = 4 * L;            // lanes per problem
+    static constexpr int PPW = 64 / LPP;         // problems per wave
+    static constexpr int SLOTS = 4 * PPW;        // problems per workgroup iteration
+    static constexpr int JPL = L / 4;            // scores per lane
+    static constexpr int CPL = HD / 4;           // output columns per lane
+    static constexpr int RS = HD + kPad;         // LDS row stride
+    static constexpr int NE = 2 * L - 1;
+    static constexpr int FWD_FLOATS = (3 * L + NE) * RS + L * (L + 1);
+    static constexpr int BWD_FLOATS = (4 * L + NE) * RS + 2 * L * (L + 1);
+};
+
+// cooperative copy of an L x HD matrix (row stride ld in global) into LDS (row stride RS) by the 4L lanes of a problem
+template <int L, int HD>
+__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, int64_t ld, int sl, float mul) {
+    constexpr int LPP = 4 * L, RS = HD + kPad, V = HD / 4;
+#pragma unroll
+    for (int e = sl; e < L * V; e += LPP) {
+        const int row = e / V, c4 = e % V;
+        float4 v = *reinterpret_cast<const float4*>(src + row * ld + c4 * 4);
+        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+        *reinterpret_cast<float4*>(dst + row * RS + c4 * 4) = v;
+    }
+}
+
+template <int L, int HD>
+__device__ __forceinline__ void stage_erel(float* dst, const float* __restrict__ e1, const float* __restrict__ e2, int h,
+                                           int sl) {
+    constexpr int LPP = 4 * L, RS = HD + kPad, V = HD / 4, NE = 2 * L - 1;
+#pragma unroll
+    for (int e = sl; e < NE * V; e += LPP) {
+        const int r = e / V, c4 = e % V;
+        const float* src = r < L ? e1 + ((int64_t)h * L + r) * HD : e2 + ((int64_t)h * L + (r - L + 1)) * HD;
+        *reinterpret_cast<float4*>(dst + r * RS + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+    }
+}
+
+// =====================================================================================================================
+template <int L, int HD>
+__global__ __launch_bounds__(kAttThreads) void relattn_fwd_kernel(const float* __restrict__ qkv, int64_t ldq,
+                                                                  const float* __restrict__ e1,
+                                                                  const float* __restrict__ e2, float* __restrict__ ctx,
+                                                                  int64_t ldo, float* __restrict__ probs,
+                                                                  int64_t n_blocks, int H, float scale, uint32_t thr,
+                                                                  float inv_keep, uint64_t seed) {
+    using C = AttCfg<L, HD>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane % C::LPP, slot = wave * C::PPW + lane / C::LPP;
+    float* base = lds + slot * C::FWD_FLOATS;
+    float* Qs = base;
+    float* Ks = Qs + L * C::RS;
+    float* Vs = Ks + L * C::RS;
+    float* Er = Vs + L * C::RS;
+    float* Ps = Er + C::NE * C::RS;                 // [L][L+1]
+    const int d = H * HD;
+    const int64_t total = n_blocks * H;
+    const int64_t prob = (int64_t)blockIdx.x * C::SLOTS + slot;
+    const bool live = prob < total;
+    const int64_t n = live ? prob / H : 0;
+    const int h = live ? (int)(prob % H) : 0;
+    const int i = sl >> 2, jg = sl & 3;
+
+    if (live) {
+        const float* qp = qkv + n * L * ldq + h * HD;
+        stage_rows<L, HD>(Qs, qp, ldq, sl, scale);
+        stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f);
+        stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f);
+        stage_erel<L, HD>(Er, e1, e2, h, sl);
+    }
+    __syncthreads();
+    float s[C::JPL];
+    if (live) {
+#pragma unroll
+        for (int jj = 0; jj < C::JPL; ++jj) s[jj] = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < HD / 4; ++c4) {
+            const float4 q = *reinterpret_cast<const float4*>(Qs + i * C::RS + c4 * 4);
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) {
+                const int j = jj * 4 + jg;
+                const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
+                const float4 e = *reinterpret_cast<const float4*>(Er + (j - i + L - 1) * C::RS + c4 * 4);
+                s[jj] += q.x * (k.x + e.x) + q.y * (k.y + e.y) + q.z * (k.z + e.z) + q.w * (k.w + e.w);
+            }
+        }
+        float m = s[0];
+#pragma unroll
+        for (int jj = 1; jj < C::JPL; ++jj) m = fmaxf(m, s[jj]);
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < C::JPL; ++jj) {
+            s[jj] = __expf(s[jj] - m);
+            sum += s[jj];
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        const float inv = 1.0f / sum;
+        float* pg = probs + prob * L * L + i * L;
+#pragma unroll
+        for (int jj = 0; jj < C::JPL; ++jj) {
+            const int j = jj * 4 + jg;
+            const float p = s[jj] * inv;
+            pg[j] = p;                                                          // saved BEFORE dropout
+            Ps[i * (L + 1) + j] = p * drop_scale(seed, (uint64_t)(prob * L + i) * L + j, thr, inv_keep);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        float o[C::CPL];
+#pragma unroll
+        for (int c = 0; c < C::CPL; ++c) o[c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const float p = Ps[i * (L + 1) + j];
+#pragma unroll
+            for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                const float4 v = *reinterpret_cast<const float4*>(Vs + j * C::RS + jg * C::CPL + c4 * 4);
+                o[c4 * 4 + 0] += p * v.x;
+                o[c4 * 4 + 1] += p * v.y;
+                o[c4 * 4 + 2] += p * v.z;
+                o[c4 * 4 + 3] += p * v.w;
+            }
+        }
+        float* op = ctx + (n * L + i) * ldo + h * HD + jg * C::CPL;
+#pragma unroll
+        for (int c4 = 0; c4 < C::CPL / 4; ++c4)
+            *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+    }
+}
+
+// =====================================================================================================================
+// backward.  grid = (chunks, head groups).  Every slot keeps the same head for the whole loop over its blocks, so the
+// relative-embedding gradient accumulates in registers and is written once per slot (deterministic).
+// ws layout: [chunk][nsub][H][2L-1][HD]
+template <int L, int HD>
+__global__ __launch_bounds__(kAttThreads) void relattn_bwd_kernel(
+    const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ qkv, int64_t ldq,
+    const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
+    float* __restrict__ d_qkv, int64_t ldg, float* __restrict__ ws, int64_t n_blocks, int H, int blocks_per_wg,
+    float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    using C = AttCfg<L, HD>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sl = lane % C::LPP, slot = wave * C::PPW + lane / C::LPP;
+    float* base = lds + slot * C::BWD_FLOATS;
+    float* Qs = base;
+    float* Ks = Qs + L * C::RS;
+    float* Vs = Ks + L * C::RS;
+    float* Os = Vs + L * C::RS;                     // d_ctx rows
+    float* Er = Os + L * C::RS;
+    float* Ss = Er + C::NE * C::RS;                 // dS   [L][L+1]
+    float* Ps = Ss + L * (L + 1);                   // P after dropout [L][L+1]
+    const int d = H * HD;
+    // slot -> (head, block sub-index)
+    int h, nsub, NS;
+    if (C::SLOTS >= H) {
+        NS = C::SLOTS / H;
+        h = slot % H;
+        nsub = slot / H;
+    } else {
+        NS = 1;
+        h = blockIdx.y * C::SLOTS + slot;
+        nsub = 0;
+    }
+    const int i = sl >> 2, jg = sl & 3;
+    stage_erel<L, HD>(Er, e1, e2, h, sl);
+    float de[2][C::CPL];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < C::CPL; ++c) de[a][c] = 0.0f;
+
+    const int64_t n_begin = (int64_t)blockIdx.x * blocks_per_wg;
+    for (int it = 0; it < blocks_per_wg; it += NS) {
+        const int64_t n = n_begin + it + nsub;
+        const bool live = (it + nsub < blocks_per_wg) && n < n_blocks;
+        const int64_t prob = n * H + h;
+        __syncthreads();
+        if (live) {
+            const float* qp = qkv + n * L * ldq + h * HD;
+            stage_rows<L, HD>(Qs, qp, ldq, sl, scale);
+            stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f);
+            stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f);
+            stage_rows<L, HD>(Os, d_ctx + n * L * ldo + h * HD, ldo, sl, 1.0f);
+        }
+        __syncthreads();
+        if (live) {
+            // dPd[i][j] = dO_i . V_j ; softmax backward
+            float dp[C::JPL], p[C::JPL];
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) dp[jj] = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < HD / 4; ++c4) {
+                const float4 o = *reinterpret_cast<const float4*>(Os + i * C::RS + c4 * 4);
+#pragma unroll
+                for (int jj = 0; jj < C::JPL; ++jj) {
+                    const float4 v = *reinterpret_cast<const float4*>(Vs + (jj * 4 + jg) * C::RS + c4 * 4);
+                    dp[jj] += o.x * v.x + o.y * v.y + o.z * v.z + o.w * v.w;
+                }
+            }
+            const float* pg = probs + prob * L * L + i * L;
+            float rowdot = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) {
+                const int j = jj * 4 + jg;
+                p[jj] = pg[j];
+                const float mk = drop_scale(seed, (uint64_t)(prob * L + i) * L + j, thr, inv_keep);
+                dp[jj] *= mk;                                   // dP = dPd * mask / (1-p)
+                Ps[i * (L + 1) + j] = p[jj] * mk;
+                rowdot += dp[jj] * p[jj];
+            }
+            rowdot += __shfl_xor(rowdot, 1, 64);
+            rowdot += __shfl_xor(rowdot, 2, 64);
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) Ss[i * (L + 1) + jj * 4 + jg] = p[jj] * (dp[jj] - rowdot);
+        }
+        __syncthreads();
+        if (live) {
+            // row index `i` doubles as the key index j for dK / dV
+            float dk[C::CPL], dv[C::CPL], dq[C::CPL];
+#pragma unroll
+            for (int c = 0; c < C::CPL; ++c) dk[c] = dv[c] = dq[c] = 0.0f;
+            const int j = i;
+#pragma unroll
+            for (int ii = 0; ii < L; ++ii) {
+                const float pd = Ps[ii * (L + 1) + j], ds = Ss[ii * (L + 1) + j];
+#pragma unroll
+                for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                    const float4 o = *reinterpret_cast<const float4*>(Os + ii * C::RS + jg * C::CPL + c4 * 4);
+                    const float4 q = *reinterpret_cast<const float4*>(Qs + ii * C::RS + jg * C::CPL + c4 * 4);
+                    dv[c4 * 4 + 0] += pd * o.x; dv[c4 * 4 + 1] += pd * o.y; dv[c4 * 4 + 2] += pd * o.z; dv[c4 * 4 + 3] += pd * o.w;
+                    dk[c4 * 4 + 0] += ds * q.x; dk[c4 * 4 + 1] += ds * q.y; dk[c4 * 4 + 2] += ds * q.z; dk[c4 * 4 + 3] += ds * q.w;
+                }
+            }
+            // dq_i = scale * sum_j dS[i][j] (k_j + Erel[j - i + L - 1])
+#pragma unroll
+            for (int jj = 0; jj < L; ++jj) {
+                const float ds = Ss[i * (L + 1) + jj];
+#pragma unroll
+                for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                    const float4 k = *reinterpret_cast<const float4*>(Ks + jj * C::RS + jg * C::CPL + c4 * 4);
+                    const float4 e = *reinterpret_cast<const float4*>(Er + (jj - i + L - 1) * C::RS + jg * C::CPL + c4 * 4);
+                    dq[c4 * 4 + 0] += ds * (k.x + e.x); dq[c4 * 4 + 1] += ds * (k.y + e.y);
+                    dq[c4 * 4 + 2] += ds * (k.z + e.z); dq[c4 * 4 + 3] += ds * (k.w + e.w);
+                }
+            }
+            float* gp = d_qkv + (n * L + i) * ldg + h * HD + jg * C::CPL;
+#pragma unroll
+            for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                *reinterpret_cast<float4*>(gp + c4 * 4) =
+                    make_float4(dq[c4 * 4] * scale, dq[c4 * 4 + 1] * scale, dq[c4 * 4 + 2] * scale, dq[c4 * 4 + 3] * scale);
+                *reinterpret_cast<float4*>(gp + d + c4 * 4) = make_float4(dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3]);
+                *reinterpret_cast<float4*>(gp + 2 * d + c4 * 4) = make_float4(dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3]);
+            }
+            // dErel[r] += sum_{i', j: j - i' + L - 1 = r} dS[i'][j] * qs[i']      rows r = i and r = i + L
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int r = i + a * L;
+                if (r < C::NE) {
+#pragma unroll
+                    for (int ii = 0; ii < L; ++ii) {
+                        const int jx = ii + r - (L - 1);
+                        if (jx >= 0 && jx < L) {
+                            const float ds = Ss[ii * (L + 1) + jx];
+#pragma unroll
+                            for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                                const float4 q = *reinterpret_cast<const float4*>(Qs + ii * C::RS + jg * C::CPL + c4 * 4);
+                                de[a][c4 * 4 + 0] += ds * q.x; de[a][c4 * 4 + 1] += ds * q.y;
+                                de[a][c4 * 4 + 2] += ds * q.z; de[a][c4 * 4 + 3] += ds * q.w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // one partial per (workgroup, nsub, head)
+    float* dst = ws + ((((int64_t)blockIdx.x * NS + nsub) * H + h) * C::NE) * HD;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int r = i + a * L;
+        if (r < C::NE) {
+#pragma unroll
+            for (int c = 0; c < C::CPL; ++c) dst[r * HD + jg * C::CPL + c] = de[a][c];
+        }
+    }
+}
+
+// sum the partials and split Erel back into e1 / e2 (row 0 of e2 is never used by the closed form: gradient 0)
+__global__ __launch_bounds__(256) void relattn_de_reduce(const float* __restrict__ ws, int nparts, int H, int L, int HD,
+                                                         float* __restrict__ d_e1, float* __restrict__ d_e2) {
+    const int NE = 2 * L - 1;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= H * NE * HD) return;
+    const int c = o % HD, r = (o / HD) % NE, h = o / (HD * NE);
+    float acc = 0.0f;
+    for (int p = 0; p < nparts; ++p) acc += ws[(int64_t)p * H * NE * HD + o];
+    if (r < L) d_e1[((int64_t)h * L + r) * HD + c] = acc;
+    else d_e2[((int64_t)h * L + (r - L + 1)) * HD + c] = acc;
+    if (r == 0) d_e2[((int64_t)h * L) * HD + c] = 0.0f;
+}
+
+static int att_blocks_per_wg(int64_t n_blocks, int slots, int H) {
+    // aim at ~2048 workgroups; a workgroup iteration covers max(1, slots / H) blocks
+    const int ns = std::max(1, slots / H);
+    int64_t b = ceil_div(n_blocks, 2048);
+    b = round_up(std::max<int64_t>(b, ns), ns);
+    return (int)b;
+}
+
+template <int L, int HD>
+static int launch_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
+                      float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
+    using C = AttCfg<L, HD>;
+    const size_t lds = (size_t)C::SLOTS * C::FWD_FLOATS * sizeof(float);
+    auto kern = relattn_fwd_kernel<L, HD>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t grid = ceil_div(n_blocks * H, C::SLOTS);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kAttThreads), lds, s, qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks,
+                       H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("relattn_fwd");
+    return VQCPC_OK;
+}
+
+template <int L, int HD>
+static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
+                      const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int H,
+                      float drop_p, uint64_t seed, float* ws, hipStream_t s) {
+    using C = AttCfg<L, HD>;
+    const size_t lds = (size_t)C::SLOTS * C::BWD_FLOATS * sizeof(float);
+    auto kern = relattn_bwd_kernel<L, HD>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int bpw = att_blocks_per_wg(n_blocks, C::SLOTS, H);
+    const int chunks = (int)ceil_div(n_blocks, bpw);
+    const int gy = C::SLOTS >= H ? 1 : H / C::SLOTS;
+    const int NS = C::SLOTS >= H ? C::SLOTS / H : 1;
+    hipLaunchKernelGGL(kern, dim3(chunks, gy), dim3(kAttThreads), lds, s, d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg,
+                       ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("relattn_bwd");
+    const int total = H * C::NE * HD;
+    hipLaunchKernelGGL(relattn_de_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, s, ws, chunks * NS, H, L, HD, d_e1, d_e2);
+    VQ_CHECK_LAUNCH("relattn_de_reduce");
+    return VQCPC_OK;
+}
+
+static bool att_supported(int L, int H, int hd) {
+    if (!(L == 16 || L == 4)) return false;
+    if (!(hd == 16 || hd == 32 || hd == 64)) return false;
+    const int slots = 4 * (64 / (4 * L));
+    return H >= 1 && ((slots % H) == 0 || (H % slots) == 0);
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+#define VQ_ATT_DISPATCH(CALL)                                              \
+    if (L == 16 && hd == 16) return CALL(16, 16);                          \
+    if (L == 16 && hd == 32) return CALL(16, 32);                          \
+    if (L == 16 && hd == 64) return CALL(16, 64);                          \
+    if (L == 4 && hd == 16) return CALL(4, 16);                            \
+    if (L == 4 && hd == 32) return CALL(4, 32);                            \
+    if (L == 4 && hd == 64) return CALL(4, 64);
+
+extern "C" {
+
+int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
+                      float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* stream) {
+    VQ_REQUIRE(qkv && e1 && e2 && ctx && probs, "relattn_fwd: null pointer");
+    VQ_REQUIRE(att_supported(L, H, hd), "relattn_fwd: unsupported L=%d H=%d hd=%d (L in {16,4}, hd in {16,32,64})", L, H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= 3 * H * hd && ldo >= H * hd && n_blocks >= 0, "relattn_fwd: bad strides");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_fwd: bad dropout probability");
+    if (n_blocks == 0) return VQCPC_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LL, DD) launch_fwd<LL, DD>(qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s)
+    VQ_ATT_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd) {
+    const int slots = 4 * (64 / (4 * std::max(L, 1)));
+    const int bpw = att_blocks_per_wg(std::max<int64_t>(n_blocks, 1), slots, std::max(H, 1));
+    const int64_t chunks = ceil_div(std::max<int64_t>(n_blocks, 1), bpw);
+    const int NS = slots >= H ? slots / H : 1;
+    return chunks * NS * H * (2 * L - 1) * hd * (int64_t)sizeof(float);
+}
+
+int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
+                      const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
+                      int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(d_ctx && qkv && probs && e1 && e2 && d_qkv && d_e1 && d_e2 && workspace, "relattn_bwd: null pointer");
+    VQ_REQUIRE(att_supported(L, H, hd), "relattn_bwd: unsupported L=%d H=%d hd=%d", L, H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldq >= 3 * H * hd && ldg >= 3 * H * hd && ldo >= H * hd &&
+                   n_blocks >= 1,
+               "relattn_bwd: bad strides");
+    if (workspace_bytes < vqcpc_relattn_bwd_workspace(n_blocks, L, H, hd)) {
+        set_error("relattn_bwd: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LL, DD) \
+    launch_bwd<LL, DD>(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, H, drop_p, seed, (float*)workspace, s)
+    VQ_ATT_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+}  // extern "C"

@@ -1,0 +1,238 @@
+// Error plumbing, partial-sum reduction, dropout mask probe, transposes, upscaler activation, flat-buffer optimiser.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace vq {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ ws, int64_t stride, int nsplit,
+                                                            float* __restrict__ out, int64_t count, int accumulate) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < count; i += step) {
+        float acc = accumulate ? out[i] : 0.0f;
+        for (int s = 0; s < nsplit; ++s) acc += ws[(int64_t)s * stride + i];
+        out[i] = acc;
+    }
+}
+
+int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
+                         hipStream_t stream) {
+    if (count <= 0) return VQCPC_OK;
+    int blocks = (int)std::min<int64_t>(ceil_div(count, 256), 2048);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, stream, ws, stride, nsplit, out, count,
+                       accumulate);
+    VQ_CHECK_LAUNCH("reduce_splits");
+    return VQCPC_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void dropout_mask_kernel(float* mask, int64_t n, uint32_t thr, uint64_t seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) mask[i] = (thr == 0 || rng_u24(seed, (uint64_t)i) >= thr) ? 1.0f : 0.0f;
+}
+
+// 32x32 LDS-tiled transpose
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R,
+                                                        int C) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int r = r0 + ty + k * 8, c = c0 + tx;
+        if (r < R && c < C) tile[ty + k * 8][tx] = in[(int64_t)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int c = c0 + ty + k * 8, r = r0 + tx;
+        if (r < R && c < C) out[(int64_t)c * R + r] = tile[tx][ty + k * 8];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float selu_f(float x) {
+    const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
+    return scale * (x > 0.0f ? x : alpha * (__expf(x) - 1.0f));
+}
+__device__ __forceinline__ float selu_grad(float x) {
+    const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
+    return scale * (x > 0.0f ? 1.0f : alpha * __expf(x));
+}
+
+__global__ __launch_bounds__(256) void dropout_selu_fwd_kernel(const float* __restrict__ h, float* __restrict__ out,
+                                                               int64_t n, uint32_t thr, float inv_keep, uint64_t seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) out[i] = selu_f(h[i] * drop_scale(seed, (uint64_t)i, thr, inv_keep));
+}
+
+__global__ __launch_bounds__(256) void dropout_selu_bwd_kernel(const float* __restrict__ h, const float* __restrict__ g,
+                                                               float* __restrict__ gh, int64_t n, uint32_t thr,
+                                                               float inv_keep, uint64_t seed) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const float s = drop_scale(seed, (uint64_t)i, thr, inv_keep);
+        gh[i] = g[i] * selu_grad(h[i] * s) * s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// sum of squares, two deterministic stages with double accumulation
+constexpr int kSumsqBlocks = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, int64_t n, float scale,
+                                                    double* __restrict__ partial) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    const int64_t n4 = n >> 2;
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n4; i += step) {
+        float4 v = g4[i];
+        float s = (v.x * scale) * (v.x * scale) + (v.y * scale) * (v.y * scale) + (v.z * scale) * (v.z * scale) +
+                  (v.w * scale) * (v.w * scale);
+        acc += (double)s;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+        float v = g[(n4 << 2) + threadIdx.x] * scale;
+        acc += (double)(v * v);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void sumsq_stage2(const double* __restrict__ partial, int nparts,
+                                                    double* __restrict__ out) {
+    __shared__ double red[4];
+    double acc = 0.0;
+    for (int i = threadIdx.x; i < nparts; i += 256) acc += partial[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, int64_t n, float lr_over_bc1, float beta1,
+                                                   float beta2, float eps, float inv_sqrt_bc2, float grad_scale,
+                                                   float max_norm, const double* __restrict__ sumsq) {
+    float coef = grad_scale;
+    if (sumsq != nullptr) {
+        const float total = (float)sqrt(sumsq[0]);
+        coef *= fminf(1.0f, max_norm / (total + 1e-6f));
+    }
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t step = (int64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) {
+        const float gi = g[i] * coef;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        g[i] = gi;   // gradients are left clipped in place, as clip_grad_norm_ does
+        p[i] -= lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+extern "C" {
+
+int vqcpc_abi_version(void) { return VQCPC_ABI_VERSION; }
+const char* vqcpc_last_error(void) { return vq::g_err; }
+
+int vqcpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream) {
+    VQ_REQUIRE(mask != nullptr && n >= 0 && p >= 0.f && p < 1.f, "dropout_mask: bad arguments");
+    if (n == 0) return VQCPC_OK;
+    int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, n, drop_threshold(p),
+                       seed);
+    VQ_CHECK_LAUNCH("dropout_mask");
+    return VQCPC_OK;
+}
+
+int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream) {
+    VQ_REQUIRE(in && out && R > 0 && C > 0, "transpose: bad arguments");
+    hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, (hipStream_t)stream, in,
+                       out, R, C);
+    VQ_CHECK_LAUNCH("transpose");
+    return VQCPC_OK;
+}
+
+int vqcpc_dropout_selu_fwd(const float* h, float* out, int64_t n, float drop_p, uint64_t seed, void* stream) {
+    VQ_REQUIRE(h && out && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_selu_fwd: bad arguments");
+    if (n == 0) return VQCPC_OK;
+    int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(dropout_selu_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, out, n,
+                       drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("dropout_selu_fwd");
+    return VQCPC_OK;
+}
+
+int vqcpc_dropout_selu_bwd(const float* h, const float* g_out, float* g_h, int64_t n, float drop_p, uint64_t seed,
+                           void* stream) {
+    VQ_REQUIRE(h && g_out && g_h && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_selu_bwd: bad arguments");
+    if (n == 0) return VQCPC_OK;
+    int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(dropout_selu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, g_out, g_h, n,
+                       drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("dropout_selu_bwd");
+    return VQCPC_OK;
+}
+
+int64_t vqcpc_sumsq_workspace(int64_t n) {
+    (void)n;
+    return (int64_t)kSumsqBlocks * sizeof(double);
+}
+
+int vqcpc_sumsq(const float* g, int64_t n, float grad_scale, double* out, void* workspace, int64_t workspace_bytes,
+                void* stream) {
+    VQ_REQUIRE(g && out && workspace && n > 0, "sumsq: bad arguments");
+    VQ_REQUIRE(aligned16(g), "sumsq: g must be 16-byte aligned");
+    if (workspace_bytes < vqcpc_sumsq_workspace(n)) {
+        set_error("sumsq: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    int blocks = (int)std::min<int64_t>(ceil_div(n / 4 + 1, 256), kSumsqBlocks);
+    hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, n, grad_scale,
+                       (double*)workspace);
+    VQ_CHECK_LAUNCH("sumsq_stage1");
+    hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, (hipStream_t)stream, (const double*)workspace, blocks, out);
+    VQ_CHECK_LAUNCH("sumsq_stage2");
+    return VQCPC_OK;
+}
+
+int vqcpc_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                    int step, float grad_scale, float max_norm, const double* sumsq, void* stream) {
+    VQ_REQUIRE(p && g && m && v && n > 0 && step >= 1, "adam_step: bad arguments");
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1),
+                       beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale, max_norm, sumsq);
+    VQ_CHECK_LAUNCH("adam_step");
+    return VQCPC_OK;
+}
+
+}  // extern "C"

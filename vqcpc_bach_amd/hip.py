@@ -1,0 +1,117 @@
+"""ctypes binding of libvqcpc_hip.so (include/vqcpc.h).  No torch types cross the ABI: only raw device pointers,
+sizes and the current HIP stream handle.  There is NO CPU fallback: if the library is missing or a call fails this
+module raises -- a silent eager path would void every parity claim.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libvqcpc_hip.so')
+ABI_VERSION = 1
+
+_lib = None
+
+c_i64, c_int, c_f32, c_u64, c_ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float, ctypes.c_uint64, ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/vqcpc.h declares (tests/test_abi.py checks it)
+SIGNATURES = {
+    'vqcpc_abi_version': (c_int, []),
+    'vqcpc_last_error': (ctypes.c_char_p, []),
+    'vqcpc_dropout_mask': (c_int, [c_ptr, c_i64, c_f32, c_u64, c_ptr]),
+    'vqcpc_embed_pos_fwd': (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
+    'vqcpc_embed_pos_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int, c_int, c_int]),
+    'vqcpc_embed_pos_bwd': (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                    c_i64, c_ptr]),
+    'vqcpc_gemm_nt': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64,
+                              c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr]),
+    'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'vqcpc_transpose': (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
+    'vqcpc_relattn_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_f32,
+                                  c_u64, c_ptr]),
+    'vqcpc_relattn_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int]),
+    'vqcpc_relattn_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
+                                  c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_add_layernorm_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32,
+                                        c_f32, c_u64, c_ptr]),
+    'vqcpc_add_layernorm_bwd_workspace': (c_i64, [c_i64, c_int]),
+    'vqcpc_add_layernorm_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                        c_i64, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_vq_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_vq_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int]),
+    'vqcpc_vq_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_ptr, c_ptr,
+                             c_ptr, c_i64, c_ptr]),
+    'vqcpc_dropout_selu_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_f32, c_u64, c_ptr]),
+    'vqcpc_dropout_selu_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_u64, c_ptr]),
+    'vqcpc_nce_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr,
+                              c_ptr]),
+    'vqcpc_nce_bwd_workspace': (c_i64, [c_int, c_int, c_int, c_int, c_int]),
+    'vqcpc_nce_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_int, c_int, c_int, c_int, c_ptr,
+                              c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
+    'vqcpc_sumsq_workspace': (c_i64, [c_i64]),
+    'vqcpc_sumsq': (c_int, [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_i64, c_ptr]),
+    'vqcpc_adam_step': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_f32, c_ptr,
+                                c_ptr]),
+}
+
+
+class VqcpcHipError(RuntimeError):
+    pass
+
+
+def load(path=None):
+    """dlopen the library (after torch, so that its libamdhip64.so.7 is the one HIP runtime in the process)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = path or os.environ.get('VQCPC_HIP_LIB', LIB_PATH)
+    if not os.path.exists(path):
+        raise VqcpcHipError(f'{path} not found: build it with `python -m vqcpc_bach_amd.build` '
+                            f'(hipcc --offload-arch=gfx950). There is no CPU fallback.')
+    lib = ctypes.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype, fn.argtypes = res, args
+    if lib.vqcpc_abi_version() != ABI_VERSION:
+        raise VqcpcHipError(f'ABI version mismatch: library {lib.vqcpc_abi_version()} != binding {ABI_VERSION}')
+    _lib = lib
+    return lib
+
+
+def is_loaded():
+    return _lib is not None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _p(t):
+    if t is None:
+        return None
+    assert t.is_cuda, 'libvqcpc_hip takes device pointers only'
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def _check(rc, name):
+    if rc != 0:
+        raise VqcpcHipError(f'{name} failed ({rc}): {load().vqcpc_last_error().decode()}')
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point; tensors become device pointers, the stream is appended."""
+    lib = load()
+    conv = [(_p(a) if isinstance(a, torch.Tensor) or a is None else a) for a in args]
+    rc = getattr(lib, name)(*conv, _stream())
+    _check(rc, name)
+
+
+def query(name, *args):
+    """Invoke an int64-returning host-only workspace query."""
+    return int(getattr(load(), name)(*args))
+
+
+def workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=device)

@@ -1,0 +1,329 @@
+"""torch.autograd glue over the C-ABI kernels (vqcpc_bach_amd/hip.py).  PyTorch only provides device memory, the
+stream and the autograd tape here; every numerical operation below is a libvqcpc_hip.so kernel.
+
+Layout convention: activations are 2-D `(rows, features)` fp32 tensors whose rows may be strided (`stride(1) == 1`);
+row = block * L + token (block-major), i.e. the reference's time-first `(L, N, E)` transposed.
+"""
+import torch
+
+from . import hip
+
+
+def _f32(t):
+    assert t.dtype == torch.float32 and t.is_cuda, 'expected an fp32 device tensor'
+    return t
+
+
+def _rows(t):
+    """2-D view with unit inner stride; returns (tensor, leading dimension)."""
+    assert t.dim() == 2 and t.stride(1) == 1, f'expected row-major 2-D tensor, got strides {t.stride()}'
+    return t, (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def dropout_mask(n, p, seed, device):
+    """Keep-mask (1/0) the kernels derive for element indices [0, n) -- test helper (vqcpc_dropout_mask)."""
+    m = torch.empty(n, dtype=torch.float32, device=device)
+    hip.call('vqcpc_dropout_mask', m, n, float(p), int(seed))
+    return m
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# raw kernel wrappers (no autograd)
+# ------------------------------------------------------------------------------------------------------------------
+def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, add=None, out=None):
+    """out[M,N] = epilogue(a[M,K] @ b[N,K]^T); see include/vqcpc.h."""
+    a, lda = _rows(_f32(a))
+    b, ldb = _rows(_f32(b))
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    out, ldc = _rows(out)
+    ldg = lda_ = 0
+    if gate is not None:
+        gate, ldg = _rows(gate)
+    if add is not None:
+        add, lda_ = _rows(add)
+    hip.call('vqcpc_gemm_nt', a, lda, b, ldb, out, ldc, M, N, K, bias, int(act), float(drop_p), int(seed), gate, ldg,
+             float(gate_scale), add, lda_)
+    return out
+
+
+def gemm_tn(a, b, want_bias=True):
+    """dW[N,K] = a[M,N]^T @ b[M,K], db[N] = column sums of a."""
+    a, lda = _rows(_f32(a))
+    b, ldb = _rows(_f32(b))
+    M, N = a.shape
+    K = b.shape[1]
+    assert b.shape[0] == M
+    dw = torch.empty(N, K, dtype=torch.float32, device=a.device)
+    db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
+    nbytes = hip.query('vqcpc_gemm_tn_workspace', M, N, K)
+    ws = hip.workspace(nbytes, a.device)
+    hip.call('vqcpc_gemm_tn', a, lda, b, ldb, dw, db, M, N, K, 0, ws, nbytes)
+    return dw, db
+
+
+def transpose(w):
+    w = _f32(w).contiguous()
+    out = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
+    hip.call('vqcpc_transpose', w, out, w.shape[0], w.shape[1])
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A2 + input_linear + positional concat
+# ------------------------------------------------------------------------------------------------------------------
+class EmbedPosFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, tokens, table, chan, event, tokens_per_block):
+        # tokens (rows,) int64 ; table (nv, vmax, dlin) ; chan (nv, pos) ; event (nev, pos)
+        nv, vmax, dlin = table.shape
+        pos = chan.shape[1]
+        rows = tokens.numel()
+        out = torch.empty(rows, dlin + 2 * pos, dtype=torch.float32, device=table.device)
+        hip.call('vqcpc_embed_pos_fwd', tokens, rows, tokens_per_block, nv, table.contiguous(), vmax, dlin,
+                 chan.contiguous(), event.contiguous(), pos, out)
+        ctx.save_for_backward(tokens)
+        ctx.meta = (rows, tokens_per_block, nv, vmax, dlin, pos, event.shape[0])
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (tokens,) = ctx.saved_tensors
+        rows, tpb, nv, vmax, dlin, pos, nev = ctx.meta
+        g = g.contiguous()
+        d_table = torch.empty(nv, vmax, dlin, dtype=torch.float32, device=g.device)
+        d_chan = torch.empty(nv, pos, dtype=torch.float32, device=g.device)
+        d_event = torch.empty(nev, pos, dtype=torch.float32, device=g.device)
+        nbytes = hip.query('vqcpc_embed_pos_bwd_workspace', rows, tpb, nv, vmax, dlin, pos)
+        ws = hip.workspace(nbytes, g.device)
+        hip.call('vqcpc_embed_pos_bwd', tokens, rows, tpb, nv, vmax, dlin, pos, g, d_table, d_chan, d_event, ws, nbytes)
+        return None, d_table, d_chan, d_event, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# plain linear (output_linear, upscaler)
+# ------------------------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return gemm_nt(x, weight, bias=bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        dx = gemm_nt(g, transpose(weight)) if ctx.needs_input_grad[0] else None
+        dw, db = gemm_tn(g, x, want_bias=ctx.has_bias)
+        return dx, dw, db
+
+
+def linear(x, weight, bias=None):
+    """F.linear on the last dimension through the MFMA GEMM."""
+    lead = x.shape[:-1]
+    x2 = x.reshape(-1, x.shape[-1])
+    if x2.stride(1) != 1:
+        x2 = x2.contiguous()
+    return LinearFn.apply(x2, weight, bias).reshape(*lead, weight.shape[0])
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# one post-LN relative-attention encoder layer (A6/A7/A8), forward + hand-scheduled backward
+# ------------------------------------------------------------------------------------------------------------------
+class EncoderLayerFn(torch.autograd.Function):
+    """y = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)),  x1 = LN1(x + drop(Wo attn(x) + bo)).
+    Parameter order: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, e1, e2, linear1.weight,
+    linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias."""
+
+    @staticmethod
+    def forward(ctx, x, L, H, drop_p, seed, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1, g2, be2):
+        x, ldx = _rows(_f32(x))
+        M, d = x.shape
+        hd = d // H
+        nblk = M // L
+        dev = x.device
+        p = float(drop_p)
+        s = [int(seed) + 0x1000 * i for i in range(4)]     # attention probs, dropout1, ffn dropout, dropout2
+        qkv = gemm_nt(x, wqkv, bias=bqkv)
+        att = torch.empty(M, d, dtype=torch.float32, device=dev)
+        probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
+        hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+        a = gemm_nt(att, wo, bias=bo)
+        x1 = torch.empty(M, d, dtype=torch.float32, device=dev)
+        mean1 = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd1 = torch.empty(M, dtype=torch.float32, device=dev)
+        hip.call('vqcpc_add_layernorm_fwd', x, ldx, a, g1, be1, x1, mean1, rstd1, M, d, 1e-5, p, s[1])
+        h2 = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2])
+        f = gemm_nt(h2, w2, bias=b2)
+        y = torch.empty(M, d, dtype=torch.float32, device=dev)
+        mean2 = torch.empty(M, dtype=torch.float32, device=dev)
+        rstd2 = torch.empty(M, dtype=torch.float32, device=dev)
+        hip.call('vqcpc_add_layernorm_fwd', x1, d, f, g2, be2, y, mean2, rstd2, M, d, 1e-5, p, s[3])
+        ctx.save_for_backward(x, qkv, probs, att, a, x1, mean1, rstd1, h2, f, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1, g2)
+        ctx.meta = (L, H, p, s)
+        ctx.mark_non_differentiable(probs)
+        return y, probs
+
+    @staticmethod
+    def backward(ctx, dy, _dprobs):
+        (x, qkv, probs, att, a, x1, mean1, rstd1, h2, f, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1, g2) = ctx.saved_tensors
+        L, H, p, s = ctx.meta
+        x, ldx = _rows(x)
+        M, d = x.shape
+        hd, nblk, dev = d // H, M // L, x.device
+        dy = dy.contiguous()
+
+        def ln_bwd(dyv, xin, ldxin, r, gamma, mean, rstd, seed):
+            ds = torch.empty(M, d, dtype=torch.float32, device=dev)
+            dr = torch.empty(M, d, dtype=torch.float32, device=dev) if p > 0 else None
+            dg = torch.empty(d, dtype=torch.float32, device=dev)
+            db = torch.empty(d, dtype=torch.float32, device=dev)
+            nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', M, d)
+            ws = hip.workspace(nbytes, dev)
+            hip.call('vqcpc_add_layernorm_bwd', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, dg, db, M, d, p, seed, ws,
+                     nbytes)
+            return ds, (dr if dr is not None else ds), dg, db
+
+        ds2, df, dg2, dbe2 = ln_bwd(dy, x1, d, f, g2, mean2, rstd2, s[3])
+        # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
+        da = gemm_nt(df, transpose(w2), gate=h2, gate_scale=1.0 / (1.0 - p))
+        dw2, db2 = gemm_tn(df, h2)
+        dw1, db1 = gemm_tn(da, x1)
+        dx1 = gemm_nt(da, transpose(w1), add=ds2)
+        del da, df, ds2
+        ds1, dA, dg1, dbe1 = ln_bwd(dx1, x, ldx, a, g1, mean1, rstd1, s[1])
+        dwo, dbo = gemm_tn(dA, att)
+        datt = gemm_nt(dA, transpose(wo))
+        dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
+        de1 = torch.empty_like(e1)
+        de2 = torch.empty_like(e2)
+        nbytes = hip.query('vqcpc_relattn_bwd_workspace', nblk, L, H, hd)
+        ws = hip.workspace(nbytes, dev)
+        hip.call('vqcpc_relattn_bwd', datt, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd, p, s[0], ws,
+                 nbytes)
+        dwqkv, dbqkv = gemm_tn(dqkv, x)
+        dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if ctx.needs_input_grad[0] else None
+        return (dx, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A9/A10: product vector quantiser
+# ------------------------------------------------------------------------------------------------------------------
+class VQFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, codebooks, beta, squared):
+        # z (R, D) contiguous ; codebooks (ncb, K, dsub)
+        z = _f32(z).contiguous()
+        codebooks = _f32(codebooks).contiguous()
+        R, D = z.shape
+        ncb, K, dsub = codebooks.shape
+        assert ncb * dsub == D
+        idx = torch.empty(R, ncb, dtype=torch.int64, device=z.device)
+        zq = torch.empty_like(z)
+        loss = torch.empty(R, dtype=torch.float32, device=z.device)
+        hip.call('vqcpc_vq_fwd', z, codebooks, R, ncb, K, dsub, float(beta), int(bool(squared)), idx, zq, loss)
+        ctx.save_for_backward(z, codebooks, idx)
+        ctx.meta = (float(beta), int(bool(squared)))
+        ctx.mark_non_differentiable(idx)
+        return zq, idx, loss
+
+    @staticmethod
+    def backward(ctx, g_zq, _g_idx, g_loss):
+        z, codebooks, idx = ctx.saved_tensors
+        beta, squared = ctx.meta
+        R, D = z.shape
+        ncb, K, dsub = codebooks.shape
+        g_zq = g_zq.contiguous() if g_zq is not None else torch.zeros_like(z)
+        g_loss = g_loss.contiguous() if g_loss is not None else torch.zeros(R, dtype=torch.float32, device=z.device)
+        dz = torch.empty_like(z)
+        dcb = torch.empty_like(codebooks)
+        nbytes = hip.query('vqcpc_vq_bwd_workspace', R, ncb, K, dsub)
+        ws = hip.workspace(nbytes, z.device)
+        hip.call('vqcpc_vq_bwd', z, codebooks, idx, g_zq, g_loss, R, ncb, K, dsub, beta, squared, dz, dcb, ws, nbytes)
+        return dz, dcb, None, None
+
+
+class DropoutSeluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, h, p, seed):
+        h = _f32(h).contiguous()
+        out = torch.empty_like(h)
+        hip.call('vqcpc_dropout_selu_fwd', h, out, h.numel(), float(p), int(seed))
+        ctx.save_for_backward(h)
+        ctx.meta = (float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (h,) = ctx.saved_tensors
+        p, seed = ctx.meta
+        gh = torch.empty_like(h)
+        hip.call('vqcpc_dropout_selu_bwd', h, g.contiguous(), gh, h.numel(), p, seed)
+        return gh, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A16/A17: bilinear scores + InfoNCE + hits
+# ------------------------------------------------------------------------------------------------------------------
+class NCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, c, W, z_pos, z_neg):
+        c, W, z_pos, z_neg = (_f32(t).contiguous() for t in (c, W, z_pos, z_neg))
+        B, cdim = c.shape
+        zdim, cdim2, K = W.shape
+        N = z_neg.shape[1]
+        assert cdim2 == cdim and z_pos.shape == (B, K, zdim) and z_neg.shape == (B, N, K, zdim)
+        dev = c.device
+        f_pos = torch.empty(B, K, dtype=torch.float32, device=dev)
+        f_neg = torch.empty(B, K, N, dtype=torch.float32, device=dev)
+        loss_b = torch.empty(B, dtype=torch.float32, device=dev)
+        hits = torch.empty(B, K, dtype=torch.float32, device=dev)
+        hip.call('vqcpc_nce_fwd', c, W, z_pos, z_neg, B, K, N, zdim, cdim, f_pos, f_neg, loss_b, hits)
+        ctx.save_for_backward(c, W, z_pos, z_neg, f_pos, f_neg)
+        ctx.mark_non_differentiable(hits, f_pos, f_neg)
+        return loss_b, hits, f_pos, f_neg
+
+    @staticmethod
+    def backward(ctx, g_loss_b, _gh, _gp, _gn):
+        c, W, z_pos, z_neg, f_pos, f_neg = ctx.saved_tensors
+        B, cdim = c.shape
+        zdim, _, K = W.shape
+        N = z_neg.shape[1]
+        d_c, d_W, d_zp, d_zn = (torch.empty_like(t) for t in (c, W, z_pos, z_neg))
+        nbytes = hip.query('vqcpc_nce_bwd_workspace', B, K, N, zdim, cdim)
+        ws = hip.workspace(nbytes, c.device)
+        hip.call('vqcpc_nce_bwd', c, W, z_pos, z_neg, f_pos, f_neg, g_loss_b.contiguous(), B, K, N, zdim, cdim, d_c, d_W,
+                 d_zp, d_zn, ws, nbytes)
+        return d_c, d_W, d_zp, d_zn
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# flat-buffer optimiser
+# ------------------------------------------------------------------------------------------------------------------
+class FlatAdam:
+    """clip_grad_norm_(., max_norm) + Adam on one flat fp32 buffer (params / grads / m / v), no host sync."""
+
+    def __init__(self, flat_param, flat_grad, lr, betas=(0.9, 0.999), eps=1e-8, max_norm=5.0):
+        self.p, self.g = flat_param, flat_grad
+        self.m = torch.zeros_like(flat_param)
+        self.v = torch.zeros_like(flat_param)
+        self.lr, self.betas, self.eps, self.max_norm = lr, betas, eps, max_norm
+        self.step_count = 0
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=flat_param.device)
+        self._ws_bytes = hip.query('vqcpc_sumsq_workspace', flat_param.numel())
+        self._ws = hip.workspace(self._ws_bytes, flat_param.device)
+
+    def step(self, lr=None, grad_scale=1.0):
+        self.step_count += 1
+        n = self.p.numel()
+        hip.call('vqcpc_sumsq', self.g, n, float(grad_scale), self.sumsq, self._ws, self._ws_bytes)
+        hip.call('vqcpc_adam_step', self.p, self.g, self.m, self.v, n, float(self.lr if lr is None else lr),
+                 float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, float(grad_scale),
+                 float(self.max_norm), self.sumsq)
+
+    def grad_norm(self):
+        return float(self.sumsq.sqrt().item())

@@ -122,13 +122,14 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
  *   z [R][D], codebooks [ncb][K][dsub] (D = ncb*dsub), idx [R][ncb] int64, zq_sg [R][D] = z + (q - z), loss [R].
  * Distance order is canonical: d = 0; for t ascending d = d + (z_t - e_t)^2 with separately rounded sub/mul/add;
  * k ascending, strict '<' (first index wins ties) -- bit-identical to oracle/vqcpc_oracle.py:vq_distances_canonical.
+ * assign != 0: idx is computed (argmin); assign == 0: idx is an INPUT (label-corruption path, vector_quantizer.py:119-132).
  * squared != 0: loss = (1 + beta) * sum (q - z)^2 computed as q_latent + beta * e_latent;
  * squared == 0: loss = (1 + beta) * || (q - z) + 1e-5 ||_2.
  * bwd: d_z = g_zq + g_loss * d(loss)/dz ; d_codebooks [ncb][K][dsub] = segment-sum of g_loss * d(loss)/dq
  * (this is the slot the north_star calls "codebook update": the reference trains codebooks by Adam, not EMA).
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_vq_fwd(const float* z, const float* codebooks, int64_t R, int ncb, int K, int dsub, float beta, int squared,
-                 int64_t* idx, float* zq_sg, float* loss, void* stream);
+                 int assign, int64_t* idx, float* zq_sg, float* loss, void* stream);
 int64_t vqcpc_vq_bwd_workspace(int64_t R, int ncb, int K, int dsub);
 int vqcpc_vq_bwd(const float* z, const float* codebooks, const int64_t* idx, const float* g_zq, const float* g_loss,
                  int64_t R, int ncb, int K, int dsub, float beta, int squared, float* d_z, float* d_codebooks,
@@ -148,7 +149,7 @@ int vqcpc_dropout_selu_bwd(const float* h, const float* g_out, float* g_h, int64
  *   c [B][cdim], W [zdim][cdim][K], z_pos [B][K][zdim], z_neg [B][N][K][zdim]
  *   f_pos [B][K], f_neg [B][K][N] (saved for bwd), loss_b [B] = -sum_k (pos - logsumexp([neg, pos])),
  *   hits [B][K] = (pos > max_n neg) as 0/1.   loss = mean_b loss_b, accuracy[k] = mean_b hits.
- * bwd (g = dLoss/d(mean loss), a device scalar): d_c, d_W (deterministic two-stage), d_z_pos, d_z_neg.
+ * bwd (g [B] = dLoss/d loss_b): d_c, d_W (deterministic two-stage), d_z_pos, d_z_neg.
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_nce_fwd(const float* c, const float* W, const float* z_pos, const float* z_neg, int B, int K, int N, int zdim,
                   int cdim, float* f_pos, float* f_neg, float* loss_b, float* hits, void* stream);

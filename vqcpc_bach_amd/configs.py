@@ -1,0 +1,37 @@
+"""BASELINE.json configurations in the reference's config-dict schema (VQCPCB/configs/encoder_random_transfo_config.py)."""
+import copy
+
+_SIZES = {
+    # name: d_model, heads, layers, ff, codebook_dim, codebook_size, num_codebooks, B, Kl, Kr
+    'C0': (128, 4, [1, 1], 512, 16, 64, 1, 8, 2, 2),
+    'C1': (256, 8, [2, 2], 1024, 32, 512, 2, 256, 8, 8),
+    'C4': (512, 8, [4, 4], 2048, 64, 1024, 4, 256, 16, 16),
+}
+
+
+def make_config(name='C1', dropout=0.1, **over):
+    d, H, layers, ff, D, K, ncb, B, Kl, Kr = _SIZES[name]
+    cfg = {
+        'training_method': 'vqcpc', 'dataset': 'bach',
+        'dataloader_generator_kwargs': dict(num_tokens_per_block=16, num_blocks_left=Kl, num_blocks_right=Kr,
+                                            negative_sampling_method='random', num_negative_samples=15,
+                                            sequences_size=1),
+        'subdivision': 4,
+        'data_processor_type': 'bach_cpc', 'data_processor_kwargs': dict(embedding_size=32),
+        'downscaler_type': 'relative_transformer_downscaler',
+        'downscaler_kwargs': dict(downscale_factors=[4, 4], num_channels=4, d_model=d, n_head=H,
+                                  list_of_num_layers=layers, dim_feedforward=ff, dropout=dropout),
+        'quantizer_type': 'commitment',
+        'quantizer_kwargs': dict(num_codebooks=ncb, codebook_size=K, codebook_dim=D, commitment_cost=0.25,
+                                 use_batch_norm=False, squared_l2_norm=True, initialize=True),
+        'upscaler_type': 'mlp_upscaler', 'upscaler_kwargs': dict(output_dim=32, hidden_size=512, dropout=dropout),
+        'auxiliary_networks_kwargs': {'quantization_weighting': 0.5,
+                                      'c_net_kwargs': dict(output_dim=32, hidden_size=512, num_layers=2, dropout=dropout,
+                                                           bidirectional=False)},
+        'lr': 1e-4, 'schedule_lr': False, 'batch_size': B, 'num_batches': 256, 'num_epochs': 1,
+        'quantizer_regularization': dict(corrupt_labels=False), 'timestamp': None, 'savename': f'encoder_cpc_{name}',
+    }
+    cfg = copy.deepcopy(cfg)
+    for k, v in over.items():
+        cfg[k] = v
+    return cfg

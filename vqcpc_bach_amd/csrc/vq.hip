@@ -6,7 +6,6 @@
 namespace vq {
 
 constexpr int kVqThreads = 256;
-constexpr int kVqMaxD = 256;          // max codebook_dim (full D) handled in registers-free form
 constexpr int kVqLdsFloats = 36 * 1024;  // 144 KiB of codebook per workgroup at most
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -15,7 +14,7 @@ constexpr int kVqLdsFloats = 36 * 1024;  // 144 KiB of codebook per workgroup at
 template <int DSUB>
 __global__ __launch_bounds__(kVqThreads) void vq_fwd_kernel(const float* __restrict__ z, const float* __restrict__ cb,
                                                             int64_t R, int ncb, int K, int dsub_rt, float beta,
-                                                            int squared, int64_t* __restrict__ idx_out,
+                                                            int squared, int assign, int64_t* __restrict__ idx_out,
                                                             float* __restrict__ zq_out, float* __restrict__ loss_out) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int dsub = DSUB > 0 ? DSUB : dsub_rt;
@@ -38,8 +37,8 @@ __global__ __launch_bounds__(kVqThreads) void vq_fwd_kernel(const float* __restr
             for (int t = 0; t < DSUB; ++t) x[t] = zr[c * DSUB + t];
         }
         float best = 0.0f;
-        int bi = 0;
-        for (int k = 0; k < K; ++k) {
+        int bi = assign ? 0 : (int)idx_out[r * ncb + c];   // assign == 0: indices are given (label corruption path)
+        for (int k = 0; k < (assign ? K : 0); ++k) {
             const float* e = lds + k * dsub;
             float d = 0.0f;
             if (DSUB > 0) {
@@ -59,7 +58,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_fwd_kernel(const float* __restr
                 bi = k;
             }
         }
-        idx_out[r * ncb + c] = (int64_t)bi;
+        if (assign) idx_out[r * ncb + c] = (int64_t)bi;
         const float* q = lds + bi * dsub;
         for (int t = 0; t < dsub; ++t) {
             const float xv = DSUB > 0 ? zr[c * dsub + t] : zr[c * dsub + t];
@@ -147,7 +146,7 @@ using namespace vq;
 extern "C" {
 
 int vqcpc_vq_fwd(const float* z, const float* codebooks, int64_t R, int ncb, int K, int dsub, float beta, int squared,
-                 int64_t* idx, float* zq_sg, float* loss, void* stream) {
+                 int assign, int64_t* idx, float* zq_sg, float* loss, void* stream) {
     VQ_REQUIRE(z && codebooks && idx && zq_sg && loss, "vq_fwd: null pointer");
     VQ_REQUIRE(R >= 0 && ncb >= 1 && K >= 1 && dsub >= 1, "vq_fwd: bad shape R=%lld ncb=%d K=%d dsub=%d", (long long)R, ncb,
                K, dsub);
@@ -159,8 +158,8 @@ int vqcpc_vq_fwd(const float* z, const float* codebooks, int64_t R, int ncb, int
 #define VQ_LAUNCH(DS)                                                                                                  \
     if (lds > 64 * 1024)                                                                                               \
         (void)hipFuncSetAttribute((const void*)vq_fwd_kernel<DS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    hipLaunchKernelGGL(vq_fwd_kernel<DS>, grid, block, lds, s, z, codebooks, R, ncb, K, dsub, beta, squared, idx, zq_sg, \
-                       loss)
+    hipLaunchKernelGGL(vq_fwd_kernel<DS>, grid, block, lds, s, z, codebooks, R, ncb, K, dsub, beta, squared, assign, idx, \
+                       zq_sg, loss)
     switch (dsub) {
         case 3: VQ_LAUNCH(3); break;
         case 4: VQ_LAUNCH(4); break;

@@ -39,7 +39,7 @@ SIGNATURES = {
     'vqcpc_add_layernorm_bwd_workspace': (c_i64, [c_i64, c_int]),
     'vqcpc_add_layernorm_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                         c_i64, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
-    'vqcpc_vq_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_vq_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     'vqcpc_vq_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int]),
     'vqcpc_vq_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_ptr, c_ptr,
                              c_ptr, c_i64, c_ptr]),

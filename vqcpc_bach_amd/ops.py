@@ -215,17 +215,19 @@ class EncoderLayerFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------------
 class VQFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, z, codebooks, beta, squared):
-        # z (R, D) contiguous ; codebooks (ncb, K, dsub)
+    def forward(ctx, z, codebooks, beta, squared, given_idx=None):
+        # z (R, D) contiguous ; codebooks (ncb, K, dsub) ; given_idx (R, ncb) int64 forces the assignment
         z = _f32(z).contiguous()
         codebooks = _f32(codebooks).contiguous()
         R, D = z.shape
         ncb, K, dsub = codebooks.shape
         assert ncb * dsub == D
-        idx = torch.empty(R, ncb, dtype=torch.int64, device=z.device)
+        idx = (torch.empty(R, ncb, dtype=torch.int64, device=z.device) if given_idx is None
+               else given_idx.to(torch.int64).contiguous().clone())
         zq = torch.empty_like(z)
         loss = torch.empty(R, dtype=torch.float32, device=z.device)
-        hip.call('vqcpc_vq_fwd', z, codebooks, R, ncb, K, dsub, float(beta), int(bool(squared)), idx, zq, loss)
+        hip.call('vqcpc_vq_fwd', z, codebooks, R, ncb, K, dsub, float(beta), int(bool(squared)), int(given_idx is None), idx,
+                 zq, loss)
         ctx.save_for_backward(z, codebooks, idx)
         ctx.meta = (float(beta), int(bool(squared)))
         ctx.mark_non_differentiable(idx)
@@ -244,7 +246,7 @@ class VQFn(torch.autograd.Function):
         nbytes = hip.query('vqcpc_vq_bwd_workspace', R, ncb, K, dsub)
         ws = hip.workspace(nbytes, z.device)
         hip.call('vqcpc_vq_bwd', z, codebooks, idx, g_zq, g_loss, R, ncb, K, dsub, beta, squared, dz, dcb, ws, nbytes)
-        return dz, dcb, None, None
+        return dz, dcb, None, None, None
 
 
 class DropoutSeluFn(torch.autograd.Function):

@@ -1,0 +1,59 @@
+"""Small helpers with the reference's names (VQCPCB/utils.py:5-21,52-81)."""
+import torch
+
+
+class DropoutSeeds:
+    """Counter-based seed source for the in-kernel dropout RNG: every dropout site draws a fresh 64-bit seed, so masks
+    are reproducible from (base seed, call order) and never stored."""
+
+    def __init__(self, base=0x5EED):
+        self.base = int(base) & 0xFFFFFFFF
+        self.counter = 0
+
+    def manual_seed(self, base):
+        self.base = int(base) & 0xFFFFFFFF
+        self.counter = 0
+
+    def next(self):
+        self.counter += 1
+        return (self.base << 32) + self.counter * 0x10000
+
+
+SEEDS = DropoutSeeds()
+
+
+def current_device():
+    """Device of the calling rank.  The reference's cuda_variable (utils.py:5-9) moves to the DEFAULT 'cuda' device;
+    with one process per GPU the launcher calls torch.cuda.set_device(local_rank) first, so this is the same thing."""
+    if not torch.cuda.is_available():
+        raise RuntimeError('vqcpc_bach_amd needs an MI355X: there is no CPU path (the CPU oracle lives in oracle/)')
+    return torch.device('cuda', torch.cuda.current_device())
+
+
+def cuda_variable(tensor):
+    return tensor.to(current_device(), non_blocking=True)
+
+
+def to_numpy(tensor):
+    return tensor.detach().to('cpu').numpy()
+
+
+def dict_pretty_print(d, endstr='\n'):
+    for key, value in d.items():
+        if isinstance(value, list):
+            print(f'{key.capitalize()}: [%s]' % ', '.join(map(str, value)))
+        else:
+            print(f'{key.capitalize()}: {value:.6}', end=endstr)
+
+
+def flatten(x):
+    """(batch, num_events, num_channels, ...) -> (batch, num_events * num_channels, ...)"""
+    size = x.size()
+    assert len(size) >= 3
+    return x.reshape(size[0], size[1] * size[2], *size[3:])
+
+
+def unflatten(sequence, num_channels):
+    size = sequence.size()
+    assert len(size) >= 2 and size[1] % num_channels == 0
+    return sequence.reshape(size[0], size[1] // num_channels, num_channels, *size[2:])

@@ -1,0 +1,221 @@
+"""VQCPCEncoderTrainer -- the hot path (reference: VQCPCB/vqcpc_encoder_trainer.py:14-354).
+
+One iteration of `epoch()`:
+  1. every block of the batch (negatives, [negatives_back,] left, right: R = B (N Kr [x2] + Kl + Kr) blocks) goes through
+     the encoder in ONE pass (Encoder.encode_many);
+  2. GRU context on z_left, fused bilinear scores + InfoNCE + hits (vqcpc_nce_*), quantisation loss;
+  3. backward (hand-scheduled per layer), ONE RCCL all-reduce of the flat gradient, global-norm clip + Adam as two flat
+     kernels (no host synchronisation anywhere in the step);
+  4. metrics accumulate on the device and are read once at the end of the epoch (the reference syncs 6+ times a step).
+"""
+import os
+from itertools import islice
+
+import numpy as np
+import torch
+
+from . import ops, vqcpc_helper
+from .encoder import EncoderTrainer
+from .parallel import DataParallelContext, FlatParameters
+from .vqcpc_helper import cpc_scores_and_loss
+
+
+class VQCPCEncoderTrainer(EncoderTrainer):
+    def __init__(self, model_dir, dataloader_generator, encoder, c_net_kwargs, quantization_weighting):
+        super().__init__(dataloader_generator=dataloader_generator)
+        self.model_dir = model_dir
+        self.dataloader_generator = dataloader_generator
+        self.encoder = encoder
+        self.data_processor = encoder.data_processor
+        self.codebook_dim = self.encoder.quantizer.codebook_dim
+        self.upscale_factors = list(reversed(self.encoder.downscaler.downscale_factors))
+        self.num_tokens_per_channel = self.encoder.data_processor.num_tokens_per_channel
+        self.num_channels = len(self.num_tokens_per_channel)
+        assert self.data_processor.num_tokens % np.prod(self.upscale_factors) == 0
+        z_dim = encoder.upscaler.output_dim if encoder.upscaler is not None else self.codebook_dim
+        c_dim = c_net_kwargs['output_dim']
+        k_max = self.dataloader_generator.num_blocks_right
+
+        def c_net():
+            return vqcpc_helper.CModule(input_dim=z_dim, hidden_size=c_net_kwargs['hidden_size'], output_dim=c_dim,
+                                        num_layers=c_net_kwargs['num_layers'], dropout=c_net_kwargs['dropout'])
+
+        self.c_module = c_net()
+        self.fks_module = vqcpc_helper.FksModule(z_dim=z_dim, c_dim=c_dim, k_max=k_max)
+        # the shipped transformer configs omit 'bidirectional' (defect 2): default to False
+        if c_net_kwargs.get('bidirectional', False):
+            self.c_module_back = c_net()
+            self.fks_module_back = vqcpc_helper.FksModule(z_dim=z_dim, c_dim=c_dim, k_max=k_max)
+        else:
+            self.c_module_back = None
+        self.quantization_weighting = quantization_weighting
+        self.optimizer = None
+        self.scheduler = None
+        self.schedule_lr = False
+        self.flat = None
+        self.dp = None
+        self.lr = None
+        self.global_step = 0
+
+    # ---- optimiser ---------------------------------------------------------------------------------------------
+    def _modules_with_params(self):
+        mods = [self.c_module, self.fks_module, self.encoder]
+        if self.c_module_back is not None:
+            mods += [self.fks_module_back, self.c_module_back]
+        return mods
+
+    @staticmethod
+    def lr_lambda(step):
+        """init_optimizers' LambdaLR factor (:96-107): linear warm-up 0.1 -> 1 over 10 000 steps, then a 10x slower
+        linear decay, floored at 0.1."""
+        warmup, lo, hi = 10000, 0.1, 1.0
+        s1 = (hi - lo) / warmup
+        return max(min(lo + s1 * step, hi + (step - warmup) * (-s1 * 0.1)), lo)
+
+    def init_optimizers(self, lr, schedule_lr, dp=None):
+        dev = next(self.encoder.parameters()).device
+        assert dev.type == 'cuda', 'call .to(device) first: the training step has no CPU path'
+        self.dp = dp if dp is not None else (self.dp or DataParallelContext(device=dev))
+        self.is_main = self.dp.rank == 0
+        self.flat = FlatParameters(self._modules_with_params())
+        self.dp.broadcast_(self.flat.flat, src=0)                       # identical replicas
+        if self.dp.distributed:
+            self.encoder.quantizer.init_broadcast = lambda tensors: [self.dp.broadcast_(t.data, 0) for t in tensors]
+        self.lr, self.schedule_lr = lr, schedule_lr
+        self.optimizer = ops.FlatAdam(self.flat.flat, self.flat.flat_grad, lr=lr, max_norm=5.0)
+        self.scheduler = self.lr_lambda if schedule_lr else None
+        self.global_step = 0
+
+    def current_lr(self):
+        return self.lr * (self.lr_lambda(self.global_step) if self.schedule_lr else 1.0)
+
+    def to(self, device):
+        for m in self._modules_with_params():
+            m.to(device)
+        return self
+
+    # ---- checkpoints (:117-151) ----------------------------------------------------------------------------------
+    def _dir(self, early_stopped):
+        return f'{self.model_dir}/early_stopped' if early_stopped else f'{self.model_dir}/overfitted'
+
+    def save(self, early_stopped):
+        model_dir = self._dir(early_stopped)
+        os.makedirs(model_dir, exist_ok=True)
+        self.encoder.save(early_stopped=early_stopped)
+        torch.save(self.c_module.state_dict(), f'{model_dir}/c_module')
+        torch.save(self.fks_module.state_dict(), f'{model_dir}/fks_module')
+        if self.c_module_back is not None:
+            torch.save(self.c_module_back.state_dict(), f'{model_dir}/c_module_back')
+            torch.save(self.fks_module_back.state_dict(), f'{model_dir}/fks_module_back')
+        if self.optimizer is not None:       # extension: the reference drops optimiser state on resume
+            torch.save(dict(m=self.optimizer.m, v=self.optimizer.v, step=self.optimizer.step_count,
+                            global_step=self.global_step), f'{model_dir}/optimizer')
+
+    def load(self, early_stopped, device):
+        print(f'Loading models {self.__repr__()}')
+        model_dir = self._dir(early_stopped)
+        if not os.path.exists(model_dir):
+            model_dir = self.model_dir
+        ml = torch.device(device)
+        self.encoder.load(early_stopped=early_stopped, device=device)
+        self.c_module.load_state_dict(torch.load(f'{model_dir}/c_module', map_location=ml))
+        self.fks_module.load_state_dict(torch.load(f'{model_dir}/fks_module', map_location=ml))
+        if self.c_module_back is not None:
+            self.c_module_back.load_state_dict(torch.load(f'{model_dir}/c_module_back', map_location=ml))
+            self.fks_module_back.load_state_dict(torch.load(f'{model_dir}/fks_module_back', map_location=ml))
+
+    def train(self, mode=True):
+        for m in self._modules_with_params():
+            m.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- one step ------------------------------------------------------------------------------------------------
+    def compute_losses(self, tensor_dict, corrupt_labels=False):
+        """Forward half of one iteration (:195-307).  Returns (loss, dict of device tensors)."""
+        neg = tensor_dict['negative_samples']
+        B, N, Kr, num_events, num_channels = neg.shape
+        xs = [neg.reshape(B * N * Kr, num_events, num_channels)]
+        corrupt = [corrupt_labels]
+        bidir = self.c_module_back is not None
+        if bidir:
+            xs.append(tensor_dict['negative_samples_back'].reshape(B * N * Kr, num_events, num_channels))
+            corrupt.append(corrupt_labels)
+        xs += [tensor_dict['x_left'], tensor_dict['x_right']]
+        corrupt += [False, False]
+        enc = self.encoder.encode_many(xs, corrupt)
+        (z_neg, idx_neg, ql_neg) = enc[0]
+        (z_left, idx_left, ql_left), (z_right, idx_right, ql_right) = enc[-2], enc[-1]
+        zdim = z_neg.shape[-1]
+        z_neg = z_neg.reshape(B, N, Kr, -1, zdim)[:, :, :, 0, :]                  # (B, N, K, z), first block (:245)
+
+        c = self.c_module(z_left, h=None)
+        contrastive, hits = cpc_scores_and_loss(self.fks_module, c, z_right, z_neg)
+        ql_total = ql_left.sum() + ql_right.sum() + ql_neg.sum()
+        n_terms = 3 * B
+        hits_back = None
+        if bidir:                                                                 # :277-296
+            z_nb, _, ql_nb = enc[1]
+            # reference quirk kept for parity: the backward negatives are NOT permuted to negative-major before
+            # FksModule's raw .view (:286-292), so window b is scored against rows n*B + b of the (B*N, K, z) tensor
+            z_nb = z_nb.reshape(B, N, Kr, -1, zdim)[:, :, :, 0, :].reshape(B * N, Kr, zdim)
+            z_nb = z_nb.reshape(N, B, Kr, zdim).permute(1, 0, 2, 3)
+            c_back = self.c_module_back(z_right.flip(dims=[1]), h=None)
+            contrastive_back, hits_back = cpc_scores_and_loss(self.fks_module_back, c_back, z_left, z_nb)
+            contrastive = contrastive + contrastive_back
+            ql_total = ql_total + ql_nb.sum()
+            n_terms = 4 * B
+        q_loss = ql_total / n_terms                                               # quantization_loss, helper :32-51
+        loss = contrastive + self.quantization_weighting * q_loss
+        accuracy = hits.mean(0)
+        if hits_back is not None:
+            accuracy = (accuracy + hits_back.mean(0)) / 2
+        return loss, dict(loss=loss.detach(), loss_contrastive=contrastive.detach(), loss_quantize=q_loss.detach(),
+                          accuracy=accuracy, idx_left=idx_left, idx_right=idx_right, idx_negative=idx_neg)
+
+    def _count_codewords(self, *idx_tensors):
+        """len(torch.unique(.)) without a host sync: sort + count boundaries, on merged product-codebook indices."""
+        K = self.encoder.quantizer.codebook_size
+        merged = torch.cat([self.encoder.merge_codes(i.reshape(-1, i.shape[-1])) for i in idx_tensors])
+        s = torch.sort(merged)[0]
+        return (s[1:] != s[:-1]).sum().float() + 1.0
+
+    def train_step(self, tensor_dict, train=True, corrupt_labels=False):
+        """zero_grad / forward / backward / all-reduce / clip / Adam (:310-316).  Returns device-side metrics."""
+        with torch.set_grad_enabled(train):
+            loss, out = self.compute_losses(tensor_dict, corrupt_labels)
+        if train:
+            self.flat.zero_grad()
+            loss.backward()
+            self.dp.all_reduce_sum_(self.flat.flat_grad)
+            self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)
+            self.global_step += 1
+        return out
+
+    def epoch(self, data_loader, train, num_batches, corrupt_labels):
+        assert self.optimizer is not None, 'call init_optimizers(lr, schedule_lr) first'
+        dev = self.flat.flat.device
+        if self.is_main:
+            print(f'lr: {self.current_lr()}')
+        self.train() if train else self.eval()
+        k_r = self.dataloader_generator.num_blocks_right
+        sums = torch.zeros(5 + k_r, dtype=torch.float32, device=dev)   # loss, quantize, contrastive, ncw, ncw_neg, acc[k]
+        n = 0
+        for tensor_dict in islice(data_loader, num_batches):
+            out = self.train_step(tensor_dict, train=train, corrupt_labels=corrupt_labels)
+            step = torch.cat([torch.stack([out['loss'], out['loss_quantize'], out['loss_contrastive'],
+                                           self._count_codewords(out['idx_left'], out['idx_right']),
+                                           self._count_codewords(out['idx_negative'])]), out['accuracy']])
+            sums += step
+            n += 1
+        sums /= max(n, 1)
+        if self.dp.distributed:                                       # metrics are means over ranks
+            self.dp.all_reduce_sum_(sums)
+            sums /= self.dp.world_size
+        host = sums.cpu().tolist()                                    # the only host sync of the epoch
+        means = dict(loss=host[0], accuracy=host[5:], loss_quantize=host[1], loss_contrastive=host[2],
+                     num_codewords=host[3], num_codewords_negative=host[4])
+        means['loss_monitor'] = -sum(means['accuracy']) / len(means['accuracy'])
+        return means

@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- encoder-train windows/sec of the VQ-CPC encoder training step on N MI355X (one rank per GPU).
+
+    python bench.py                                   # N=1, finishes in a few minutes
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = one full iteration of VQCPCEncoderTrainer.epoch(train=True) on one synthetic batch per rank (BASELINE.json
+configs[1] = C1: seq_len 256 = 8+8 blocks, B = 256 windows / GPU, 15 negatives, product-VQ 2x512, d_model 256, dropout
+0.1): forward of all 34 816 blocks, InfoNCE + quantisation loss, backward, RCCL all-reduce, global-norm clip, Adam.
+Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+
+roofline  : the dominant kernel is the fp32 MFMA GEMM `gemm_nt` (forward + dgrad = 2/3 of the GEMM FLOPs); achieved =
+            algorithmic FLOPs (2 M N K per launch) / launch durations measured with HIP events on the launch stream inside
+            the timed region; peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md).
+cpu_baseline: the CPU oracle (oracle/vqcpc_oracle.py, a port of the reference's path) timed on this host's cores on a
+            bounded sample of the same workload (same model, smaller batch: windows/s is batch-normalised).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--config', default='C1')
+    ap.add_argument('--batch', type=int, default=None, help='windows per GPU (default: the config\'s)')
+    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    return ap.parse_args()
+
+
+class GemmTimer:
+    """HIP-event bracket around every gemm launch of the timed region (events go to the stream the kernel is launched
+    on: torch's current stream, which is the stream handle passed through the C ABI)."""
+
+    def __init__(self):
+        self.records = {'gemm_nt': [], 'gemm_tn': []}
+        self.enabled = False
+
+    def install(self, ops):
+        timer = self
+        raw_nt, raw_tn = ops.gemm_nt, ops.gemm_tn
+
+        def gemm_nt(a, b, *args, **kw):
+            if not timer.enabled:
+                return raw_nt(a, b, *args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = raw_nt(a, b, *args, **kw)
+            e1.record()
+            timer.records['gemm_nt'].append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            return out
+
+        def gemm_tn(a, b, *args, **kw):
+            if not timer.enabled:
+                return raw_tn(a, b, *args, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = raw_tn(a, b, *args, **kw)
+            e1.record()
+            timer.records['gemm_tn'].append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1]))
+            return out
+
+        ops.gemm_nt, ops.gemm_tn = gemm_nt, gemm_tn
+
+    def summary(self, name):
+        recs = self.records[name]
+        if not recs:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
+        flops = sum(f for _, _, f in recs)
+        return dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), tflops=flops / (ms * 1e-3) / 1e12,
+                    flops_per_launch=flops / len(recs))
+
+
+def cpu_baseline(cfg_name, dropout, batch, steps):
+    from oracle import vqcpc_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = O.make_cfg(cfg_name, dropout=dropout, B=batch)
+    otr = O.OracleTrainer(cfg, O.init_state(cfg, seed=0), lr=1e-4)
+    gen = torch.Generator().manual_seed(0)
+    batches = [O.synthetic_batch(cfg, seed=1234 + i) for i in range(steps + 1)]
+    otr.step(batches[0], train=True, gen=gen)                      # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    for b in batches[1:]:
+        otr.step(b, train=True, gen=gen)
+    dt = time.perf_counter() - t0
+    return dict(value=batch * steps / dt, unit='windows/s', cores=cores, kind='port',
+                sample=f'{cfg_name} model, B={batch} windows/step, {steps} timed steps after 1 warm-up, fp32, '
+                       f'dropout {dropout}, torch CPU {torch.__version__}, {dt:.1f} s')
+
+
+def main():
+    args = parse()
+    from vqcpc_bach_amd import configs, getters, hip, ops
+    from vqcpc_bach_amd.parallel import DataParallelContext
+    from vqcpc_bach_amd.utils import SEEDS
+    assert torch.cuda.is_available(), 'bench.py measures the HIP path: it needs an MI355X'
+    hip.load()
+    dp = DataParallelContext()
+    assert dp.world_size == args.gpus or dp.world_size == 1, f'--gpus {args.gpus} but WORLD_SIZE={dp.world_size}'
+    dev = dp.device
+    torch.manual_seed(0)                                           # identical initial weights on every rank
+    SEEDS.manual_seed(1000 + dp.rank)
+
+    config = configs.make_config(args.config, dropout=args.dropout)
+    B = args.batch or config['batch_size']
+    dlg_kw = dict(config['dataloader_generator_kwargs'], seed=1234, rank=dp.rank, device=dev)
+    dlg = getters.get_dataloader_generator(config['dataset'], config['training_method'], dlg_kw)
+    encoder = getters.get_encoder('/tmp/vqcpc_bench_model', dlg, config)
+    trainer = getters.get_encoder_trainer('/tmp/vqcpc_bench_model', dlg, config['training_method'], encoder,
+                                          config['auxiliary_networks_kwargs'])
+    trainer.to(dev)
+    trainer.init_optimizers(lr=config['lr'], schedule_lr=config['schedule_lr'], dp=dp)
+    trainer.train()
+    n_params = trainer.flat.numel
+
+    timer = GemmTimer()
+    if not args.no_kernel_timing:
+        timer.install(ops)
+
+    # synthetic batches resident in HBM before the timed region (4 distinct batches, cycled)
+    stream = dlg.dataloaders(batch_size=B)[0]
+    pool = [next(stream) for _ in range(4)]
+    torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        trainer.train_step(pool[i % len(pool)], train=True)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = trainer.train_step(pool[i % len(pool)], train=True)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    timer.enabled = False
+    dt = dp.max_over_ranks(dt)
+    last_loss = float(out['loss'])
+
+    if dp.rank == 0:
+        value = B * dp.world_size * args.steps / dt
+        nt, tn = timer.summary('gemm_nt'), timer.summary('gemm_tn')
+        roofline = None
+        if nt:
+            roofline = dict(bound='mfma', kernel='gemm_nt_kernel (fp32 v_mfma_f32_32x32x2_f32)',
+                            achieved=round(nt['tflops'], 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
+                            frac=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+                            launches_per_step=nt['launches'] // args.steps, avg_launch_us=round(nt['avg_us'], 1),
+                            flops_per_launch=nt['flops_per_launch'],
+                            share_of_step=round(nt['total_ms'] / (dt * 1e3), 3))
+        line = {
+            'metric': 'encoder-train windows/sec (Bach 4-voice, seq=256)', 'value': round(value, 2), 'unit': 'windows/s',
+            'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'config': {'workload': f'encoder_cpc {args.config}: seq_len={16 * (dlg.num_blocks_left + dlg.num_blocks_right)}, '
+                                   f'batch={B}/GPU, {dlg.num_negative_samples} negatives, product-VQ '
+                                   f'{config["quantizer_kwargs"]["num_codebooks"]}x{config["quantizer_kwargs"]["codebook_size"]}, '
+                                   f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}',
+                       'global_batch': B * dp.world_size, 'seq_len': 16 * (dlg.num_blocks_left + dlg.num_blocks_right),
+                       'parallelism': f'dp{dp.world_size}', 'params': n_params},
+            'roofline': roofline,
+            'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
+                         'share_of_step': round(tn['total_ms'] / (dt * 1e3), 3)} if tn else None),
+            'final_loss': round(last_loss, 5),
+        }
+        if dp.world_size == 1 and not args.no_cpu_baseline:
+            line['cpu_baseline'] = cpu_baseline(args.config, args.dropout, args.cpu_batch, args.cpu_steps)
+            line['speedup_vs_cpu'] = round(value / line['cpu_baseline']['value'], 1)
+        else:
+            line['cpu_baseline'] = None
+        print(json.dumps(line), flush=True)
+    dp.shutdown()
+
+
+if __name__ == '__main__':
+    main()

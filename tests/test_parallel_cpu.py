@@ -1,0 +1,106 @@
+"""N > 1 path on CPU: world_size-2 `gloo` runs of the data-parallel plumbing (vqcpc_bach_amd/parallel.py).
+The compute of a rank is played by the CPU oracle (the product has no CPU path); what is checked is the DP contract:
+mean of shard gradients == gradient of the global batch, flat-buffer all-reduce, rank-0 broadcasts, per-rank shards."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from conftest import ROOT  # noqa: F401
+from oracle import vqcpc_oracle as O
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _tiny_cfg():
+    return O.make_cfg(emb=8, vocab=[11] * 4, d=32, H=2, layers=[1, 1], ff=32, D=4, K=8, ncb=1, zdim=8, up_hidden=16, cdim=8,
+                      gru_hidden=8, B=4, N=3, Kl=2, Kr=2)
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from vqcpc_bach_amd.dataloaders.synthetic_cpc_dataloader import SyntheticCPCDataloaderGenerator
+    from vqcpc_bach_amd.parallel import DataParallelContext, FlatParameters
+    dp = DataParallelContext(device='cpu')
+    assert dp.distributed and dp.world_size == world and dp.rank == rank
+    cfg = _tiny_cfg()
+    sd = O.init_state(cfg, seed=0)
+    full = O.synthetic_batch(cfg, seed=5)
+    B = cfg['B']
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    shard = {k: v[lo:hi] for k, v in full.items()}
+
+    # parameters live in one flat buffer; gradients are views into the flat all-reduce bucket
+    holder = torch.nn.ParameterDict({k.replace('.', '/'): torch.nn.Parameter(v.clone()) for k, v in sd.items()})
+    if rank == 1:                        # rank 1 starts from garbage: the rank-0 broadcast must fix it
+        with torch.no_grad():
+            for p in holder.values():
+                p.add_(1.0)
+    flat = FlatParameters([holder])
+    assert flat.check_views()
+    dp.broadcast_(flat.flat, src=0)
+    P = {k.replace('/', '.'): p for k, p in holder.items()}
+    for k in sd:
+        assert torch.equal(P[k].detach(), sd[k]), k
+
+    flat.zero_grad()
+    loss = O.cpc_losses(shard, P, cfg)['loss']
+    loss.backward()                                   # autograd accumulates IN PLACE into the flat views
+    assert flat.check_views()
+    dp.all_reduce_sum_(flat.flat_grad)
+    flat.flat_grad.mul_(1.0 / world)                  # the product does this inside the optimiser kernel (grad_scale)
+
+    ref_tr = O.OracleTrainer(cfg, sd)
+    ref_tr.step(full, train=True)
+    worst = 0.0
+    for k, p in P.items():
+        r = ref_tr.last_grads[k]
+        worst = max(worst, float((p.grad - r).abs().max() / (r.abs().max() + 1e-12)))
+    # per-rank synthetic shards differ, same-rank streams are reproducible
+    a = next(SyntheticCPCDataloaderGenerator(num_blocks_left=2, num_blocks_right=2, num_negative_samples=3, rank=rank)
+             .dataloaders(batch_size=2)[0])['x_left']
+    t = a.float().sum().reshape(1).clone()
+    gathered = [torch.zeros(1) for _ in range(world)]
+    torch.distributed.all_gather(gathered, t)
+    mx = dp.max_over_ranks(float(rank + 1))
+    torch.save(dict(worst=worst, sums=[float(g) for g in gathered], mx=mx), os.path.join(out_dir, f'r{rank}.pt'))
+    dp.barrier()
+    dp.shutdown()
+
+
+def test_dp_gradient_mean_equals_global_batch(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [torch.load(tmp_path / f'r{r}.pt') for r in range(world)]
+    for r in res:
+        assert r['worst'] < 2e-5, r['worst']          # mean of shard grads == global-batch grads
+        assert r['mx'] == float(world)
+        assert r['sums'][0] != r['sums'][1]           # ranks draw different synthetic shards
+    assert res[0]['sums'] == res[1]['sums']
+
+
+def test_flat_parameters_views_and_alignment():
+    from vqcpc_bach_amd.parallel import FlatParameters
+    m = torch.nn.Sequential(torch.nn.Linear(3, 5), torch.nn.LayerNorm(5), torch.nn.Linear(5, 7))
+    ref = [p.detach().clone() for p in m.parameters()]
+    flat = FlatParameters([m])
+    assert flat.check_views() and all(o % 4 == 0 for o in flat.offsets)
+    for p, r in zip(m.parameters(), ref):
+        assert torch.equal(p.detach(), r)
+    x = torch.randn(4, 3)
+    flat.zero_grad()
+    m(x).sum().backward()
+    m(x).sum().backward()                              # accumulation happens in the flat buffer
+    assert flat.check_views()
+    g = torch.autograd.grad(m(x).sum(), list(m.parameters()))
+    for p, gi in zip(m.parameters(), g):
+        assert torch.allclose(p.grad, 2 * gi, atol=1e-6)
+    assert float(flat.flat_grad.abs().sum()) > 0

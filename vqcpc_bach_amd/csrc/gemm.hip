@@ -32,18 +32,25 @@ struct EpiParams {
     int64_t ldadd;
 };
 
+// epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)
+enum { E_BIAS = 1, E_RELU = 2, E_DROP = 4, E_GATE = 8, E_ADD = 16, E_RUNTIME = 32 };
+
 // bijective XCD-aware remap: consecutive tiles (which share an A row panel) land on the same XCD / L2
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// FULL: M % 128 == 0, N % 128 == 0, K % 32 == 0 -> no bounds checks anywhere (all hot-path shapes).
+// Two LDS buffers: tile t+1 is staged (global -> registers -> other buffer) while tile t feeds the MFMAs; one barrier
+// per K tile.
+template <bool FULL, int EPI>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ B, int64_t ldb,
                                                                  float* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                  int K, int tiles_n, EpiParams ep) {
-    __shared__ __attribute__((aligned(16))) float As[BM * LDS_S];
-    __shared__ __attribute__((aligned(16))) float Bs[BN * LDS_S];
+    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_S];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_S];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
@@ -61,35 +68,45 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
 
     // global -> register staging: 4 float4 of A and 4 of B per thread per k-tile
     const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
+    const float* a_src = A + (m0 + ld_row) * lda + ld_c4;
+    const float* b_src = B + (int64_t)(n0 + ld_row) * ldb + ld_c4;
     float4 ra[4], rb[4];
     auto load_tiles = [&](int k0) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = ld_row + 32 * i;
-            const bool kok = k0 + ld_c4 < K;
-            ra[i] = (kok && m0 + r < M) ? *reinterpret_cast<const float4*>(A + (m0 + r) * lda + k0 + ld_c4)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[i] = (kok && n0 + r < N) ? *reinterpret_cast<const float4*>(B + (int64_t)(n0 + r) * ldb + k0 + ld_c4)
-                                        : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL) {
+                ra[i] = *reinterpret_cast<const float4*>(a_src + (int64_t)(32 * i) * lda + k0);
+                rb[i] = *reinterpret_cast<const float4*>(b_src + (int64_t)(32 * i) * ldb + k0);
+            } else {
+                const int r = ld_row + 32 * i;
+                const bool kok = k0 + ld_c4 < K;
+                ra[i] = (kok && m0 + r < M) ? *reinterpret_cast<const float4*>(a_src + (int64_t)(32 * i) * lda + k0)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = (kok && n0 + r < N) ? *reinterpret_cast<const float4*>(b_src + (int64_t)(32 * i) * ldb + k0)
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
-    auto store_tiles = [&]() {
+    auto store_tiles = [&](int buf) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = ld_row + 32 * i;
-            *reinterpret_cast<float4*>(As + r * LDS_S + ld_c4) = ra[i];
-            *reinterpret_cast<float4*>(Bs + r * LDS_S + ld_c4) = rb[i];
+            *reinterpret_cast<float4*>(&As[buf][r * LDS_S + ld_c4]) = ra[i];
+            *reinterpret_cast<float4*>(&Bs[buf][r * LDS_S + ld_c4]) = rb[i];
         }
     };
 
     load_tiles(0);
-    store_tiles();
+    store_tiles(0);
     __syncthreads();
-    const float* ap = As + (wm * 64 + li) * LDS_S + kh * 4;
-    const float* bp = Bs + (wn * 64 + li) * LDS_S + kh * 4;
+    const int a_off = (wm * 64 + li) * LDS_S + kh * 4;
+    const int b_off = (wn * 64 + li) * LDS_S + kh * 4;
+    int cur = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
         const bool more = k0 + BK < K;
         if (more) load_tiles(k0 + BK);           // HBM/L2 latency hides under the MFMAs below
+        const float* ap = &As[cur][a_off];
+        const float* bp = &Bs[cur][b_off];
 #pragma unroll
         for (int kc = 0; kc < BK / 8; ++kc) {
             const float4 a0 = *reinterpret_cast<const float4*>(ap + kc * 8);
@@ -107,29 +124,37 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
             }
         }
         if (more) {
+            store_tiles(cur ^ 1);                // nobody reads buf[cur^1] any more: barrier of the previous iteration
             __syncthreads();
-            store_tiles();
-            __syncthreads();
+            cur ^= 1;
         }
     }
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    constexpr bool RT = (EPI & E_RUNTIME) != 0;
+    const bool has_bias = RT ? ep.bias != nullptr : (EPI & E_BIAS) != 0;
+    const bool relu = RT ? ep.act == 1 : (EPI & E_RELU) != 0;
+    const bool drop = RT ? ep.thr != 0 : (EPI & E_DROP) != 0;
+    const bool has_gate = RT ? ep.gate != nullptr : (EPI & E_GATE) != 0;
+    const bool has_add = RT ? ep.add != nullptr : (EPI & E_ADD) != 0;
+    const int64_t row_base = m0 + wm * 64 + 4 * kh;
+    const int col_base = n0 + wn * 64 + li;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int nt = 0; nt < 2; ++nt) {
+        const int col = col_base + nt * 32;
+        if (!FULL && col >= N) continue;
+        const float bv = has_bias ? ep.bias[col] : 0.0f;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            const int col = n0 + wn * 64 + nt * 32 + li;
-            if (col >= N) continue;
-            const float bv = ep.bias ? ep.bias[col] : 0.0f;
+        for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int64_t row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row >= M) continue;
+                const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+                if (!FULL && row >= M) continue;
                 float v = acc[mt][nt][r] + bv;
-                if (ep.act == 1) v = fmaxf(v, 0.0f);
-                if (ep.thr) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);
-                if (ep.gate) v *= (ep.gate[row * ep.ldgate + col] > 0.0f ? ep.gate_scale : 0.0f);
-                if (ep.add) v += ep.add[row * ep.ldadd + col];
+                if (relu) v = fmaxf(v, 0.0f);
+                if (drop) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);
+                if (has_gate) v *= (ep.gate[row * ep.ldgate + col] > 0.0f ? ep.gate_scale : 0.0f);
+                if (has_add) v += ep.add[row * ep.ldadd + col];
                 C[row * ldc + col] = v;
             }
         }
@@ -139,6 +164,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int TM = 32;   // rows of the contraction (M) dimension per step
 
+// FULL: N % 128 == 0, K % 128 == 0, M % 32 == 0 -> no bounds checks.
+template <bool FULL>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ B, int64_t ldb, int64_t M,
                                                                  int N, int K, int tiles_k, int64_t rows_per_split,
@@ -169,11 +196,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const float* _
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int64_t r = mm + ld_row + 8 * i;
-            const bool rok = r < m_end;
-            ra[i] = (rok && n0 + ld_c4 < N) ? *reinterpret_cast<const float4*>(A + r * lda + n0 + ld_c4)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            rb[i] = (rok && k0 + ld_c4 < K) ? *reinterpret_cast<const float4*>(B + r * ldb + k0 + ld_c4)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (FULL) {
+                ra[i] = *reinterpret_cast<const float4*>(A + r * lda + n0 + ld_c4);
+                rb[i] = *reinterpret_cast<const float4*>(B + r * ldb + k0 + ld_c4);
+            } else {
+                const bool rok = r < m_end;
+                ra[i] = (rok && n0 + ld_c4 < N) ? *reinterpret_cast<const float4*>(A + r * lda + n0 + ld_c4)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+                rb[i] = (rok && k0 + ld_c4 < K) ? *reinterpret_cast<const float4*>(B + r * ldb + k0 + ld_c4)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
         }
     };
     auto store_tiles = [&]() {
@@ -195,16 +227,27 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const float* _
     for (int64_t mm = m_begin; mm < m_end; mm += TM) {
         const bool more = mm + TM < m_end;
         if (more) load_tiles(mm + TM);
+        // operands of 4 contraction steps (8 rows of M) are fetched per batch: one LDS latency per 16 MFMAs
 #pragma unroll
-        for (int s = 0; s < TM / 2; ++s) {
-            const float a0 = ap[2 * s * BM], a1 = ap[2 * s * BM + 32];
-            const float b0 = bp[2 * s * BN], b1 = bp[2 * s * BN + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-            bsum[0] += a0;
-            bsum[1] += a1;
+        for (int g = 0; g < TM / 8; ++g) {
+            float a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                a0[u] = ap[(8 * g + 2 * u) * BM];
+                a1[u] = ap[(8 * g + 2 * u) * BM + 32];
+                b0[u] = bp[(8 * g + 2 * u) * BN];
+                b1[u] = bp[(8 * g + 2 * u) * BN + 32];
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the 8 reads ahead of the 16 MFMAs (hipcc sinks them otherwise)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b0[u], acc[0][0], 0, 0, 0);
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[u], b1[u], acc[0][1], 0, 0, 0);
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b0[u], acc[1][0], 0, 0, 0);
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[u], b1[u], acc[1][1], 0, 0, 0);
+                bsum[0] += a0[u];
+                bsum[1] += a1[u];
+            }
         }
         if (more) {
             __syncthreads();
@@ -219,11 +262,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const float* _
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             const int col = k0 + wn * 64 + nt * 32 + li;
-            if (col >= K) continue;
+            if (!FULL && col >= K) continue;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = n0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < N) out[(int64_t)row * K + col] = acc[mt][nt][r];
+                if (FULL || row < N) out[(int64_t)row * K + col] = acc[mt][nt][r];
             }
         }
     }
@@ -266,8 +309,32 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const int64_t tiles = ceil_div(M, BM) * tiles_n;
     VQ_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");
     EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd};
-    hipLaunchKernelGGL(gemm_nt_kernel, dim3((unsigned)tiles), dim3(kGemmThreads), 0, (hipStream_t)stream, A, lda, B, ldb, C,
-                       ldc, M, N, K, tiles_n, ep);
+    const bool full = (M % BM == 0) && (N % BN == 0) && (K % BK == 0);
+    const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (gate ? E_GATE : 0) |
+                      (add ? E_ADD : 0);
+    const dim3 grid((unsigned)tiles), block(kGemmThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define NT_LAUNCH(FULLV, EPIV) \
+    hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep)
+#define NT_CASE(EPIV)                     \
+    case EPIV:                            \
+        if (full) NT_LAUNCH(true, EPIV);  \
+        else NT_LAUNCH(false, EPIV);      \
+        break;
+    switch (flags) {
+        NT_CASE(0)
+        NT_CASE(E_BIAS)
+        NT_CASE(E_BIAS | E_RELU)
+        NT_CASE(E_BIAS | E_RELU | E_DROP)
+        NT_CASE(E_GATE)
+        NT_CASE(E_ADD)
+        default:
+            if (full) NT_LAUNCH(true, E_RUNTIME);
+            else NT_LAUNCH(false, E_RUNTIME);
+            break;
+    }
+#undef NT_CASE
+#undef NT_LAUNCH
     VQ_CHECK_LAUNCH("gemm_nt");
     return VQCPC_OK;
 }
@@ -295,8 +362,12 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     float* ws = (float*)workspace;
     float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(gemm_tn_kernel, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N, K, tiles_k,
-                       rows_per_split, ws, ws_bias);
+    if ((N % BM == 0) && (K % BN == 0) && (M % TM == 0))
+        hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N, K,
+                           tiles_k, rows_per_split, ws, ws_bias);
+    else
+        hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N, K,
+                           tiles_k, rows_per_split, ws, ws_bias);
     VQ_CHECK_LAUNCH("gemm_tn");
     int rc = launch_reduce_splits(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, accumulate, s);
     if (rc) return rc;

@@ -307,15 +307,14 @@ __global__ __launch_bounds__(kAttThreads) void relattn_bwd_kernel(
     }
 }
 
-// sum the partials and split Erel back into e1 / e2 (row 0 of e2 is never used by the closed form: gradient 0)
-__global__ __launch_bounds__(256) void relattn_de_reduce(const float* __restrict__ ws, int nparts, int H, int L, int HD,
-                                                         float* __restrict__ d_e1, float* __restrict__ d_e2) {
+// split the reduced Erel gradient [H][2L-1][HD] back into e1 / e2 (row 0 of e2 is never used by the closed form: 0)
+__global__ __launch_bounds__(256) void relattn_de_split(const float* __restrict__ tot, int H, int L, int HD,
+                                                        float* __restrict__ d_e1, float* __restrict__ d_e2) {
     const int NE = 2 * L - 1;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
     if (o >= H * NE * HD) return;
     const int c = o % HD, r = (o / HD) % NE, h = o / (HD * NE);
-    float acc = 0.0f;
-    for (int p = 0; p < nparts; ++p) acc += ws[(int64_t)p * H * NE * HD + o];
+    const float acc = tot[o];
     if (r < L) d_e1[((int64_t)h * L + r) * HD + c] = acc;
     else d_e2[((int64_t)h * L + (r - L + 1)) * HD + c] = acc;
     if (r == 0) d_e2[((int64_t)h * L) * HD + c] = 0.0f;
@@ -359,8 +358,11 @@ static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
                        ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
     VQ_CHECK_LAUNCH("relattn_bwd");
     const int total = H * C::NE * HD;
-    hipLaunchKernelGGL(relattn_de_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, s, ws, chunks * NS, H, L, HD, d_e1, d_e2);
-    VQ_CHECK_LAUNCH("relattn_de_reduce");
+    float* tot = ws + (int64_t)chunks * NS * total;            // tail of the workspace
+    int rc = launch_reduce_splits(ws, total, chunks * NS, tot, total, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(relattn_de_split, dim3(ceil_div(total, 256)), dim3(256), 0, s, tot, H, L, HD, d_e1, d_e2);
+    VQ_CHECK_LAUNCH("relattn_de_split");
     return VQCPC_OK;
 }
 
@@ -404,7 +406,7 @@ int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd) {
     const int bpw = att_blocks_per_wg(std::max<int64_t>(n_blocks, 1), slots, std::max(H, 1));
     const int64_t chunks = ceil_div(std::max<int64_t>(n_blocks, 1), bpw);
     const int NS = slots >= H ? slots / H : 1;
-    return chunks * NS * H * (2 * L - 1) * hd * (int64_t)sizeof(float);
+    return (chunks * NS + 1) * H * (2 * L - 1) * hd * (int64_t)sizeof(float);
 }
 
 int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,

@@ -15,23 +15,45 @@ void set_error(const char* fmt, ...) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void reduce_splits_kernel(const float* __restrict__ ws, int64_t stride, int nsplit,
-                                                            float* __restrict__ out, int64_t count, int accumulate) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t step = (int64_t)gridDim.x * blockDim.x;
-    for (; i < count; i += step) {
-        float acc = accumulate ? out[i] : 0.0f;
-        for (int s = 0; s < nsplit; ++s) acc += ws[(int64_t)s * stride + i];
-        out[i] = acc;
+// 64 columns x 16 split-groups per workgroup: group g sums splits g, g+16, ... (4 independent loads in flight), the 16
+// group partials are combined in a fixed order -> deterministic, and no lane walks more than nsplit/16 dependent loads.
+constexpr int kRedCols = 64, kRedGroups = 16;
+
+__global__ __launch_bounds__(kRedCols * kRedGroups) void reduce_splits_kernel(const float* __restrict__ ws,
+                                                                              int64_t stride, int nsplit,
+                                                                              float* __restrict__ out, int64_t count,
+                                                                              int accumulate) {
+    __shared__ float part[kRedGroups][kRedCols];
+    const int tx = threadIdx.x % kRedCols, ty = threadIdx.x / kRedCols;
+    const int64_t col = (int64_t)blockIdx.x * kRedCols + tx;
+    float acc = 0.0f;
+    if (col < count) {
+        int s = ty;
+        for (; s + 3 * kRedGroups < nsplit; s += 4 * kRedGroups) {
+            const float a = ws[(int64_t)s * stride + col];
+            const float b = ws[(int64_t)(s + kRedGroups) * stride + col];
+            const float c = ws[(int64_t)(s + 2 * kRedGroups) * stride + col];
+            const float d = ws[(int64_t)(s + 3 * kRedGroups) * stride + col];
+            acc = ((acc + a) + b) + (c + d);
+        }
+        for (; s < nsplit; s += kRedGroups) acc += ws[(int64_t)s * stride + col];
+    }
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && col < count) {
+        float tot = accumulate ? out[col] : 0.0f;
+#pragma unroll
+        for (int g = 0; g < kRedGroups; ++g) tot += part[g][tx];
+        out[col] = tot;
     }
 }
 
 int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
                          hipStream_t stream) {
     if (count <= 0) return VQCPC_OK;
-    int blocks = (int)std::min<int64_t>(ceil_div(count, 256), 2048);
-    hipLaunchKernelGGL(reduce_splits_kernel, dim3(blocks), dim3(256), 0, stream, ws, stride, nsplit, out, count,
-                       accumulate);
+    const int64_t blocks = ceil_div(count, kRedCols);
+    hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(kRedCols * kRedGroups), 0, stream, ws, stride,
+                       nsplit, out, count, accumulate);
     VQ_CHECK_LAUNCH("reduce_splits");
     return VQCPC_OK;
 }

@@ -67,14 +67,15 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
  *
  * vqcpc_gemm_nt:  C[M,N] = epilogue( A[M,K] . B[N,K]^T )      (forward: B = weight; dgrad: B = weight^T)
  *   epilogue order:  + bias[N] (nullable) -> ReLU (act==1) -> dropout(p, seed; element index m*N+n, scaled 1/(1-p))
- *                    -> * (gate[m,n] > 0 ? gate_scale : 0) (nullable) -> + add[m,n] (nullable) -> store.
+ *                    -> * (gate[m,n] > 0 ? gate_scale : 0) (nullable) -> + add[m,n] (+ add2[m,n]) (nullable) -> store.
+ *                    add / add2 may alias C element-wise (each element is read before it is written by the same lane).
  * vqcpc_gemm_tn:  dW[N,K] (+)= A[M,N]^T . B[M,K],  db[N] (+)= column sums of A (db nullable)
  *   split over M into partials in `workspace`, then reduced deterministically; accumulate!=0 adds to dW/db.
  * K % 4 == 0, lda/ldb % 4 == 0 required (16-byte vector loads).
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
-                  float gate_scale, const float* add, int64_t ldadd, void* stream);
+                  float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream);
 int64_t vqcpc_gemm_tn_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
@@ -97,6 +98,20 @@ int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd);
 int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
                       const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
                       int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* Query-subsampled variant for the LAST layer of a stack: `output[::F]` (relative_transformer_downscaler.py:125) keeps
+ * only positions 0, F, 2F.. and everything after the attention is per-token, so only those queries are evaluated
+ * (keys / values still span the block).  q [n_blocks*L/F][ldq] (projected from x[::F], unscaled), kv [n_blocks*L][ldkv]
+ * (k | v at columns 0, d), ctx [n_blocks*L/F][ldo], probs [n_blocks][H][L/F][L].  F = 4.
+ * Results equal the full layer followed by the row selection; dropped rows have zero gradient in the reference too. */
+int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                          float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd,
+                          float drop_p, uint64_t seed, void* stream);
+int64_t vqcpc_relattn_sub_bwd_workspace(int64_t n_blocks, int L, int F, int H, int hd);
+int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                          const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
+                          int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd,
+                          float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused residual + dropout + LayerNorm:  y = LN(x + dropout(r)) * gamma + beta   (eps inside the sqrt, biased var).

@@ -51,7 +51,7 @@ def test_workspace_queries_are_host_only(lib):
 
 def test_argument_validation_without_gpu(lib):
     # bad arguments are rejected before any HIP call, with a message
-    rc = lib.vqcpc_gemm_nt(None, 0, None, 0, None, 0, 4, 4, 4, None, 0, 0.0, 0, None, 0, 1.0, None, 0, None)
+    rc = lib.vqcpc_gemm_nt(None, 0, None, 0, None, 0, 4, 4, 4, None, 0, 0.0, 0, None, 0, 1.0, None, 0, None, 0, None)
     assert rc == -1 and b'gemm_nt' in lib.vqcpc_last_error()
     rc = lib.vqcpc_vq_fwd(None, None, 1, 1, 1, 1, 0.25, 1, 1, None, None, None, None)
     assert rc == -1 and b'vq_fwd' in lib.vqcpc_last_error()

@@ -105,6 +105,19 @@ def test_gemm_nt_is_transpose_detecting(ops):
     assert torch.equal(out.cpu(), b.t().contiguous())
 
 
+def test_gemm_nt_two_residuals_in_place(ops):
+    gen = torch.Generator().manual_seed(8)
+    M, N, K = 256, 128, 64
+    a, b = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen)
+    add, base = torch.randn(M, N, generator=gen), torch.randn(4 * M, N, generator=gen)
+    based = dev(base)
+    view = based[::4]
+    ops.gemm_nt(dev(a), dev(b), add=dev(add), add2=view, out=view)            # out aliases add2 element-wise
+    ref = a.double() @ b.double().t() + add.double() + base[::4].double()
+    assert rel_err(based[::4].cpu(), ref) < 1e-5
+    assert torch.equal(based[1::4].cpu(), base[1::4])
+
+
 def test_gemm_nt_strided_rows_and_epilogue(ops):
     gen = torch.Generator().manual_seed(5)
     M, N, K = 300, 200, 64
@@ -262,6 +275,89 @@ def test_relattn(ops, n, L, H, hd, p):
     assert float(de2.cpu().reshape(H, L, hd)[:, 0].abs().max()) == 0.0   # e2 row 0 is never used (j > i strictly)
 
 
+@pytest.mark.parametrize('n,L,H,hd,p', [(37, 16, 2, 16, 0.0), (64, 16, 8, 32, 0.0), (129, 4, 8, 32, 0.0), (40, 16, 8, 64, 0.0),
+                                        (33, 4, 4, 16, 0.0), (50, 16, 4, 32, 0.15), (70, 4, 2, 16, 0.15), (5000, 16, 8, 32, 0.0),
+                                        (4100, 4, 8, 32, 0.0)])
+def test_relattn_query_subsampled(ops, n, L, H, hd, p):
+    """Last-layer variant: only the queries at positions 0, 4, 8, .. -- must equal the full attention's rows [::4]."""
+    from vqcpc_bach_amd import hip
+    F = 4
+    LQ = L // F
+    gen = torch.Generator().manual_seed(n + L + H + 1)
+    d = H * hd
+    qkv = torch.randn(n * L, 3 * d, generator=gen)
+    e1, e2 = torch.randn(H * L, hd, generator=gen), torch.randn(H * L, hd, generator=gen)
+    dctx = torch.randn(n * LQ, d, generator=gen)
+    seed = 777
+    mask_full = None
+    if p > 0:
+        m = ops.dropout_mask(n * H * LQ * L, p, seed, 'cuda').cpu().reshape(n, H, LQ, L) / (1 - p)
+        mask_full = torch.ones(n, H, L, L)
+        mask_full[:, :, ::F] = m
+    qc, e1c, e2c = (t.clone().requires_grad_(True) for t in (qkv, e1, e2))
+    ctx_ref, probs_ref = _attn_ref(qc, e1c, e2c, L, H, hd, mask_full)
+    ctx_sel = ctx_ref.reshape(n, L, d)[:, ::F].reshape(n * LQ, d)
+    (ctx_sel * dctx).sum().backward()
+    g = qc.grad.reshape(n, L, 3 * d)
+
+    q_in = dev(qkv.reshape(n, L, 3 * d)[:, ::F, :d].reshape(n * LQ, d))
+    kv_in = dev(qkv[:, d:])
+    e1d, e2d = dev(e1), dev(e2)
+    ctx = torch.empty(n * LQ, d, device='cuda')
+    probs = torch.empty(n, H, LQ, L, device='cuda')
+    hip.call('vqcpc_relattn_sub_fwd', q_in, d, kv_in, 2 * d, e1d, e2d, ctx, d, probs, n, L, F, H, hd, p, seed)
+    assert rel_err(probs.cpu(), probs_ref.detach()[:, :, ::F]) < FWD_TOL
+    assert rel_err(ctx.cpu(), ctx_sel.detach()) < FWD_TOL
+    dq = torch.empty(n * LQ, d, device='cuda')
+    dkv = torch.empty(n * L, 2 * d, device='cuda')
+    de1, de2 = torch.empty_like(e1d), torch.empty_like(e2d)
+    nbytes = hip.query('vqcpc_relattn_sub_bwd_workspace', n, L, F, H, hd)
+    ws = hip.workspace(nbytes, 'cuda')
+    hip.call('vqcpc_relattn_sub_bwd', dev(dctx), d, q_in, d, kv_in, 2 * d, probs, e1d, e2d, dq, d, dkv, 2 * d, de1, de2, n, L,
+             F, H, hd, p, seed, ws, nbytes)
+    assert rel_err(dq.cpu(), g[:, ::F, :d].reshape(n * LQ, d)) < GRAD_TOL
+    assert rel_err(dkv.cpu(), g[:, :, d:].reshape(n * L, 2 * d)) < GRAD_TOL
+    assert rel_err(de1.cpu(), e1c.grad) < GRAD_TOL
+    assert rel_err(de2.cpu(), e2c.grad) < GRAD_TOL
+    assert float(g[:, :, :d].reshape(n, L // F, F, d)[:, :, 1:].abs().max()) == 0.0   # dropped queries: zero gradient
+
+
+@pytest.mark.parametrize('L,H,d,ff', [(16, 2, 32, 64), (4, 2, 32, 48), (16, 8, 256, 512)])
+def test_encoder_layer_query_stride_equals_full_then_select(ops, L, H, d, ff):
+    """EncoderLayerFn(qstride=4) == oracle layer followed by [::4]: outputs, input gradient, parameter gradients."""
+    gen = torch.Generator().manual_seed(L + d)
+    n = 24
+    sdl = {}
+    cfg = O.make_cfg(d=d, H=H, layers=[1, 1], ff=ff)
+    full = O.init_state(cfg, seed=2)
+    pre = 'encoder.downscaler.transformers.0.layers.0.'
+    order = ['self_attn.in_proj_weight', 'self_attn.in_proj_bias', 'self_attn.out_proj.weight', 'self_attn.out_proj.bias',
+             'self_attn.attn_bias.e1', 'self_attn.attn_bias.e2', 'linear1.weight', 'linear1.bias', 'linear2.weight',
+             'linear2.bias', 'norm1.weight', 'norm1.bias', 'norm2.weight', 'norm2.bias']
+    for k in order:
+        t = full[pre + k].clone()
+        if k.endswith('attn_bias.e1') or k.endswith('attn_bias.e2'):
+            t = torch.randn(H * L, d // H, generator=gen)
+        if t.dim() == 1:
+            t = t + 0.1 * torch.randn(t.shape, generator=gen)
+        sdl[k] = t
+    x = torch.randn(n, L, d, generator=gen)
+    gy = torch.randn(n, L // 4, d, generator=gen)
+    P = {k: v.clone().requires_grad_(True) for k, v in sdl.items()}
+    xc = x.clone().requires_grad_(True)
+    y_ref, _ = O.encoder_layer(xc, P, '', H)
+    (y_ref[:, ::4] * gy).sum().backward()
+    params = [dev(sdl[k]).requires_grad_(True) for k in order]
+    xd = dev(x.reshape(n * L, d)).requires_grad_(True)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 4, *params)
+    assert y.shape == (n * L // 4, d)
+    assert rel_err(y.detach().cpu(), y_ref.detach()[:, ::4].reshape(-1, d)) < FWD_TOL
+    (y * dev(gy.reshape(-1, d))).sum().backward()
+    assert rel_err(xd.grad.cpu(), xc.grad.reshape(n * L, d)) < GRAD_TOL
+    for k, prm in zip(order, params):
+        assert rel_err(prm.grad.cpu(), P[k].grad) < GRAD_TOL, k
+
+
 @pytest.mark.parametrize('name,L', [('layer_L16', 16), ('layer_L4', 4)])
 def test_encoder_layer_golden(ops, name, L):
     """One TransformerEncoderLayerCustom forward/backward against the reference's own output."""
@@ -275,7 +371,7 @@ def test_encoder_layer_golden(ops, name, L):
     x = T(g['x']).transpose(0, 1).contiguous()                   # (n, L, d) block-major
     n, _, d = x.shape
     xd = dev(x.reshape(n * L, d)).requires_grad_(True)
-    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, *params)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 1, *params)
     y_ref = T(g['y']).transpose(0, 1).reshape(n * L, d)
     assert rel_err(y.detach().cpu(), y_ref) < FWD_TOL
     assert rel_err(probs.cpu(), g['attn']) < FWD_TOL

@@ -30,6 +30,8 @@ struct EpiParams {
     float gate_scale;
     const float* add;
     int64_t ldadd;
+    const float* add2;   // second residual (only honoured together with `add`)
+    int64_t ldadd2;
 };
 
 // epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)
@@ -70,41 +72,37 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
     const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
     const float* a_src = A + (m0 + ld_row) * lda + ld_c4;
     const float* b_src = B + (int64_t)(n0 + ld_row) * ldb + ld_c4;
-    float4 ra[4], rb[4];
-    auto load_tiles = [&](int k0) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            if (FULL) {
-                ra[i] = *reinterpret_cast<const float4*>(a_src + (int64_t)(32 * i) * lda + k0);
-                rb[i] = *reinterpret_cast<const float4*>(b_src + (int64_t)(32 * i) * ldb + k0);
-            } else {
-                const int r = ld_row + 32 * i;
-                const bool kok = k0 + ld_c4 < K;
-                ra[i] = (kok && m0 + r < M) ? *reinterpret_cast<const float4*>(a_src + (int64_t)(32 * i) * lda + k0)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[i] = (kok && n0 + r < N) ? *reinterpret_cast<const float4*>(b_src + (int64_t)(32 * i) * ldb + k0)
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto store_tiles = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = ld_row + 32 * i;
-            *reinterpret_cast<float4*>(&As[buf][r * LDS_S + ld_c4]) = ra[i];
-            *reinterpret_cast<float4*>(&Bs[buf][r * LDS_S + ld_c4]) = rb[i];
-        }
-    };
+    // named registers (arrays captured by lambdas ended up in scratch memory on this compiler)
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define NT_LOAD1(RA, RB, I, K0)                                                                                   \
+    if (FULL) {                                                                                                   \
+        RA = *reinterpret_cast<const float4*>(a_src + (int64_t)(32 * (I)) * lda + (K0));                            \
+        RB = *reinterpret_cast<const float4*>(b_src + (int64_t)(32 * (I)) * ldb + (K0));                            \
+    } else {                                                                                                      \
+        const bool kok_ = (K0) + ld_c4 < K;                                                                       \
+        RA = (kok_ && m0 + ld_row + 32 * (I) < M)                                                                 \
+                 ? *reinterpret_cast<const float4*>(a_src + (int64_t)(32 * (I)) * lda + (K0)) : zero4;             \
+        RB = (kok_ && n0 + ld_row + 32 * (I) < N)                                                                 \
+                 ? *reinterpret_cast<const float4*>(b_src + (int64_t)(32 * (I)) * ldb + (K0)) : zero4;             \
+    }
+#define NT_LOAD(K0) \
+    NT_LOAD1(ra0, rb0, 0, K0) NT_LOAD1(ra1, rb1, 1, K0) NT_LOAD1(ra2, rb2, 2, K0) NT_LOAD1(ra3, rb3, 3, K0)
+#define NT_STORE1(RA, RB, I, BUF)                                                             \
+    *reinterpret_cast<float4*>(&As[BUF][(ld_row + 32 * (I)) * LDS_S + ld_c4]) = RA;           \
+    *reinterpret_cast<float4*>(&Bs[BUF][(ld_row + 32 * (I)) * LDS_S + ld_c4]) = RB;
+#define NT_STORE(BUF) \
+    NT_STORE1(ra0, rb0, 0, BUF) NT_STORE1(ra1, rb1, 1, BUF) NT_STORE1(ra2, rb2, 2, BUF) NT_STORE1(ra3, rb3, 3, BUF)
 
-    load_tiles(0);
-    store_tiles(0);
+    NT_LOAD(0)
+    NT_STORE(0)
     __syncthreads();
     const int a_off = (wm * 64 + li) * LDS_S + kh * 4;
     const int b_off = (wn * 64 + li) * LDS_S + kh * 4;
     int cur = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
         const bool more = k0 + BK < K;
-        if (more) load_tiles(k0 + BK);           // HBM/L2 latency hides under the MFMAs below
+        if (more) { NT_LOAD(k0 + BK) }           // HBM/L2 latency hides under the MFMAs below
         const float* ap = &As[cur][a_off];
         const float* bp = &Bs[cur][b_off];
 #pragma unroll
@@ -124,12 +122,16 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
             }
         }
         if (more) {
-            store_tiles(cur ^ 1);                // nobody reads buf[cur^1] any more: barrier of the previous iteration
+            if (cur) { NT_STORE(0) } else { NT_STORE(1) }   // nobody reads the other buffer any more (previous barrier)
             __syncthreads();
             cur ^= 1;
         }
     }
 
+#undef NT_LOAD
+#undef NT_LOAD1
+#undef NT_STORE
+#undef NT_STORE1
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     constexpr bool RT = (EPI & E_RUNTIME) != 0;
     const bool has_bias = RT ? ep.bias != nullptr : (EPI & E_BIAS) != 0;
@@ -154,7 +156,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
                 if (relu) v = fmaxf(v, 0.0f);
                 if (drop) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);
                 if (has_gate) v *= (ep.gate[row * ep.ldgate + col] > 0.0f ? ep.gate_scale : 0.0f);
-                if (has_add) v += ep.add[row * ep.ldadd + col];
+                if (has_add) {
+                    v += ep.add[row * ep.ldadd + col];
+                    if (ep.add2) v += ep.add2[row * ep.ldadd2 + col];
+                }
                 C[row * ldc + col] = v;
             }
         }
@@ -191,42 +196,36 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const float* _
     float bsum[2] = {0.0f, 0.0f};
 
     const int ld_row = tid >> 5, ld_c4 = (tid & 31) * 4;
-    float4 ra[4], rb[4];
-    auto load_tiles = [&](int64_t mm) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int64_t r = mm + ld_row + 8 * i;
-            if (FULL) {
-                ra[i] = *reinterpret_cast<const float4*>(A + r * lda + n0 + ld_c4);
-                rb[i] = *reinterpret_cast<const float4*>(B + r * ldb + k0 + ld_c4);
-            } else {
-                const bool rok = r < m_end;
-                ra[i] = (rok && n0 + ld_c4 < N) ? *reinterpret_cast<const float4*>(A + r * lda + n0 + ld_c4)
-                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[i] = (rok && k0 + ld_c4 < K) ? *reinterpret_cast<const float4*>(B + r * ldb + k0 + ld_c4)
-                                                : make_float4(0.f, 0.f, 0.f, 0.f);
-            }
-        }
-    };
-    auto store_tiles = [&]() {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = ld_row + 8 * i;
-            *reinterpret_cast<float4*>(As + r * BM + ld_c4) = ra[i];
-            *reinterpret_cast<float4*>(Bs + r * BN + ld_c4) = rb[i];
-        }
-    };
+    float4 ra0, ra1, ra2, ra3, rb0, rb1, rb2, rb3;
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define TN_LOAD1(RA, RB, I, MM)                                                                              \
+    {                                                                                                        \
+        const int64_t r_ = (MM) + ld_row + 8 * (I);                                                          \
+        if (FULL) {                                                                                          \
+            RA = *reinterpret_cast<const float4*>(A + r_ * lda + n0 + ld_c4);                                \
+            RB = *reinterpret_cast<const float4*>(B + r_ * ldb + k0 + ld_c4);                                \
+        } else {                                                                                             \
+            const bool rok_ = r_ < m_end;                                                                    \
+            RA = (rok_ && n0 + ld_c4 < N) ? *reinterpret_cast<const float4*>(A + r_ * lda + n0 + ld_c4) : zero4; \
+            RB = (rok_ && k0 + ld_c4 < K) ? *reinterpret_cast<const float4*>(B + r_ * ldb + k0 + ld_c4) : zero4; \
+        }                                                                                                    \
+    }
+#define TN_LOAD(MM) TN_LOAD1(ra0, rb0, 0, MM) TN_LOAD1(ra1, rb1, 1, MM) TN_LOAD1(ra2, rb2, 2, MM) TN_LOAD1(ra3, rb3, 3, MM)
+#define TN_STORE1(RA, RB, I)                                                   \
+    *reinterpret_cast<float4*>(As + (ld_row + 8 * (I)) * BM + ld_c4) = RA;     \
+    *reinterpret_cast<float4*>(Bs + (ld_row + 8 * (I)) * BN + ld_c4) = RB;
+#define TN_STORE() TN_STORE1(ra0, rb0, 0) TN_STORE1(ra1, rb1, 1) TN_STORE1(ra2, rb2, 2) TN_STORE1(ra3, rb3, 3)
 
     if (m_begin < m_end) {
-        load_tiles(m_begin);
-        store_tiles();
+        TN_LOAD(m_begin)
+        TN_STORE()
     }
     __syncthreads();
     const float* ap = As + kh * BM + wm * 64 + li;
     const float* bp = Bs + kh * BN + wn * 64 + li;
     for (int64_t mm = m_begin; mm < m_end; mm += TM) {
         const bool more = mm + TM < m_end;
-        if (more) load_tiles(mm + TM);
+        if (more) { TN_LOAD(mm + TM) }
         // operands of 4 contraction steps (8 rows of M) are fetched per batch: one LDS latency per 16 MFMAs
 #pragma unroll
         for (int g = 0; g < TM / 8; ++g) {
@@ -251,10 +250,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const float* _
         }
         if (more) {
             __syncthreads();
-            store_tiles();
+            TN_STORE()
             __syncthreads();
         }
     }
+#undef TN_LOAD
+#undef TN_LOAD1
+#undef TN_STORE
+#undef TN_STORE1
 
     float* out = ws + (int64_t)blockIdx.y * N * K;
 #pragma unroll
@@ -295,7 +298,7 @@ extern "C" {
 
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
-                  float gate_scale, const float* add, int64_t ldadd, void* stream) {
+                  float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream) {
     VQ_REQUIRE(A && B && C, "gemm_nt: null pointer");
     VQ_REQUIRE(M >= 0 && N >= 1 && K >= 4 && K % 4 == 0, "gemm_nt: bad shape M=%lld N=%d K=%d (K %% 4 == 0 required)",
                (long long)M, N, K);
@@ -303,12 +306,13 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     VQ_REQUIRE(aligned16(A) && aligned16(B), "gemm_nt: A and B must be 16-byte aligned");
     VQ_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (relu)");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt: bad dropout probability");
-    VQ_REQUIRE((!gate || ldgate >= N) && (!add || ldadd >= N), "gemm_nt: bad gate/add strides");
+    VQ_REQUIRE((!gate || ldgate >= N) && (!add || ldadd >= N) && (!add2 || (add && ldadd2 >= N)),
+               "gemm_nt: bad gate/add strides (add2 needs add)");
     if (M == 0) return VQCPC_OK;
     const int tiles_n = (int)ceil_div(N, BN);
     const int64_t tiles = ceil_div(M, BM) * tiles_n;
     VQ_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");
-    EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd};
+    EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, add2, ldadd2};
     const bool full = (M % BM == 0) && (N % BN == 0) && (K % BK == 0);
     const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (gate ? E_GATE : 0) |
                       (add ? E_ADD : 0);

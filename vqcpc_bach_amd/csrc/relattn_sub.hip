@@ -1,0 +1,434 @@
+// Query-subsampled relative attention for the LAST layer of a downscaler stack.
+//
+// `output[::f]` (relative_transformer_downscaler.py:125) keeps only positions 0, f, 2f, ... of the last layer's output,
+// and everything after the attention of that layer is per-token (out-proj, LayerNorm, FFN).  So only the queries at
+// positions i = f*iq are needed, while keys / values still cover the whole block.  Results are identical to computing
+// the full layer and discarding rows; the dropped rows receive zero gradient in the reference as well.
+//   q   [n_blocks*LQ][ldq]   (projected from x[::f]; UNSCALED),  LQ = L / F
+//   kv  [n_blocks*L ][ldkv]  k | v at column offsets 0, d
+// One problem = (block, head); 4*LQ lanes per problem; one wavefront per workgroup (PPW = 64 / (4 LQ) problems).
+#include "common.h"
+
+namespace vq {
+
+constexpr int kSubPad = 4;
+
+template <int L, int HD, int F>
+struct SubCfg {
+    static constexpr int LQ = L / F;
+    static constexpr int LPP = 4 * LQ;           // lanes per problem
+    static constexpr int PPW = 64 / LPP;         // problems per wave (= per workgroup)
+    static constexpr int JPL = L / 4;            // scores per lane
+    static constexpr int CPL = HD / 4;           // output columns per lane
+    static constexpr int RS = HD + kSubPad;
+    static constexpr int NE = 2 * L - 1;
+    static constexpr int NER = (NE + LQ - 1) / LQ;   // Erel rows per lane in the dE accumulation
+    static constexpr int FWD_FLOATS = (LQ + 2 * L + NE) * RS + LQ * (L + 1);
+    static constexpr int BWD_FLOATS = (2 * LQ + 2 * L + NE) * RS + 2 * LQ * (L + 1);
+};
+
+template <int ROWS, int HD, int LPP>
+__device__ __forceinline__ void sub_stage(float* dst, const float* __restrict__ src, int64_t ld, int sl, float mul) {
+    constexpr int RS = HD + kSubPad, V = HD / 4;
+    for (int e = sl; e < ROWS * V; e += LPP) {
+        const int row = e / V, c4 = e % V;
+        float4 v = *reinterpret_cast<const float4*>(src + row * ld + c4 * 4);
+        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+        *reinterpret_cast<float4*>(dst + row * RS + c4 * 4) = v;
+    }
+}
+
+template <int L, int HD, int LPP>
+__device__ __forceinline__ void sub_stage_erel(float* dst, const float* __restrict__ e1, const float* __restrict__ e2,
+                                               int h, int sl) {
+    constexpr int RS = HD + kSubPad, V = HD / 4, NE = 2 * L - 1;
+    for (int e = sl; e < NE * V; e += LPP) {
+        const int r = e / V, c4 = e % V;
+        const float* src = r < L ? e1 + ((int64_t)h * L + r) * HD : e2 + ((int64_t)h * L + (r - L + 1)) * HD;
+        *reinterpret_cast<float4*>(dst + r * RS + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+    }
+}
+
+// =====================================================================================================================
+template <int L, int HD, int F>
+__global__ __launch_bounds__(64) void relattn_sub_fwd_kernel(const float* __restrict__ q, int64_t ldq,
+                                                             const float* __restrict__ kv, int64_t ldkv,
+                                                             const float* __restrict__ e1, const float* __restrict__ e2,
+                                                             float* __restrict__ ctx, int64_t ldo,
+                                                             float* __restrict__ probs, int64_t n_blocks, int H,
+                                                             float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    using C = SubCfg<L, HD, F>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int sl = lane % C::LPP, slot = lane / C::LPP;
+    float* Qs = lds + slot * C::FWD_FLOATS;
+    float* Ks = Qs + C::LQ * C::RS;
+    float* Vs = Ks + L * C::RS;
+    float* Er = Vs + L * C::RS;
+    float* Ps = Er + C::NE * C::RS;                 // [LQ][L+1]
+    const int d = H * HD;
+    const int64_t total = n_blocks * H;
+    const int64_t prob = (int64_t)blockIdx.x * C::PPW + slot;
+    const bool live = prob < total;
+    const int64_t n = live ? prob / H : 0;
+    const int h = live ? (int)(prob % H) : 0;
+    const int iq = sl >> 2, jg = sl & 3;
+    const int i = iq * F;                           // absolute position of this query inside the block
+
+    if (live) {
+        sub_stage<C::LQ, HD, C::LPP>(Qs, q + n * C::LQ * ldq + h * HD, ldq, sl, scale);
+        sub_stage<L, HD, C::LPP>(Ks, kv + n * L * ldkv + h * HD, ldkv, sl, 1.0f);
+        sub_stage<L, HD, C::LPP>(Vs, kv + n * L * ldkv + d + h * HD, ldkv, sl, 1.0f);
+        sub_stage_erel<L, HD, C::LPP>(Er, e1, e2, h, sl);
+    }
+    __syncthreads();
+    if (live) {
+        float s[C::JPL];
+#pragma unroll
+        for (int jj = 0; jj < C::JPL; ++jj) s[jj] = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < HD / 4; ++c4) {
+            const float4 qv = *reinterpret_cast<const float4*>(Qs + iq * C::RS + c4 * 4);
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) {
+                const int j = jj * 4 + jg;
+                const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
+                const float4 e = *reinterpret_cast<const float4*>(Er + (j - i + L - 1) * C::RS + c4 * 4);
+                s[jj] += qv.x * (k.x + e.x) + qv.y * (k.y + e.y) + qv.z * (k.z + e.z) + qv.w * (k.w + e.w);
+            }
+        }
+        float m = s[0];
+#pragma unroll
+        for (int jj = 1; jj < C::JPL; ++jj) m = fmaxf(m, s[jj]);
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        float sum = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < C::JPL; ++jj) {
+            s[jj] = __expf(s[jj] - m);
+            sum += s[jj];
+        }
+        sum += __shfl_xor(sum, 1, 64);
+        sum += __shfl_xor(sum, 2, 64);
+        const float inv = 1.0f / sum;
+        const int64_t pbase = (prob * C::LQ + iq) * L;
+#pragma unroll
+        for (int jj = 0; jj < C::JPL; ++jj) {
+            const int j = jj * 4 + jg;
+            const float p = s[jj] * inv;
+            probs[pbase + j] = p;
+            Ps[iq * (L + 1) + j] = p * drop_scale(seed, (uint64_t)(pbase + j), thr, inv_keep);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        float o[C::CPL];
+#pragma unroll
+        for (int c = 0; c < C::CPL; ++c) o[c] = 0.0f;
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+            const float p = Ps[iq * (L + 1) + j];
+#pragma unroll
+            for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                const float4 v = *reinterpret_cast<const float4*>(Vs + j * C::RS + jg * C::CPL + c4 * 4);
+                o[c4 * 4 + 0] += p * v.x; o[c4 * 4 + 1] += p * v.y; o[c4 * 4 + 2] += p * v.z; o[c4 * 4 + 3] += p * v.w;
+            }
+        }
+        float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + jg * C::CPL;
+#pragma unroll
+        for (int c4 = 0; c4 < C::CPL / 4; ++c4)
+            *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+    }
+}
+
+// =====================================================================================================================
+// backward: grid = (chunks, head groups); a slot keeps its head for the whole loop (dErel accumulates in registers).
+// ws layout: [chunk][nsub][H][2L-1][HD]
+template <int L, int HD, int F>
+__global__ __launch_bounds__(64) void relattn_sub_bwd_kernel(
+    const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ q, int64_t ldq, const float* __restrict__ kv,
+    int64_t ldkv, const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
+    float* __restrict__ d_q, int64_t ldgq, float* __restrict__ d_kv, int64_t ldgkv, float* __restrict__ ws,
+    int64_t n_blocks, int H, int blocks_per_wg, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    using C = SubCfg<L, HD, F>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x;
+    const int sl = lane % C::LPP, slot = lane / C::LPP;
+    float* Qs = lds + slot * C::BWD_FLOATS;
+    float* Os = Qs + C::LQ * C::RS;                 // d_ctx rows [LQ]
+    float* Ks = Os + C::LQ * C::RS;
+    float* Vs = Ks + L * C::RS;
+    float* Er = Vs + L * C::RS;
+    float* Ss = Er + C::NE * C::RS;                 // dS [LQ][L+1]
+    float* Ps = Ss + C::LQ * (L + 1);               // P after dropout [LQ][L+1]
+    const int d = H * HD;
+    int h, nsub, NS;
+    if (C::PPW >= H) {
+        NS = C::PPW / H;
+        h = slot % H;
+        nsub = slot / H;
+    } else {
+        NS = 1;
+        h = blockIdx.y * C::PPW + slot;
+        nsub = 0;
+    }
+    const int iq = sl >> 2, jg = sl & 3;
+    const int i = iq * F;
+    sub_stage_erel<L, HD, C::LPP>(Er, e1, e2, h, sl);
+    float de[C::NER][C::CPL];
+#pragma unroll
+    for (int a = 0; a < C::NER; ++a)
+#pragma unroll
+        for (int c = 0; c < C::CPL; ++c) de[a][c] = 0.0f;
+
+    const int64_t n_begin = (int64_t)blockIdx.x * blocks_per_wg;
+    for (int it = 0; it < blocks_per_wg; it += NS) {
+        const int64_t n = n_begin + it + nsub;
+        const bool live = n < n_blocks;
+        const int64_t prob = n * H + h;
+        __syncthreads();
+        if (live) {
+            sub_stage<C::LQ, HD, C::LPP>(Qs, q + n * C::LQ * ldq + h * HD, ldq, sl, scale);
+            sub_stage<C::LQ, HD, C::LPP>(Os, d_ctx + n * C::LQ * ldo + h * HD, ldo, sl, 1.0f);
+            sub_stage<L, HD, C::LPP>(Ks, kv + n * L * ldkv + h * HD, ldkv, sl, 1.0f);
+            sub_stage<L, HD, C::LPP>(Vs, kv + n * L * ldkv + d + h * HD, ldkv, sl, 1.0f);
+        }
+        __syncthreads();
+        if (live) {
+            float dp[C::JPL], p[C::JPL];
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) dp[jj] = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < HD / 4; ++c4) {
+                const float4 o = *reinterpret_cast<const float4*>(Os + iq * C::RS + c4 * 4);
+#pragma unroll
+                for (int jj = 0; jj < C::JPL; ++jj) {
+                    const float4 v = *reinterpret_cast<const float4*>(Vs + (jj * 4 + jg) * C::RS + c4 * 4);
+                    dp[jj] += o.x * v.x + o.y * v.y + o.z * v.z + o.w * v.w;
+                }
+            }
+            const int64_t pbase = (prob * C::LQ + iq) * L;
+            float rowdot = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) {
+                const int j = jj * 4 + jg;
+                p[jj] = probs[pbase + j];
+                const float mk = drop_scale(seed, (uint64_t)(pbase + j), thr, inv_keep);
+                dp[jj] *= mk;
+                Ps[iq * (L + 1) + j] = p[jj] * mk;
+                rowdot += dp[jj] * p[jj];
+            }
+            rowdot += __shfl_xor(rowdot, 1, 64);
+            rowdot += __shfl_xor(rowdot, 2, 64);
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) Ss[iq * (L + 1) + jj * 4 + jg] = p[jj] * (dp[jj] - rowdot);
+        }
+        __syncthreads();
+        if (live) {
+            // dK / dV for key rows j = iq + LQ*u
+#pragma unroll
+            for (int u = 0; u < F; ++u) {
+                const int j = iq + C::LQ * u;
+                float dk[C::CPL], dv[C::CPL];
+#pragma unroll
+                for (int c = 0; c < C::CPL; ++c) dk[c] = dv[c] = 0.0f;
+#pragma unroll
+                for (int ii = 0; ii < C::LQ; ++ii) {
+                    const float pd = Ps[ii * (L + 1) + j], ds = Ss[ii * (L + 1) + j];
+#pragma unroll
+                    for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                        const float4 o = *reinterpret_cast<const float4*>(Os + ii * C::RS + jg * C::CPL + c4 * 4);
+                        const float4 qq = *reinterpret_cast<const float4*>(Qs + ii * C::RS + jg * C::CPL + c4 * 4);
+                        dv[c4 * 4 + 0] += pd * o.x; dv[c4 * 4 + 1] += pd * o.y; dv[c4 * 4 + 2] += pd * o.z; dv[c4 * 4 + 3] += pd * o.w;
+                        dk[c4 * 4 + 0] += ds * qq.x; dk[c4 * 4 + 1] += ds * qq.y; dk[c4 * 4 + 2] += ds * qq.z; dk[c4 * 4 + 3] += ds * qq.w;
+                    }
+                }
+                float* gp = d_kv + (n * L + j) * ldgkv + h * HD + jg * C::CPL;
+#pragma unroll
+                for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                    *reinterpret_cast<float4*>(gp + c4 * 4) = make_float4(dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3]);
+                    *reinterpret_cast<float4*>(gp + d + c4 * 4) = make_float4(dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3]);
+                }
+            }
+            // dq_iq = scale * sum_j dS[iq][j] (k_j + Erel[j - i + L - 1])
+            float dq[C::CPL];
+#pragma unroll
+            for (int c = 0; c < C::CPL; ++c) dq[c] = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < L; ++jj) {
+                const float ds = Ss[iq * (L + 1) + jj];
+#pragma unroll
+                for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                    const float4 k = *reinterpret_cast<const float4*>(Ks + jj * C::RS + jg * C::CPL + c4 * 4);
+                    const float4 e = *reinterpret_cast<const float4*>(Er + (jj - i + L - 1) * C::RS + jg * C::CPL + c4 * 4);
+                    dq[c4 * 4 + 0] += ds * (k.x + e.x); dq[c4 * 4 + 1] += ds * (k.y + e.y);
+                    dq[c4 * 4 + 2] += ds * (k.z + e.z); dq[c4 * 4 + 3] += ds * (k.w + e.w);
+                }
+            }
+            float* gq = d_q + (n * C::LQ + iq) * ldgq + h * HD + jg * C::CPL;
+#pragma unroll
+            for (int c4 = 0; c4 < C::CPL / 4; ++c4)
+                *reinterpret_cast<float4*>(gq + c4 * 4) =
+                    make_float4(dq[c4 * 4] * scale, dq[c4 * 4 + 1] * scale, dq[c4 * 4 + 2] * scale, dq[c4 * 4 + 3] * scale);
+            // dErel[r] += sum_{i'} dS[i'][jx] * qs[i'],  jx = F*i' + r - (L-1);  this lane owns rows r = iq + LQ*a
+#pragma unroll
+            for (int a = 0; a < C::NER; ++a) {
+                const int r = iq + C::LQ * a;
+                if (r < C::NE) {
+#pragma unroll
+                    for (int ii = 0; ii < C::LQ; ++ii) {
+                        const int jx = F * ii + r - (L - 1);
+                        if (jx >= 0 && jx < L) {
+                            const float ds = Ss[ii * (L + 1) + jx];
+#pragma unroll
+                            for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                                const float4 qq = *reinterpret_cast<const float4*>(Qs + ii * C::RS + jg * C::CPL + c4 * 4);
+                                de[a][c4 * 4 + 0] += ds * qq.x; de[a][c4 * 4 + 1] += ds * qq.y;
+                                de[a][c4 * 4 + 2] += ds * qq.z; de[a][c4 * 4 + 3] += ds * qq.w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float* dst = ws + ((((int64_t)blockIdx.x * NS + nsub) * H + h) * C::NE) * HD;
+#pragma unroll
+    for (int a = 0; a < C::NER; ++a) {
+        const int r = iq + C::LQ * a;
+        if (r < C::NE) {
+#pragma unroll
+            for (int c = 0; c < C::CPL; ++c) dst[r * HD + jg * C::CPL + c] = de[a][c];
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void relattn_sub_de_split(const float* __restrict__ tot, int H, int L, int HD,
+                                                            float* __restrict__ d_e1, float* __restrict__ d_e2) {
+    const int NE = 2 * L - 1;
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= H * NE * HD) return;
+    const int c = o % HD, r = (o / HD) % NE, h = o / (HD * NE);
+    const float acc = tot[o];
+    if (r < L) d_e1[((int64_t)h * L + r) * HD + c] = acc;
+    else d_e2[((int64_t)h * L + (r - L + 1)) * HD + c] = acc;
+    if (r == 0) d_e2[((int64_t)h * L) * HD + c] = 0.0f;
+}
+
+static int sub_blocks_per_wg(int64_t n_blocks, int ppw, int H) {
+    const int ns = std::max(1, ppw / H);
+    int64_t b = ceil_div(n_blocks, 4096);
+    return (int)round_up(std::max<int64_t>(b, ns), ns);
+}
+
+static bool sub_supported(int L, int F, int H, int hd) {
+    if (!((L == 16 || L == 4) && F == 4)) return false;
+    if (!(hd == 16 || hd == 32 || hd == 64)) return false;
+    const int ppw = 64 / (4 * (L / F));
+    return H >= 1 && ((ppw % H) == 0 || (H % ppw) == 0);
+}
+
+template <int L, int HD, int F>
+static int sub_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                          float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed,
+                          hipStream_t s) {
+    using C = SubCfg<L, HD, F>;
+    const size_t lds = (size_t)C::PPW * C::FWD_FLOATS * sizeof(float);
+    auto kern = relattn_sub_fwd_kernel<L, HD, F>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t grid = ceil_div(n_blocks * H, C::PPW);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H,
+                       1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("relattn_sub_fwd");
+    return VQCPC_OK;
+}
+
+template <int L, int HD, int F>
+static int sub_launch_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                          const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
+                          int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int H, float drop_p, uint64_t seed,
+                          float* ws, hipStream_t s) {
+    using C = SubCfg<L, HD, F>;
+    const size_t lds = (size_t)C::PPW * C::BWD_FLOATS * sizeof(float);
+    auto kern = relattn_sub_bwd_kernel<L, HD, F>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int bpw = sub_blocks_per_wg(n_blocks, C::PPW, H);
+    const int chunks = (int)ceil_div(n_blocks, bpw);
+    const int gy = C::PPW >= H ? 1 : H / C::PPW;
+    const int NS = C::PPW >= H ? C::PPW / H : 1;
+    hipLaunchKernelGGL(kern, dim3(chunks, gy), dim3(64), lds, s, d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq,
+                       d_kv, ldgkv, ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
+                       1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("relattn_sub_bwd");
+    const int total = H * C::NE * HD;
+    float* tot = ws + (int64_t)chunks * NS * total;
+    int rc = launch_reduce_splits(ws, total, chunks * NS, tot, total, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(relattn_sub_de_split, dim3(ceil_div(total, 256)), dim3(256), 0, s, tot, H, L, HD, d_e1, d_e2);
+    VQ_CHECK_LAUNCH("relattn_sub_de_split");
+    return VQCPC_OK;
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+#define VQ_SUB_DISPATCH(CALL)                        \
+    if (L == 16 && hd == 16) return CALL(16, 16, 4); \
+    if (L == 16 && hd == 32) return CALL(16, 32, 4); \
+    if (L == 16 && hd == 64) return CALL(16, 64, 4); \
+    if (L == 4 && hd == 16) return CALL(4, 16, 4);   \
+    if (L == 4 && hd == 32) return CALL(4, 32, 4);   \
+    if (L == 4 && hd == 64) return CALL(4, 64, 4);
+
+extern "C" {
+
+int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                          float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd,
+                          float drop_p, uint64_t seed, void* stream) {
+    VQ_REQUIRE(q && kv && e1 && e2 && ctx && probs, "relattn_sub_fwd: null pointer");
+    VQ_REQUIRE(sub_supported(L, F, H, hd), "relattn_sub_fwd: unsupported L=%d F=%d H=%d hd=%d", L, F, H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= H * hd && ldkv >= 2 * H * hd && ldo >= H * hd &&
+                   n_blocks >= 0,
+               "relattn_sub_fwd: bad strides");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_sub_fwd: bad dropout probability");
+    if (n_blocks == 0) return VQCPC_OK;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LL, DD, FF) sub_launch_fwd<LL, DD, FF>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s)
+    VQ_SUB_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+int64_t vqcpc_relattn_sub_bwd_workspace(int64_t n_blocks, int L, int F, int H, int hd) {
+    const int ppw = 64 / (4 * std::max(1, L / std::max(F, 1)));
+    const int bpw = sub_blocks_per_wg(std::max<int64_t>(n_blocks, 1), ppw, std::max(H, 1));
+    const int64_t chunks = ceil_div(std::max<int64_t>(n_blocks, 1), bpw);
+    const int NS = ppw >= H ? ppw / H : 1;
+    return (chunks * NS + 1) * H * (2 * L - 1) * hd * (int64_t)sizeof(float);
+}
+
+int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                          const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
+                          int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd,
+                          float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(d_ctx && q && kv && probs && e1 && e2 && d_q && d_kv && d_e1 && d_e2 && workspace,
+               "relattn_sub_bwd: null pointer");
+    VQ_REQUIRE(sub_supported(L, F, H, hd), "relattn_sub_bwd: unsupported L=%d F=%d H=%d hd=%d", L, F, H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldgq % 4 == 0 && ldgkv % 4 == 0 && ldq >= H * hd &&
+                   ldgq >= H * hd && ldkv >= 2 * H * hd && ldgkv >= 2 * H * hd && ldo >= H * hd && n_blocks >= 1,
+               "relattn_sub_bwd: bad strides");
+    if (workspace_bytes < vqcpc_relattn_sub_bwd_workspace(n_blocks, L, F, H, hd)) {
+        set_error("relattn_sub_bwd: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LL, DD, FF)                                                                                                \
+    sub_launch_bwd<LL, DD, FF>(d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv, ldgkv, d_e1, d_e2, n_blocks, H, \
+                               drop_p, seed, (float*)workspace, s)
+    VQ_SUB_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+}  // extern "C"

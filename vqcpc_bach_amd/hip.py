@@ -25,7 +25,7 @@ SIGNATURES = {
     'vqcpc_embed_pos_bwd': (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                     c_i64, c_ptr]),
     'vqcpc_gemm_nt': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64,
-                              c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr]),
+                              c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_transpose': (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
@@ -34,6 +34,12 @@ SIGNATURES = {
     'vqcpc_relattn_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int]),
     'vqcpc_relattn_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
                                   c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_relattn_sub_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int,
+                                      c_int, c_int, c_f32, c_u64, c_ptr]),
+    'vqcpc_relattn_sub_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int, c_int]),
+    'vqcpc_relattn_sub_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
+                                      c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64,
+                                      c_ptr]),
     'vqcpc_add_layernorm_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32,
                                         c_f32, c_u64, c_ptr]),
     'vqcpc_add_layernorm_bwd_workspace': (c_i64, [c_i64, c_int]),

@@ -30,7 +30,7 @@ def dropout_mask(n, p, seed, device):
 # ------------------------------------------------------------------------------------------------------------------
 # raw kernel wrappers (no autograd)
 # ------------------------------------------------------------------------------------------------------------------
-def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, add=None, out=None):
+def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, add=None, add2=None, out=None):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T); see include/vqcpc.h."""
     a, lda = _rows(_f32(a))
     b, ldb = _rows(_f32(b))
@@ -40,13 +40,15 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     out, ldc = _rows(out)
-    ldg = lda_ = 0
+    ldg = lda_ = lda2_ = 0
     if gate is not None:
         gate, ldg = _rows(gate)
     if add is not None:
         add, lda_ = _rows(add)
+    if add2 is not None:
+        add2, lda2_ = _rows(add2)
     hip.call('vqcpc_gemm_nt', a, lda, b, ldb, out, ldc, M, N, K, bias, int(act), float(drop_p), int(seed), gate, ldg,
-             float(gate_scale), add, lda_)
+             float(gate_scale), add, lda_, add2, lda2_)
     return out
 
 
@@ -137,77 +139,118 @@ def linear(x, weight, bias=None):
 class EncoderLayerFn(torch.autograd.Function):
     """y = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)),  x1 = LN1(x + drop(Wo attn(x) + bo)).
     Parameter order: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, e1, e2, linear1.weight,
-    linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias."""
+    linear1.bias, linear2.weight, linear2.bias, norm1.weight, norm1.bias, norm2.weight, norm2.bias.
+
+    qstride = f > 1 (last layer of a stack): only rows 0, f, 2f, ... of the output are produced -- the reference computes
+    all rows and keeps `output[::f]` (relative_transformer_downscaler.py:125); everything after the attention is
+    per-token, so queries / out-proj / LayerNorms / FFN run on M/f rows while keys and values still cover every token.
+    Identical results, ~60 % fewer FLOPs in that layer."""
 
     @staticmethod
-    def forward(ctx, x, L, H, drop_p, seed, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1, g2, be2):
+    def forward(ctx, x, L, H, drop_p, seed, qstride, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1, g2, be2):
         x, ldx = _rows(_f32(x))
         M, d = x.shape
         hd = d // H
         nblk = M // L
         dev = x.device
         p = float(drop_p)
+        f = int(qstride)
         s = [int(seed) + 0x1000 * i for i in range(4)]     # attention probs, dropout1, ffn dropout, dropout2
-        qkv = gemm_nt(x, wqkv, bias=bqkv)
-        att = torch.empty(M, d, dtype=torch.float32, device=dev)
-        probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
-        hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+        if f == 1:
+            Mq, xs, ldxs = M, x, ldx
+            qkv = gemm_nt(x, wqkv, bias=bqkv)
+            att = torch.empty(M, d, dtype=torch.float32, device=dev)
+            probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
+            hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+            qproj = qkv
+        else:
+            assert L % f == 0
+            Mq = M // f
+            xs, ldxs = _rows(x[::f])                                       # query / residual rows: a stride, not a copy
+            qkv = gemm_nt(x, wqkv[d:], bias=bqkv[d:])                      # k | v for every token   (M, 2d)
+            qproj = gemm_nt(xs, wqkv[:d], bias=bqkv[:d])                   # q for the kept rows     (Mq, d)
+            att = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+            probs = torch.empty(nblk, H, L // f, L, dtype=torch.float32, device=dev)
+            hip.call('vqcpc_relattn_sub_fwd', qproj, d, qkv, 2 * d, e1, e2, att, d, probs, nblk, L, f, H, hd, p, s[0])
         a = gemm_nt(att, wo, bias=bo)
-        x1 = torch.empty(M, d, dtype=torch.float32, device=dev)
-        mean1 = torch.empty(M, dtype=torch.float32, device=dev)
-        rstd1 = torch.empty(M, dtype=torch.float32, device=dev)
-        hip.call('vqcpc_add_layernorm_fwd', x, ldx, a, g1, be1, x1, mean1, rstd1, M, d, 1e-5, p, s[1])
+        x1 = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+        mean1 = torch.empty(Mq, dtype=torch.float32, device=dev)
+        rstd1 = torch.empty(Mq, dtype=torch.float32, device=dev)
+        hip.call('vqcpc_add_layernorm_fwd', xs, ldxs, a, g1, be1, x1, mean1, rstd1, Mq, d, 1e-5, p, s[1])
         h2 = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2])
-        f = gemm_nt(h2, w2, bias=b2)
-        y = torch.empty(M, d, dtype=torch.float32, device=dev)
-        mean2 = torch.empty(M, dtype=torch.float32, device=dev)
-        rstd2 = torch.empty(M, dtype=torch.float32, device=dev)
-        hip.call('vqcpc_add_layernorm_fwd', x1, d, f, g2, be2, y, mean2, rstd2, M, d, 1e-5, p, s[3])
-        ctx.save_for_backward(x, qkv, probs, att, a, x1, mean1, rstd1, h2, f, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1, g2)
-        ctx.meta = (L, H, p, s)
+        ff = gemm_nt(h2, w2, bias=b2)
+        y = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+        mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
+        rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
+        hip.call('vqcpc_add_layernorm_fwd', x1, d, ff, g2, be2, y, mean2, rstd2, Mq, d, 1e-5, p, s[3])
+        ctx.save_for_backward(x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1,
+                              w2, g1, g2)
+        ctx.meta = (L, H, p, s, f)
         ctx.mark_non_differentiable(probs)
         return y, probs
 
     @staticmethod
     def backward(ctx, dy, _dprobs):
-        (x, qkv, probs, att, a, x1, mean1, rstd1, h2, f, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1, g2) = ctx.saved_tensors
-        L, H, p, s = ctx.meta
+        (x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
+         g2) = ctx.saved_tensors
+        L, H, p, s, f = ctx.meta
         x, ldx = _rows(x)
         M, d = x.shape
         hd, nblk, dev = d // H, M // L, x.device
+        Mq = M // f
+        xs, ldxs = (x, ldx) if f == 1 else _rows(x[::f])
         dy = dy.contiguous()
 
         def ln_bwd(dyv, xin, ldxin, r, gamma, mean, rstd, seed):
-            ds = torch.empty(M, d, dtype=torch.float32, device=dev)
-            dr = torch.empty(M, d, dtype=torch.float32, device=dev) if p > 0 else None
+            ds = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+            dr = torch.empty(Mq, d, dtype=torch.float32, device=dev) if p > 0 else None
             dg = torch.empty(d, dtype=torch.float32, device=dev)
             db = torch.empty(d, dtype=torch.float32, device=dev)
-            nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', M, d)
+            nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', Mq, d)
             ws = hip.workspace(nbytes, dev)
-            hip.call('vqcpc_add_layernorm_bwd', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, dg, db, M, d, p, seed, ws,
+            hip.call('vqcpc_add_layernorm_bwd', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, dg, db, Mq, d, p, seed, ws,
                      nbytes)
             return ds, (dr if dr is not None else ds), dg, db
 
-        ds2, df, dg2, dbe2 = ln_bwd(dy, x1, d, f, g2, mean2, rstd2, s[3])
+        ds2, df, dg2, dbe2 = ln_bwd(dy, x1, d, ff, g2, mean2, rstd2, s[3])
         # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
         da = gemm_nt(df, transpose(w2), gate=h2, gate_scale=1.0 / (1.0 - p))
         dw2, db2 = gemm_tn(df, h2)
         dw1, db1 = gemm_tn(da, x1)
         dx1 = gemm_nt(da, transpose(w1), add=ds2)
         del da, df, ds2
-        ds1, dA, dg1, dbe1 = ln_bwd(dx1, x, ldx, a, g1, mean1, rstd1, s[1])
+        ds1, dA, dg1, dbe1 = ln_bwd(dx1, xs, ldxs, a, g1, mean1, rstd1, s[1])
         dwo, dbo = gemm_tn(dA, att)
         datt = gemm_nt(dA, transpose(wo))
-        dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
         de1 = torch.empty_like(e1)
         de2 = torch.empty_like(e2)
-        nbytes = hip.query('vqcpc_relattn_bwd_workspace', nblk, L, H, hd)
-        ws = hip.workspace(nbytes, dev)
-        hip.call('vqcpc_relattn_bwd', datt, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd, p, s[0], ws,
-                 nbytes)
-        dwqkv, dbqkv = gemm_tn(dqkv, x)
-        dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if ctx.needs_input_grad[0] else None
-        return (dx, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1, dg2, dbe2)
+        need_dx = ctx.needs_input_grad[0]
+        if f == 1:
+            dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
+            nbytes = hip.query('vqcpc_relattn_bwd_workspace', nblk, L, H, hd)
+            ws = hip.workspace(nbytes, dev)
+            hip.call('vqcpc_relattn_bwd', datt, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd, p, s[0],
+                     ws, nbytes)
+            dwqkv, dbqkv = gemm_tn(dqkv, x)
+            dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if need_dx else None
+        else:
+            dq = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+            dkv = torch.empty(M, 2 * d, dtype=torch.float32, device=dev)
+            nbytes = hip.query('vqcpc_relattn_sub_bwd_workspace', nblk, L, f, H, hd)
+            ws = hip.workspace(nbytes, dev)
+            hip.call('vqcpc_relattn_sub_bwd', datt, d, qproj, d, qkv, 2 * d, probs, e1, e2, dq, d, dkv, 2 * d, de1, de2, nblk,
+                     L, f, H, hd, p, s[0], ws, nbytes)
+            dwq, dbq = gemm_tn(dq, xs)
+            dwkv, dbkv = gemm_tn(dkv, x)
+            dwqkv, dbqkv = torch.cat([dwq, dwkv], dim=0), torch.cat([dbq, dbkv], dim=0)
+            dx = None
+            if need_dx:
+                wt = transpose(wqkv)                                       # (d, 3d): columns q | k | v
+                dx = gemm_nt(dkv, wt[:, d:])                               # every row: keys / values path
+                dxs = dx[::f]                                              # kept rows also get the query + residual paths
+                gemm_nt(dq, wt[:, :d], add=ds1, add2=dxs, out=dxs)
+        return (dx, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1, dg2,
+                dbe2)
 
 
 # ------------------------------------------------------------------------------------------------------------------

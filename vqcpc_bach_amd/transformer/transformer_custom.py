@@ -38,10 +38,12 @@ class TransformerEncoderLayerCustom(nn.Module):
                 self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm1.weight,
                 self.norm1.bias, self.norm2.weight, self.norm2.bias)
 
-    def forward_rows(self, x):
-        """x: (blocks * L, d) block-major rows (may be row-strided) -> (y, probs (blocks, H, L, L))."""
+    def forward_rows(self, x, qstride=1):
+        """x: (blocks * L, d) block-major rows (may be row-strided) -> (y (blocks * L / qstride, d), probs).
+        qstride = f > 1 evaluates only the output rows 0, f, 2f, ... (what `output[::f]` would keep)."""
         p = self.p if self.training else 0.0
-        return ops.EncoderLayerFn.apply(x, self.seq_len, self.nhead, p, SEEDS.next() if p > 0 else 0, *self._params())
+        return ops.EncoderLayerFn.apply(x, self.seq_len, self.nhead, p, SEEDS.next() if p > 0 else 0, qstride,
+                                        *self._params())
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
         """API-compatible entry: src (L, N, E) time-first -> (out (L, N, E), {'a_self_encoder': (N, H, L, L)})."""
@@ -59,10 +61,13 @@ class TransformerEncoderCustom(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
-    def forward_rows(self, x):
+    def forward_rows(self, x, out_stride=1):
+        """Runs the stack on block-major rows; `out_stride` = f returns only rows 0, f, 2f, ... of the stack output
+        (the downscaler's `output[::f]`), which lets the last layer skip the dropped rows."""
         attentions = []
-        for layer in self.layers:
-            x, probs = layer.forward_rows(x)
+        for li, layer in enumerate(self.layers):
+            last = li == len(self.layers) - 1
+            x, probs = layer.forward_rows(x, qstride=out_stride if last else 1)
             attentions.append(dict(a_self_encoder=probs))
         return x, attentions
 

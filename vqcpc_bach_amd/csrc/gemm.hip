@@ -35,7 +35,7 @@ struct EpiParams {
 };
 
 // epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)
-enum { E_BIAS = 1, E_RELU = 2, E_DROP = 4, E_GATE = 8, E_ADD = 16, E_RUNTIME = 32 };
+enum { E_BIAS = 1, E_RELU = 2, E_DROP = 4, E_GATE = 8, E_ADD = 16, E_RUNTIME = 32, E_ADD2 = 64 };
 
 // bijective XCD-aware remap: consecutive tiles (which share an A row panel) land on the same XCD / L2
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -99,10 +99,48 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
     __syncthreads();
     const int a_off = (wm * 64 + li) * LDS_S + kh * 4;
     const int b_off = (wn * 64 + li) * LDS_S + kh * 4;
+    // epilogue operands (gate or residual) are prefetched into registers under the LAST K tile's MFMAs: one global
+    // round trip per tile instead of one per element (a load->use->store chain per element serialises on latency)
+    constexpr bool RT = (EPI & E_RUNTIME) != 0;
+    constexpr bool PREF = !RT && ((EPI & (E_GATE | E_ADD)) != 0) && ((EPI & (E_GATE | E_ADD)) != (E_GATE | E_ADD));
+    const int64_t row_base = m0 + wm * 64 + 4 * kh;
+    const int col_base = n0 + wn * 64 + li;
+    float aux[2][2][16];
     int cur = 0;
     for (int k0 = 0; k0 < K; k0 += BK) {
         const bool more = k0 + BK < K;
         if (more) { NT_LOAD(k0 + BK) }           // HBM/L2 latency hides under the MFMAs below
+        if (PREF && !more) {
+            const float* src = (EPI & E_GATE) ? ep.gate : ep.add;
+            const int64_t lds_ = (EPI & E_GATE) ? ep.ldgate : ep.ldadd;
+            if (FULL) {
+                // one VGPR of per-lane offset + a scalar offset per element (buffer addressing): no 64-bit address
+                // arithmetic per load, so all 64 loads are in flight together
+                const __amdgpu_buffer_rsrc_t rs =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(src + m0 * lds_ + n0), 0, 0x7FFFFFFF, 0x00020000);
+                const int ldi = (int)lds_;
+                const int voff = ((wm * 64 + 4 * kh) * ldi + wn * 64 + li) * 4;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            aux[mt][nt][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                rs, voff, ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldi + nt * 32) * 4, 0));
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+                            const int col = col_base + nt * 32;
+                            aux[mt][nt][r] = (row < M && col < N) ? src[row * lds_ + col] : 0.0f;
+                        }
+            }
+        }
         const float* ap = &As[cur][a_off];
         const float* bp = &Bs[cur][b_off];
 #pragma unroll
@@ -133,14 +171,14 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
 #undef NT_STORE
 #undef NT_STORE1
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    constexpr bool RT = (EPI & E_RUNTIME) != 0;
     const bool has_bias = RT ? ep.bias != nullptr : (EPI & E_BIAS) != 0;
     const bool relu = RT ? ep.act == 1 : (EPI & E_RELU) != 0;
     const bool drop = RT ? ep.thr != 0 : (EPI & E_DROP) != 0;
     const bool has_gate = RT ? ep.gate != nullptr : (EPI & E_GATE) != 0;
     const bool has_add = RT ? ep.add != nullptr : (EPI & E_ADD) != 0;
-    const int64_t row_base = m0 + wm * 64 + 4 * kh;
-    const int col_base = n0 + wn * 64 + li;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ldc + n0), 0, 0x7FFFFFFF, 0x00020000);
+    const int ldci = (int)ldc;
+    const int voff_c = ((wm * 64 + 4 * kh) * ldci + wn * 64 + li) * 4;
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) {
         const int col = col_base + nt * 32;
@@ -155,12 +193,19 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
                 float v = acc[mt][nt][r] + bv;
                 if (relu) v = fmaxf(v, 0.0f);
                 if (drop) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);
-                if (has_gate) v *= (ep.gate[row * ep.ldgate + col] > 0.0f ? ep.gate_scale : 0.0f);
-                if (has_add) {
-                    v += ep.add[row * ep.ldadd + col];
-                    if (ep.add2) v += ep.add2[row * ep.ldadd2 + col];
+                if (has_gate) {
+                    const float gv = PREF ? aux[mt][nt][r] : ep.gate[row * ep.ldgate + col];
+                    v *= (gv > 0.0f ? ep.gate_scale : 0.0f);
                 }
-                C[row * ldc + col] = v;
+                if (has_add) {
+                    v += PREF ? aux[mt][nt][r] : ep.add[row * ep.ldadd + col];
+                    if ((RT && ep.add2) || (EPI & E_ADD2)) v += ep.add2[row * ep.ldadd2 + col];
+                }
+                if (FULL)
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,
+                                                          ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);
+                else
+                    C[row * ldc + col] = v;
             }
         }
     }
@@ -306,6 +351,7 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     VQ_REQUIRE(aligned16(A) && aligned16(B), "gemm_nt: A and B must be 16-byte aligned");
     VQ_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (relu)");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt: bad dropout probability");
+    VQ_REQUIRE(ldc < (1 << 22) && ldgate < (1 << 22) && ldadd < (1 << 22), "gemm_nt: leading dimension too large");
     VQ_REQUIRE((!gate || ldgate >= N) && (!add || ldadd >= N) && (!add2 || (add && ldadd2 >= N)),
                "gemm_nt: bad gate/add strides (add2 needs add)");
     if (M == 0) return VQCPC_OK;
@@ -315,7 +361,7 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, add2, ldadd2};
     const bool full = (M % BM == 0) && (N % BN == 0) && (K % BK == 0);
     const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (gate ? E_GATE : 0) |
-                      (add ? E_ADD : 0);
+                      (add ? E_ADD : 0) | (add2 ? E_ADD2 : 0);
     const dim3 grid((unsigned)tiles), block(kGemmThreads);
     hipStream_t st = (hipStream_t)stream;
 #define NT_LAUNCH(FULLV, EPIV) \
@@ -332,6 +378,7 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         NT_CASE(E_BIAS | E_RELU | E_DROP)
         NT_CASE(E_GATE)
         NT_CASE(E_ADD)
+        NT_CASE(E_ADD | E_ADD2)
         default:
             if (full) NT_LAUNCH(true, E_RUNTIME);
             else NT_LAUNCH(false, E_RUNTIME);

@@ -42,6 +42,8 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'f32'), choices=['f32', 'bf16x6', '0', '1'],
+                    help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -170,6 +172,8 @@ def main():
     from vqcpc_bach_amd.utils import SEEDS
     assert torch.cuda.is_available(), 'bench.py measures the HIP path: it needs an MI355X'
     hip.load()
+    gemm_mode = 1 if args.gemm_mode in ('bf16x6', '1') else 0
+    hip.set_gemm_mode(gemm_mode)
     dp = DataParallelContext()
     assert dp.world_size == args.gpus or dp.world_size == 1, f'--gpus {args.gpus} but WORLD_SIZE={dp.world_size}'
     dev = dp.device

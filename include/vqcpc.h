@@ -73,6 +73,12 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
  *   split over M into partials in `workspace`, then reduced deterministically; accumulate!=0 adds to dW/db.
  * K % 4 == 0, lda/ldb % 4 == 0 required (16-byte vector loads).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* GEMM arithmetic: mode 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chains);
+ * mode 1 = "bf16x6": each fp32 operand is split exactly into 3 bf16 pieces and a product is evaluated with 6 bf16 MFMAs
+ * (v_mfma_f32_32x32x16_bf16) and fp32 accumulation -- fp32-class accuracy at 2.67x the fp32 MFMA rate.
+ * Process-wide; the initial value comes from the environment variable VQCPC_GEMM_MODE (default 0). */
+int vqcpc_gemm_set_mode(int mode);
+int vqcpc_gemm_get_mode(void);
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                   float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream);

@@ -97,6 +97,60 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert rel_err(out.cpu(), ref) < 2e-6 * max(1, K ** 0.5)
 
 
+@pytest.fixture()
+def bf16x6(ops):
+    from vqcpc_bach_amd import hip
+    hip.set_gemm_mode(1)
+    yield
+    hip.set_gemm_mode(0)
+
+
+@pytest.mark.parametrize('M,N,K', [(256, 128, 64), (1000, 96, 32), (130, 33, 36), (4096, 768, 256), (513, 256, 1024), (7, 5, 4)])
+def test_gemm_nt_bf16x6_has_fp32_class_accuracy(ops, bf16x6, M, N, K):
+    """mode 1: fp32 operands split exactly into 3 bf16 pieces, 6 bf16 MFMAs per product, fp32 accumulation."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    a[0, :] *= 1e-3                                   # mixed magnitudes inside one contraction
+    b[:, 0] *= 1e3
+    out = ops.gemm_nt(dev(a), dev(b), bias=dev(bias))
+    ref = (a.double() @ b.double().t() + bias.double())
+    err_x6 = rel_err(out.cpu(), ref)
+    err_f32 = rel_err(a @ b.t() + bias, ref)          # plain fp32 matmul on the host, for scale
+    assert err_x6 < 2e-6 * max(1, K ** 0.5), (err_x6, err_f32)
+    # element-wise: error relative to the magnitude sum |a|.|b| of each output (the natural fp32 error scale)
+    scale = (a.abs().double() @ b.abs().double().t()) + bias.abs().double()
+    err_el = float(((out.cpu().double() - ref).abs() / scale).max())
+    ref_el = float((((a @ b.t() + bias).double() - ref).abs() / scale).max())      # a host fp32 matmul, same measure
+    assert err_el < max(2e-7, 3 * ref_el), (err_el, ref_el)
+
+
+def test_gemm_nt_bf16x6_exact_on_bf16_representable_inputs(ops, bf16x6):
+    """Inputs with <= 8 significant bits have m = l = 0: the result must equal the exact integer matmul."""
+    n = 128
+    a = torch.randint(-7, 8, (n, 64)).float()
+    b = torch.arange(n * 64, dtype=torch.float32).reshape(n, 64) % 13 - 6      # asymmetric: transpose-detecting
+    out = ops.gemm_nt(dev(a), dev(b))
+    assert torch.equal(out.cpu(), a @ b.t())
+    eye = torch.eye(n)
+    bb = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)
+    assert torch.equal(ops.gemm_nt(dev(eye), dev(bb)).cpu(), bb.t().contiguous())
+
+
+def test_gemm_nt_bf16x6_epilogues(ops, bf16x6):
+    gen = torch.Generator().manual_seed(15)
+    M, N, K = 384, 256, 64
+    a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    gate, add = torch.randn(M, N, generator=gen), torch.randn(M, N, generator=gen)
+    out = ops.gemm_nt(dev(a), dev(b), gate=dev(gate), gate_scale=1.25)
+    assert rel_err(out.cpu(), (a.double() @ b.double().t()) * (gate.double() > 0) * 1.25) < 1e-5
+    out = ops.gemm_nt(dev(a), dev(b), add=dev(add))
+    assert rel_err(out.cpu(), a.double() @ b.double().t() + add.double()) < 1e-5
+    p, seed = 0.3, 99
+    out = ops.gemm_nt(dev(a), dev(b), bias=dev(bias), act=1, drop_p=p, seed=seed)
+    mask = ops.dropout_mask(M * N, p, seed, 'cuda').cpu().reshape(M, N)
+    assert rel_err(out.cpu(), torch.relu(a.double() @ b.double().t() + bias.double()) * mask.double() / (1 - p)) < 1e-5
+
+
 def test_gemm_nt_is_transpose_detecting(ops):
     # A = I with an ASYMMETRIC B catches a swapped C-write
     n = 128
@@ -154,6 +208,31 @@ def test_gemm_tn(ops, M, N, K):
     dw, db = ops.gemm_tn(dev(a), dev(b))
     assert rel_err(dw.cpu(), a.double().t() @ b.double()) < 2e-6 * max(1, M ** 0.5)
     assert rel_err(db.cpu(), a.double().sum(0)) < 2e-6 * max(1, M ** 0.5)
+
+
+@pytest.mark.parametrize('M,N,K', [(1000, 128, 128), (4097, 96, 36), (50000, 768, 256), (333, 4, 256), (20000, 32, 512)])
+def test_gemm_tn_bf16x6(ops, bf16x6, M, N, K):
+    gen = torch.Generator().manual_seed(M + N)
+    a, b = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+    a[:, 0] *= 1e3
+    b[0] *= 1e-3
+    dw, db = ops.gemm_tn(dev(a), dev(b))
+    ref = a.double().t() @ b.double()
+    assert rel_err(dw.cpu(), ref) < 2e-6 * max(1, M ** 0.5)
+    scale = a.abs().double().t() @ b.abs().double()
+    err_el = float(((dw.cpu().double() - ref).abs() / scale).max())
+    ref_el = float((((a.t() @ b).double() - ref).abs() / scale).max())
+    assert err_el < max(2e-7, 3 * ref_el), (err_el, ref_el)
+    assert rel_err(db.cpu(), a.double().sum(0)) < 2e-6 * max(1, M ** 0.5)
+
+
+def test_gemm_tn_bf16x6_exact_and_transpose_detecting(ops, bf16x6):
+    M, N, K = 512, 128, 256
+    a = (torch.arange(M * N, dtype=torch.float32).reshape(M, N) % 7) - 3
+    b = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 11) - 5
+    dw, db = ops.gemm_tn(dev(a), dev(b))
+    assert torch.equal(dw.cpu(), a.t() @ b)
+    assert torch.equal(db.cpu(), a.sum(0))
 
 
 def test_gemm_tn_strided_b(ops):

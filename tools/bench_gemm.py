@@ -27,6 +27,9 @@ def time_it(fn, reps):
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
     hip.load()
+    if len(sys.argv) > 2:
+        hip.set_gemm_mode(int(sys.argv[2]))
+    print('gemm mode', hip.get_gemm_mode())
     dev = 'cuda'
     M1, M2 = 557056, 139264
     nt_shapes = [(M1, 768, 256, 'qkv fwd'), (M1, 256, 256, 'out-proj'), (M1, 1024, 256, 'ffn1 fwd'), (M1, 256, 1024, 'ffn2 fwd'),

@@ -9,6 +9,9 @@
 //           128x128 output tile, 32 rows of M per step, operands staged [m][128]; MFMA operands are ds_read_b32
 //           (consecutive lanes -> consecutive banks).  M is split over blockIdx.y; partials are reduced deterministically.
 //           The bias gradient (column sums of A) is accumulated from the A operand registers for free.
+#include <atomic>
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace vq {
@@ -43,16 +46,50 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
 }
 
+// ---- bf16x6 helpers -------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int kX6Stride = BK + 8;                    // bf16 per LDS row: 80 B -> conflict-free ds_read_b128 across 16 rows
+constexpr int kX6Plane = BM * kX6Stride * 2;         // bytes per plane (BM == BN)
+
+// exact 3-way split of an fp32 value into bf16 pieces by truncation: x == h + m + l (as fp32 values whose low 16 bits are 0)
+__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
+    h = __float_as_uint(x) & 0xFFFF0000u;
+    const float r = x - __uint_as_float(h);
+    m = __float_as_uint(r) & 0xFFFF0000u;
+    l = __float_as_uint(r - __uint_as_float(m));     // at most 8 significant bits are left: truncation is exact
+}
+// pack the high halves of two fp32 bit patterns into one dword (element 0 in the low half)
+__device__ __forceinline__ uint32_t pack_hi(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+__device__ __forceinline__ void split3x4(const float4& v, uint2& h, uint2& m, uint2& l) {
+    uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
+    split3(v.x, h0, m0, l0);
+    split3(v.y, h1, m1, l1);
+    split3(v.z, h2, m2, l2);
+    split3(v.w, h3, m3, l3);
+    h = make_uint2(pack_hi(h0, h1), pack_hi(h2, h3));
+    m = make_uint2(pack_hi(m0, m1), pack_hi(m2, m3));
+    l = make_uint2(pack_hi(l0, l1), pack_hi(l2, l3));
+}
+
 // FULL: M % 128 == 0, N % 128 == 0, K % 32 == 0 -> no bounds checks anywhere (all hot-path shapes).
 // Two LDS buffers: tile t+1 is staged (global -> registers -> other buffer) while tile t feeds the MFMAs; one barrier
 // per K tile.
-template <bool FULL, int EPI>
+//
+// MODE 0: v_mfma_f32_32x32x2_f32 on fp32 operands (bit-exact fp32 fmaf chains), two LDS buffers, one barrier per K tile.
+// MODE 1 ("bf16x6"): every fp32 operand element is split EXACTLY into three bf16 pieces x = h + m + l (8 + 8 + 8 mantissa
+//         bits, by truncation) while it is staged to LDS, and a product a*b is evaluated as
+//         h*h + (h*m + m*h) + (h*l + l*h + m*m) on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the dropped terms
+//         (m*l, l*m, l*l) are <= 2^-23 of the product, i.e. fp32 rounding level.  6 bf16 MFMAs at 16x the fp32 MFMA rate
+//         = 2.67x the fp32-MFMA throughput at fp32-class accuracy (verified by the same parity tests).
+template <bool FULL, int EPI, int MODE>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* __restrict__ A, int64_t lda,
                                                                  const float* __restrict__ B, int64_t ldb,
                                                                  float* __restrict__ C, int64_t ldc, int64_t M, int N,
                                                                  int K, int tiles_n, EpiParams ep) {
-    __shared__ __attribute__((aligned(16))) float As[2][BM * LDS_S];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BN * LDS_S];
+    constexpr int kLdsBytes = MODE == 0 ? 2 * (BM + BN) * LDS_S * 4 : 6 * kX6Plane;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kLdsBytes];
+    float* const As0 = reinterpret_cast<float*>(smem);                       // MODE 0: As[2][BM*LDS_S] | Bs[2][BN*LDS_S]
+    float* const Bs0 = As0 + 2 * BM * LDS_S;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
@@ -88,14 +125,29 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
     }
 #define NT_LOAD(K0) \
     NT_LOAD1(ra0, rb0, 0, K0) NT_LOAD1(ra1, rb1, 1, K0) NT_LOAD1(ra2, rb2, 2, K0) NT_LOAD1(ra3, rb3, 3, K0)
-#define NT_STORE1(RA, RB, I, BUF)                                                             \
-    *reinterpret_cast<float4*>(&As[BUF][(ld_row + 32 * (I)) * LDS_S + ld_c4]) = RA;           \
-    *reinterpret_cast<float4*>(&Bs[BUF][(ld_row + 32 * (I)) * LDS_S + ld_c4]) = RB;
+#define NT_STORE1(RA, RB, I, BUF)                                                                      \
+    *reinterpret_cast<float4*>(As0 + (BUF) * BM * LDS_S + (ld_row + 32 * (I)) * LDS_S + ld_c4) = RA;   \
+    *reinterpret_cast<float4*>(Bs0 + (BUF) * BN * LDS_S + (ld_row + 32 * (I)) * LDS_S + ld_c4) = RB;
 #define NT_STORE(BUF) \
     NT_STORE1(ra0, rb0, 0, BUF) NT_STORE1(ra1, rb1, 1, BUF) NT_STORE1(ra2, rb2, 2, BUF) NT_STORE1(ra3, rb3, 3, BUF)
+    // MODE 1: split into bf16 planes  A_h | A_m | A_l | B_h | B_m | B_l, each [128][kX6Stride] bf16
+#define X6_STORE1(RA, RB, I)                                                                           \
+    {                                                                                                  \
+        const int o_ = ((ld_row + 32 * (I)) * kX6Stride + ld_c4) * 2;                                  \
+        uint2 h_, m_, l_;                                                                              \
+        split3x4(RA, h_, m_, l_);                                                                      \
+        *reinterpret_cast<uint2*>(smem + 0 * kX6Plane + o_) = h_;                                      \
+        *reinterpret_cast<uint2*>(smem + 1 * kX6Plane + o_) = m_;                                      \
+        *reinterpret_cast<uint2*>(smem + 2 * kX6Plane + o_) = l_;                                      \
+        split3x4(RB, h_, m_, l_);                                                                      \
+        *reinterpret_cast<uint2*>(smem + 3 * kX6Plane + o_) = h_;                                      \
+        *reinterpret_cast<uint2*>(smem + 4 * kX6Plane + o_) = m_;                                      \
+        *reinterpret_cast<uint2*>(smem + 5 * kX6Plane + o_) = l_;                                      \
+    }
+#define X6_STORE() X6_STORE1(ra0, rb0, 0) X6_STORE1(ra1, rb1, 1) X6_STORE1(ra2, rb2, 2) X6_STORE1(ra3, rb3, 3)
 
     NT_LOAD(0)
-    NT_STORE(0)
+    if (MODE == 0) { NT_STORE(0) } else { X6_STORE() }
     __syncthreads();
     const int a_off = (wm * 64 + li) * LDS_S + kh * 4;
     const int b_off = (wn * 64 + li) * LDS_S + kh * 4;
@@ -141,28 +193,64 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
                         }
             }
         }
-        const float* ap = &As[cur][a_off];
-        const float* bp = &Bs[cur][b_off];
+        if (MODE == 0) {
+            const float* ap = As0 + cur * BM * LDS_S + a_off;
+            const float* bp = Bs0 + cur * BN * LDS_S + b_off;
 #pragma unroll
-        for (int kc = 0; kc < BK / 8; ++kc) {
-            const float4 a0 = *reinterpret_cast<const float4*>(ap + kc * 8);
-            const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDS_S + kc * 8);
-            const float4 b0 = *reinterpret_cast<const float4*>(bp + kc * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDS_S + kc * 8);
-            const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
-            const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+            for (int kc = 0; kc < BK / 8; ++kc) {
+                const float4 a0 = *reinterpret_cast<const float4*>(ap + kc * 8);
+                const float4 a1 = *reinterpret_cast<const float4*>(ap + 32 * LDS_S + kc * 8);
+                const float4 b0 = *reinterpret_cast<const float4*>(bp + kc * 8);
+                const float4 b1 = *reinterpret_cast<const float4*>(bp + 32 * LDS_S + kc * 8);
+                const float av0[4] = {a0.x, a0.y, a0.z, a0.w}, av1[4] = {a1.x, a1.y, a1.z, a1.w};
+                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w}, bv1[4] = {b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+                for (int s = 0; s < 4; ++s) {
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv0[s], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[s], bv1[s], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv0[s], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[s], bv1[s], acc[1][1], 0, 0, 0);
+                }
             }
-        }
-        if (more) {
-            if (cur) { NT_STORE(0) } else { NT_STORE(1) }   // nobody reads the other buffer any more (previous barrier)
-            __syncthreads();
-            cur ^= 1;
+            if (more) {
+                if (cur) { NT_STORE(0) } else { NT_STORE(1) }   // nobody reads the other buffer any more (previous barrier)
+                __syncthreads();
+                cur ^= 1;
+            }
+        } else {
+            // lane (i = lane & 31, kg = lane >> 5) holds A[i][kg*8 .. kg*8+7] / B[kg*8 .. +7][j] of a 32x32x16 bf16 MFMA
+            const unsigned char* abase = smem + ((wm * 64 + li) * kX6Stride + kh * 8) * 2;
+            const unsigned char* bbase = smem + 3 * kX6Plane + ((wn * 64 + li) * kX6Stride + kh * 8) * 2;
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                bf16x8 a[3][2], b[3][2];
+#pragma unroll
+                for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                    for (int tl = 0; tl < 2; ++tl) {
+                        a[pc][tl] = *reinterpret_cast<const bf16x8*>(abase + pc * kX6Plane + (tl * 32 * kX6Stride + ks * 16) * 2);
+                        b[pc][tl] = *reinterpret_cast<const bf16x8*>(bbase + pc * kX6Plane + (tl * 32 * kX6Stride + ks * 16) * 2);
+                    }
+                // term-major order: consecutive MFMAs hit the 4 different accumulators (an MFMA that depends on the
+                // previous one stalls for its full latency); smallest terms first
+#define X6_TERM(PA, PB)                                                                                        \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][0], acc[0][0], 0, 0, 0);                \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[0][1], 0, 0, 0);                \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[1][0], 0, 0, 0);                \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[1][1], 0, 0, 0);
+                X6_TERM(2, 0)   // l*h
+                X6_TERM(0, 2)   // h*l
+                X6_TERM(1, 1)   // m*m
+                X6_TERM(1, 0)   // m*h
+                X6_TERM(0, 1)   // h*m
+                X6_TERM(0, 0)   // h*h
+#undef X6_TERM
+            }
+            if (more) {
+                __syncthreads();                 // every wave is done reading the (single) staging buffer
+                X6_STORE()
+                __syncthreads();
+            }
         }
     }
 
@@ -170,6 +258,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
 #undef NT_LOAD1
 #undef NT_STORE
 #undef NT_STORE1
+#undef X6_STORE
+#undef X6_STORE1
     // epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const bool has_bias = RT ? ep.bias != nullptr : (EPI & E_BIAS) != 0;
     const bool relu = RT ? ep.act == 1 : (EPI & E_RELU) != 0;
@@ -328,6 +418,179 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_kernel(const float* _
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x6 weight-gradient GEMM.  The contraction index (m) is the ROW index of both operands, while the bf16 MFMA wants
+// 8 consecutive contraction elements per lane.  Each thread therefore stages a 2(m) x 4(n) block: the exact 3-way split
+// is done in registers and the two rows are interleaved into dwords (row 2r in the low half, 2r+1 in the high half), so
+// the LDS planes are [row pair][128 columns] dwords and a fragment is 4 conflict-free ds_read_b32 (no transposes).
+constexpr int kTnRS = BM * 4 + 16;                    // bytes per row pair (128 dwords + 16 B pad)
+constexpr int kTnPlane = (TM / 2) * kTnRS;            // bytes per plane
+
+__device__ __forceinline__ void split3_pair4(const float4& r0, const float4& r1, uint4& h, uint4& m, uint4& l) {
+    uint32_t h0, m0, l0, h1, m1, l1;
+#define TN_SPLIT_E(E, X)                       \
+    split3(r0.E, h0, m0, l0);                  \
+    split3(r1.E, h1, m1, l1);                  \
+    h.X = pack_hi(h0, h1);                     \
+    m.X = pack_hi(m0, m1);                     \
+    l.X = pack_hi(l0, l1);
+    TN_SPLIT_E(x, x) TN_SPLIT_E(y, y) TN_SPLIT_E(z, z) TN_SPLIT_E(w, w)
+#undef TN_SPLIT_E
+}
+
+template <bool FULL>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float* __restrict__ A, int64_t lda,
+                                                                    const float* __restrict__ B, int64_t ldb, int64_t M,
+                                                                    int N, int K, int tiles_k, int64_t rows_per_split,
+                                                                    float* __restrict__ ws, float* __restrict__ ws_bias) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[6 * kTnPlane];   // A_h A_m A_l B_h B_m B_l
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * BM, k0 = tk * BN;
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(m_begin + rows_per_split, M);
+    const bool want_bias = (ws_bias != nullptr) && tk == 0;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);    // column sums of A for this thread's 4 columns
+
+    // staging: thread = (column quad c4, row pair rp0 / rp0 + 8)
+    const int c4 = (tid & 31) * 4, rp0 = tid >> 5;
+    float4 a00, a01, a10, a11, b00, b01, b10, b11;    // [item][row of the pair]
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#define X6_LD(DST, P, LD, COL0, LIM, ROW)                                                                   \
+    DST = (FULL || ((ROW) < m_end && (COL0) + c4 < (LIM))) ? *reinterpret_cast<const float4*>((P) + (ROW) * (LD) + (COL0) + c4) : zero4;
+#define X6_LOAD(MM)                                            \
+    {                                                          \
+        const int64_t r0_ = (MM) + 2 * rp0, r1_ = r0_ + 16;    \
+        X6_LD(a00, A, lda, n0, N, r0_)                         \
+        X6_LD(a01, A, lda, n0, N, r0_ + 1)                     \
+        X6_LD(a10, A, lda, n0, N, r1_)                         \
+        X6_LD(a11, A, lda, n0, N, r1_ + 1)                     \
+        X6_LD(b00, B, ldb, k0, K, r0_)                         \
+        X6_LD(b01, B, ldb, k0, K, r0_ + 1)                     \
+        X6_LD(b10, B, ldb, k0, K, r1_)                         \
+        X6_LD(b11, B, ldb, k0, K, r1_ + 1)                     \
+    }
+#define X6_ST(R0, R1, PLANE0, RP)                                                              \
+    {                                                                                          \
+        uint4 h_, m_, l_;                                                                      \
+        split3_pair4(R0, R1, h_, m_, l_);                                                      \
+        const int o_ = (RP) * kTnRS + c4 * 4;                                                  \
+        *reinterpret_cast<uint4*>(smem + ((PLANE0) + 0) * kTnPlane + o_) = h_;                 \
+        *reinterpret_cast<uint4*>(smem + ((PLANE0) + 1) * kTnPlane + o_) = m_;                 \
+        *reinterpret_cast<uint4*>(smem + ((PLANE0) + 2) * kTnPlane + o_) = l_;                 \
+    }
+#define X6_STORE()                                                                             \
+    X6_ST(a00, a01, 0, rp0) X6_ST(a10, a11, 0, rp0 + 8) X6_ST(b00, b01, 3, rp0) X6_ST(b10, b11, 3, rp0 + 8) \
+    if (want_bias) {                                                                           \
+        bsum.x += (a00.x + a01.x) + (a10.x + a11.x);                                           \
+        bsum.y += (a00.y + a01.y) + (a10.y + a11.y);                                           \
+        bsum.z += (a00.z + a01.z) + (a10.z + a11.z);                                           \
+        bsum.w += (a00.w + a01.w) + (a10.w + a11.w);                                           \
+    }
+
+    if (m_begin < m_end) {
+        X6_LOAD(m_begin)
+        X6_STORE()
+    }
+    __syncthreads();
+    // fragment of k16 step ks, lane (li, kh): row pairs ks*8 + kh*4 + 0..3, one dword each
+    const unsigned char* abase = smem + (kh * 4) * kTnRS + (wm * 64 + li) * 4;
+    const unsigned char* bbase = smem + 3 * kTnPlane + (kh * 4) * kTnRS + (wn * 64 + li) * 4;
+    for (int64_t mm = m_begin; mm < m_end; mm += TM) {
+        const bool more = mm + TM < m_end;
+        if (more) { X6_LOAD(mm + TM) }
+#pragma unroll
+        for (int ks = 0; ks < TM / 16; ++ks) {
+            bf16x8 a[3][2], b[3][2];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+                for (int tl = 0; tl < 2; ++tl) {
+                    uint4 ua, ub;
+                    const unsigned char* pa = abase + pc * kTnPlane + ks * 8 * kTnRS + tl * 128;
+                    const unsigned char* pb = bbase + pc * kTnPlane + ks * 8 * kTnRS + tl * 128;
+                    ua.x = *reinterpret_cast<const uint32_t*>(pa);
+                    ua.y = *reinterpret_cast<const uint32_t*>(pa + kTnRS);
+                    ua.z = *reinterpret_cast<const uint32_t*>(pa + 2 * kTnRS);
+                    ua.w = *reinterpret_cast<const uint32_t*>(pa + 3 * kTnRS);
+                    ub.x = *reinterpret_cast<const uint32_t*>(pb);
+                    ub.y = *reinterpret_cast<const uint32_t*>(pb + kTnRS);
+                    ub.z = *reinterpret_cast<const uint32_t*>(pb + 2 * kTnRS);
+                    ub.w = *reinterpret_cast<const uint32_t*>(pb + 3 * kTnRS);
+                    a[pc][tl] = __builtin_bit_cast(bf16x8, ua);
+                    b[pc][tl] = __builtin_bit_cast(bf16x8, ub);
+                }
+#define X6_TERM(PA, PB)                                                                                        \
+    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][0], acc[0][0], 0, 0, 0);                \
+    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[0][1], 0, 0, 0);                \
+    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[1][0], 0, 0, 0);                \
+    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[1][1], 0, 0, 0);
+            X6_TERM(2, 0) X6_TERM(0, 2) X6_TERM(1, 1) X6_TERM(1, 0) X6_TERM(0, 1) X6_TERM(0, 0)
+#undef X6_TERM
+        }
+        if (more) {
+            __syncthreads();
+            X6_STORE()
+            __syncthreads();
+        }
+    }
+#undef X6_LD
+#undef X6_LOAD
+#undef X6_ST
+#undef X6_STORE
+
+    float* out = ws + (int64_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = k0 + wn * 64 + nt * 32 + li;
+            if (!FULL && col >= K) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (FULL || row < N) out[(int64_t)row * K + col] = acc[mt][nt][r];
+            }
+        }
+    }
+    if (want_bias) {
+        // the 8 threads that share a column quad (one per row-pair group) are combined through LDS in a fixed order
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smem);          // [8][128]
+        *reinterpret_cast<float4*>(red + rp0 * BM + c4) = bsum;
+        __syncthreads();
+        if (tid < BM) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) tot += red[g * BM + tid];
+            if (n0 + tid < N) ws_bias[(int64_t)blockIdx.y * N + n0 + tid] = tot;
+        }
+    }
+}
+
+// GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate).
+// Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
+static std::atomic<int> g_gemm_mode{-1};
+static int gemm_mode() {
+    int m = g_gemm_mode.load(std::memory_order_relaxed);
+    if (m < 0) {
+        const char* e = getenv("VQCPC_GEMM_MODE");
+        m = (e && (e[0] == '1' || e[0] == 'x' || e[0] == 'b')) ? 1 : 0;
+        g_gemm_mode.store(m, std::memory_order_relaxed);
+    }
+    return m;
+}
+
 static int tn_splits(int64_t M, int N, int K) {
     const int64_t tiles = ceil_div(N, BM) * ceil_div(K, BN);
     int64_t s = ceil_div(1024, tiles);
@@ -340,6 +603,14 @@ static int tn_splits(int64_t M, int N, int K) {
 using namespace vq;
 
 extern "C" {
+
+int vqcpc_gemm_set_mode(int mode) {
+    VQ_REQUIRE(mode == 0 || mode == 1, "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
+    g_gemm_mode.store(mode, std::memory_order_relaxed);
+    return VQCPC_OK;
+}
+
+int vqcpc_gemm_get_mode(void) { return gemm_mode(); }
 
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
@@ -364,12 +635,16 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                       (add ? E_ADD : 0) | (add2 ? E_ADD2 : 0);
     const dim3 grid((unsigned)tiles), block(kGemmThreads);
     hipStream_t st = (hipStream_t)stream;
-#define NT_LAUNCH(FULLV, EPIV) \
-    hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep)
-#define NT_CASE(EPIV)                     \
-    case EPIV:                            \
-        if (full) NT_LAUNCH(true, EPIV);  \
-        else NT_LAUNCH(false, EPIV);      \
+    const int mode = gemm_mode();
+#define NT_LAUNCH(FULLV, EPIV)                                                                                            \
+    if (mode == 1)                                                                                                        \
+        hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV, 1>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep); \
+    else                                                                                                                  \
+        hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV, 0>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep)
+#define NT_CASE(EPIV)                       \
+    case EPIV:                              \
+        if (full) { NT_LAUNCH(true, EPIV); }  \
+        else { NT_LAUNCH(false, EPIV); }      \
         break;
     switch (flags) {
         NT_CASE(0)
@@ -380,8 +655,8 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         NT_CASE(E_ADD)
         NT_CASE(E_ADD | E_ADD2)
         default:
-            if (full) NT_LAUNCH(true, E_RUNTIME);
-            else NT_LAUNCH(false, E_RUNTIME);
+            if (full) { NT_LAUNCH(true, E_RUNTIME); }
+            else { NT_LAUNCH(false, E_RUNTIME); }
             break;
     }
 #undef NT_CASE
@@ -413,7 +688,15 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     float* ws = (float*)workspace;
     float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if ((N % BM == 0) && (K % BN == 0) && (M % TM == 0))
+    const bool full_tn = (N % BM == 0) && (K % BN == 0) && (M % TM == 0);
+    if (gemm_mode() == 1) {
+        if (full_tn)
+            hipLaunchKernelGGL(gemm_tn_x6_kernel<true>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N,
+                               K, tiles_k, rows_per_split, ws, ws_bias);
+        else
+            hipLaunchKernelGGL(gemm_tn_x6_kernel<false>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N,
+                               K, tiles_k, rows_per_split, ws, ws_bias);
+    } else if (full_tn)
         hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N, K,
                            tiles_k, rows_per_split, ws, ws_bias);
     else

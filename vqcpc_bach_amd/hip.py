@@ -26,6 +26,8 @@ SIGNATURES = {
                                     c_i64, c_ptr]),
     'vqcpc_gemm_nt': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64,
                               c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_gemm_set_mode': (c_int, [c_int]),
+    'vqcpc_gemm_get_mode': (c_int, []),
     'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_transpose': (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
@@ -117,6 +119,16 @@ def call(name, *args):
 def query(name, *args):
     """Invoke an int64-returning host-only workspace query."""
     return int(getattr(load(), name)(*args))
+
+
+def set_gemm_mode(mode):
+    """0 = fp32 MFMA (exact), 1 = bf16x6 split MFMA (fp32-class accuracy, faster)."""
+    rc = load().vqcpc_gemm_set_mode(int(mode))
+    _check(rc, 'vqcpc_gemm_set_mode')
+
+
+def get_gemm_mode():
+    return int(load().vqcpc_gemm_get_mode())
 
 
 def workspace(nbytes, device):

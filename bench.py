@@ -27,7 +27,8 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3
+PEAK_F32_MFMA_TFLOPS = 157.3          # v_mfma_f32_32x32x2_f32, dense (MI355X_MICROARCH.md)
+PEAK_BF16_MFMA_TFLOPS = 2500.0        # v_mfma_f32_32x32x16_bf16, dense
 
 
 def parse():
@@ -42,7 +43,7 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=2)
     ap.add_argument('--no-kernel-timing', action='store_true')
-    ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'f32'), choices=['f32', 'bf16x6', '0', '1'],
+    ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', '0', '1'],
                     help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -223,12 +224,17 @@ def main():
         nt, tn = timer.summary('gemm_nt'), timer.summary('gemm_tn')
         roofline = None
         if nt:
-            roofline = dict(bound='mfma', kernel='gemm_nt_kernel (fp32 v_mfma_f32_32x32x2_f32)',
-                            achieved=round(nt['tflops'], 2), peak=PEAK_F32_MFMA_TFLOPS, unit='TFLOP/s',
-                            frac=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 4), traffic=None,
+            if gemm_mode == 1:
+                # 6 bf16 MFMAs per fp32 product: the MFMA ceiling for ALGORITHMIC fp32 FLOPs is bf16 dense peak / 6
+                peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, 'gemm_nt_kernel<MODE=1> (bf16x6: exact 3-way bf16 split, 6x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)'
+            else:
+                peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt_kernel<MODE=0> (fp32 v_mfma_f32_32x32x2_f32)'
+            roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
+                            frac=round(nt['tflops'] / peak, 4), traffic=None,
                             launches_per_step=nt['launches'] // args.steps, avg_launch_us=round(nt['avg_us'], 1),
                             flops_per_launch=nt['flops_per_launch'],
-                            share_of_step=round(nt['total_ms'] / (dt * 1e3), 3))
+                            share_of_step=round(nt['total_ms'] / (dt * 1e3), 3),
+                            vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3))
         line = {
             'metric': 'encoder-train windows/sec (Bach 4-voice, seq=256)', 'value': round(value, 2), 'unit': 'windows/s',
             'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
@@ -239,7 +245,8 @@ def main():
                                    f'{config["quantizer_kwargs"]["num_codebooks"]}x{config["quantizer_kwargs"]["codebook_size"]}, '
                                    f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}',
                        'global_batch': B * dp.world_size, 'seq_len': 16 * (dlg.num_blocks_left + dlg.num_blocks_right),
-                       'parallelism': f'dp{dp.world_size}', 'params': n_params},
+                       'parallelism': f'dp{dp.world_size}', 'params': n_params,
+                       'gemm': 'bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else 'fp32 MFMA'},
             'roofline': roofline,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
                          'share_of_step': round(tn['total_ms'] / (dt * 1e3), 3)} if tn else None),

@@ -13,6 +13,17 @@ from oracle import vqcpc_oracle as O
 
 pytestmark = pytest.mark.gpu
 T = torch.from_numpy
+
+
+@pytest.fixture(params=['f32', 'bf16x6'], autouse=True)
+def gemm_mode(request):
+    """Every end-to-end parity test runs with both GEMM arithmetic modes (exact fp32 MFMA, and the bf16x6 split)."""
+    from vqcpc_bach_amd import hip
+    hip.load()
+    hip.set_gemm_mode(1 if request.param == 'bf16x6' else 0)
+    yield request.param
+    hip.set_gemm_mode(0)
+
 FWD_TOL, GRAD_TOL = 5e-5, 5e-4
 
 

@@ -136,9 +136,10 @@ def test_gemm_nt_bf16x6_exact_on_bf16_representable_inputs(ops, bf16x6):
     assert torch.equal(ops.gemm_nt(dev(eye), dev(bb)).cpu(), bb.t().contiguous())
 
 
-def test_gemm_nt_bf16x6_epilogues(ops, bf16x6):
+@pytest.mark.parametrize('M,N,K', [(384, 256, 64), (512, 512, 48), (1024, 256, 256)])
+def test_gemm_nt_bf16x6_epilogues(ops, bf16x6, M, N, K):
+    """(384, 256, .) runs the 128x128-tile kernel, the others the 256x256-tile kernel."""
     gen = torch.Generator().manual_seed(15)
-    M, N, K = 384, 256, 64
     a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
     gate, add = torch.randn(M, N, generator=gen), torch.randn(M, N, generator=gen)
     out = ops.gemm_nt(dev(a), dev(b), gate=dev(gate), gate_scale=1.25)
@@ -149,6 +150,21 @@ def test_gemm_nt_bf16x6_epilogues(ops, bf16x6):
     out = ops.gemm_nt(dev(a), dev(b), bias=dev(bias), act=1, drop_p=p, seed=seed)
     mask = ops.dropout_mask(M * N, p, seed, 'cuda').cpu().reshape(M, N)
     assert rel_err(out.cpu(), torch.relu(a.double() @ b.double().t() + bias.double()) * mask.double() / (1 - p)) < 1e-5
+    big = torch.randn(4 * M, K, generator=gen)          # strided A rows and strided C rows
+    dst = torch.zeros(4 * M, N, device='cuda')
+    ops.gemm_nt(dev(big)[::4], dev(b), bias=dev(bias), out=dst[::4])
+    assert rel_err(dst[::4].cpu(), big[::4].double() @ b.double().t() + bias.double()) < 1e-5
+    assert float(dst[1::4].abs().max()) == 0.0
+
+
+def test_gemm_nt_bf16x6_256_tile_is_transpose_detecting(ops, bf16x6):
+    n = 512
+    a = torch.randint(-7, 8, (n, 64)).float()
+    b = torch.arange(n * 64, dtype=torch.float32).reshape(n, 64) % 13 - 6
+    assert torch.equal(ops.gemm_nt(dev(a), dev(b)).cpu(), a @ b.t())
+    eye = torch.eye(n)
+    bb = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)
+    assert torch.equal(ops.gemm_nt(dev(eye), dev(bb)).cpu(), bb.t().contiguous())
 
 
 def test_gemm_nt_is_transpose_detecting(ops):

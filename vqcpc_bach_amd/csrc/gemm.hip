@@ -302,6 +302,162 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// bf16x6 NT GEMM, 256 x 256 x 16 tile, 8 waves (2 x 4, wave tile 128 x 64), one workgroup per CU, two LDS buffers.
+// At 128 x 128 the bf16x6 kernel is bound by operand delivery (32 FLOP per operand byte -> ~5.5 TB/s of L2->CU traffic at
+// 175 TFLOP/s); the 256^2 tile doubles the arithmetic intensity.  Shapes must be full tiles (M, N % 256, K % 16).
+// Epilogue operands (gate / add) are fetched per 32x32 MFMA tile, one tile ahead of their use.
+constexpr int kT2 = 256;                               // tile edge
+constexpr int kT2BK = 16;
+constexpr int kT2Stride = (kT2BK + 8) * 2;             // 48 B per row: 16 rows of a ds_read_b128 group -> 16 distinct slots
+constexpr int kT2Plane = kT2 * kT2Stride;              // 12 288 B
+constexpr int kT2Buf = 6 * kT2Plane;                   // A_h A_m A_l B_h B_m B_l = 73 728 B; two buffers = 147 456 B
+constexpr int kT2Threads = 512;
+
+template <int EPI>
+__global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ B, int64_t ldb,
+                                                                      float* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                                      int K, int tiles_n, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(t / tiles_n) * kT2;
+    const int n0 = (t % tiles_n) * kT2;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // staging: thread -> (row = tid >> 2 (+128), 4 consecutive k); 2 float4 of A and 2 of B per K tile
+    const int ld_row = tid >> 2, ld_c4 = (tid & 3) * 4;
+    const float* a_src = A + (m0 + ld_row) * lda + ld_c4;
+    const float* b_src = B + (int64_t)(n0 + ld_row) * ldb + ld_c4;
+    // two register sets: the loads of K tile t+2 are issued while tile t is computed (one K tile of MFMAs is shorter
+    // than the memory latency under load, so a prefetch distance of 1 leaves the loop latency-bound)
+    float4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+#define T2_LOAD(S, K0)                                                                  \
+    S##a0 = *reinterpret_cast<const float4*>(a_src + (K0));                             \
+    S##a1 = *reinterpret_cast<const float4*>(a_src + (int64_t)128 * lda + (K0));        \
+    S##b0 = *reinterpret_cast<const float4*>(b_src + (K0));                             \
+    S##b1 = *reinterpret_cast<const float4*>(b_src + (int64_t)128 * ldb + (K0));
+#define T2_ST1(R, PLANE0, ROW, BUFP)                                                 \
+    {                                                                                \
+        uint2 h_, m_, l_;                                                            \
+        split3x4(R, h_, m_, l_);                                                     \
+        const int o_ = (ROW) * kT2Stride + ld_c4 * 2;                                \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 0) * kT2Plane + o_) = h_;     \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 1) * kT2Plane + o_) = m_;     \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 2) * kT2Plane + o_) = l_;     \
+    }
+#define T2_STORE(S, BUFP) \
+    T2_ST1(S##a0, 0, ld_row, BUFP) T2_ST1(S##a1, 0, ld_row + 128, BUFP) T2_ST1(S##b0, 3, ld_row, BUFP) T2_ST1(S##b1, 3, ld_row + 128, BUFP)
+#define T2_COMPUTE(BUFP)                                                                                                  \
+    {                                                                                                                     \
+        const unsigned char* bufp = (BUFP);                                                                               \
+        bf16x8 b[3][2];                                                                                                   \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                                  \
+            _Pragma("unroll") for (int tl = 0; tl < 2; ++tl)                                                              \
+                b[pc][tl] = *reinterpret_cast<const bf16x8*>(bufp + b_off + pc * kT2Plane + tl * 32 * kT2Stride);         \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                                \
+            bf16x8 a[3][2];                                                                                               \
+            _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                              \
+                _Pragma("unroll") for (int tl = 0; tl < 2; ++tl)                                                          \
+                    a[pc][tl] = *reinterpret_cast<const bf16x8*>(bufp + a_off + pc * kT2Plane + (hf * 2 + tl) * 32 * kT2Stride); \
+            T2_TERM(2, 0) T2_TERM(0, 2) T2_TERM(1, 1) T2_TERM(1, 0) T2_TERM(0, 1) T2_TERM(0, 0)                            \
+        }                                                                                                                 \
+    }
+#define T2_TERM(PA, PB)                                                                                                   \
+    acc[hf * 2 + 0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][0], acc[hf * 2 + 0][0], 0, 0, 0);          \
+    acc[hf * 2 + 0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[hf * 2 + 0][1], 0, 0, 0);          \
+    acc[hf * 2 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[hf * 2 + 1][0], 0, 0, 0);          \
+    acc[hf * 2 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[hf * 2 + 1][1], 0, 0, 0);
+
+    const int a_off = (wm * 128 + li) * kT2Stride + kh * 16;
+    const int b_off = 3 * kT2Plane + (wn * 64 + li) * kT2Stride + kh * 16;
+    unsigned char* const buf0 = smem2;
+    unsigned char* const buf1 = smem2 + kT2Buf;
+    // K % 32 == 0 (checked on the host): the steady-state loop has NO conditionals, so the waitcnt pass can keep the
+    // youngest 4 loads in flight (a conditional load/store makes it assume the shorter queue and drain everything).
+    // sched_barrier pins "issue loads -> MFMAs -> split/store" (hipcc otherwise hoists the split above the MFMAs).
+    T2_LOAD(x, 0)
+    T2_LOAD(y, kT2BK)
+    T2_STORE(x, buf0)
+    __syncthreads();
+    for (int k0 = 0; k0 < K - 2 * kT2BK; k0 += 2 * kT2BK) {
+        T2_LOAD(x, k0 + 2 * kT2BK)                      // tile t+2 while tile t is computed (y = tile t+1 in flight)
+        __builtin_amdgcn_sched_barrier(0);
+        T2_COMPUTE(buf0)
+        T2_STORE(y, buf1)                               // free to interleave with the MFMAs above (other buffer)
+        __syncthreads();
+        T2_LOAD(y, k0 + 3 * kT2BK)
+        __builtin_amdgcn_sched_barrier(0);
+        T2_COMPUTE(buf1)
+        T2_STORE(x, buf0)
+        __syncthreads();
+    }
+    T2_COMPUTE(buf0)
+    __builtin_amdgcn_sched_barrier(0);
+    T2_STORE(y, buf1)
+    __syncthreads();
+    T2_COMPUTE(buf1)
+#undef T2_TERM
+#undef T2_COMPUTE
+#undef T2_LOAD
+#undef T2_ST1
+#undef T2_STORE
+
+    // epilogue (buffer addressing); gate / add operands are fetched one 32x32 tile ahead
+    constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ldc + n0), 0, 0x7FFFFFFF, 0x00020000);
+    const int ldci = (int)ldc;
+    const int voff_c = ((wm * 128 + 4 * kh) * ldci + wn * 64 + li) * 4;
+    const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;
+    const int ldxi = (int)((EPI & E_GATE) ? ep.ldgate : ep.ldadd);
+    const __amdgpu_buffer_rsrc_t rx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_AUX ? xsrc + m0 * (int64_t)ldxi + n0 : C), 0, 0x7FFFFFFF, 0x00020000);
+    const int voff_x = ((wm * 128 + 4 * kh) * ldxi + wn * 64 + li) * 4;
+    float aux[2][16];
+    if (HAS_AUX) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            aux[0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                rx, voff_x, (((r & 3) + 8 * (r >> 2)) * ldxi) * 4, 0));
+    }
+    const int64_t row_base = m0 + wm * 128 + 4 * kh;
+    const int col_base = n0 + wn * 64 + li;
+#pragma unroll
+    for (int tile = 0; tile < 8; ++tile) {
+        const int mt = tile >> 1, nt = tile & 1;
+        if (HAS_AUX && tile + 1 < 8) {
+            const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                aux[(tile + 1) & 1][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rx, voff_x, ((mt2 * 32 + (r & 3) + 8 * (r >> 2)) * ldxi + nt2 * 32) * 4, 0));
+        }
+        const int col = col_base + nt * 32;
+        const float bv = (EPI & E_BIAS) ? ep.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
+            float v = acc[mt][nt][r] + bv;
+            if (EPI & E_RELU) v = fmaxf(v, 0.0f);
+            if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);
+            if (EPI & E_GATE) v *= (aux[tile & 1][r] > 0.0f ? ep.gate_scale : 0.0f);
+            if (EPI & E_ADD) v += aux[tile & 1][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,
+                                                  ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 constexpr int TM = 32;   // rows of the contraction (M) dimension per step
 
 // FULL: N % 128 == 0, K % 128 == 0, M % 32 == 0 -> no bounds checks.
@@ -581,6 +737,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
 // GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate).
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
 static std::atomic<int> g_gemm_mode{-1};
+static std::atomic<int> g_use_t2{1};   // bf16x6 NT: use the 256x256 tile kernel where shapes allow (A/B switch)
 static int gemm_mode() {
     int m = g_gemm_mode.load(std::memory_order_relaxed);
     if (m < 0) {
@@ -605,7 +762,10 @@ using namespace vq;
 extern "C" {
 
 int vqcpc_gemm_set_mode(int mode) {
-    VQ_REQUIRE(mode == 0 || mode == 1, "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6)");
+    // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing)
+    VQ_REQUIRE(mode >= 0 && mode <= 3, "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6) [+2: 128-tile only]");
+    g_use_t2.store((mode & 2) ? 0 : 1, std::memory_order_relaxed);
+    mode &= 1;
     g_gemm_mode.store(mode, std::memory_order_relaxed);
     return VQCPC_OK;
 }
@@ -636,6 +796,34 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const dim3 grid((unsigned)tiles), block(kGemmThreads);
     hipStream_t st = (hipStream_t)stream;
     const int mode = gemm_mode();
+    // bf16x6, full 256 x 256 tiles: the high-arithmetic-intensity kernel (one workgroup of 8 waves per CU)
+    if (mode == 1 && g_use_t2.load(std::memory_order_relaxed) && (M % kT2 == 0) && (N % kT2 == 0) && (K % (2 * kT2BK) == 0) && !add2) {
+        const int tn2 = N / kT2;
+        const dim3 grid2((unsigned)((M / kT2) * tn2)), block2(kT2Threads);
+        const size_t lds2 = 2 * kT2Buf;
+#define T2_LAUNCH(EPIV)                                                                                                    \
+    {                                                                                                                      \
+        static bool attr_done = false;                                                                                     \
+        if (!attr_done) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_256_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds2);                                                                          \
+            attr_done = true;                                                                                              \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((gemm_nt_x6_256_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, ep);  \
+        VQ_CHECK_LAUNCH("gemm_nt_x6_256");                                                                                 \
+        return VQCPC_OK;                                                                                                   \
+    }
+        switch (flags) {
+            case 0: T2_LAUNCH(0)
+            case E_BIAS: T2_LAUNCH(E_BIAS)
+            case E_BIAS | E_RELU: T2_LAUNCH(E_BIAS | E_RELU)
+            case E_BIAS | E_RELU | E_DROP: T2_LAUNCH(E_BIAS | E_RELU | E_DROP)
+            case E_GATE: T2_LAUNCH(E_GATE)
+            case E_ADD: T2_LAUNCH(E_ADD)
+            default: break;
+        }
+#undef T2_LAUNCH
+    }
 #define NT_LAUNCH(FULLV, EPIV)                                                                                            \
     if (mode == 1)                                                                                                        \
         hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV, 1>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep); \

@@ -303,6 +303,251 @@ __global__ __launch_bounds__(64) void relattn_sub_bwd_kernel(
     }
 }
 
+// =====================================================================================================================
+// L = 16, F = 4 specialisation: ONE (block, head) problem per wavefront, 4 waves per workgroup.
+// The generic kernel above packs 4 problems into one 64-thread workgroup whose LDS footprint (43 KB) leaves 3 waves per
+// CU; here a wave owns ~10 KB, so 12-16 waves per CU are resident and every phase uses all 64 lanes:
+//   scores / softmax : lane (iq = lane >> 4, j = lane & 15), one score per lane, 16-lane shuffles
+//   P.V, dq          : lane (iq, column group of HD/16)
+//   dK, dV           : lane (key j = lane & 15, column group of HD/4)
+//   dErel            : lane (row pair rr = lane >> 2 -> rows rr, rr + 16; column group of HD/4), accumulated in registers
+// =====================================================================================================================
+template <int HD>
+struct Sub16 {
+    static constexpr int L = 16, F = 4, LQ = 4, NE = 31;
+    static constexpr int RS = HD + kSubPad;
+    static constexpr int C16 = HD / 16;          // columns per lane when 16 lanes span a row
+    static constexpr int C4 = HD / 4;            // columns per lane when 4 lanes span a row
+    static constexpr int FWD_FLOATS = (LQ + 2 * L + NE) * RS + LQ * (L + 1);
+    static constexpr int BWD_FLOATS = (2 * LQ + 2 * L + NE) * RS + 2 * LQ * (L + 1);
+};
+
+template <int ROWS, int HD>
+__device__ __forceinline__ void stage64(float* dst, const float* __restrict__ src, int64_t ld, int lane, float mul) {
+    constexpr int RS = HD + kSubPad, V = HD / 4;
+    for (int e = lane; e < ROWS * V; e += 64) {
+        const int row = e / V, c4 = e % V;
+        float4 v = *reinterpret_cast<const float4*>(src + row * ld + c4 * 4);
+        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+        *reinterpret_cast<float4*>(dst + row * RS + c4 * 4) = v;
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void relattn_sub16_fwd_kernel(const float* __restrict__ q, int64_t ldq,
+                                                                const float* __restrict__ kv, int64_t ldkv,
+                                                                const float* __restrict__ e1, const float* __restrict__ e2,
+                                                                float* __restrict__ ctx, int64_t ldo,
+                                                                float* __restrict__ probs, int64_t n_blocks, int H,
+                                                                float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    using C = Sub16<HD>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* Qs = lds + wave * C::FWD_FLOATS;
+    float* Ks = Qs + C::LQ * C::RS;
+    float* Vs = Ks + C::L * C::RS;
+    float* Er = Vs + C::L * C::RS;
+    float* Ps = Er + C::NE * C::RS;                // [4][17]
+    const int d = H * HD;
+    const int64_t prob = (int64_t)blockIdx.x * 4 + wave;
+    const bool live = prob < n_blocks * H;
+    const int64_t n = live ? prob / H : 0;
+    const int h = live ? (int)(prob % H) : 0;
+    const int iq = lane >> 4, j = lane & 15;
+
+    if (live) {
+        stage64<C::LQ, HD>(Qs, q + n * C::LQ * ldq + h * HD, ldq, lane, scale);
+        stage64<C::L, HD>(Ks, kv + n * C::L * ldkv + h * HD, ldkv, lane, 1.0f);
+        stage64<C::L, HD>(Vs, kv + n * C::L * ldkv + d + h * HD, ldkv, lane, 1.0f);
+        for (int e = lane; e < C::NE * (HD / 4); e += 64) {
+            const int r = e / (HD / 4), c4 = e % (HD / 4);
+            const float* src = r < C::L ? e1 + ((int64_t)h * C::L + r) * HD : e2 + ((int64_t)h * C::L + (r - C::L + 1)) * HD;
+            *reinterpret_cast<float4*>(Er + r * C::RS + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+        }
+    }
+    __syncthreads();
+    if (live) {
+        const float* er = Er + (j - C::F * iq + C::L - 1) * C::RS;
+        float s = 0.0f;
+#pragma unroll
+        for (int c4 = 0; c4 < HD / 4; ++c4) {
+            const float4 qv = *reinterpret_cast<const float4*>(Qs + iq * C::RS + c4 * 4);
+            const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
+            const float4 e = *reinterpret_cast<const float4*>(er + c4 * 4);
+            s += qv.x * (k.x + e.x) + qv.y * (k.y + e.y) + qv.z * (k.z + e.z) + qv.w * (k.w + e.w);
+        }
+        float m = s;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        const float ex = __expf(s - m);
+        float sum = ex;
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+        const float p = ex / sum;
+        const int64_t pidx = prob * 64 + lane;                       // probs[prob][iq][j]: fully coalesced
+        probs[pidx] = p;
+        Ps[iq * (C::L + 1) + j] = p * drop_scale(seed, (uint64_t)pidx, thr, inv_keep);
+    }
+    __syncthreads();
+    if (live) {
+        float o[C::C16];
+#pragma unroll
+        for (int c = 0; c < C::C16; ++c) o[c] = 0.0f;
+#pragma unroll
+        for (int jj = 0; jj < C::L; ++jj) {
+            const float p = Ps[iq * (C::L + 1) + jj];
+#pragma unroll
+            for (int c = 0; c < C::C16; ++c) o[c] += p * Vs[jj * C::RS + j * C::C16 + c];
+        }
+        float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + j * C::C16;
+#pragma unroll
+        for (int c = 0; c < C::C16; ++c) op[c] = o[c];
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(256) void relattn_sub16_bwd_kernel(
+    const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ q, int64_t ldq, const float* __restrict__ kv,
+    int64_t ldkv, const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
+    float* __restrict__ d_q, int64_t ldgq, float* __restrict__ d_kv, int64_t ldgkv, float* __restrict__ ws,
+    int64_t n_blocks, int H, int blocks_per_wg, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    using C = Sub16<HD>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float* Qs = lds + wave * C::BWD_FLOATS;
+    float* Os = Qs + C::LQ * C::RS;
+    float* Ks = Os + C::LQ * C::RS;
+    float* Vs = Ks + C::L * C::RS;
+    float* Er = Vs + C::L * C::RS;
+    float* Ss = Er + C::NE * C::RS;                // dS [4][17]
+    float* Pd = Ss + C::LQ * (C::L + 1);           // P after dropout [4][17]
+    const int d = H * HD;
+    int h, nsub, NS;
+    if (4 >= H) {
+        NS = 4 / H;
+        h = wave % H;
+        nsub = wave / H;
+    } else {
+        NS = 1;
+        h = blockIdx.y * 4 + wave;
+        nsub = 0;
+    }
+    const int iq = lane >> 4, j = lane & 15;       // score phase
+    const int cg4 = lane >> 4;                     // dK/dV phase: key = lane & 15, columns [cg4*C4, +C4)
+    const int rr = lane >> 2, cgE = lane & 3;      // dErel phase
+    for (int e = lane; e < C::NE * (HD / 4); e += 64) {
+        const int r = e / (HD / 4), c4 = e % (HD / 4);
+        const float* src = r < C::L ? e1 + ((int64_t)h * C::L + r) * HD : e2 + ((int64_t)h * C::L + (r - C::L + 1)) * HD;
+        *reinterpret_cast<float4*>(Er + r * C::RS + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
+    }
+    float de[2][C::C4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < C::C4; ++c) de[a][c] = 0.0f;
+
+    const int64_t n_begin = (int64_t)blockIdx.x * blocks_per_wg;
+    for (int it = 0; it < blocks_per_wg; it += NS) {
+        const int64_t n = n_begin + it + nsub;
+        const bool live = n < n_blocks;
+        const int64_t prob = n * H + h;
+        __syncthreads();
+        if (live) {
+            stage64<C::LQ, HD>(Qs, q + n * C::LQ * ldq + h * HD, ldq, lane, scale);
+            stage64<C::LQ, HD>(Os, d_ctx + n * C::LQ * ldo + h * HD, ldo, lane, 1.0f);
+            stage64<C::L, HD>(Ks, kv + n * C::L * ldkv + h * HD, ldkv, lane, 1.0f);
+            stage64<C::L, HD>(Vs, kv + n * C::L * ldkv + d + h * HD, ldkv, lane, 1.0f);
+        }
+        __syncthreads();
+        if (live) {
+            float dp = 0.0f;
+#pragma unroll
+            for (int c4 = 0; c4 < HD / 4; ++c4) {
+                const float4 o = *reinterpret_cast<const float4*>(Os + iq * C::RS + c4 * 4);
+                const float4 v = *reinterpret_cast<const float4*>(Vs + j * C::RS + c4 * 4);
+                dp += o.x * v.x + o.y * v.y + o.z * v.z + o.w * v.w;
+            }
+            const int64_t pidx = prob * 64 + lane;
+            const float p = probs[pidx];
+            const float mk = drop_scale(seed, (uint64_t)pidx, thr, inv_keep);
+            dp *= mk;
+            float rowdot = dp * p;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) rowdot += __shfl_xor(rowdot, o, 64);
+            Pd[iq * (C::L + 1) + j] = p * mk;
+            Ss[iq * (C::L + 1) + j] = p * (dp - rowdot);
+        }
+        __syncthreads();
+        if (live) {
+            // dK / dV: key row j, columns [cg4*C4, +C4)
+            float dk[C::C4], dv[C::C4];
+#pragma unroll
+            for (int c = 0; c < C::C4; ++c) dk[c] = dv[c] = 0.0f;
+#pragma unroll
+            for (int ii = 0; ii < C::LQ; ++ii) {
+                const float pd = Pd[ii * (C::L + 1) + j], ds = Ss[ii * (C::L + 1) + j];
+#pragma unroll
+                for (int c4 = 0; c4 < C::C4 / 4; ++c4) {
+                    const float4 o = *reinterpret_cast<const float4*>(Os + ii * C::RS + cg4 * C::C4 + c4 * 4);
+                    const float4 qq = *reinterpret_cast<const float4*>(Qs + ii * C::RS + cg4 * C::C4 + c4 * 4);
+                    dv[c4 * 4 + 0] += pd * o.x; dv[c4 * 4 + 1] += pd * o.y; dv[c4 * 4 + 2] += pd * o.z; dv[c4 * 4 + 3] += pd * o.w;
+                    dk[c4 * 4 + 0] += ds * qq.x; dk[c4 * 4 + 1] += ds * qq.y; dk[c4 * 4 + 2] += ds * qq.z; dk[c4 * 4 + 3] += ds * qq.w;
+                }
+            }
+            float* gp = d_kv + (n * C::L + j) * ldgkv + h * HD + cg4 * C::C4;
+#pragma unroll
+            for (int c4 = 0; c4 < C::C4 / 4; ++c4) {
+                *reinterpret_cast<float4*>(gp + c4 * 4) = make_float4(dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3]);
+                *reinterpret_cast<float4*>(gp + d + c4 * 4) = make_float4(dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3]);
+            }
+            // dq: lane (iq, column group j of C16 columns)
+            float dq[C::C16];
+#pragma unroll
+            for (int c = 0; c < C::C16; ++c) dq[c] = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < C::L; ++jj) {
+                const float ds = Ss[iq * (C::L + 1) + jj];
+                const float* kr = Ks + jj * C::RS + j * C::C16;
+                const float* er = Er + (jj - C::F * iq + C::L - 1) * C::RS + j * C::C16;
+#pragma unroll
+                for (int c = 0; c < C::C16; ++c) dq[c] += ds * (kr[c] + er[c]);
+            }
+            float* gq = d_q + (n * C::LQ + iq) * ldgq + h * HD + j * C::C16;
+#pragma unroll
+            for (int c = 0; c < C::C16; ++c) gq[c] = dq[c] * scale;
+            // dErel rows rr and rr + 16, columns [cgE*C4, +C4):  r = jx - 4 i' + 15
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+                const int r = rr + 16 * a;
+                if (r < C::NE) {
+#pragma unroll
+                    for (int ii = 0; ii < C::LQ; ++ii) {
+                        const int jx = r - (C::L - 1) + C::F * ii;
+                        if (jx >= 0 && jx < C::L) {
+                            const float ds = Ss[ii * (C::L + 1) + jx];
+#pragma unroll
+                            for (int c4 = 0; c4 < C::C4 / 4; ++c4) {
+                                const float4 qq = *reinterpret_cast<const float4*>(Qs + ii * C::RS + cgE * C::C4 + c4 * 4);
+                                de[a][c4 * 4 + 0] += ds * qq.x; de[a][c4 * 4 + 1] += ds * qq.y;
+                                de[a][c4 * 4 + 2] += ds * qq.z; de[a][c4 * 4 + 3] += ds * qq.w;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    float* dst = ws + ((((int64_t)blockIdx.x * NS + nsub) * H + h) * C::NE) * HD;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+        const int r = rr + 16 * a;
+        if (r < C::NE) {
+#pragma unroll
+            for (int c = 0; c < C::C4; ++c) dst[r * HD + cgE * C::C4 + c] = de[a][c];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void relattn_sub_de_split(const float* __restrict__ tot, int H, int L, int HD,
                                                             float* __restrict__ d_e1, float* __restrict__ d_e2) {
     const int NE = 2 * L - 1;
@@ -369,6 +614,53 @@ static int sub_launch_bwd(const float* d_ctx, int64_t ldo, const float* q, int64
     return VQCPC_OK;
 }
 
+static int sub16_blocks_per_wg(int64_t n_blocks, int H) {
+    const int ns = std::max(1, 4 / H);
+    int64_t b = ceil_div(n_blocks, 4096);
+    return (int)round_up(std::max<int64_t>(b, ns), ns);
+}
+
+template <int HD>
+static int sub16_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                            float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed,
+                            hipStream_t s) {
+    using C = Sub16<HD>;
+    const size_t lds = (size_t)4 * C::FWD_FLOATS * sizeof(float);
+    auto kern = relattn_sub16_fwd_kernel<HD>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int64_t grid = ceil_div(n_blocks * H, 4);
+    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H,
+                       1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("relattn_sub16_fwd");
+    return VQCPC_OK;
+}
+
+template <int HD>
+static int sub16_launch_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                            const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
+                            int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int H, float drop_p, uint64_t seed,
+                            float* ws, hipStream_t s) {
+    using C = Sub16<HD>;
+    const size_t lds = (size_t)4 * C::BWD_FLOATS * sizeof(float);
+    auto kern = relattn_sub16_bwd_kernel<HD>;
+    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int bpw = sub16_blocks_per_wg(n_blocks, H);
+    const int chunks = (int)ceil_div(n_blocks, bpw);
+    const int gy = 4 >= H ? 1 : H / 4;
+    const int NS = 4 >= H ? 4 / H : 1;
+    hipLaunchKernelGGL(kern, dim3(chunks, gy), dim3(256), lds, s, d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv,
+                       ldgkv, ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p),
+                       seed);
+    VQ_CHECK_LAUNCH("relattn_sub16_bwd");
+    const int total = H * C::NE * HD;
+    float* tot = ws + (int64_t)chunks * NS * total;
+    int rc = launch_reduce_splits(ws, total, chunks * NS, tot, total, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(relattn_sub_de_split, dim3(ceil_div(total, 256)), dim3(256), 0, s, tot, H, 16, HD, d_e1, d_e2);
+    VQ_CHECK_LAUNCH("relattn_sub_de_split");
+    return VQCPC_OK;
+}
+
 }  // namespace vq
 
 using namespace vq;
@@ -394,6 +686,11 @@ int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t 
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_sub_fwd: bad dropout probability");
     if (n_blocks == 0) return VQCPC_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (L == 16 && (4 % H == 0 || H % 4 == 0)) {
+        if (hd == 16) return sub16_launch_fwd<16>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
+        if (hd == 32) return sub16_launch_fwd<32>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
+        if (hd == 64) return sub16_launch_fwd<64>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
+    }
 #define CALL(LL, DD, FF) sub_launch_fwd<LL, DD, FF>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s)
     VQ_SUB_DISPATCH(CALL)
 #undef CALL
@@ -401,6 +698,12 @@ int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t 
 }
 
 int64_t vqcpc_relattn_sub_bwd_workspace(int64_t n_blocks, int L, int F, int H, int hd) {
+    if (L == 16 && H >= 1 && (4 % H == 0 || H % 4 == 0)) {
+        const int bpw16 = sub16_blocks_per_wg(std::max<int64_t>(n_blocks, 1), H);
+        const int64_t chunks16 = ceil_div(std::max<int64_t>(n_blocks, 1), bpw16);
+        const int NS16 = 4 >= H ? 4 / H : 1;
+        return (chunks16 * NS16 + 1) * H * 31 * hd * (int64_t)sizeof(float);
+    }
     const int ppw = 64 / (4 * std::max(1, L / std::max(F, 1)));
     const int bpw = sub_blocks_per_wg(std::max<int64_t>(n_blocks, 1), ppw, std::max(H, 1));
     const int64_t chunks = ceil_div(std::max<int64_t>(n_blocks, 1), bpw);
@@ -423,6 +726,15 @@ int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64
         return VQCPC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (L == 16 && (4 % H == 0 || H % 4 == 0)) {
+#define CALL16(DD)                                                                                                     \
+    sub16_launch_bwd<DD>(d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv, ldgkv, d_e1, d_e2, n_blocks, H, drop_p, \
+                         seed, (float*)workspace, s)
+        if (hd == 16) return CALL16(16);
+        if (hd == 32) return CALL16(32);
+        if (hd == 64) return CALL16(64);
+#undef CALL16
+    }
 #define CALL(LL, DD, FF)                                                                                                \
     sub_launch_bwd<LL, DD, FF>(d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv, ldgkv, d_e1, d_e2, n_blocks, H, \
                                drop_p, seed, (float*)workspace, s)

@@ -734,6 +734,157 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16x6 weight-gradient GEMM, 256 x 256 output tile, 16 rows of M per step, 8 waves (2 x 4, wave tile 128 x 64), two LDS
+// buffers, prefetch distance 2, branch-free steady-state loop (same structure as gemm_nt_x6_256_kernel; staging as
+// gemm_tn_x6_kernel: 2(m) x 4(n) register blocks, rows interleaved into dwords -> fragments are 4 ds_read_b32).
+constexpr int kW2TM = 16;                                  // contraction rows per step
+constexpr int kW2RS = kT2 * 4 + 16;                        // bytes per row pair (256 dwords + pad)
+constexpr int kW2Plane = (kW2TM / 2) * kW2RS;              // 8 320 B
+constexpr int kW2Buf = 6 * kW2Plane;                       // 49 920 B; two buffers = 99 840 B
+
+__global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ B, int64_t ldb, int64_t M,
+                                                                      int N, int K, int tiles_k, int64_t rows_per_split,
+                                                                      float* __restrict__ ws, float* __restrict__ ws_bias) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * kT2, k0 = tk * kT2;
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(m_begin + rows_per_split, M);          // (m_end - m_begin) % 32 == 0 (host)
+    const bool want_bias = (ws_bias != nullptr) && tk == 0;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // staging: thread = (column quad c4 of 64, row pair rp of 8): rows 2rp, 2rp+1 of the 16-row step
+    const int c4 = (tid & 63) * 4, rp = tid >> 6;
+    const float* a_src = A + (m_begin + 2 * rp) * lda + n0 + c4;
+    const float* b_src = B + (m_begin + 2 * rp) * ldb + k0 + c4;
+    float4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+#define W2_LOAD(S, MM)                                                                   \
+    S##a0 = *reinterpret_cast<const float4*>(a_src + (int64_t)(MM) * lda);               \
+    S##a1 = *reinterpret_cast<const float4*>(a_src + (int64_t)((MM) + 1) * lda);         \
+    S##b0 = *reinterpret_cast<const float4*>(b_src + (int64_t)(MM) * ldb);               \
+    S##b1 = *reinterpret_cast<const float4*>(b_src + (int64_t)((MM) + 1) * ldb);
+#define W2_STORE(S, BUFP)                                                                \
+    {                                                                                    \
+        uint4 h_, m_, l_;                                                                \
+        const int o_ = rp * kW2RS + c4 * 4;                                              \
+        split3_pair4(S##a0, S##a1, h_, m_, l_);                                          \
+        *reinterpret_cast<uint4*>((BUFP) + 0 * kW2Plane + o_) = h_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 1 * kW2Plane + o_) = m_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 2 * kW2Plane + o_) = l_;                      \
+        split3_pair4(S##b0, S##b1, h_, m_, l_);                                          \
+        *reinterpret_cast<uint4*>((BUFP) + 3 * kW2Plane + o_) = h_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 4 * kW2Plane + o_) = m_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 5 * kW2Plane + o_) = l_;                      \
+        if (want_bias) {                                                                 \
+            bsum.x += S##a0.x + S##a1.x;                                                 \
+            bsum.y += S##a0.y + S##a1.y;                                                 \
+            bsum.z += S##a0.z + S##a1.z;                                                 \
+            bsum.w += S##a0.w + S##a1.w;                                                 \
+        }                                                                                \
+    }
+#define W2_FRAG(DST, BASE)                                                               \
+    {                                                                                    \
+        uint4 u_;                                                                        \
+        u_.x = *reinterpret_cast<const uint32_t*>(BASE);                                 \
+        u_.y = *reinterpret_cast<const uint32_t*>((BASE) + kW2RS);                       \
+        u_.z = *reinterpret_cast<const uint32_t*>((BASE) + 2 * kW2RS);                   \
+        u_.w = *reinterpret_cast<const uint32_t*>((BASE) + 3 * kW2RS);                   \
+        DST = __builtin_bit_cast(bf16x8, u_);                                            \
+    }
+#define W2_TERM(PA, PB)                                                                                                   \
+    acc[hf * 2 + 0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][0], acc[hf * 2 + 0][0], 0, 0, 0);          \
+    acc[hf * 2 + 0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[hf * 2 + 0][1], 0, 0, 0);          \
+    acc[hf * 2 + 1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[hf * 2 + 1][0], 0, 0, 0);          \
+    acc[hf * 2 + 1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[hf * 2 + 1][1], 0, 0, 0);
+#define W2_COMPUTE(BUFP)                                                                                                  \
+    {                                                                                                                     \
+        const unsigned char* ab_ = (BUFP) + (kh * 4) * kW2RS + (wm * 128 + li) * 4;                                       \
+        const unsigned char* bb_ = (BUFP) + 3 * kW2Plane + (kh * 4) * kW2RS + (wn * 64 + li) * 4;                         \
+        bf16x8 b[3][2];                                                                                                   \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                                  \
+            _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) W2_FRAG(b[pc][tl], bb_ + pc * kW2Plane + tl * 128)           \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                                                \
+            bf16x8 a[3][2];                                                                                               \
+            _Pragma("unroll") for (int pc = 0; pc < 3; ++pc)                                                              \
+                _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) W2_FRAG(a[pc][tl], ab_ + pc * kW2Plane + (hf * 2 + tl) * 128) \
+            W2_TERM(2, 0) W2_TERM(0, 2) W2_TERM(1, 1) W2_TERM(1, 0) W2_TERM(0, 1) W2_TERM(0, 0)                            \
+        }                                                                                                                 \
+    }
+
+    unsigned char* const buf0 = smemw;
+    unsigned char* const buf1 = smemw + kW2Buf;
+    const int64_t rows = m_end - m_begin;                     // multiple of 32, >= 32 when non-empty
+    if (rows > 0) {
+        W2_LOAD(x, 0)
+        W2_LOAD(y, kW2TM)
+        W2_STORE(x, buf0)
+        __syncthreads();
+        for (int64_t mm = 0; mm < rows - 2 * kW2TM; mm += 2 * kW2TM) {
+            W2_LOAD(x, mm + 2 * kW2TM)
+            __builtin_amdgcn_sched_barrier(0);
+            W2_COMPUTE(buf0)
+            __builtin_amdgcn_sched_barrier(0);
+            W2_STORE(y, buf1)
+            __syncthreads();
+            W2_LOAD(y, mm + 3 * kW2TM)
+            __builtin_amdgcn_sched_barrier(0);
+            W2_COMPUTE(buf1)
+            __builtin_amdgcn_sched_barrier(0);
+            W2_STORE(x, buf0)
+            __syncthreads();
+        }
+        W2_COMPUTE(buf0)
+        __builtin_amdgcn_sched_barrier(0);
+        W2_STORE(y, buf1)
+        __syncthreads();
+        W2_COMPUTE(buf1)
+    }
+#undef W2_LOAD
+#undef W2_STORE
+#undef W2_FRAG
+#undef W2_TERM
+#undef W2_COMPUTE
+
+    float* out = ws + (int64_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = k0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(int64_t)row * K + col] = acc[mt][nt][r];
+            }
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smemw);          // [8][256]
+        *reinterpret_cast<float4*>(red + rp * kT2 + c4) = bsum;
+        __syncthreads();
+        if (tid < kT2) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) tot += red[g * kT2 + tid];
+            ws_bias[(int64_t)blockIdx.y * N + n0 + tid] = tot;
+        }
+    }
+}
+
 // GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate).
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
 static std::atomic<int> g_gemm_mode{-1};
@@ -877,7 +1028,18 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
     hipStream_t s = (hipStream_t)stream;
     const bool full_tn = (N % BM == 0) && (K % BN == 0) && (M % TM == 0);
-    if (gemm_mode() == 1) {
+    if (gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && (N % kT2 == 0) && (K % kT2 == 0) && (M % 32 == 0) &&
+        rows_per_split % 32 == 0) {
+        static bool attr_done = false;
+        if (!attr_done) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_x6_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      2 * kW2Buf);
+            attr_done = true;
+        }
+        const int tk2 = K / kT2;
+        hipLaunchKernelGGL(gemm_tn_x6_256_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kW2Buf, s, A, lda, B,
+                           ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
+    } else if (gemm_mode() == 1) {
         if (full_tn)
             hipLaunchKernelGGL(gemm_tn_x6_kernel<true>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N,
                                K, tiles_k, rows_per_split, ws, ws_bias);

@@ -905,6 +905,15 @@ static int tn_splits(int64_t M, int N, int K) {
     s = std::min<int64_t>(s, ceil_div(M, 8 * TM));   // at least 256 rows per split
     return (int)std::max<int64_t>(s, 1);
 }
+// 256-tile kernel: one workgroup per CU, so tiles * splits must not exceed the CU count (a 257th workgroup would wait
+// for a whole round)
+static bool tn_can_use_256(int64_t M, int N, int K) { return (N % kT2 == 0) && (K % kT2 == 0) && (M % 32 == 0); }
+static int tn_splits_256(int64_t M, int N, int K) {
+    const int64_t tiles = (int64_t)(N / kT2) * (K / kT2);
+    int64_t s = std::max<int64_t>(1, kNumCU / tiles);
+    s = std::min<int64_t>(s, std::max<int64_t>(1, M / 256));
+    return (int)s;
+}
 
 }  // namespace vq
 
@@ -948,7 +957,16 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     hipStream_t st = (hipStream_t)stream;
     const int mode = gemm_mode();
     // bf16x6, full 256 x 256 tiles: the high-arithmetic-intensity kernel (one workgroup of 8 waves per CU)
-    if (mode == 1 && g_use_t2.load(std::memory_order_relaxed) && (M % kT2 == 0) && (N % kT2 == 0) && (K % (2 * kT2BK) == 0) && !add2) {
+    // the 256-tile kernel runs ONE workgroup per CU: pick it only when its last (partial) round of tiles does not waste
+    // more than the ~8 % it gains per tile over the 128-tile kernel (2 workgroups per CU, 4x more tiles)
+    bool t2_ok = mode == 1 && g_use_t2.load(std::memory_order_relaxed) && (M % kT2 == 0) && (N % kT2 == 0) &&
+                 (K % (2 * kT2BK) == 0) && !add2;
+    if (t2_ok) {
+        const double r256 = (double)((M / kT2) * (N / kT2)) / kNumCU, r128 = (double)tiles / (2 * kNumCU);
+        const double eff256 = r256 / ceil(r256), eff128 = r128 / ceil(r128);
+        t2_ok = eff256 * 1.08 >= eff128;
+    }
+    if (t2_ok) {
         const int tn2 = N / kT2;
         const dim3 grid2((unsigned)((M / kT2) * tn2)), block2(kT2Threads);
         const size_t lds2 = 2 * kT2Buf;
@@ -1005,7 +1023,8 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 }
 
 int64_t vqcpc_gemm_tn_workspace(int64_t M, int N, int K) {
-    const int s = tn_splits(std::max<int64_t>(M, 1), N, K);
+    int s = tn_splits(std::max<int64_t>(M, 1), N, K);
+    if (tn_can_use_256(M, N, K)) s = std::max(s, tn_splits_256(M, N, K));
     return (int64_t)s * ((int64_t)N * K + N) * (int64_t)sizeof(float);
 }
 
@@ -1020,7 +1039,8 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         set_error("gemm_tn: workspace too small");
         return VQCPC_EWORKSPACE;
     }
-    const int splits = tn_splits(M, N, K);
+    const bool use256 = gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && tn_can_use_256(M, N, K);
+    const int splits = use256 ? tn_splits_256(M, N, K) : tn_splits(M, N, K);
     const int64_t rows_per_split = round_up(ceil_div(M, splits), TM);
     const int tiles_k = (int)ceil_div(K, BN);
     const int tiles = (int)ceil_div(N, BM) * tiles_k;
@@ -1028,8 +1048,7 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
     hipStream_t s = (hipStream_t)stream;
     const bool full_tn = (N % BM == 0) && (K % BN == 0) && (M % TM == 0);
-    if (gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && (N % kT2 == 0) && (K % kT2 == 0) && (M % 32 == 0) &&
-        rows_per_split % 32 == 0) {
+    if (use256) {
         static bool attr_done = false;
         if (!attr_done) {
             (void)hipFuncSetAttribute((const void*)gemm_tn_x6_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,

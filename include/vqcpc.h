@@ -36,7 +36,8 @@ int vqcpc_abi_version(void);
 const char* vqcpc_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Dropout RNG shared by all kernels: keep(seed, i) = (u24(splitmix64(seed + i * 0x9E3779B97F4A7C15)) >= p * 2^24).
+ * Dropout RNG shared by all kernels: keep(seed, i) = (u24(mix32((uint32)i * 0x9E3779B1 + lo(seed) ^ hi(seed))) >= p * 2^24)
+ * with mix32 = the 'lowbias32' integer finaliser (8 VALU ops per element).
  * vqcpc_dropout_mask writes that keep-mask (1.0f / 0.0f) for i in [0, n) so that tests can reproduce every
  * in-kernel mask (element index conventions are documented per kernel).
  * ------------------------------------------------------------------------------------------------------------------ */

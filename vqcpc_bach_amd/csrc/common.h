@@ -34,15 +34,17 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 constexpr int kWave = 64;
 constexpr int kNumCU = 256;   // MI355X
 
-// ---- dropout RNG: stateless, one 64-bit mix per element (splitmix64 finaliser) -----------------------------------
+// ---- dropout RNG: stateless, one 32-bit integer mix per element (8 VALU ops; a 64-bit splitmix cost ~25 and doubled the
+// instruction count of the K = 256 GEMM epilogues).  The element index enters modulo 2^32 (tensors of the path stay below).
 __host__ __device__ __forceinline__ uint32_t rng_u24(uint64_t seed, uint64_t idx) {
-    uint64_t x = seed + idx * 0x9E3779B97F4A7C15ull;
-    x ^= x >> 30;
-    x *= 0xBF58476D1CE4E5B9ull;
-    x ^= x >> 27;
-    x *= 0x94D049BB133111EBull;
-    x ^= x >> 31;
-    return static_cast<uint32_t>(x >> 40);   // top 24 bits
+    uint32_t x = static_cast<uint32_t>(idx) * 0x9E3779B1u + static_cast<uint32_t>(seed);
+    x ^= static_cast<uint32_t>(seed >> 32);
+    x ^= x >> 16;
+    x *= 0x7FEB352Du;
+    x ^= x >> 15;
+    x *= 0x846CA68Bu;
+    x ^= x >> 16;
+    return x >> 8;   // top 24 bits
 }
 __host__ __device__ __forceinline__ uint32_t drop_threshold(float p) { return static_cast<uint32_t>(p * 16777216.0f); }
 // keep-mask value: 0 or 1/(1-p).  thr == 0 (p == 0) keeps everything with scale 1.

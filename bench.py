@@ -93,6 +93,17 @@ class GemmTimer:
                     flops_per_launch=flops / len(recs))
 
 
+def hbm_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
+    WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
+    for gfx950 -- calibrated on the QKV launch: WRITE_SIZE == M*N*4 exactly).  None when the file is absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')))
+        return {'hbm_bytes_per_launch': round(d[kernel]['hbm_bytes_per_launch']), 'source': 'profiles/r01_gemm_hbm_traffic.json'}
+    except Exception:
+        return None
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
     whole host and oversubscribing OpenMP threads on a quota-limited container is catastrophically slow)."""
@@ -230,7 +241,7 @@ def main():
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt_kernel<MODE=0> (fp32 v_mfma_f32_32x32x2_f32)'
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
-                            frac=round(nt['tflops'] / peak, 4), traffic=None,
+                            frac=round(nt['tflops'] / peak, 4), traffic=hbm_traffic('gemm_nt'),
                             launches_per_step=nt['launches'] // args.steps, avg_launch_us=round(nt['avg_us'], 1),
                             flops_per_launch=nt['flops_per_launch'],
                             share_of_step=round(nt['total_ms'] / (dt * 1e3), 3),

@@ -184,3 +184,53 @@ def test_dropout_training_step_runs_and_is_reproducible():
         losses.append(m['loss'])
         assert np.isfinite(m['loss'])
     assert losses[0] == losses[1], 'same seeds -> same masks -> same loss'
+
+
+def test_c0_config_vs_oracle():
+    """BASELINE.json configs[0] (encoder_cpc_small: seq_len 64, batch 8, 1 codebook x 64 codes): one training step of the
+    product against the CPU oracle at the configuration's full size."""
+    cfg = O.make_cfg('C0')
+    sd = O.init_state(cfg, seed=7)
+    batch = O.synthetic_batch(cfg, seed=8)
+    st = {}
+    O.encoder_forward(batch['negative_samples'].reshape(-1, 4, 4), sd, cfg, stages=st)
+    zp = st['z'].reshape(-1, cfg['D'])
+    sd['encoder.quantizer.embeddings.0'] = zp[:cfg['K']].clone() + 0.01       # data-placed codebook (as _initialize does)
+    otr = O.OracleTrainer(cfg, sd, lr=1e-4)
+    ref = otr.step(batch, train=True)
+    tr = build_trainer(cfg, sd, lr=1e-4)
+    tr.train()
+    loss, out = tr.compute_losses(batch)
+    tr.flat.zero_grad()
+    loss.backward()
+    for k in ('idx_left', 'idx_right', 'idx_negative'):
+        assert torch.equal(out[k].cpu().reshape(ref[k].shape), ref[k]), k
+    for k in ('loss', 'loss_contrastive', 'loss_quantize'):
+        assert abs(float(out[k].detach()) - float(ref[k].detach())) < FWD_TOL * max(1.0, abs(float(ref[k].detach()))), k
+    for n, p in tr.named_parameters():
+        assert rel_err(p.grad.cpu(), otr.last_grads[n]) < GRAD_TOL, n
+
+
+def test_codebook_data_initialisation_and_epoch_contract():
+    """initialize=True: the first (negatives) segment seeds the codebooks (vector_quantizer.py:57-70); epoch() returns the
+    reference's metric dict (vqcpc_encoder_trainer.py:343-354)."""
+    from vqcpc_bach_amd import configs, getters
+    config = configs.make_config('C0', dropout=0.1)
+    dlg = getters.get_dataloader_generator('bach', 'vqcpc', dict(config['dataloader_generator_kwargs'], device='cuda'))
+    enc = getters.get_encoder('/tmp/vqcpc_test_model', dlg, config)
+    tr = getters.get_encoder_trainer('/tmp/vqcpc_test_model', dlg, 'vqcpc', enc, config['auxiliary_networks_kwargs'])
+    tr.to('cuda')
+    tr.init_optimizers(lr=1e-4, schedule_lr=True)
+    before = enc.quantizer.embeddings[0].detach().clone()
+    assert enc.quantizer.initialize
+    gen_train, gen_val, _ = dlg.dataloaders(batch_size=8)
+    m = tr.epoch(gen_train, train=True, num_batches=3, corrupt_labels=True)
+    assert not enc.quantizer.initialize and not torch.equal(before, enc.quantizer.embeddings[0].detach())
+    assert tr.flat.check_views(), 'data initialisation must write INTO the flat parameter buffer'
+    assert set(m) == {'loss', 'accuracy', 'loss_quantize', 'loss_contrastive', 'num_codewords', 'num_codewords_negative',
+                      'loss_monitor'}
+    assert isinstance(m['accuracy'], list) and len(m['accuracy']) == dlg.num_blocks_right
+    assert np.isfinite(m['loss']) and 1 <= m['num_codewords'] <= 64
+    assert abs(tr.current_lr() - 1e-4 * (0.1 + 9e-5 * 3)) < 1e-12      # LambdaLR stepped once per training batch
+    v = tr.epoch(gen_val, train=False, num_batches=1, corrupt_labels=False)
+    assert np.isfinite(v['loss']) and tr.global_step == 3

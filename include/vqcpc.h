@@ -90,7 +90,7 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
- * Fused small-L self-attention with learned relative bias (L = 16 or 4, whole block in one wavefront).
+ * Fused self-attention with learned relative bias.
  * Replaces MultiheadAttentionCustom.forward :247-343 and SubsampledRelativeAttention.forward
  * (VQCPCB/transformer/subsampled_relative_attention.py:30-122) through its closed form
  *   bias[h,i,j] = q[h,i].e1[h, L-1-(i-j)] (j <= i) | q[h,i].e2[h, j-i] (j > i).
@@ -99,6 +99,10 @@ int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream);
  *   dropout element index = ((block*H + h)*L + i)*L + j.
  * bwd: d_qkv [n_blocks*L][ldg] (all 3d columns written), d_e1/d_e2 overwritten (deterministic partials in workspace).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* L = 16 and L = 4 run the one-wavefront-per-block kernels; any other L <= 1024 (teacher_relative.py L = 384,
+ * auxiliary_decoder_relative.py L = 24 / 96) runs the strip kernels of relattn_gen.hip with identical semantics.
+ * vqcpc_relattn_force_general(1) routes every L through the latter (parity tests between the two). */
+int vqcpc_relattn_force_general(int on);
 int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
                       float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* stream);
 int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd);

@@ -338,6 +338,28 @@ def _attn_ref(qkv, e1, e2, L, H, hd, mask=None):
 @pytest.mark.parametrize('n,L,H,hd,p', [(37, 16, 2, 16, 0.0), (64, 16, 8, 32, 0.0), (129, 4, 8, 32, 0.0), (40, 16, 8, 64, 0.0),
                                         (33, 4, 4, 16, 0.0), (50, 16, 4, 32, 0.15), (70, 4, 2, 16, 0.15), (3000, 16, 8, 32, 0.0)])
 def test_relattn(ops, n, L, H, hd, p):
+    _relattn_case(ops, n, L, H, hd, p)
+
+
+# general-L strip kernels (student path: teacher L = 384, auxiliary decoder L = 24 / 96); ragged L and hd < 32 included
+@pytest.mark.parametrize('n,L,H,hd,p', [(5, 24, 2, 16, 0.0), (3, 96, 8, 64, 0.0), (2, 384, 8, 64, 0.0), (7, 40, 4, 32, 0.0),
+                                        (4, 33, 2, 64, 0.0), (9, 1, 2, 16, 0.0), (3, 96, 4, 32, 0.1), (2, 384, 2, 64, 0.1),
+                                        (70, 24, 8, 64, 0.1), (2, 200, 1, 16, 0.2)])
+def test_relattn_general_L(ops, n, L, H, hd, p):
+    _relattn_case(ops, n, L, H, hd, p)
+
+
+@pytest.mark.parametrize('n,L,H,hd,p', [(37, 16, 2, 16, 0.0), (64, 16, 8, 32, 0.15), (129, 4, 8, 32, 0.0), (40, 16, 8, 64, 0.1)])
+def test_relattn_general_kernels_match_small_L_kernels(ops, n, L, H, hd, p):
+    from vqcpc_bach_amd import hip
+    hip.force_general_attention(True)
+    try:
+        _relattn_case(ops, n, L, H, hd, p)
+    finally:
+        hip.force_general_attention(False)
+
+
+def _relattn_case(ops, n, L, H, hd, p):
     from vqcpc_bach_amd import hip
     gen = torch.Generator().manual_seed(n + L + H)
     d = H * hd

@@ -69,4 +69,13 @@ __device__ __forceinline__ float wave_max(float v) {
 int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
                          hipStream_t stream);
 
+// general-L relative attention (relattn_gen.hip); relattn.hip dispatches to it for L other than 16 / 4
+bool relattn_gen_supported(int L, int H, int hd);
+int64_t relattn_gen_bwd_workspace(int64_t n_blocks, int L, int H, int hd);
+int relattn_gen_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo, float* probs,
+                    int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, hipStream_t s);
+int relattn_gen_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
+                    const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
+                    int hd, float drop_p, uint64_t seed, float* ws, hipStream_t s);
+
 }  // namespace vq

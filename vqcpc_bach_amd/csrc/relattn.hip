@@ -366,7 +366,10 @@ static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
     return VQCPC_OK;
 }
 
+static int g_force_general = 0;   // tests: route L = 16 / 4 through the general-L kernels too
+
 static bool att_supported(int L, int H, int hd) {
+    if (g_force_general) return false;
     if (!(L == 16 || L == 4)) return false;
     if (!(hd == 16 || hd == 32 || hd == 64)) return false;
     const int slots = 4 * (64 / (4 * L));
@@ -387,14 +390,26 @@ using namespace vq;
 
 extern "C" {
 
+int vqcpc_relattn_force_general(int on) {
+    g_force_general = on ? 1 : 0;
+    return VQCPC_OK;
+}
+
 int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
                       float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* stream) {
     VQ_REQUIRE(qkv && e1 && e2 && ctx && probs, "relattn_fwd: null pointer");
-    VQ_REQUIRE(att_supported(L, H, hd), "relattn_fwd: unsupported L=%d H=%d hd=%d (L in {16,4}, hd in {16,32,64})", L, H, hd);
+    const bool small = att_supported(L, H, hd);
+    VQ_REQUIRE(small || relattn_gen_supported(L, H, hd), "relattn_fwd: unsupported L=%d H=%d hd=%d (L <= 1024, hd in {16,32,64})",
+               L, H, hd);
     VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= 3 * H * hd && ldo >= H * hd && n_blocks >= 0, "relattn_fwd: bad strides");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_fwd: bad dropout probability");
     if (n_blocks == 0) return VQCPC_OK;
     hipStream_t s = (hipStream_t)stream;
+    if (!small) {
+        VQ_REQUIRE(aligned16(qkv) && aligned16(e1) && aligned16(e2), "relattn_fwd: qkv / e1 / e2 must be 16-byte aligned");
+        VQ_REQUIRE(n_blocks * H * (int64_t)((L + 31) / 32) < (1ll << 31), "relattn_fwd: too many strips");
+        return relattn_gen_fwd(qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks, L, H, hd, drop_p, seed, s);
+    }
 #define CALL(LL, DD) launch_fwd<LL, DD>(qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s)
     VQ_ATT_DISPATCH(CALL)
 #undef CALL
@@ -402,6 +417,7 @@ int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
 }
 
 int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd) {
+    if (!att_supported(L, H, hd)) return relattn_gen_bwd_workspace(std::max<int64_t>(n_blocks, 1), std::max(L, 1), std::max(H, 1), hd);
     const int slots = 4 * (64 / (4 * std::max(L, 1)));
     const int bpw = att_blocks_per_wg(std::max<int64_t>(n_blocks, 1), slots, std::max(H, 1));
     const int64_t chunks = ceil_div(std::max<int64_t>(n_blocks, 1), bpw);
@@ -413,7 +429,8 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
                       const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
                       int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
     VQ_REQUIRE(d_ctx && qkv && probs && e1 && e2 && d_qkv && d_e1 && d_e2 && workspace, "relattn_bwd: null pointer");
-    VQ_REQUIRE(att_supported(L, H, hd), "relattn_bwd: unsupported L=%d H=%d hd=%d", L, H, hd);
+    const bool small = att_supported(L, H, hd);
+    VQ_REQUIRE(small || relattn_gen_supported(L, H, hd), "relattn_bwd: unsupported L=%d H=%d hd=%d", L, H, hd);
     VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldq >= 3 * H * hd && ldg >= 3 * H * hd && ldo >= H * hd &&
                    n_blocks >= 1,
                "relattn_bwd: bad strides");
@@ -422,6 +439,11 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
         return VQCPC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (!small) {
+        VQ_REQUIRE(aligned16(qkv) && aligned16(d_ctx) && aligned16(workspace), "relattn_bwd: buffers must be 16-byte aligned");
+        return relattn_gen_bwd(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, L, H, hd, drop_p, seed,
+                               (float*)workspace, s);
+    }
 #define CALL(LL, DD) \
     launch_bwd<LL, DD>(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, H, drop_p, seed, (float*)workspace, s)
     VQ_ATT_DISPATCH(CALL)

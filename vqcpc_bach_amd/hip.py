@@ -31,6 +31,7 @@ SIGNATURES = {
     'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_transpose': (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
+    'vqcpc_relattn_force_general': (c_int, [c_int]),
     'vqcpc_relattn_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_f32,
                                   c_u64, c_ptr]),
     'vqcpc_relattn_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int]),
@@ -125,6 +126,11 @@ def set_gemm_mode(mode):
     """0 = fp32 MFMA (exact), 1 = bf16x6 split MFMA (fp32-class accuracy, faster)."""
     rc = load().vqcpc_gemm_set_mode(int(mode))
     _check(rc, 'vqcpc_gemm_set_mode')
+
+
+def force_general_attention(on):
+    """Tests: route L = 16 / 4 through the general-L strip kernels too."""
+    _check(load().vqcpc_relattn_force_general(int(bool(on))), 'vqcpc_relattn_force_general')
 
 
 def get_gemm_mode():

@@ -53,6 +53,8 @@ int vqcpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* str
  *   out    [n_rows][d], d = dlin + 2*pos :  out[r] = [ table[v][tokens[r]] | chan[v] | event[e] ],
  *          p = r % tokens_per_block, v = p % n_voices, e = p / n_voices.
  * bwd accumulates d_table / d_chan / d_event (overwritten, deterministic two-stage reduction).
+ * event == NULL (d_event == NULL in bwd): rows are [table | chan] only, width dlin + pos -- the teacher's input
+ * `cat(linear_to_input_transformer(embed(x)), channel_embeddings)` (teacher_relative.py:63-75).
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_embed_pos_fwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, const float* table,
                         int vmax, int dlin, const float* chan, const float* event, int pos, float* out, void* stream);
@@ -198,6 +200,25 @@ int vqcpc_sumsq(const float* g, int64_t n, float grad_scale, double* out, void* 
                 void* stream);
 int vqcpc_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                     int step, float grad_scale, float max_norm, const double* sumsq, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
+ * Student (distilled VQ-VAE) step, SURVEY.md section 8 row A23.
+ *
+ * vqcpc_softmax_ce: one row = one (batch row, masked event, channel) logit vector.
+ *   target != NULL        : loss[r] = -log_softmax(logits[r])[target[r]]      utils.categorical_crossentropy (utils.py:24-49)
+ *   target_logits != NULL : loss[r] = -sum_v softmax(target_logits[r])[v] log_softmax(logits[r])[v]
+ *                                                                  utils.distilled_categorical_crossentropy (utils.py:131-159)
+ *   grad [R][V] = d loss[r] / d logits[r] = softmax(logits[r]) - target distribution  (backward = vqcpc_scale_rows).
+ * vqcpc_upscale_*: AuxiliaryDecoderRelative.upscale (auxiliary_decoder_relative.py:116-130):
+ *   out[(r*f + u)][:] = x[r][:] + emb[u][:]; bwd: dx[r] = sum_u g[r*f+u], d_emb[u] = sum_r g[r*f+u] (f <= 8).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_softmax_ce(const float* logits, int64_t ld, const int64_t* target, const float* target_logits, int64_t ldt,
+                     float* loss, float* grad, int64_t R, int V, void* stream);
+int vqcpc_scale_rows(const float* in, const float* g, float* out, int64_t R, int V, void* stream);
+int vqcpc_upscale_fwd(const float* x, const float* emb, float* out, int64_t rows, int f, int d, void* stream);
+int64_t vqcpc_upscale_bwd_workspace(int64_t rows, int f, int d);
+int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int f, int d, void* workspace,
+                      int64_t workspace_bytes, void* stream);
 
 #ifdef __cplusplus
 }

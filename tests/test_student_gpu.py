@@ -1,0 +1,211 @@
+"""Student path: the product StudentEncoderTrainer (HIP kernels through the C ABI) against
+  (1) fixtures produced by the reference's own StudentEncoderTrainer.epoch (tests/golden/student_*.npz),
+  (2) the CPU oracle on a mid-size seeded configuration with the real sequence lengths' kernel paths
+      (teacher L = 128, decoder L = 8 / 32, hd = 32).
+Codebook indices bit-exact; forward quantities within 5e-5, gradients within 5e-4 (relative to max |ref|)."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err
+from oracle import student_oracle as S
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+FWD_TOL, GRAD_TOL = 5e-5, 5e-4
+
+
+@pytest.fixture(params=['f32', 'bf16x6'], autouse=True)
+def gemm_mode(request):
+    from vqcpc_bach_amd import hip
+    hip.load()
+    hip.set_gemm_mode(1 if request.param == 'bf16x6' else 0)
+    yield request.param
+    hip.set_gemm_mode(0)
+
+
+def build_student(cfg, sd, lr=1e-3, dropout=0.0):
+    from vqcpc_bach_amd import hip
+    from vqcpc_bach_amd.auxiliary_decoders.auxiliary_decoder_relative import AuxiliaryDecoderRelative
+    from vqcpc_bach_amd.data_processor.bach_data_processor import BachDataProcessor
+    from vqcpc_bach_amd.dataloaders.synthetic_student_dataloader import SyntheticStudentDataloaderGenerator
+    from vqcpc_bach_amd.downscalers.relative_transformer_downscaler_linear import RelativeTransformerDownscalerLinear
+    from vqcpc_bach_amd.encoder import Encoder
+    from vqcpc_bach_amd.quantizer.vector_quantizer import ProductVectorQuantizer
+    from vqcpc_bach_amd.student_encoder_trainer import StudentEncoderTrainer
+    from vqcpc_bach_amd.teachers.teacher_relative import TeacherRelative
+    hip.load()
+    nc = len(cfg['vocab'])
+    dlg = SyntheticStudentDataloaderGenerator(sequences_size=cfg['ticks'] // 4, subdivision=4, vocab=cfg['vocab'])
+    dp = BachDataProcessor(embedding_size=cfg['emb'], num_events=cfg['ticks'], num_tokens_per_channel=cfg['vocab'])
+    ds = RelativeTransformerDownscalerLinear(input_dim=cfg['emb'], output_dim=cfg['D'], num_channels=nc,
+                                             downscale_factors=list(cfg['factors']), d_model=cfg['d'], n_head=cfg['H'],
+                                             list_of_num_layers=list(cfg['enc_layers']), dim_feedforward=cfg['ff'],
+                                             dropout=dropout)
+    q = ProductVectorQuantizer(codebook_size=cfg['K'], codebook_dim=cfg['D'], commitment_cost=cfg['beta'],
+                               num_codebooks=cfg['ncb'], use_batch_norm=False, initialize=False, squared_l2_norm=True)
+    enc = Encoder('/tmp/vqcpc_test_student', dp, ds, q, None)
+    tdp = BachDataProcessor(embedding_size=cfg['emb'], num_events=cfg['ticks'], num_tokens_per_channel=cfg['vocab'])
+    teacher = TeacherRelative(data_processor=tdp, num_layers=cfg['teacher_layers'], num_tokens_per_channel=cfg['vocab'],
+                              positional_embedding_size=cfg['teacher_pos'], d_model=cfg['d'], dim_feedforward=cfg['ff'],
+                              n_head=cfg['H'], num_tokens=cfg['ticks'] * nc, dropout=dropout)
+    dec = AuxiliaryDecoderRelative(num_tokens_per_channel=cfg['vocab'], codebook_dim=cfg['D'],
+                                   upscale_factors=list(reversed(cfg['factors'])),
+                                   list_of_num_layers=list(cfg['dec_layers']), n_head=cfg['H'], d_model=cfg['d'],
+                                   dim_feedforward=cfg['ff'],
+                                   num_tokens_bottleneck=cfg['ticks'] * nc // int(np.prod(cfg['factors'])),
+                                   dropout=dropout)
+    tr = StudentEncoderTrainer('/tmp/vqcpc_test_student', dlg, enc, num_events_masked=cfg['num_events_masked'],
+                               teacher=teacher, auxiliary_decoder=dec, quantization_weighting=cfg['qw'])
+    for name in ('encoder', 'teacher', 'auxiliary_decoder'):
+        sub = {k[len(name) + 1:]: v for k, v in sd.items() if k.startswith(name + '.')}
+        getattr(tr, name).load_state_dict(sub)
+    tr.to('cuda')
+    tr.init_optimizers(lr=lr, schedule_lr=False)
+    assert tr.flat.check_views()
+    return tr
+
+
+def golden_state(g, tag='sd0'):
+    sd = {}
+    for k, v in g.items():
+        if k.startswith(tag + '/'):
+            mod, rest = k[len(tag) + 1:].split('/', 1)
+            sd[mod + '.' + rest] = T(np.array(v))
+    return sd
+
+
+def named_params(tr):
+    for grp in ('encoder', 'teacher', 'auxiliary_decoder'):
+        for n, p in getattr(tr, grp).named_parameters():
+            yield f'{grp}.{n}', p
+
+
+@pytest.mark.parametrize('name', ['student_tiny', 'student_tiny_clip'])
+def test_student_epoch_golden(name):
+    g = load_golden(name)
+    cfg = S.make_cfg(**json.loads(str(g['cfg_json'])))
+    lr = float(g['lr'])
+    tr = build_student(cfg, golden_state(g), lr=lr)
+    batch = {'x': T(g['batch/x'])}
+    nc = len(cfg['vocab'])
+
+    # ---- eval: forward quantities at the reference's masked event; the draw itself must reproduce under the seed
+    tr.eval()
+    torch.manual_seed(int(g['eval_seed']))
+    with torch.no_grad():
+        _, _, out = tr.compute_losses(batch)
+    m = int(g['eval_masked_event_index'])
+    assert out['masked_event_index'] == m
+    assert torch.equal(out['encoding_indices'].cpu(), T(g['eval_fwd/idx'])), 'index assignment must be bit-exact'
+    for c in range(nc):
+        assert rel_err(out['teacher_logits'][c].cpu(), g[f'eval_fwd/teacher_logits.{c}'][:, m]) < FWD_TOL
+        assert rel_err(out['student_logits'][c].cpu(), g[f'eval_fwd/student_logits.{c}'][:, m]) < FWD_TOL
+    torch.manual_seed(int(g['eval_seed']))
+    ev = tr.epoch(iter([batch]), train=False, num_batches=1)
+    assert set(ev) == {'loss_teacher', 'loss_quantization', 'loss_reconstruction', 'loss_encdec', 'loss_monitor'}
+    for k, v in ev.items():
+        ref = float(g[f'eval/{k}'])
+        assert abs(v - ref) < FWD_TOL * max(1.0, abs(ref)), (k, v, ref)
+
+    # ---- gradients BEFORE the clips: forward + backward only
+    tr.train()
+    lt, le, out = tr.compute_losses(batch, masked_event_index=int(g['train_masked_event_index']))
+    tr.flat.zero_grad()
+    (lt + le).backward()
+    for n, p in named_params(tr):
+        ref = g.get('grad/' + n)
+        if ref is None:
+            assert float(p.grad.abs().max()) == 0.0, n
+            continue
+        assert rel_err(p.grad.cpu(), ref) < GRAD_TOL, n
+
+    # ---- one full training epoch from the same state: losses, clip norms, parameters after clip + Adam
+    tr = build_student(cfg, golden_state(g), lr=lr)
+    torch.manual_seed(int(g['train_seed']))
+    trn = tr.epoch(iter([batch]), train=True, num_batches=1)
+    for k, v in trn.items():
+        ref = float(g[f'train/{k}'])
+        assert abs(v - ref) < FWD_TOL * max(1.0, abs(ref)), (k, v, ref)
+    norms = dict(zip(('teacher', 'auxiliary_decoder', 'encoder'), g['grad_norms_teacher_decoder_encoder']))
+    opts = dict(teacher=tr.optimizer_teacher, auxiliary_decoder=tr.optimizer_enc_dec[0], encoder=tr.optimizer_enc_dec[1])
+    for grp, ref in norms.items():
+        assert abs(opts[grp].grad_norm() - ref) < 2e-4 * ref, grp
+    after = golden_state(g, 'sd1')
+    for n, p in named_params(tr):
+        ref, gref = after[n], g.get('grad/' + n)
+        got = p.detach().cpu()
+        if gref is None:
+            assert torch.equal(got, ref), n
+            continue
+        coef = min(1.0, 5.0 / (norms[n.split('.', 1)[0]] + 1e-6))
+        sig = T(np.abs(gref) * coef > 1e-4)
+        assert float((got - ref).abs().max()) <= 1.01 * lr + 1e-7, n
+        if sig.any():
+            assert float((got - ref)[sig].abs().max()) < 2e-2 * lr + 1e-7, n
+
+
+def test_student_step_vs_oracle_midsize():
+    """Oracle parity on the kernel paths of the full configuration: hd = 32, teacher L = 128 (general-L attention with
+    4 key tiles), decoder L = 8 / 32, encoder L = 16 / 4, ragged vocabularies (GEMM padding)."""
+    cfg = S.make_cfg(ticks=32, d=128, H=4, ff=256, enc_layers=[2, 2], K=16, teacher_layers=3, dec_layers=[2, 2],
+                     num_events_masked=3, B=5, vocab=[23, 19, 30, 14], emb=16)
+    sd = S.init_state(cfg, seed=5)
+    batch = S.synthetic_batch(cfg, seed=6)
+    with torch.no_grad():       # codebook on encoder outputs so that several codes are in use
+        z = S.encoder_forward(batch['x'], sd, cfg)[3].reshape(-1, cfg['D'])
+        sd['encoder.quantizer.embeddings.0'] = z[:cfg['K']].clone() + 0.01
+    otr = S.StudentOracleTrainer(cfg, sd, lr=1e-3)
+    m = 17
+    ref = otr.step(batch, train=True, masked_event_index=m)
+    tr = build_student(cfg, sd, lr=1e-3)
+    tr.train()
+    lt, le, out = tr.compute_losses(batch, masked_event_index=m)
+    assert torch.equal(out['encoding_indices'].cpu(), ref['idx'])
+    assert len(torch.unique(ref['idx'])) > 3
+    for k in ('loss_teacher', 'loss_encdec', 'loss_quantization', 'loss_reconstruction'):
+        assert abs(float(out[k]) - float(ref[k])) < FWD_TOL * max(1.0, abs(float(ref[k]))), k
+    tr.flat.zero_grad()
+    (lt + le).backward()
+    for n, p in named_params(tr):
+        assert rel_err(p.grad.cpu(), otr.last_grads[n]) < GRAD_TOL, n
+
+
+def test_student_dropout_is_reproducible_and_active():
+    cfg = S.make_cfg('tiny')
+    sd = S.init_state(cfg, seed=3)
+    batch = S.synthetic_batch(cfg, seed=4)
+    from vqcpc_bach_amd.utils import SEEDS
+    losses = []
+    for _ in range(2):
+        tr = build_student(cfg, sd, dropout=0.2)
+        tr.train()
+        SEEDS.manual_seed(1234)
+        lt, le, _ = tr.compute_losses(batch, masked_event_index=5)
+        losses.append((float(lt), float(le)))
+    assert losses[0] == losses[1]
+    tr = build_student(cfg, sd, dropout=0.0)
+    tr.train()
+    lt, le, _ = tr.compute_losses(batch, masked_event_index=5)
+    assert abs(float(lt) - losses[0][0]) > 1e-4
+
+
+def test_student_c3_configuration_builds_and_steps():
+    """BASELINE configs[3] through the reference's getters / config schema, two epochs of one batch: finite losses."""
+    from vqcpc_bach_amd import configs, getters
+    cfg = configs.make_config('C3')
+    dlg = getters.get_dataloader_generator(cfg['dataset'], cfg['training_method'], cfg['dataloader_generator_kwargs'])
+    enc = getters.get_encoder('/tmp/vqcpc_test_c3', dlg, cfg)
+    tr = getters.get_encoder_trainer('/tmp/vqcpc_test_c3', dlg, cfg['training_method'], enc,
+                                     cfg['auxiliary_networks_kwargs'])
+    tr.to('cuda')
+    tr.init_optimizers(lr=cfg['lr'], schedule_lr=True)
+    gen_train, gen_val, _ = dlg.dataloaders(batch_size=cfg['batch_size'])
+    a = tr.epoch(gen_train, train=True, num_batches=2)
+    b = tr.epoch(gen_val, train=False, num_batches=1)
+    for res in (a, b):
+        assert all(np.isfinite(v) for v in res.values()), res
+    assert a['loss_monitor'] == a['loss_reconstruction']
+    assert tr.global_step == 2

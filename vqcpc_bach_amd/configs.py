@@ -9,7 +9,42 @@ _SIZES = {
 }
 
 
+def make_student_config(dropout=0.1, **over):
+    """BASELINE.json configs[3] / SURVEY.md C3: VQCPCB/configs/encoder_student_config.py:5-99."""
+    cfg = {
+        'training_method': 'Student', 'dataset': 'bach',
+        'dataloader_generator_kwargs': dict(sequences_size=24),
+        'subdivision': 4,
+        'data_processor_type': 'bach', 'data_processor_kwargs': dict(embedding_size=32),
+        'downscaler_type': 'relative_transformer_downscaler_linear',
+        'downscaler_kwargs': dict(downscale_factors=[4, 4], d_model=512, n_head=8, list_of_num_layers=[4, 4],
+                                  dim_feedforward=2048, attention_bias_type='relative_attention', dropout=dropout),
+        'quantizer_type': 'commitment',
+        'quantizer_kwargs': dict(num_codebooks=1, codebook_size=32, codebook_dim=3, commitment_cost=0.25,
+                                 use_batch_norm=False, squared_l2_norm=True),
+        'upscaler_type': None,
+        'auxiliary_networks_kwargs': {
+            'quantization_weighting': 0.1, 'num_events_masked': 4, 'teacher_type': 'relative',
+            'teacher_kwargs': dict(data_processor_config=dict(data_processor_type='bach',
+                                                              data_processor_kwargs=dict(embedding_size=32)),
+                                   num_layers=8, positional_embedding_size=8, d_model=512, dim_feedforward=2048, n_head=8,
+                                   dropout=dropout),
+            'auxiliary_decoder_type': 'relative',
+            'auxiliary_decoder_kwargs': dict(positional_embedding_size=8, d_model=512, dim_feedforward=2048, n_head=8,
+                                             dropout=dropout, list_of_num_layers=[4, 4]),
+        },
+        'lr': 1e-5, 'schedule_lr': False, 'batch_size': 8, 'num_batches': 512, 'num_epochs': 1,
+        'quantizer_regularization': dict(corrupt_labels=False), 'timestamp': None, 'savename': 'encoder_student_C3',
+    }
+    cfg = copy.deepcopy(cfg)
+    for k, v in over.items():
+        cfg[k] = v
+    return cfg
+
+
 def make_config(name='C1', dropout=0.1, **over):
+    if name == 'C3':
+        return make_student_config(dropout=dropout, **over)
     d, H, layers, ff, D, K, ncb, B, Kl, Kr = _SIZES[name]
     cfg = {
         'training_method': 'vqcpc', 'dataset': 'bach',

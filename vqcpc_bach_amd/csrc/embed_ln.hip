@@ -10,7 +10,7 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __res
                                                             int nv, const float* __restrict__ table, int vmax, int dlin,
                                                             const float* __restrict__ chan, const float* __restrict__ ev,
                                                             int pos, float* __restrict__ out) {
-    const int d = dlin + 2 * pos;
+    const int d = dlin + (ev ? 2 : 1) * pos;          // ev == nullptr: no event part (teacher input)
     const int d4 = d >> 2;
     const int64_t total = n_rows * d4;
     int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -42,11 +42,11 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __res
 constexpr int kEmbRowsPerChunk = 2048;   // rows of ALL voices per chunk
 
 __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __restrict__ tokens, int64_t n_rows, int tpb,
-                                                            int nv, int vmax, int dlin, int pos,
+                                                            int nv, int vmax, int dlin, int pos, int has_ev,
                                                             const float* __restrict__ g, float* __restrict__ ws) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int d = dlin + 2 * pos;
-    const int nev = tpb / nv;
+    const int d = dlin + (has_ev ? 2 : 1) * pos;
+    const int nev = has_ev ? tpb / nv : 0;
     // LDS: tab [vmax][dlin] | chan_sum [pos] | ev_sum [nev][pos]
     float* tab = lds;
     float* csum = tab + vmax * dlin;
@@ -88,6 +88,7 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
 __global__ __launch_bounds__(256) void embed_pos_bwd_reduce(const float* __restrict__ ws, int nchunks, int nv, int vmax,
                                                             int dlin, int pos, int nev, float* __restrict__ d_table,
                                                             float* __restrict__ d_chan, float* __restrict__ d_event) {
+    // nev == 0: no event part
     const int lds_floats = vmax * dlin + pos + nev * pos;
     const int n_tab = nv * vmax * dlin, n_chan = nv * pos, n_ev = nev * pos;
     const int o = blockIdx.x * blockDim.x + threadIdx.x;
@@ -285,13 +286,13 @@ extern "C" {
 
 int vqcpc_embed_pos_fwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, const float* table,
                         int vmax, int dlin, const float* chan, const float* event, int pos, float* out, void* stream) {
-    VQ_REQUIRE(tokens && table && chan && event && out, "embed_pos_fwd: null pointer");
+    VQ_REQUIRE(tokens && table && chan && out, "embed_pos_fwd: null pointer");
     VQ_REQUIRE(n_rows >= 0 && tokens_per_block > 0 && n_voices > 0 && tokens_per_block % n_voices == 0 && vmax > 0,
                "embed_pos_fwd: bad shape");
     VQ_REQUIRE(dlin % 4 == 0 && pos % 4 == 0 && dlin > 0, "embed_pos_fwd: dlin and pos must be multiples of 4");
     VQ_REQUIRE(n_rows % tokens_per_block == 0, "embed_pos_fwd: n_rows must be a whole number of blocks");
     if (n_rows == 0) return VQCPC_OK;
-    const int64_t total = n_rows * ((dlin + 2 * pos) / 4);
+    const int64_t total = n_rows * ((dlin + (event ? 2 : 1) * pos) / 4);
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 8192);
     hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tokens, n_rows,
                        tokens_per_block, n_voices, table, vmax, dlin, chan, event, pos, out);
@@ -308,11 +309,11 @@ int64_t vqcpc_embed_pos_bwd_workspace(int64_t n_rows, int tokens_per_block, int 
 int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin,
                         int pos, const float* g_out, float* d_table, float* d_chan, float* d_event, void* workspace,
                         int64_t workspace_bytes, void* stream) {
-    VQ_REQUIRE(tokens && g_out && d_table && d_chan && d_event && workspace, "embed_pos_bwd: null pointer");
+    VQ_REQUIRE(tokens && g_out && d_table && d_chan && workspace, "embed_pos_bwd: null pointer");
     VQ_REQUIRE(n_rows > 0 && tokens_per_block > 0 && n_voices > 0 && tokens_per_block % n_voices == 0 &&
                    kEmbRowsPerChunk % tokens_per_block == 0 && n_rows % tokens_per_block == 0,
                "embed_pos_bwd: bad shape");
-    const int nev = tokens_per_block / n_voices;
+    const int nev = d_event ? tokens_per_block / n_voices : 0;
     const size_t lds = ((size_t)vmax * dlin + pos + (size_t)nev * pos) * sizeof(float);
     VQ_REQUIRE(lds <= 160 * 1024, "embed_pos_bwd: table of %d x %d floats does not fit the LDS", vmax, dlin);
     if (workspace_bytes < vqcpc_embed_pos_bwd_workspace(n_rows, tokens_per_block, n_voices, vmax, dlin, pos)) {
@@ -324,7 +325,7 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)embed_pos_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(nchunks, n_voices), dim3(256), lds, s, tokens, n_rows,
-                       tokens_per_block, n_voices, vmax, dlin, pos, g_out, (float*)workspace);
+                       tokens_per_block, n_voices, vmax, dlin, pos, d_event ? 1 : 0, g_out, (float*)workspace);
     VQ_CHECK_LAUNCH("embed_pos_bwd");
     const int total = n_voices * vmax * dlin + n_voices * pos + nev * pos;
     hipLaunchKernelGGL(embed_pos_bwd_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)workspace,

@@ -50,9 +50,13 @@ class Encoder(nn.Module):
         launch sequence.  The FIRST tensor plays the role of the reference's first call for the data-dependent
         codebook initialisation.  Returns a list of (z_quantized, encoding_indices, quantization_loss)."""
         corrupt_flags = corrupt_flags or [False] * len(xs)
+        tpb = self.downscaler.sequence_length
         toks = [self.data_processor.preprocess(x) for x in xs]               # (batch_i, nb_i, 16)
+        # BachDataProcessor (student configuration) keeps (batch, events, voices): cut it into blocks of `tpb` tokens,
+        # token p of a block = (event p // voices, voice p % voices), i.e. utils.flatten + the view of
+        # relative_transformer_downscaler_linear.py:104-107
+        toks = [t if t.shape[-1] == tpb else t.reshape(t.shape[0], -1, tpb) for t in toks]
         sizes = [t.shape[0] * t.shape[1] for t in toks]
-        tpb = toks[0].shape[-1]
         tokens = torch.cat([t.reshape(-1, tpb) for t in toks], dim=0) if len(toks) > 1 else toks[0].reshape(-1, tpb)
         z = self.downscaler.forward_tokens(tokens.unsqueeze(0), self.data_processor)[0]        # (R, D)
         starts = [sum(sizes[:i]) for i in range(len(sizes))]

@@ -80,15 +80,15 @@ def transpose(w):
 class EmbedPosFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, tokens, table, chan, event, tokens_per_block):
-        # tokens (rows,) int64 ; table (nv, vmax, dlin) ; chan (nv, pos) ; event (nev, pos)
+        # tokens (rows,) int64 ; table (nv, vmax, dlin) ; chan (nv, pos) ; event (nev, pos) or None (no event part)
         nv, vmax, dlin = table.shape
         pos = chan.shape[1]
         rows = tokens.numel()
-        out = torch.empty(rows, dlin + 2 * pos, dtype=torch.float32, device=table.device)
+        out = torch.empty(rows, dlin + (2 if event is not None else 1) * pos, dtype=torch.float32, device=table.device)
         hip.call('vqcpc_embed_pos_fwd', tokens, rows, tokens_per_block, nv, table.contiguous(), vmax, dlin,
-                 chan.contiguous(), event.contiguous(), pos, out)
+                 chan.contiguous(), event.contiguous() if event is not None else None, pos, out)
         ctx.save_for_backward(tokens)
-        ctx.meta = (rows, tokens_per_block, nv, vmax, dlin, pos, event.shape[0])
+        ctx.meta = (rows, tokens_per_block, nv, vmax, dlin, pos, event.shape[0] if event is not None else 0)
         return out
 
     @staticmethod
@@ -98,7 +98,7 @@ class EmbedPosFn(torch.autograd.Function):
         g = g.contiguous()
         d_table = torch.empty(nv, vmax, dlin, dtype=torch.float32, device=g.device)
         d_chan = torch.empty(nv, pos, dtype=torch.float32, device=g.device)
-        d_event = torch.empty(nev, pos, dtype=torch.float32, device=g.device)
+        d_event = torch.empty(nev, pos, dtype=torch.float32, device=g.device) if nev else None
         nbytes = hip.query('vqcpc_embed_pos_bwd_workspace', rows, tpb, nv, vmax, dlin, pos)
         ws = hip.workspace(nbytes, g.device)
         hip.call('vqcpc_embed_pos_bwd', tokens, rows, tpb, nv, vmax, dlin, pos, g, d_table, d_chan, d_event, ws, nbytes)
@@ -125,12 +125,21 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None):
-    """F.linear on the last dimension through the MFMA GEMM."""
+    """F.linear on the last dimension through the MFMA GEMM.  The GEMMs work on multiples of 4 features; other sizes
+    (the student's codebook_dim = 3, per-voice vocabularies) are zero-padded, which changes no result."""
     lead = x.shape[:-1]
     x2 = x.reshape(-1, x.shape[-1])
     if x2.stride(1) != 1:
         x2 = x2.contiguous()
-    return LinearFn.apply(x2, weight, bias).reshape(*lead, weight.shape[0])
+    N, K = weight.shape
+    pk, pn = -K % 4, -N % 4
+    if pk or pn:
+        pad = torch.nn.functional.pad
+        if pk:
+            x2 = pad(x2, (0, pk))
+        y = LinearFn.apply(x2, pad(weight, (0, pk, 0, pn)), pad(bias, (0, pn)) if bias is not None else None)
+        return y[:, :N].reshape(*lead, N)
+    return LinearFn.apply(x2, weight, bias).reshape(*lead, N)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -344,6 +353,63 @@ class NCEFn(torch.autograd.Function):
         hip.call('vqcpc_nce_bwd', c, W, z_pos, z_neg, f_pos, f_neg, g_loss_b.contiguous(), B, K, N, zdim, cdim, d_c, d_W,
                  d_zp, d_zn, ws, nbytes)
         return d_c, d_W, d_zp, d_zn
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# A23 (student step): cross-entropy rows and the auxiliary decoder's upscale
+# ------------------------------------------------------------------------------------------------------------------
+class SoftmaxCEFn(torch.autograd.Function):
+    """Rows of softmax cross-entropy against hard targets (int64 (R,)) or soft targets given as logits ((R, V), no
+    gradient flows into them: the reference detaches the teacher, student_encoder_trainer.py:197-198)."""
+
+    @staticmethod
+    def forward(ctx, logits, target, target_logits):
+        logits, ld = _rows(_f32(logits))
+        R, V = logits.shape
+        loss = torch.empty(R, dtype=torch.float32, device=logits.device)
+        grad = torch.empty(R, V, dtype=torch.float32, device=logits.device)
+        ldt = 0
+        if target_logits is not None:
+            target_logits, ldt = _rows(_f32(target_logits))
+            assert target is None and target_logits.shape == (R, V)
+        else:
+            target = target.to(torch.int64).contiguous()
+            assert target.shape == (R,)
+        hip.call('vqcpc_softmax_ce', logits, ld, target, target_logits, ldt, loss, grad, R, V)
+        ctx.save_for_backward(grad)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        out = torch.empty_like(grad)
+        hip.call('vqcpc_scale_rows', grad, g.contiguous(), out, grad.shape[0], grad.shape[1])
+        return out, None, None
+
+
+class UpscaleFn(torch.autograd.Function):
+    """(rows, d) -> (rows * f, d): row r becomes f consecutive rows r*f + u = x[r] + emb[u]."""
+
+    @staticmethod
+    def forward(ctx, x, emb):
+        x, emb = _f32(x).contiguous(), _f32(emb).contiguous()
+        rows, d = x.shape
+        f = emb.shape[0]
+        out = torch.empty(rows * f, d, dtype=torch.float32, device=x.device)
+        hip.call('vqcpc_upscale_fwd', x, emb, out, rows, f, d)
+        ctx.meta = (rows, f, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        rows, f, d = ctx.meta
+        g = g.contiguous()
+        dx = torch.empty(rows, d, dtype=torch.float32, device=g.device)
+        demb = torch.empty(f, d, dtype=torch.float32, device=g.device)
+        nbytes = hip.query('vqcpc_upscale_bwd_workspace', rows, f, d)
+        ws = hip.workspace(nbytes, g.device)
+        hip.call('vqcpc_upscale_bwd', g, dx, demb, rows, f, d, ws, nbytes)
+        return dx, demb
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -100,6 +100,16 @@ class FlatParameters:
                 p.data = view
                 p.grad = self.flat_grad[off:off + p.numel()].view(p.shape)
 
+    def range_of(self, module):
+        """[start, end) of the flat buffers covered by `module`'s parameters (they must be contiguous, i.e. the module
+        was passed as one entry of `modules`): lets one clip + Adam kernel pair run per parameter group."""
+        ids = {id(p) for p in module.parameters()}
+        hits = [i for i, p in enumerate(self.params) if id(p) in ids]
+        assert hits and hits == list(range(hits[0], hits[-1] + 1)), 'parameters of the module are not contiguous'
+        last = hits[-1]
+        end = self.offsets[last + 1] if last + 1 < len(self.params) else self.numel
+        return self.offsets[hits[0]], end
+
     def zero_grad(self):
         self.flat_grad.zero_()
         for p, off in zip(self.params, self.offsets):        # autograd may have replaced a view: re-attach

@@ -1,0 +1,197 @@
+"""StudentEncoderTrainer -- distilled VQ-VAE training (reference: VQCPCB/student_encoder_trainer.py:13-293;
+SURVEY.md section 8 row A23, BASELINE configs[3]).
+
+One iteration of `epoch()`:
+  1. one masked event index per batch from the host generator (:159-160, no device sync), events [m-k, m+k] replaced by
+     the mask token of their voice;
+  2. teacher forward on the masked tokens, hard-target cross-entropy on the masked event (:120-142);
+  3. encoder (linear-aggregation downscaler + VQ) -> auxiliary decoder, soft-target cross-entropy against the detached
+     teacher logits of the masked event, + weighted quantisation loss (:186-218);
+  4. ONE backward over both (disjoint) graphs, ONE RCCL all-reduce of the flat gradient, then three global-norm clips
+     (teacher | auxiliary decoder | encoder, :252, :268-269) + Adam as flat kernels.  The reference steps the teacher
+     before the encoder/decoder forward; the latter only reads teacher logits computed before that step, so deferring
+     the teacher update to the end of the iteration gives the same numbers.  Adam is element-wise: the reference's
+     single Adam over decoder + encoder parameters (:51-55) equals one Adam per clip group with a shared step count.
+  5. metrics accumulate on the device; the reference's five `.item()` syncs per step (:137, :211-215) and the
+     384 `.item()` calls of its loss loop (utils.py:155) disappear.
+"""
+import os
+from itertools import islice
+
+import numpy as np
+import torch
+
+from . import ops
+from .encoder import EncoderTrainer
+from .parallel import DataParallelContext, FlatParameters
+from .vqcpc_encoder_trainer import VQCPCEncoderTrainer
+
+
+class StudentEncoderTrainer(EncoderTrainer):
+    def __init__(self, model_dir, dataloader_generator, encoder, num_events_masked, teacher, auxiliary_decoder,
+                 quantization_weighting, num_gpus=1):
+        super().__init__(dataloader_generator=dataloader_generator)
+        self.model_dir = model_dir
+        self.dataloader_generator = dataloader_generator
+        self.encoder = encoder
+        self.teacher = teacher
+        self.auxiliary_decoder = auxiliary_decoder
+        self.codebook_dim = self.encoder.quantizer.codebook_dim
+        self.upscale_factors = self.auxiliary_decoder.upscale_factors
+        self.num_tokens_per_channel = self.encoder.data_processor.num_tokens_per_channel
+        self.num_channels = len(self.num_tokens_per_channel)
+        self.num_events_masked = num_events_masked
+        assert self.encoder.data_processor.num_tokens % np.prod(self.upscale_factors) == 0
+        self.quantization_weighting = quantization_weighting
+        self.optimizer_enc_dec = None      # (decoder, encoder) clip groups
+        self.optimizer_teacher = None
+        self.scheduler_enc_dec = None
+        self.scheduler_teacher = None
+        self.schedule_lr = False
+        self.flat = None
+        self.dp = None
+        self.lr = None
+        self.global_step = 0
+
+    # ---- optimiser (:49-76) --------------------------------------------------------------------------------------
+    def _modules_with_params(self):
+        return [self.teacher, self.auxiliary_decoder, self.encoder]
+
+    lr_lambda = staticmethod(VQCPCEncoderTrainer.lr_lambda)
+
+    def init_optimizers(self, lr, schedule_lr, dp=None):
+        dev = next(self.encoder.parameters()).device
+        assert dev.type == 'cuda', 'call .to(device) first: the training step has no CPU path'
+        self.dp = dp if dp is not None else (self.dp or DataParallelContext(device=dev))
+        self.is_main = self.dp.rank == 0
+        self.flat = FlatParameters(self._modules_with_params())
+        self.dp.broadcast_(self.flat.flat, src=0)
+        if self.dp.distributed:
+            self.encoder.quantizer.init_broadcast = lambda tensors: [self.dp.broadcast_(t.data, 0) for t in tensors]
+        self.lr, self.schedule_lr = lr, schedule_lr
+
+        def adam(module):
+            a, b = self.flat.range_of(module)
+            return ops.FlatAdam(self.flat.flat[a:b], self.flat.flat_grad[a:b], lr=lr, max_norm=5.0)
+
+        self.optimizer_teacher = adam(self.teacher)
+        self.optimizer_enc_dec = (adam(self.auxiliary_decoder), adam(self.encoder))
+        self.scheduler_enc_dec = self.scheduler_teacher = self.lr_lambda if schedule_lr else None
+        self.global_step = 0
+
+    def current_lr(self):
+        return self.lr * (self.lr_lambda(self.global_step) if self.schedule_lr else 1.0)
+
+    def to(self, device):
+        for m in self._modules_with_params():
+            m.to(device)
+        return self
+
+    # ---- checkpoints (:85-107): encoder files + `decoder` + `teacher` -------------------------------------------------
+    def _dir(self, early_stopped):
+        return f'{self.model_dir}/early_stopped' if early_stopped else f'{self.model_dir}/overfitted'
+
+    def save(self, early_stopped):
+        model_dir = self._dir(early_stopped)
+        os.makedirs(model_dir, exist_ok=True)
+        self.encoder.save(early_stopped=early_stopped)
+        torch.save(self.auxiliary_decoder.state_dict(), f'{model_dir}/decoder')
+        torch.save(self.teacher.state_dict(), f'{model_dir}/teacher')
+
+    def load(self, early_stopped, device):
+        print(f'Loading models {self.__repr__()}')
+        print(f'Loading from {self.model_dir}')
+        model_dir = self._dir(early_stopped)
+        ml = torch.device(device)
+        self.encoder.load(early_stopped=early_stopped, device=device)
+        self.auxiliary_decoder.load_state_dict(torch.load(f'{model_dir}/decoder', map_location=ml))
+        self.teacher.load_state_dict(torch.load(f'{model_dir}/teacher', map_location=ml))
+
+    def train(self, mode=True):
+        for m in self._modules_with_params():
+            m.train(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    # ---- masking (:144-184) --------------------------------------------------------------------------------------
+    def draw_masked_event(self, num_events):
+        """One index per batch from the global CPU generator, exactly the reference's draw (:159-160)."""
+        return int(torch.randint(high=num_events, size=()).item())
+
+    def mask_teacher(self, x, num_events_masked, masked_event_index=None):
+        """x (batch, num_events, num_channels) -> (masked_x, notes_to_be_predicted), same shapes: the tokens of events
+        [m - k, m + k] become the mask token V_c of their voice, notes_to_be_predicted marks event m."""
+        B, E, C = x.shape
+        assert C == self.num_channels
+        m = self.draw_masked_event(E) if masked_event_index is None else int(masked_event_index)
+        lo, hi = max(m - num_events_masked, 0), min(m + num_events_masked + 1, E)
+        masked_x = x.clone()
+        masked_x[:, lo:hi] = torch.tensor(self.num_tokens_per_channel, dtype=x.dtype, device=x.device).view(1, 1, C)
+        notes = torch.zeros_like(x)
+        notes[:, m] = 1
+        self._last_masked_event = m
+        return masked_x, notes
+
+    # ---- the two forward halves ------------------------------------------------------------------------------------
+    def forward_teacher(self, x, masked_event_index=None):
+        """:120-142.  `weights_per_category` holds the logits of the masked event only, (batch, V_c) per voice."""
+        masked_x, notes = self.mask_teacher(x, self.num_events_masked, masked_event_index)
+        m = self._last_masked_event
+        logits = self.teacher.forward_events(masked_x, m)
+        loss = sum(ops.SoftmaxCEFn.apply(lg, x[:, m, c], None) for c, lg in enumerate(logits)).mean()
+        return {'loss': loss, 'notes_to_be_predicted': notes, 'weights_per_category': logits, 'masked_event_index': m,
+                'monitored_quantities': {'loss_teacher': loss.detach()}}
+
+    def forward_encdec(self, x, weights_per_category_teacher, notes_to_be_predicted, masked_event_index=None):
+        """:186-218 with the teacher / student logits restricted to the masked event."""
+        m = self._last_masked_event if masked_event_index is None else masked_event_index
+        z_quantized, encoding_indices, quantization_loss = self.encoder(x)
+        logits = self.auxiliary_decoder.forward_events(z_quantized, m)
+        rec = sum(ops.SoftmaxCEFn.apply(lg, None, t.detach()) for lg, t in zip(logits, weights_per_category_teacher))
+        q_mean, rec_mean = quantization_loss.mean(), rec.mean()
+        loss = self.quantization_weighting * q_mean + rec_mean
+        return {'loss': loss, 'encoding_indices': encoding_indices, 'weights_per_category': logits,
+                'monitored_quantities': {'loss_quantization': q_mean.detach(), 'loss_reconstruction': rec_mean.detach(),
+                                         'loss_encdec': loss.detach(), 'loss_monitor': rec_mean.detach()}}
+
+    def compute_losses(self, tensor_dict, masked_event_index=None):
+        x = self.teacher.data_processor.preprocess(tensor_dict['x'])
+        t = self.forward_teacher(x, masked_event_index)
+        e = self.forward_encdec(x, t['weights_per_category'], t['notes_to_be_predicted'], t['masked_event_index'])
+        out = dict(t['monitored_quantities'], **e['monitored_quantities'])
+        out.update(masked_event_index=t['masked_event_index'], encoding_indices=e['encoding_indices'],
+                   teacher_logits=t['weights_per_category'], student_logits=e['weights_per_category'])
+        return t['loss'], e['loss'], out
+
+    def train_step(self, tensor_dict, train=True, masked_event_index=None):
+        with torch.set_grad_enabled(train):
+            loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, masked_event_index)
+        if train:
+            self.flat.zero_grad()
+            (loss_teacher + loss_encdec).backward()          # disjoint graphs: the teacher logits are detached
+            self.dp.all_reduce_sum_(self.flat.flat_grad)
+            lr, scale = self.current_lr(), 1.0 / self.dp.world_size
+            self.optimizer_teacher.step(lr=lr, grad_scale=scale)
+            for opt in self.optimizer_enc_dec:
+                opt.step(lr=lr, grad_scale=scale)
+            self.global_step += 1
+        return out
+
+    KEYS = ('loss_teacher', 'loss_quantization', 'loss_reconstruction', 'loss_encdec', 'loss_monitor')
+
+    def epoch(self, data_loader, train=True, num_batches=None, corrupt_labels=False):
+        assert self.optimizer_teacher is not None, 'call init_optimizers(lr, schedule_lr) first'
+        self.train() if train else self.eval()
+        sums = torch.zeros(len(self.KEYS), dtype=torch.float32, device=self.flat.flat.device)
+        n = 0
+        for tensor_dict in islice(data_loader, num_batches):
+            out = self.train_step(tensor_dict, train=train)
+            sums += torch.stack([out[k] for k in self.KEYS])
+            n += 1
+        sums /= max(n, 1)
+        if self.dp.distributed:
+            self.dp.all_reduce_sum_(sums)
+            sums /= self.dp.world_size
+        return dict(zip(self.KEYS, sums.cpu().tolist()))      # the only host sync of the epoch

@@ -57,3 +57,27 @@ def unflatten(sequence, num_channels):
     size = sequence.size()
     assert len(size) >= 2 and size[1] % num_channels == 0
     return sequence.reshape(size[0], size[1] // num_channels, num_channels, *size[2:])
+
+
+def categorical_crossentropy(value, target, mask=None):
+    """utils.categorical_crossentropy (reference utils.py:24-49): value = list of (batch, events, V_c) logits,
+    target / mask (batch, events, channels); CE on the masked positions, summed over channels.
+    API-compatible helper (boolean selection = one host sync); the training step uses the event-only fast path."""
+    from . import ops
+    total = 0
+    for c, logits in enumerate(value):
+        sel = mask[..., c].bool()
+        total = total + ops.SoftmaxCEFn.apply(logits[sel], target[..., c][sel], None)
+    return total
+
+
+def distilled_categorical_crossentropy(value, target, mask=None):
+    """utils.distilled_categorical_crossentropy (reference utils.py:131-159): soft-target CE against teacher logits on
+    every (channel, event) whose mask is on for more than half of the batch; -> (batch,)."""
+    from . import ops
+    total = 0
+    for c, (student, teacher) in enumerate(zip(value, target)):
+        events = torch.nonzero(mask[:, :, c].float().mean(0) > 0.5).flatten().tolist()
+        for e in events:
+            total = total + ops.SoftmaxCEFn.apply(student[:, e], None, teacher[:, e].detach())
+    return total

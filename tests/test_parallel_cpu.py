@@ -104,3 +104,69 @@ def test_flat_parameters_views_and_alignment():
     for p, gi in zip(m.parameters(), g):
         assert torch.allclose(p.grad, 2 * gi, atol=1e-6)
     assert float(flat.flat_grad.abs().sum()) > 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# student step: three clip groups in ONE flat bucket, one all-reduce per step
+# ----------------------------------------------------------------------------------------------------------------------
+def _student_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    from oracle import student_oracle as S
+    from vqcpc_bach_amd.parallel import DataParallelContext, FlatParameters
+    dp = DataParallelContext(device='cpu')
+    cfg = S.make_cfg('tiny', B=4)
+    sd = S.init_state(cfg, seed=0)
+    full = S.synthetic_batch(cfg, seed=5)
+    B = cfg['B']
+    lo, hi = rank * B // world, (rank + 1) * B // world
+    shard = {'x': full['x'][lo:hi]}
+    groups = ('teacher', 'auxiliary_decoder', 'encoder')
+    holders = [torch.nn.ParameterDict({k.replace('.', '/'): torch.nn.Parameter(v.clone() + float(rank))
+                                       for k, v in sd.items() if k.startswith(g + '.')}) for g in groups]
+    flat = FlatParameters(holders)
+    dp.broadcast_(flat.flat, src=0)                    # rank 1 started from shifted weights
+    P = {k.replace('/', '.'): p for h in holders for k, p in h.items()}
+    for k in sd:
+        assert torch.equal(P[k].detach(), sd[k]), k
+    ranges = [flat.range_of(h) for h in holders]
+    assert ranges[0][0] == 0 and ranges[-1][1] == flat.numel
+    assert all(a[1] == b[0] for a, b in zip(ranges, ranges[1:]))       # contiguous, non-overlapping groups
+
+    flat.zero_grad()
+    out = S.student_losses(shard['x'], 7, P, cfg)      # same masked event on both ranks -> comparable to the global batch
+    (out['loss_teacher'] + out['loss_encdec']).backward()
+    dp.all_reduce_sum_(flat.flat_grad)
+    flat.flat_grad.mul_(1.0 / world)
+    ref = S.StudentOracleTrainer(cfg, sd)
+    ref.step(full, train=True, masked_event_index=7)
+    # (tensors whose true gradient is zero hold 1e-10 rounding noise: absolute floor in the denominator)
+    worst = max(float((p.grad - ref.last_grads[k]).abs().max() / (ref.last_grads[k].abs().max() + 1e-5))
+                for k, p in P.items())
+    # per-group norms of the reduced bucket == the three clip norms of the global batch
+    norms = [float(flat.flat_grad[a:b].double().pow(2).sum().sqrt()) for a, b in ranges]
+    refn = [float(ref.last_grad_norms[g + '.']) for g in groups]
+    torch.save(dict(worst=worst, norms=norms, refn=refn), os.path.join(out_dir, f's{rank}.pt'))
+    dp.barrier()
+    dp.shutdown()
+
+
+def test_student_dp_gradient_mean_and_group_ranges(tmp_path):
+    world = 2
+    mp.spawn(_student_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(tmp_path / f's{r}.pt')
+        assert res['worst'] < 2e-4, res['worst']       # fp32 summation order differs between 2 shards and 1 batch
+        for a, b in zip(res['norms'], res['refn']):
+            assert abs(a - b) < 1e-4 * b
+
+
+def test_flat_parameters_range_of_rejects_interleaved_modules():
+    from vqcpc_bach_amd.parallel import FlatParameters
+    a, b = torch.nn.Linear(3, 5), torch.nn.Linear(5, 2)
+    flat = FlatParameters([a, b])
+    ra, rb = flat.range_of(a), flat.range_of(b)
+    assert ra == (0, 24) and rb == (24, 24 + 12 + 4)     # 15 + 5 -> padded 16 + 8; 10 + 2 -> 12 + 4
+    both = torch.nn.ModuleList([a, b])
+    assert flat.range_of(both) == (0, flat.numel)

@@ -1,0 +1,88 @@
+"""Host-side checks of the student path that need no GPU: the product modules expose the reference's state_dict keys and
+shapes (checkpoint compatibility: files `teacher`, `decoder`, `downscaler`, ... of student_encoder_trainer.py:85-107), the
+reference's config schema builds through the getters, and the mask helper matches the oracle."""
+import json
+
+import numpy as np
+import torch
+
+from conftest import load_golden
+from oracle import student_oracle as S
+
+
+def _build(cfg):
+    from vqcpc_bach_amd.auxiliary_decoders.auxiliary_decoder_relative import AuxiliaryDecoderRelative
+    from vqcpc_bach_amd.data_processor.bach_data_processor import BachDataProcessor
+    from vqcpc_bach_amd.downscalers.relative_transformer_downscaler_linear import RelativeTransformerDownscalerLinear
+    from vqcpc_bach_amd.encoder import Encoder
+    from vqcpc_bach_amd.quantizer.vector_quantizer import ProductVectorQuantizer
+    from vqcpc_bach_amd.student_encoder_trainer import StudentEncoderTrainer
+    from vqcpc_bach_amd.teachers.teacher_relative import TeacherRelative
+    nc = len(cfg['vocab'])
+    dp = BachDataProcessor(embedding_size=cfg['emb'], num_events=cfg['ticks'], num_tokens_per_channel=cfg['vocab'])
+    ds = RelativeTransformerDownscalerLinear(input_dim=cfg['emb'], output_dim=cfg['D'], num_channels=nc,
+                                             downscale_factors=list(cfg['factors']), d_model=cfg['d'], n_head=cfg['H'],
+                                             list_of_num_layers=list(cfg['enc_layers']), dim_feedforward=cfg['ff'],
+                                             dropout=0.0)
+    q = ProductVectorQuantizer(codebook_size=cfg['K'], codebook_dim=cfg['D'], commitment_cost=0.25,
+                               num_codebooks=cfg['ncb'], use_batch_norm=False, initialize=False, squared_l2_norm=True)
+    enc = Encoder('/tmp/vqcpc_test_student_cpu', dp, ds, q, None)
+    tdp = BachDataProcessor(embedding_size=cfg['emb'], num_events=cfg['ticks'], num_tokens_per_channel=cfg['vocab'])
+    teacher = TeacherRelative(data_processor=tdp, num_layers=cfg['teacher_layers'], num_tokens_per_channel=cfg['vocab'],
+                              positional_embedding_size=cfg['teacher_pos'], d_model=cfg['d'], dim_feedforward=cfg['ff'],
+                              n_head=cfg['H'], num_tokens=cfg['ticks'] * nc, dropout=0.0)
+    dec = AuxiliaryDecoderRelative(num_tokens_per_channel=cfg['vocab'], codebook_dim=cfg['D'],
+                                   upscale_factors=list(reversed(cfg['factors'])),
+                                   list_of_num_layers=list(cfg['dec_layers']), n_head=cfg['H'], d_model=cfg['d'],
+                                   dim_feedforward=cfg['ff'],
+                                   num_tokens_bottleneck=cfg['ticks'] * nc // int(np.prod(cfg['factors'])), dropout=0.0)
+    return StudentEncoderTrainer('/tmp/vqcpc_test_student_cpu', None, enc, num_events_masked=cfg['num_events_masked'],
+                                 teacher=teacher, auxiliary_decoder=dec, quantization_weighting=cfg['qw'])
+
+
+def test_state_dict_keys_and_shapes_match_the_reference():
+    g = load_golden('student_tiny_clip')
+    cfg = S.make_cfg(**json.loads(str(g['cfg_json'])))
+    tr = _build(cfg)
+    for grp in ('encoder', 'teacher', 'auxiliary_decoder'):
+        mine = {k: tuple(v.shape) for k, v in getattr(tr, grp).state_dict().items()}
+        ref = {k[len(f'sd0/{grp}/'):]: v.shape for k, v in g.items() if k.startswith(f'sd0/{grp}/')}
+        assert mine == ref, grp
+        getattr(tr, grp).load_state_dict({k: torch.from_numpy(np.array(g[f'sd0/{grp}/{k}'])) for k in ref})
+
+
+def test_mask_teacher_matches_oracle_and_reference_draw():
+    g = load_golden('student_tiny')
+    cfg = S.make_cfg(**json.loads(str(g['cfg_json'])))
+    tr = _build(cfg)
+    x = torch.from_numpy(g['batch/x'])
+    torch.manual_seed(int(g['train_seed']))
+    masked, notes = tr.mask_teacher(x, cfg['num_events_masked'])
+    m = int(g['train_masked_event_index'])
+    assert tr._last_masked_event == m                        # same draw as the reference under the same seed
+    ref_masked, ref_notes = S.mask_teacher(x, m, cfg['num_events_masked'], cfg['vocab'])
+    assert torch.equal(masked, ref_masked) and torch.equal(notes, ref_notes)
+    for m in (0, cfg['ticks'] - 1):                          # window clipped at both ends
+        a, b = tr.mask_teacher(x, 3, masked_event_index=m)
+        c, d = S.mask_teacher(x, m, 3, cfg['vocab'])
+        assert torch.equal(a, c) and torch.equal(b, d)
+
+
+def test_c3_config_through_getters_has_reference_sizes():
+    from vqcpc_bach_amd import configs, getters
+    cfg = configs.make_config('C3')
+    dlg = getters.get_dataloader_generator(cfg['dataset'], cfg['training_method'], cfg['dataloader_generator_kwargs'])
+    enc = getters.get_encoder('/tmp/m', dlg, cfg)
+    tr = getters.get_encoder_trainer('/tmp/m', dlg, cfg['training_method'], enc, cfg['auxiliary_networks_kwargs'])
+    assert tr.teacher.transformer.layers[0].seq_len == 384 and len(tr.teacher.transformer.layers) == 8
+    assert [t.layers[0].seq_len for t in tr.auxiliary_decoder.transformers] == [24, 96]
+    assert [t.layers[0].seq_len for t in tr.encoder.downscaler.transformers] == [16, 4]
+    assert tr.encoder.downscaler.linear_aggs[0].weight.shape == (512, 2048)
+    assert tr.encoder.quantizer.embeddings[0].shape == (32, 3) and tr.encoder.upscaler is None
+    assert tr.teacher.transformer.layers[0].self_attn.attn_bias.e1.shape == (8 * 384, 64)
+    batch = next(dlg.dataloaders(batch_size=cfg['batch_size'])[0])
+    assert batch['x'].shape == (8, 96, 4) and batch['x'].dtype == torch.int64
+    # no CPU fallback: the training step refuses to run without the device
+    import pytest
+    with pytest.raises(AssertionError, match='no CPU path'):
+        tr.init_optimizers(lr=1e-5, schedule_lr=False)

@@ -125,10 +125,15 @@ def usable_cores():
 
 def cpu_baseline_worker(cfg_name, dropout, batch, steps):
     """Runs in a child process (so that a slow host cannot stall the GPU measurement): prints one JSON object."""
-    from oracle import vqcpc_oracle as O
     usable = usable_cores()
-    cfg = O.make_cfg(cfg_name, dropout=dropout, B=batch)
-    otr = O.OracleTrainer(cfg, O.init_state(cfg, seed=0), lr=1e-4)
+    if cfg_name == 'C3':                                  # student step: oracle/student_oracle.py
+        from oracle import student_oracle as O
+        cfg = O.make_cfg('C3', dropout=dropout, B=batch)
+        otr = O.StudentOracleTrainer(cfg, O.init_state(cfg, seed=0), lr=1e-5)
+    else:
+        from oracle import vqcpc_oracle as O
+        cfg = O.make_cfg(cfg_name, dropout=dropout, B=batch)
+        otr = O.OracleTrainer(cfg, O.init_state(cfg, seed=0), lr=1e-4)
     gen = torch.Generator().manual_seed(0)
     batches = [O.synthetic_batch(cfg, seed=1234 + i) for i in range(steps + 1)]
     # pick the thread count that is fastest on THIS host (all cores is often slower than 16-32 threads for tensors of
@@ -156,8 +161,9 @@ def cpu_baseline_worker(cfg_name, dropout, batch, steps):
         model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
     except Exception:
         pass
-    print(json.dumps(dict(value=round(batch * steps / dt, 3), unit='windows/s', cores=cores, kind='port',
-                          sample=f'{cfg_name} model, B={batch} windows/step, {steps} timed steps after 1 warm-up, fp32, '
+    unit = 'sequences/s' if cfg_name == 'C3' else 'windows/s'
+    print(json.dumps(dict(value=round(batch * steps / dt, 3), unit=unit, cores=cores, kind='port',
+                          sample=f'{cfg_name} model, B={batch} {unit[:-2]}/step, {steps} timed steps after 1 warm-up, fp32, '
                                  f'dropout {dropout}, torch {torch.__version__} CPU on {model} ({usable} usable cores, fastest of '
                                  f'{cands} threads used), {dt:.1f} s')), flush=True)
 
@@ -200,7 +206,7 @@ def main():
     trainer = getters.get_encoder_trainer('/tmp/vqcpc_bench_model', dlg, config['training_method'], encoder,
                                           config['auxiliary_networks_kwargs'])
     trainer.to(dev)
-    trainer.init_optimizers(lr=config['lr'], schedule_lr=config['schedule_lr'], dp=dp)
+    trainer.init_optimizers(lr=config['lr'], schedule_lr=config.get('schedule_lr', False), dp=dp)
     trainer.train()
     n_params = trainer.flat.numel
 
@@ -228,8 +234,10 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     dt = dp.max_over_ranks(dt)
-    last_loss = float(out['loss'])
+    student = config['training_method'].lower() == 'student'
+    last_loss = float(out['loss_encdec'] if student else out['loss'])
 
+    seq_len = 384 if student else 16 * (dlg.num_blocks_left + dlg.num_blocks_right)
     if dp.rank == 0:
         value = B * dp.world_size * args.steps / dt
         nt, tn = timer.summary('gemm_nt'), timer.summary('gemm_tn')
@@ -251,11 +259,11 @@ def main():
             'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'encoder_cpc {args.config}: seq_len={16 * (dlg.num_blocks_left + dlg.num_blocks_right)}, '
-                                   f'batch={B}/GPU, {dlg.num_negative_samples} negatives, product-VQ '
-                                   f'{config["quantizer_kwargs"]["num_codebooks"]}x{config["quantizer_kwargs"]["codebook_size"]}, '
-                                   f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}',
-                       'global_batch': B * dp.world_size, 'seq_len': 16 * (dlg.num_blocks_left + dlg.num_blocks_right),
+            'config': {'workload': (f'encoder_cpc {args.config}: seq_len={seq_len}, '
+                                    f'batch={B}/GPU, {getattr(dlg, "num_negative_samples", 0)} negatives, product-VQ '
+                                    f'{config["quantizer_kwargs"]["num_codebooks"]}x{config["quantizer_kwargs"]["codebook_size"]}, '
+                                    f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}'),
+                       'global_batch': B * dp.world_size, 'seq_len': seq_len,
                        'parallelism': f'dp{dp.world_size}', 'params': n_params,
                        'gemm': 'bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else 'fp32 MFMA'},
             'roofline': roofline,
@@ -263,6 +271,14 @@ def main():
                          'share_of_step': round(tn['total_ms'] / (dt * 1e3), 3)} if tn else None),
             'final_loss': round(last_loss, 5),
         }
+        if student:     # BASELINE configs[3]: an extra measurement, not the headline metric
+            line['metric'], line['unit'] = 'student-train sequences/sec (Bach 4-voice, 24 beats = 384 tokens)', 'sequences/s'
+            tk, dk = config['auxiliary_networks_kwargs']['teacher_kwargs'], config['downscaler_kwargs']
+            line['config'] = {'workload': f'encoder_student C3: x (B, 96, 4), batch={B}/GPU, teacher {tk["num_layers"]} layers '
+                                          f'L=384, encoder {dk["list_of_num_layers"]} layers (linear aggregation), decoder '
+                                          f'L=24/96, d_model={dk["d_model"]}, VQ 1x32 dim 3, dropout={args.dropout}',
+                              'global_batch': B * dp.world_size, 'seq_len': 384, 'parallelism': f'dp{dp.world_size}',
+                              'params': n_params, 'gemm': line['config']['gemm']}
         if dp.world_size == 1 and not args.no_cpu_baseline:
             line['cpu_baseline'] = cpu_baseline(args.config, args.dropout, args.cpu_batch, args.cpu_steps)
             if line['cpu_baseline'].get('value'):

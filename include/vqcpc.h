@@ -155,7 +155,9 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
  * squared == 0: loss = (1 + beta) * || (q - z) + 1e-5 ||_2.
  * bwd: d_z = g_zq + g_loss * d(loss)/dz ; d_codebooks [ncb][K][dsub] = segment-sum of g_loss * d(loss)/dq
  * (this is the slot the north_star calls "codebook update": the reference trains codebooks by Adam, not EMA).
- * ------------------------------------------------------------------------------------------------------------------ */
+ * ------------------------------------------------------------------------------------------------------------------  * zq_sg == loss == NULL (with assign = 1): index-only mode for inference consumers (decoders/decoder.py:327-336,
+ * encoder.py:137-159 only read encoding_indices).
+ */
 int vqcpc_vq_fwd(const float* z, const float* codebooks, int64_t R, int ncb, int K, int dsub, float beta, int squared,
                  int assign, int64_t* idx, float* zq_sg, float* loss, void* stream);
 int64_t vqcpc_vq_bwd_workspace(int64_t R, int ncb, int K, int dsub);
@@ -212,6 +214,13 @@ int vqcpc_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr,
  * vqcpc_upscale_*: AuxiliaryDecoderRelative.upscale (auxiliary_decoder_relative.py:116-130):
  *   out[(r*f + u)][:] = x[r][:] + emb[u][:]; bwd: dx[r] = sum_u g[r*f+u], d_emb[u] = sum_r g[r*f+u] (f <= 8).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* 'same_sequence' negative construction on the device (BachCPCDataloaderGenerator._build_negatives_sameSeq,
+ * dataloaders/bach_cpc_dataloader.py:163-181): first (B, blocks_first * tokens_per_block), second likewise, int64 tokens in
+ * (tick, voice) order; out (B, blocks_first + blocks_second - 1, blocks_second, tokens_per_block):
+ *   out[b][n][k] = first block n (n < blocks_first) | second block j' with j = n - blocks_first, j' = j < k ? j : j + 1.
+ * negative_samples = f(x_left, x_right), negative_samples_back = f(x_right, x_left) (:131-132). */
+int vqcpc_same_sequence_negatives(const int64_t* first, const int64_t* second, int64_t* out, int64_t B, int blocks_first,
+                                  int blocks_second, int tokens_per_block, void* stream);
 int vqcpc_softmax_ce(const float* logits, int64_t ld, const int64_t* target, const float* target_logits, int64_t ldt,
                      float* loss, float* grad, int64_t R, int V, void* stream);
 int vqcpc_scale_rows(const float* in, const float* g, float* out, int64_t R, int V, void* stream);

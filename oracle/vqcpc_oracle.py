@@ -142,6 +142,19 @@ def synthetic_batch(cfg, seed=1234, B=None):
     }
 
 
+def same_sequence_negatives(first, second, ticks_per_block=4):
+    """BachCPCDataloaderGenerator._build_negatives_sameSeq (dataloaders/bach_cpc_dataloader.py:163-181) in the batch-dict
+    layout (ticks, voices): for every target block k of `second`, every block of `first` followed by the blocks of
+    `second` except k.  first (B, Ta, V), second (B, Tb, V) -> (B, Ka + Kb - 1, Kb, ticks_per_block, V).
+    negative_samples = f(x_left, x_right); negative_samples_back = f(x_right, x_left) (:131-132)."""
+    B, Ta, V = first.shape
+    a = first.reshape(B, Ta // ticks_per_block, ticks_per_block, V)
+    b = second.reshape(B, second.shape[1] // ticks_per_block, ticks_per_block, V)
+    Kb = b.shape[1]
+    cols = [torch.cat([a, b[:, :k], b[:, k + 1:]], dim=1) for k in range(Kb)]      # each (B, N, tpb, V)
+    return torch.stack(cols, dim=2)
+
+
 # -----------------------------------------------------------------------------------------------
 # A1/A2: blocks and embedding
 # -----------------------------------------------------------------------------------------------

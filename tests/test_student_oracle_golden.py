@@ -131,3 +131,22 @@ def test_c3_configuration_matches_the_reference_config_file():
     assert (cfg['ticks'], cfg['d'], cfg['H'], cfg['ff']) == (96, 512, 8, 2048)
     assert cfg['enc_layers'] == [4, 4] and cfg['dec_layers'] == [4, 4] and cfg['teacher_layers'] == 8
     assert (cfg['K'], cfg['D'], cfg['ncb'], cfg['B'], cfg['qw'], cfg['num_events_masked']) == (32, 3, 1, 8, 0.1, 4)
+
+
+@pytest.mark.parametrize('name', ['negatives_same_seq', 'negatives_same_seq_uneven'])
+def test_same_sequence_negatives_restatement(name):
+    """oracle restatement of _build_negatives_sameSeq against the reference's own output."""
+    g = load_golden(name)
+    xl, xr = T(g['x_left']), T(g['x_right'])
+    neg = O.same_sequence_negatives(xl, xr)
+    assert neg.dtype == torch.int64 and torch.equal(neg, T(g['negative_samples']))
+    Kl, Kr = xl.shape[1] // 4, xr.shape[1] // 4
+    assert neg.shape == (xl.shape[0], Kl + Kr - 1, Kr, 4, 4)
+    if 'negative_samples_back' in g:
+        assert torch.equal(O.same_sequence_negatives(xr, xl), T(g['negative_samples_back']))
+    # a window never contains its own target block among the negatives of that target
+    blocks_r = xr.reshape(xr.shape[0], Kr, 4, 4)
+    for k in range(Kr):
+        tail = neg[:, Kl:, k]                              # the Kr - 1 blocks taken from x_right
+        others = torch.cat([blocks_r[:, :k], blocks_r[:, k + 1:]], dim=1)
+        assert torch.equal(tail, others)

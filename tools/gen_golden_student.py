@@ -165,7 +165,29 @@ def gen_ce(name, seed):
     save(name, **arrays)
 
 
+def gen_same_sequence(name, B, Kl, Kr, seed):
+    """_build_negatives_sameSeq through the reference's own method (unbound, on a stand-in `self`), inputs and outputs in
+    the batch-dict layout the dataloader yields (bach_cpc_dataloader.py:133-139)."""
+    import types
+    import VQCPCB.dataloaders.bach_cpc_dataloader as dl
+    g = torch.Generator().manual_seed(seed)
+    nv, tpb = dl.num_voices, 16
+    p = torch.randint(0, 50, (B, nv, (Kl + Kr) * tpb // nv), generator=g)        # (batch, voices, ticks) as the dataset yields
+    fake = types.SimpleNamespace(num_blocks_right=Kr, num_blocks_left=Kl, num_tokens_per_block=tpb)
+    x_left, x_right = p[:, :, :Kl * tpb // nv], p[:, :, Kl * tpb // nv:]
+    N = Kl + Kr - 1
+    neg = dl.BachCPCDataloaderGenerator._build_negatives_sameSeq(fake, x_left, x_right, B, N)
+    arrays = dict(x_left=npy(x_left.transpose(1, 2)), x_right=npy(x_right.transpose(1, 2)),
+                  negative_samples=npy(neg.transpose(3, 4)))
+    if Kl == Kr:        # the reference's backward direction only works for equal block counts
+        back = dl.BachCPCDataloaderGenerator._build_negatives_sameSeq(fake, x_right, x_left, B, N)
+        arrays['negative_samples_back'] = npy(back.transpose(3, 4))
+    save(name, **arrays)
+
+
 if __name__ == '__main__':
+    gen_same_sequence('negatives_same_seq', B=3, Kl=3, Kr=3, seed=70)
+    gen_same_sequence('negatives_same_seq_uneven', B=2, Kl=4, Kr=2, seed=71)
     base.gen_relbias('relbias_L24', n=2, H=2, L=24, hd=8, seed=12)
     gen_ce('student_ce', seed=50)
     tiny = dict(emb=8, vocab=[11, 9, 12, 10], ticks=16, d=32, H=2, ff=64, enc_layers=[1, 1], factors=[4, 4], pos=8, D=3,

@@ -103,6 +103,34 @@ __global__ __launch_bounds__(256) void upscale_bwd_kernel(const float* __restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 'same_sequence' negatives (bach_cpc_dataloader.py:110-181 _build_negatives_sameSeq):
+// for target block k of `second`, the negatives are every block of `first` followed by the blocks of `second` except k.
+//   first (B, Ka*ev, V), second (B, Kb*ev, V) int64 tokens (ticks x voices)  ->  out (B, Ka+Kb-1, Kb, ev, V)
+__global__ __launch_bounds__(256) void same_seq_negatives_kernel(const int64_t* __restrict__ first,
+                                                                 const int64_t* __restrict__ second,
+                                                                 int64_t* __restrict__ out, int64_t B, int Ka, int Kb,
+                                                                 int blk) {
+    const int N = Ka + Kb - 1;
+    const int64_t total = B * N * Kb * blk;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int t = (int)(e % blk);                       // token inside the block (tick-major, voice fastest)
+        int64_t r = e / blk;
+        const int k = (int)(r % Kb);
+        r /= Kb;
+        const int n = (int)(r % N);
+        const int64_t b = r / N;
+        int64_t v;
+        if (n < Ka) {
+            v = first[(b * Ka + n) * blk + t];
+        } else {
+            const int j = n - Ka;
+            v = second[(b * Kb + (j < k ? j : j + 1)) * blk + t];
+        }
+        out[e] = v;
+    }
+}
+
 }  // namespace vq
 
 using namespace vq;
@@ -118,6 +146,20 @@ int vqcpc_softmax_ce(const float* logits, int64_t ld, const int64_t* target, con
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld,
                        target, target_logits, ldt, loss, grad, R, V);
     VQ_CHECK_LAUNCH("softmax_ce");
+    return VQCPC_OK;
+}
+
+int vqcpc_same_sequence_negatives(const int64_t* first, const int64_t* second, int64_t* out, int64_t B, int blocks_first,
+                                  int blocks_second, int tokens_per_block, void* stream) {
+    VQ_REQUIRE(first && second && out && B >= 0 && blocks_first >= 0 && blocks_second >= 1 && tokens_per_block >= 1 &&
+                   blocks_first + blocks_second >= 2,
+               "same_sequence_negatives: bad arguments");
+    const int64_t total = B * (blocks_first + blocks_second - 1) * blocks_second * tokens_per_block;
+    if (total == 0) return VQCPC_OK;
+    const int grid = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
+    hipLaunchKernelGGL(same_seq_negatives_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, first, second, out, B,
+                       blocks_first, blocks_second, tokens_per_block);
+    VQ_CHECK_LAUNCH("same_sequence_negatives");
     return VQCPC_OK;
 }
 

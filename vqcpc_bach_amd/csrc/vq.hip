@@ -59,6 +59,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_fwd_kernel(const float* __restr
             }
         }
         if (assign) idx_out[r * ncb + c] = (int64_t)bi;
+        if (!zq_out) continue;                                      // index-only (inference) mode
         const float* q = lds + bi * dsub;
         for (int t = 0; t < dsub; ++t) {
             const float xv = DSUB > 0 ? zr[c * dsub + t] : zr[c * dsub + t];
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(kVqThreads) void vq_fwd_kernel(const float* __restr
             lsum = __fadd_rn(lsum, __fmul_rn(v, v));
         }
     }
-    if (live) {
+    if (live && loss_out) {
         const float l = squared ? lsum : sqrtf(lsum);
         loss_out[r] = __fadd_rn(l, __fmul_rn(beta, l));             // q_latent + commitment_cost * e_latent
     }
@@ -147,7 +148,8 @@ extern "C" {
 
 int vqcpc_vq_fwd(const float* z, const float* codebooks, int64_t R, int ncb, int K, int dsub, float beta, int squared,
                  int assign, int64_t* idx, float* zq_sg, float* loss, void* stream) {
-    VQ_REQUIRE(z && codebooks && idx && zq_sg && loss, "vq_fwd: null pointer");
+    VQ_REQUIRE(z && codebooks && idx && ((zq_sg != nullptr) == (loss != nullptr)), "vq_fwd: null pointer");
+    VQ_REQUIRE(zq_sg || assign, "vq_fwd: index-only mode (zq_sg == loss == NULL) needs assign = 1");
     VQ_REQUIRE(R >= 0 && ncb >= 1 && K >= 1 && dsub >= 1, "vq_fwd: bad shape R=%lld ncb=%d K=%d dsub=%d", (long long)R, ncb,
                K, dsub);
     VQ_REQUIRE((int64_t)K * dsub <= kVqLdsFloats, "vq_fwd: codebook of %d x %d floats does not fit the LDS", K, dsub);

@@ -22,6 +22,8 @@ class SyntheticCPCDataloaderGenerator:
         self.num_tokens_per_block = num_tokens_per_block
         self.num_blocks_left, self.num_blocks_right = num_blocks_left, num_blocks_right
         self.negative_sampling_method = negative_sampling_method
+        if negative_sampling_method == 'same_sequence':
+            num_negative_samples = num_blocks_left + num_blocks_right - 1
         self.num_negative_samples = num_negative_samples
         self.num_channels = len(vocab)
         self.vocab = list(vocab)
@@ -30,7 +32,27 @@ class SyntheticCPCDataloaderGenerator:
         self.dataset_positive = _Dataset(vocab, sequences_size, 4)     # read by getters.get_data_processor
         self.dataset = self.dataset_positive
 
+    def _batch_same_sequence(self, batch_size, gen):
+        """negative_sampling_method == 'same_sequence' (bach_cpc_dataloader.py:110-181): the negatives of a window are
+        the other blocks of the SAME window; built on the device by vqcpc_same_sequence_negatives (a gather), so only the
+        (B, (Kl+Kr)*4, 4) positives cross PCIe.  As in the reference, num_negative_samples is ignored: N = Kl + Kr - 1."""
+        from .. import ops
+        assert self.device is not None and torch.device(self.device).type == 'cuda', \
+            'same_sequence negatives are constructed on the device'
+        V = self.vocab[0]
+        Kl, Kr = self.num_blocks_left, self.num_blocks_right
+        p = torch.randint(0, V, (batch_size, (Kl + Kr) * 4, 4), generator=gen).to(self.device)
+        x_left, x_right = p[:, :Kl * 4].contiguous(), p[:, Kl * 4:].contiguous()
+        out = {'x_left': x_left, 'x_right': x_right,
+               'negative_samples': ops.same_sequence_negatives(x_left, x_right)}
+        if Kl == Kr:       # the reference's backward direction needs equal block counts (:132, loop over num_blocks_right)
+            out['negative_samples_back'] = ops.same_sequence_negatives(x_right, x_left)
+        return out
+
     def batch(self, batch_size, gen):
+        if self.negative_sampling_method == 'same_sequence':
+            return self._batch_same_sequence(batch_size, gen)
+        assert self.negative_sampling_method == 'random', self.negative_sampling_method
         V, N = self.vocab[0], self.num_negative_samples
         Kl, Kr = self.num_blocks_left, self.num_blocks_right
         out = {

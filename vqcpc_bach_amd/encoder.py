@@ -88,6 +88,23 @@ class Encoder(nn.Module):
             zq = self.upscaler(zq)
         return zq, idx, ql
 
+    @torch.no_grad()
+    def encode_indices(self, x, merged=False):
+        """Inference path (what decoders/decoder.py:327-336 and the cluster tools encoder.py:137-159 consume): token
+        tensor (batch, ticks, voices) -> encoding_indices (batch, nb, num_codebooks) int64 [or merged codes
+        (batch, nb)], without materialising the straight-through output, the loss or the upscaler.  Uses the modules'
+        current train/eval mode for dropout like `forward` does; call `.eval()` first for deterministic codes."""
+        tpb = self.downscaler.sequence_length
+        t = self.data_processor.preprocess(x)
+        t = t if t.shape[-1] == tpb else t.reshape(t.shape[0], -1, tpb)
+        z = self.downscaler.forward_tokens(t.unsqueeze(0), self.data_processor)[0]             # (batch, nb, D)
+        q = self.quantizer
+        assert not q.initialize, 'the codebooks are still waiting for their data-dependent initialisation'
+        from . import ops
+        idx = ops.vq_assign(z.reshape(-1, z.shape[-1]), torch.stack(list(q.embeddings), dim=0))
+        idx = idx.view(z.shape[0], z.shape[1], -1)
+        return self.merge_codes(idx) if merged else idx
+
     def merge_codes(self, codes):
         """sum_c codes[..., c] * codebook_size**c  (encoder.py:97-110, without its aliasing `+=`)."""
         ret = codes[..., 0].clone()

@@ -301,6 +301,18 @@ class VQFn(torch.autograd.Function):
         return dz, dcb, None, None, None
 
 
+def vq_assign(z, codebooks):
+    """Index-only product-VQ assignment (no straight-through output, no loss): z (R, D) -> (R, ncb) int64."""
+    z = _f32(z).contiguous()
+    codebooks = _f32(codebooks).contiguous()
+    R, D = z.shape
+    ncb, K, dsub = codebooks.shape
+    assert ncb * dsub == D
+    idx = torch.empty(R, ncb, dtype=torch.int64, device=z.device)
+    hip.call('vqcpc_vq_fwd', z, codebooks, R, ncb, K, dsub, 0.0, 1, 1, idx, None, None)
+    return idx
+
+
 class DropoutSeluFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, h, p, seed):
@@ -358,6 +370,20 @@ class NCEFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------------
 # A23 (student step): cross-entropy rows and the auxiliary decoder's upscale
 # ------------------------------------------------------------------------------------------------------------------
+def same_sequence_negatives(first, second, ticks_per_block=4):
+    """first (B, Ta, V), second (B, Tb, V) int64 device tokens -> (B, Ka + Kb - 1, Kb, ticks_per_block, V): for every
+    target block k of `second`, all blocks of `first` then the blocks of `second` except k."""
+    assert first.dtype == torch.int64 and second.dtype == torch.int64 and first.is_cuda and second.is_cuda
+    first, second = first.contiguous(), second.contiguous()
+    B, Ta, V = first.shape
+    Tb = second.shape[1]
+    assert Ta % ticks_per_block == 0 and Tb % ticks_per_block == 0 and second.shape[0] == B and second.shape[2] == V
+    Ka, Kb = Ta // ticks_per_block, Tb // ticks_per_block
+    out = torch.empty(B, Ka + Kb - 1, Kb, ticks_per_block, V, dtype=torch.int64, device=first.device)
+    hip.call('vqcpc_same_sequence_negatives', first, second, out, B, Ka, Kb, ticks_per_block * V)
+    return out
+
+
 class SoftmaxCEFn(torch.autograd.Function):
     """Rows of softmax cross-entropy against hard targets (int64 (R,)) or soft targets given as logits ((R, V), no
     gradient flows into them: the reference detaches the teacher, student_encoder_trainer.py:197-198)."""

@@ -78,6 +78,17 @@ class StudentEncoderTrainer(EncoderTrainer):
         self.optimizer_enc_dec = (adam(self.auxiliary_decoder), adam(self.encoder))
         self.scheduler_enc_dec = self.scheduler_teacher = self.lr_lambda if schedule_lr else None
         self.global_step = 0
+        st = getattr(self, '_resume_state', None)      # extension: Adam moments + schedule position survive a resume
+        if st is not None and st['m'].numel() == self.flat.numel:
+            for opt in (self.optimizer_teacher,) + self.optimizer_enc_dec:
+                opt.step_count = int(st['step'])
+            m, v = st['m'].to(dev), st['v'].to(dev)
+            for opt, mod in zip((self.optimizer_teacher,) + self.optimizer_enc_dec, self._modules_with_params()):
+                a, b = self.flat.range_of(mod)
+                opt.m.copy_(m[a:b])
+                opt.v.copy_(v[a:b])
+            self.global_step = int(st['global_step'])
+            self._resume_state = None
 
     def current_lr(self):
         return self.lr * (self.lr_lambda(self.global_step) if self.schedule_lr else 1.0)
@@ -97,6 +108,11 @@ class StudentEncoderTrainer(EncoderTrainer):
         self.encoder.save(early_stopped=early_stopped)
         torch.save(self.auxiliary_decoder.state_dict(), f'{model_dir}/decoder')
         torch.save(self.teacher.state_dict(), f'{model_dir}/teacher')
+        if self.optimizer_teacher is not None:      # extension: the reference drops optimiser state on resume
+            opts = (self.optimizer_teacher,) + self.optimizer_enc_dec
+            torch.save(dict(m=torch.cat([o.m for o in opts]), v=torch.cat([o.v for o in opts]),
+                            step=self.optimizer_teacher.step_count, global_step=self.global_step),
+                       f'{model_dir}/optimizer')
 
     def load(self, early_stopped, device):
         print(f'Loading models {self.__repr__()}')
@@ -106,6 +122,8 @@ class StudentEncoderTrainer(EncoderTrainer):
         self.encoder.load(early_stopped=early_stopped, device=device)
         self.auxiliary_decoder.load_state_dict(torch.load(f'{model_dir}/decoder', map_location=ml))
         self.teacher.load_state_dict(torch.load(f'{model_dir}/teacher', map_location=ml))
+        opt = f'{model_dir}/optimizer'
+        self._resume_state = torch.load(opt, map_location=ml) if os.path.exists(opt) else None
 
     def train(self, mode=True):
         for m in self._modules_with_params():

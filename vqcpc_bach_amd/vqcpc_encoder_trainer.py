@@ -85,6 +85,22 @@ class VQCPCEncoderTrainer(EncoderTrainer):
         self.optimizer = ops.FlatAdam(self.flat.flat, self.flat.flat_grad, lr=lr, max_norm=5.0)
         self.scheduler = self.lr_lambda if schedule_lr else None
         self.global_step = 0
+        self._apply_resume_state()
+
+    def _apply_resume_state(self):
+        """Extension over the reference (which restarts Adam and the LR schedule on every resume):
+        `save` writes `optimizer`; `load` stashes it; it is applied here once the flat buffers exist."""
+        st = getattr(self, '_resume_state', None)
+        if st is None:
+            return
+        if st['m'].numel() != self.optimizer.m.numel():
+            print('optimizer state ignored: parameter count differs from the checkpoint')
+            return
+        self.optimizer.m.copy_(st['m'])
+        self.optimizer.v.copy_(st['v'])
+        self.optimizer.step_count = int(st['step'])
+        self.global_step = int(st['global_step'])
+        self._resume_state = None
 
     def current_lr(self):
         return self.lr * (self.lr_lambda(self.global_step) if self.schedule_lr else 1.0)
@@ -123,6 +139,8 @@ class VQCPCEncoderTrainer(EncoderTrainer):
         if self.c_module_back is not None:
             self.c_module_back.load_state_dict(torch.load(f'{model_dir}/c_module_back', map_location=ml))
             self.fks_module_back.load_state_dict(torch.load(f'{model_dir}/fks_module_back', map_location=ml))
+        opt = f'{model_dir}/optimizer'
+        self._resume_state = torch.load(opt, map_location=ml) if os.path.exists(opt) else None
 
     def train(self, mode=True):
         for m in self._modules_with_params():

@@ -204,6 +204,21 @@ int vqcpc_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr,
                     int step, float grad_scale, float max_norm, const double* sumsq, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * GRU cell of the CPC context network (CModule.forward, vqcpc_helper.py:54-76: nn.GRU, gate order r | z | n, h0 = 0,
+ * dropout on the outputs of every layer but the last).  gi = x W_ih^T + b_ih and gh = h_prev W_hh^T + b_hh come from
+ * vqcpc_gemm_nt; these entry points do the gate arithmetic.  gi, gh [B][3H]; h_prev (NULL = zeros), h_out, y_out [B][H];
+ *   r = sigmoid(gi_r + gh_r), u = sigmoid(gi_z + gh_z), n = tanh(gi_n + r gh_n), h_out = (1 - u) n + u h_prev,
+ *   y_out (nullable) = dropout(h_out), element index = idx_base + b*H + c.
+ * bwd: dh = d_y * mask (nullable) + d_h (nullable); writes d_gi, d_gh [B][3H] and d_hprev = dh * u (the recurrent part
+ * d_gh . W_hh is a vqcpc_gemm_nt with this tensor as its `add` operand).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_gru_cell_fwd(const float* gi, const float* gh, const float* h_prev, float* h_out, float* y_out, int64_t B, int H,
+                       float drop_p, uint64_t seed, uint64_t idx_base, void* stream);
+int vqcpc_gru_cell_bwd(const float* gi, const float* gh, const float* h_prev, const float* d_y, const float* d_h, float* d_gi,
+                       float* d_gh, float* d_hprev, int64_t B, int H, float drop_p, uint64_t seed, uint64_t idx_base,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Student (distilled VQ-VAE) step, SURVEY.md section 8 row A23.
  *
  * vqcpc_softmax_ce: one row = one (batch row, masked event, channel) logit vector.

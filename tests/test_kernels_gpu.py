@@ -531,6 +531,66 @@ def test_nce_golden(ops):
     assert torch.equal(hits.mean(0).cpu(), T(g['acc']))
 
 
+@pytest.mark.parametrize('B,T,inp,hid,layers,p', [(5, 3, 8, 12, 2, 0.0), (256, 8, 32, 512, 2, 0.0), (7, 1, 16, 32, 1, 0.0),
+                                                  (33, 4, 32, 64, 3, 0.3)])
+def test_gru_context_network(ops, B, T, inp, hid, layers, p):
+    """CModule on the library's own GRU (GEMMs + gate kernels) against the oracle's explicit recurrence, forward and
+    every gradient; with p > 0 the inter-layer dropout masks are reproduced through vqcpc_dropout_mask."""
+    from vqcpc_bach_amd.utils import SEEDS
+    from vqcpc_bach_amd.vqcpc_helper import CModule
+    gen = torch.Generator().manual_seed(B + T + hid)
+    cm = CModule(input_dim=inp, hidden_size=hid, output_dim=6, num_layers=layers, dropout=p)
+    P = {'c.' + k: v.detach().clone().requires_grad_(True) for k, v in cm.state_dict().items()}
+    zs = torch.randn(B, T, inp, generator=gen)
+    gout = torch.randn(B, 6, generator=gen)
+    SEEDS.manual_seed(4321)
+    seeds = []
+    if p > 0:                         # one seed per layer but the last, drawn in forward order
+        probe = type(SEEDS)(4321)
+        seeds = [probe.next() for _ in range(layers - 1)]
+
+    # oracle with the kernel's masks: layer l output (B, T, hid) is dropped with index (t*B + b)*hid + c
+    class MaskGen:
+        def __init__(self):
+            self.l = 0
+    def oracle_forward(zs_):
+        x = zs_
+        for l in range(layers):
+            w_ih, w_hh = P[f'c.g_ar_fwd.weight_ih_l{l}'], P[f'c.g_ar_fwd.weight_hh_l{l}']
+            b_ih, b_hh = P[f'c.g_ar_fwd.bias_ih_l{l}'], P[f'c.g_ar_fwd.bias_hh_l{l}']
+            h = torch.zeros(B, hid)
+            outs = []
+            for t in range(T):
+                gi = O.linear(x[:, t], w_ih, b_ih)
+                gh = O.linear(h, w_hh, b_hh)
+                r = torch.sigmoid(gi[:, :hid] + gh[:, :hid])
+                u = torch.sigmoid(gi[:, hid:2 * hid] + gh[:, hid:2 * hid])
+                n = torch.tanh(gi[:, 2 * hid:] + r * gh[:, 2 * hid:])
+                h = (1 - u) * n + u * h
+                outs.append(h)
+            x = torch.stack(outs, dim=1)
+            if l < layers - 1 and p > 0:
+                mask = ops.dropout_mask(T * B * hid, p, seeds[l], 'cuda').cpu().view(T, B, hid).transpose(0, 1) / (1 - p)
+                x = x * mask
+        return O.linear(x[:, -1], P['c.output_linear.weight'], P['c.output_linear.bias'])
+
+    ref = oracle_forward(zs.clone().requires_grad_(True))
+    zr = zs.clone().requires_grad_(True)
+    ref = oracle_forward(zr)
+    (ref * gout).sum().backward()
+    if p == 0.0:                      # and the oracle's own packaged version agrees
+        assert rel_err(O.gru_context(zs, {k: v.detach() for k, v in P.items()}, 'c.', layers), ref.detach()) < 1e-6
+
+    cm = cm.cuda().train()
+    zd = zs.clone().cuda().requires_grad_(True)
+    out = cm(zd, None)
+    assert rel_err(out.cpu(), ref.detach()) < FWD_TOL
+    (out * gout.cuda()).sum().backward()
+    assert rel_err(zd.grad.cpu(), zr.grad) < GRAD_TOL
+    for n_, prm in cm.named_parameters():
+        assert rel_err(prm.grad.cpu(), P['c.' + n_].grad) < GRAD_TOL, n_
+
+
 @pytest.mark.parametrize('p', [0.0, 0.25])
 def test_dropout_selu(ops, p):
     gen = torch.Generator().manual_seed(11)

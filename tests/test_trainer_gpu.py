@@ -178,8 +178,8 @@ def test_dropout_training_step_runs_and_is_reproducible():
     for _ in range(2):
         torch.manual_seed(0)
         SEEDS.manual_seed(77)
-        # the GRU's inter-layer dropout is MIOpen's (stateful, cached per device): keep it off for this check
-        tr = build_trainer(cfg, sd, lr=1e-3, dropout=0.2, c_dropout=0.0)
+        # every dropout site (attention, residuals, FFN, upscaler, GRU inter-layer) draws from the counter RNG
+        tr = build_trainer(cfg, sd, lr=1e-3, dropout=0.2)
         m = tr.epoch(iter([batch, batch]), train=True, num_batches=2, corrupt_labels=False)
         losses.append(m['loss'])
         assert np.isfinite(m['loss'])

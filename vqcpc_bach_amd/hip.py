@@ -63,6 +63,9 @@ SIGNATURES = {
     'vqcpc_sumsq': (c_int, [c_ptr, c_i64, c_f32, c_ptr, c_ptr, c_i64, c_ptr]),
     'vqcpc_adam_step': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_f32, c_f32, c_f32, c_f32, c_int, c_f32, c_f32, c_ptr,
                                 c_ptr]),
+    'vqcpc_gru_cell_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64, c_ptr]),
+    'vqcpc_gru_cell_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64,
+                                   c_ptr]),
     'vqcpc_same_sequence_negatives': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr]),
     'vqcpc_softmax_ce': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'vqcpc_scale_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),

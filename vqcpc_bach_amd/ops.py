@@ -333,6 +333,60 @@ class DropoutSeluFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# A15: GRU layer of the context network (time-major rows: row = t * B + b)
+# ------------------------------------------------------------------------------------------------------------------
+class GRULayerFn(torch.autograd.Function):
+    """One nn.GRU layer with h0 = 0.  x (T*B, in) time-major -> y: all steps (T*B, H) with dropout(p) applied
+    (last_only = False, feeds the next layer) or the last step only (B, H) (last_only = True, top layer).
+    Input projections of all steps are ONE GEMM; every step is a (B, H) x (H, 3H) GEMM + the gate kernel.  Backward
+    walks the steps in reverse (gate kernel + one GEMM with the direct d h_prev term in its `add` epilogue) and ends
+    with two TN GEMMs over all steps for the weight / bias gradients."""
+
+    @staticmethod
+    def forward(ctx, x, w_ih, w_hh, b_ih, b_hh, T, drop_p, seed, last_only):
+        x = _f32(x).contiguous()
+        TB, _ = x.shape
+        B, H = TB // T, w_hh.shape[1]
+        dev = x.device
+        p = 0.0 if last_only else float(drop_p)
+        gi = gemm_nt(x, w_ih, bias=b_ih)                                     # (T*B, 3H)
+        gh = torch.empty(TB, 3 * H, dtype=torch.float32, device=dev)
+        h = torch.empty(TB + B, H, dtype=torch.float32, device=dev)          # rows [t*B, (t+1)*B) = h_{t-1}; h_{-1} = 0
+        h[:B].zero_()
+        y = None if last_only else torch.empty(TB, H, dtype=torch.float32, device=dev)
+        for t in range(T):
+            sl = slice(t * B, (t + 1) * B)
+            gemm_nt(h[sl], w_hh, bias=b_hh, out=gh[sl])
+            hip.call('vqcpc_gru_cell_fwd', gi[sl], gh[sl], h[sl], h[(t + 1) * B:(t + 2) * B],
+                     None if y is None else y[sl], B, H, p, int(seed), t * B * H)
+        ctx.save_for_backward(x, w_ih, w_hh, gi, gh, h)
+        ctx.meta = (T, B, H, p, int(seed), bool(last_only))
+        return h[T * B:].clone() if last_only else y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w_ih, w_hh, gi, gh, h = ctx.saved_tensors
+        T, B, H, p, seed, last_only = ctx.meta
+        dev = x.device
+        g = g.contiguous()
+        dgi = torch.empty_like(gi)
+        dgh = torch.empty_like(gh)
+        whh_t = transpose(w_hh)                                              # (H, 3H): dgrad operand
+        dh = None
+        dhp = torch.empty(B, H, dtype=torch.float32, device=dev)
+        for t in range(T - 1, -1, -1):
+            sl = slice(t * B, (t + 1) * B)
+            d_y = (g if t == T - 1 else None) if last_only else g[sl]
+            hip.call('vqcpc_gru_cell_bwd', gi[sl], gh[sl], h[sl], d_y, dh, dgi[sl], dgh[sl], dhp, B, H, p, seed, t * B * H)
+            if t > 0:
+                dh = gemm_nt(dgh[sl], whh_t, add=dhp)                        # d h_{t-1} = dgh W_hh + dh * u
+        dw_hh, db_hh = gemm_tn(dgh, h[:T * B])                               # step 0 multiplies the zero rows h_{-1}
+        dw_ih, db_ih = gemm_tn(dgi, x)
+        dx = gemm_nt(dgi, transpose(w_ih)) if ctx.needs_input_grad[0] else None
+        return dx, dw_ih, dw_hh, db_ih, db_hh, None, None, None, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # A16/A17: bilinear scores + InfoNCE + hits
 # ------------------------------------------------------------------------------------------------------------------
 class NCEFn(torch.autograd.Function):

@@ -1,10 +1,9 @@
 """CPC heads (reference: VQCPCB/vqcpc_helper.py:5-98)."""
-import warnings
-
 import torch
 import torch.nn as nn
 
 from . import ops
+from .utils import SEEDS
 
 
 def nce_loss(positive, negatives):
@@ -31,22 +30,32 @@ def cpc_scores_and_loss(fks_module, c, z_pos, z_neg):
 
 
 class CModule(nn.Module):
-    """Autoregressive context network: 2-layer GRU, last step, Linear (:54-76).  The GRU recurrence (0.1 % of the step,
-    SURVEY.md section 2.1) stays on PyTorch-ROCm's MIOpen RNN; the projection goes through the MFMA GEMM."""
+    """Autoregressive context network: multi-layer GRU, last step, Linear (:54-76).  `g_ar_fwd` is kept as the
+    parameter container (state_dict keys `g_ar_fwd.weight_ih_l0`, ... of the reference's checkpoints); the recurrence
+    itself runs on this library: one GEMM for the input projections of all steps, one GEMM + one gate kernel per step
+    (ops.GRULayerFn), dropout between layers from the shared counter RNG (reproducible, unlike MIOpen's stateful one)."""
 
     def __init__(self, input_dim, hidden_size, output_dim, num_layers, dropout):
         super().__init__()
         self.g_ar_fwd = torch.nn.GRU(input_size=input_dim, hidden_size=hidden_size, num_layers=num_layers, bias=True,
                                      batch_first=True, dropout=dropout, bidirectional=False)
         self.output_linear = nn.Linear(hidden_size, output_dim)
+        self.num_layers = num_layers
+        self.p = dropout
 
     def forward(self, zs, h):
-        with warnings.catch_warnings():
-            # the GRU weights are views into the trainer's flat parameter buffer (one all-reduce / one Adam launch);
-            # MIOpen then packs them per call (a few MB) and PyTorch warns about it on every forward
-            warnings.filterwarnings('ignore', message='RNN module weights are not part of single contiguous chunk')
-            c, h = self.g_ar_fwd(zs, h)
-        return ops.linear(c[:, -1], self.output_linear.weight, self.output_linear.bias)
+        """zs (B, T, input_dim), h must be None (the path always starts from h0 = 0, vqcpc_encoder_trainer.py:251)."""
+        assert h is None, 'the CPC step starts the context network from h0 = 0'
+        B, T, _ = zs.shape
+        x = zs.transpose(0, 1).reshape(T * B, -1)                            # time-major rows
+        g = self.g_ar_fwd
+        p = self.p if self.training else 0.0
+        for l in range(self.num_layers):
+            last = l == self.num_layers - 1
+            x = ops.GRULayerFn.apply(x, getattr(g, f'weight_ih_l{l}'), getattr(g, f'weight_hh_l{l}'),
+                                     getattr(g, f'bias_ih_l{l}'), getattr(g, f'bias_hh_l{l}'), T, p,
+                                     SEEDS.next() if (p > 0 and not last) else 0, last)
+        return ops.linear(x, self.output_linear.weight, self.output_linear.bias)
 
 
 class FksModule(nn.Module):

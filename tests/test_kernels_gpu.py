@@ -97,6 +97,35 @@ def test_gemm_nt_plain(ops, M, N, K):
     assert rel_err(out.cpu(), ref) < 2e-6 * max(1, K ** 0.5)
 
 
+@pytest.mark.parametrize('M,N,K,with_add', [(256, 1536, 512, False), (256, 512, 1536, True), (8, 56, 512, False),
+                                            (5, 33, 32, True), (1000, 40, 64, False), (32, 32, 4096, True)])
+@pytest.mark.parametrize('mode', [0, 1])
+def test_gemm_nt_skinny_shapes(ops, M, N, K, with_add, mode):
+    """Small-M products (GRU recurrence, per-event heads) take the wave-split-K 32x32 kernel: bias / add epilogues,
+    ragged edges, in-place add, both GEMM modes (it computes in exact fp32 MFMA either way)."""
+    from vqcpc_bach_amd import hip
+    hip.set_gemm_mode(mode)
+    try:
+        gen = torch.Generator().manual_seed(M + N + K)
+        a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+        add = torch.randn(M, N, generator=gen) if with_add else None
+        ref = a.double() @ b.double().t() + bias.double() + (add.double() if with_add else 0)
+        out = ops.gemm_nt(dev(a), dev(b), bias=dev(bias), add=dev(add) if with_add else None)
+        assert rel_err(out.cpu(), ref) < 2e-6 * max(1, K ** 0.5)
+        if with_add:                                       # C aliases add
+            buf = dev(add)
+            ops.gemm_nt(dev(a), dev(b), bias=dev(bias), add=buf, out=buf)
+            assert torch.equal(buf, out)
+        # strided A rows (every 3rd row of a taller matrix) and strided output
+        tall = torch.randn(3 * M, K, generator=gen)
+        wide = torch.zeros(M, N + 8, device='cuda')
+        ops.gemm_nt(dev(tall)[::3], dev(b), out=wide[:, 4:4 + N])
+        assert rel_err(wide[:, 4:4 + N].cpu(), tall[::3].double() @ b.double().t()) < 2e-6 * max(1, K ** 0.5)
+        assert float(wide[:, :4].abs().max()) == 0.0 and float(wide[:, 4 + N:].abs().max()) == 0.0
+    finally:
+        hip.set_gemm_mode(0)
+
+
 @pytest.fixture()
 def bf16x6(ops):
     from vqcpc_bach_amd import hip

@@ -915,6 +915,81 @@ static int tn_splits_256(int64_t M, int N, int K) {
     return (int)s;
 }
 
+// =====================================================================================================================
+// Skinny NT GEMM for latency-bound small-M products (GRU recurrence: M = batch = 256, the per-event output heads of the
+// student step: M = 8).  The 128 / 256 tiles give such shapes a handful of workgroups with long K loops (80-160 us);
+// here a workgroup owns ONE 32 x 32 output tile and its NW waves split K (wave w: [w K/NW, (w+1) K/NW)), the partial
+// tiles meet in LDS.  v_mfma_f32_32x32x2_f32 on fp32 operands in both GEMM modes (exact products).  The MFMA k index is
+// a summation index, so lane half g takes a contiguous K range of its operand row: A / B fragments are float4 loads
+// straight from global memory (both operands are K-contiguous in the NT layout), no LDS staging.
+template <int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(const float* __restrict__ A, int64_t lda,
+                                                                 const float* __restrict__ B, int64_t ldb,
+                                                                 float* __restrict__ C, int64_t ldc, int M, int N, int K,
+                                                                 const float* __restrict__ bias,
+                                                                 const float* __restrict__ add, int64_t ldadd) {
+    __shared__ float red[NW - 1][16][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 5, l31 = lane & 31;
+    const int i = blockIdx.y * 32 + l31, j = blockIdx.x * 32 + l31;
+    const int len = K / (2 * NW);                               // floats per lane half (multiple of 4)
+    const int k0 = (wave * 2 + g) * len;
+    const float* ap = A + (int64_t)min(i, M - 1) * lda + k0;
+    const float* bp = B + (int64_t)min(j, N - 1) * ldb + k0;
+    floatx16 acc = {0};
+    int kk = 0;
+    for (; kk + 16 <= len; kk += 16) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            a[v] = *reinterpret_cast<const float4*>(ap + kk + 4 * v);
+            b[v] = *reinterpret_cast<const float4*>(bp + kk + 4 * v);
+        }
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].x, b[v].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].y, b[v].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].z, b[v].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[v].w, b[v].w, acc, 0, 0, 0);
+        }
+    }
+    for (; kk < len; kk += 4) {
+        const float4 a = *reinterpret_cast<const float4*>(ap + kk);
+        const float4 b = *reinterpret_cast<const float4*>(bp + kk);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const int col = blockIdx.x * 32 + l31;
+        const float bv = (bias && col < N) ? bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float v = acc[r];
+#pragma unroll
+            for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];
+            const int row = blockIdx.y * 32 + (r & 3) + 8 * (r >> 2) + 4 * g;
+            if (row < M && col < N) {
+                v += bv;
+                if (add) v += add[(int64_t)row * ldadd + col];
+                C[(int64_t)row * ldc + col] = v;
+            }
+        }
+    }
+}
+
+static bool skinny_ok(int64_t M, int N, int K, int flags, int* nw) {
+    if (flags & ~(E_BIAS | E_ADD)) return false;
+    if (M > 1024 || ceil_div(M, BM) * ceil_div(N, BN) >= 128) return false;     // enough big tiles: use them
+    *nw = K >= 1024 ? 8 : 4;
+    return K % (8 * *nw) == 0;
+}
+
 }  // namespace vq
 
 using namespace vq;
@@ -956,6 +1031,18 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     const dim3 grid((unsigned)tiles), block(kGemmThreads);
     hipStream_t st = (hipStream_t)stream;
     const int mode = gemm_mode();
+    int nw = 0;
+    if (skinny_ok(M, N, K, flags, &nw)) {
+        const dim3 sgrid((unsigned)ceil_div(N, 32), (unsigned)ceil_div(M, 32));
+        if (nw == 8)
+            hipLaunchKernelGGL(gemm_nt_skinny_kernel<8>, sgrid, dim3(512), 0, st, A, lda, B, ldb, C, ldc, (int)M, N, K, bias, add,
+                               ldadd);
+        else
+            hipLaunchKernelGGL(gemm_nt_skinny_kernel<4>, sgrid, dim3(256), 0, st, A, lda, B, ldb, C, ldc, (int)M, N, K, bias, add,
+                               ldadd);
+        VQ_CHECK_LAUNCH("gemm_nt_skinny");
+        return VQCPC_OK;
+    }
     // bf16x6, full 256 x 256 tiles: the high-arithmetic-intensity kernel (one workgroup of 8 waves per CU)
     // the 256-tile kernel runs ONE workgroup per CU: pick it only when its last (partial) round of tiles does not waste
     // more than the ~8 % it gains per tile over the 128-tile kernel (2 workgroups per CU, 4x more tiles)

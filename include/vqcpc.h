@@ -63,6 +63,16 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
                         int pos, const float* g_out, float* d_table, float* d_chan, float* d_event, void* workspace,
                         int64_t workspace_bytes, void* stream);
 
+/* Block-table lookup of the first layer's QKV projection.  The input of the first encoder layer of a block has only
+ * vmax * L distinct rows (token id x position), so `in_proj(x)` (multihead_attention_custom.py:171) is computed once on
+ * those rows and looked up per token:  out[r][:] = table[tokens[r] * L + r % L][:],  table [vmax * L][C].
+ * segsum is its backward: d_table[t * L + p][:] = sum_{r: tokens[r] = t, r % L = p} g[r][:]  (deterministic). */
+int vqcpc_block_table_gather(const float* table, const int64_t* tokens, float* out, int64_t M, int L, int vmax, int C,
+                             void* stream);
+int64_t vqcpc_block_table_segsum_workspace(int64_t M, int L, int vmax, int C);
+int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
+                             void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32).  Replace every F.linear / nn.Linear on the path:
  * multihead_attention_custom.py:171,346 (in_proj / out_proj), transformer_custom.py:285 (linear1/linear2),

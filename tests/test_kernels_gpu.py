@@ -348,6 +348,27 @@ def test_embed_pos(ops, nblk, d, V):
     assert rel_err(ed.grad.cpu(), ec.grad) < GRAD_TOL
 
 
+@pytest.mark.parametrize('nblk,L,vmax,C', [(300, 16, 57, 768), (5000, 16, 57, 768), (33, 4, 12, 96), (1000, 16, 23, 260)])
+def test_block_table_gather_and_segment_sum(ops, nblk, L, vmax, C):
+    """First-layer QKV lookup: gather is exact; its backward (deterministic segment sum) matches index_add in fp64 and
+    is bit-reproducible run to run."""
+    gen = torch.Generator().manual_seed(nblk + C)
+    table = torch.randn(vmax * L, C, generator=gen)
+    tokens = torch.randint(0, vmax, (nblk * L,), generator=gen)
+    g = torch.randn(nblk * L, C, generator=gen)
+    ids = tokens * L + torch.arange(nblk * L) % L
+    td = dev(table).requires_grad_(True)
+    out = ops.BlockTableGatherFn.apply(td, tokens.cuda(), L)
+    assert torch.equal(out.cpu(), table[ids])
+    out.backward(dev(g))
+    ref = torch.zeros(vmax * L, C, dtype=torch.float64).index_add_(0, ids, g.double())
+    assert rel_err(td.grad.cpu(), ref) < 1e-6
+    first = td.grad.clone()
+    td.grad = None
+    ops.BlockTableGatherFn.apply(td, tokens.cuda(), L).backward(dev(g))
+    assert torch.equal(td.grad, first)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # relative attention
 # ----------------------------------------------------------------------------------------------------------------
@@ -495,7 +516,7 @@ def test_encoder_layer_query_stride_equals_full_then_select(ops, L, H, d, ff):
     (y_ref[:, ::4] * gy).sum().backward()
     params = [dev(sdl[k]).requires_grad_(True) for k in order]
     xd = dev(x.reshape(n * L, d)).requires_grad_(True)
-    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 4, *params)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 4, None, *params)
     assert y.shape == (n * L // 4, d)
     assert rel_err(y.detach().cpu(), y_ref.detach()[:, ::4].reshape(-1, d)) < FWD_TOL
     (y * dev(gy.reshape(-1, d))).sum().backward()
@@ -517,7 +538,7 @@ def test_encoder_layer_golden(ops, name, L):
     x = T(g['x']).transpose(0, 1).contiguous()                   # (n, L, d) block-major
     n, _, d = x.shape
     xd = dev(x.reshape(n * L, d)).requires_grad_(True)
-    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 1, *params)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 1, None, *params)
     y_ref = T(g['y']).transpose(0, 1).reshape(n * L, d)
     assert rel_err(y.detach().cpu(), y_ref) < FWD_TOL
     assert rel_err(probs.cpu(), g['attn']) < FWD_TOL

@@ -87,8 +87,19 @@ def test_encoder_forward_golden(name):
     assert rel_err(ql.cpu(), g['fwd_qloss']) < 2e-4
 
 
+@pytest.fixture(params=['plain_qkv', 'table_qkv'])
+def first_layer_path(request):
+    """The first layer's in_proj either as a GEMM over every token or as the block-table lookup (forced on here: the
+    fixtures are smaller than the size from which the product switches to it by itself)."""
+    from vqcpc_bach_amd.downscalers.relative_transformer_downscaler import RelativeTransformerDownscaler as D
+    old = D.table_lookup_min_ratio
+    D.table_lookup_min_ratio = 0 if request.param == 'table_qkv' else 10 ** 9
+    yield request.param
+    D.table_lookup_min_ratio = old
+
+
 @pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir', 'epoch_tiny_clip'])
-def test_epoch_golden(name):
+def test_epoch_golden(name, first_layer_path):
     """epoch(train=False), then one training step, against the reference's VQCPCEncoderTrainer.epoch."""
     g = load_golden(name)
     cfg, sd = golden_cfg_sd(g)

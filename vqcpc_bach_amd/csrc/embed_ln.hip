@@ -278,6 +278,64 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
 
 static int ln_blocks(int64_t M) { return (int)std::min<int64_t>(ceil_div(M, 4), 2048); }
 
+// =====================================================================================================================
+// Block-table gather / segment sum.  The input of the FIRST encoder layer takes only vmax * L distinct values (token id x
+// position in the block), so its QKV projection is a (vmax*L) x 3d table and the per-token product is a lookup:
+//   out[r][:] = table[tokens[r] * L + r % L][:]
+// and the weight gradient needs only the per-table-row sums of d out:
+//   d_table[t * L + p][:] = sum over rows r with tokens[r] == t and r % L == p of g[r][:]
+// (three M x 3d x d GEMMs -- forward, dgrad, wgrad -- become one gather, one segment sum and three (vmax*L)-row GEMMs).
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void block_table_gather_kernel(const float* __restrict__ table,
+                                                                 const int64_t* __restrict__ tokens,
+                                                                 float* __restrict__ out, int64_t M, int L, int C4) {
+    const int64_t total = M * C4;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = e / C4;
+        const int c = (int)(e - r * C4);
+        const int64_t id = tokens[r] * L + (r % L);
+        reinterpret_cast<float4*>(out)[e] = reinterpret_cast<const float4*>(table)[id * C4 + c];
+    }
+}
+
+// grid = (chunks, L, column tiles of 256).  Workgroup (chunk, p, ct): lane owns one column of an LDS accumulator
+// [vmax][256]; it walks the rows of position p of its chunk of blocks in ascending order, kSegU rows in flight -> the
+// read-modify-writes of a cell are ordered: deterministic, no atomics.  Partials ws[chunk][vmax][L][C].
+constexpr int kSegU = 16;
+
+__global__ __launch_bounds__(256) void block_table_segsum_kernel(const float* __restrict__ g,
+                                                                 const int64_t* __restrict__ tokens,
+                                                                 float* __restrict__ ws, int64_t n_blocks,
+                                                                 int blocks_per_chunk, int L, int vmax, int C) {
+    extern __shared__ __attribute__((aligned(16))) float acc[];          // [vmax][256]
+    for (int i = threadIdx.x; i < vmax * 256; i += 256) acc[i] = 0.0f;
+    __syncthreads();
+    const int p = blockIdx.y;
+    const int col = blockIdx.z * 256 + threadIdx.x;
+    const bool cok = col < C;
+    const int64_t b0 = (int64_t)blockIdx.x * blocks_per_chunk;
+    const int64_t b1 = min(b0 + blocks_per_chunk, n_blocks);
+    for (int64_t b = b0; b < b1; b += kSegU) {
+        float v[kSegU];
+        int tk[kSegU];
+#pragma unroll
+        for (int u = 0; u < kSegU; ++u) {
+            const int64_t row = (b + u) * L + p;
+            const bool ok = b + u < b1;
+            v[u] = (ok && cok) ? g[row * C + col] : 0.0f;
+            tk[u] = ok ? (int)tokens[row] : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < kSegU; ++u) acc[tk[u] * 256 + threadIdx.x] += v[u];
+    }
+    if (cok) {
+        float* dst = ws + (int64_t)blockIdx.x * vmax * L * C;
+        for (int t = 0; t < vmax; ++t) dst[((int64_t)t * L + p) * C + col] = acc[t * 256 + threadIdx.x];
+    }
+}
+
+static int segsum_chunks(int64_t n_blocks) { return (int)std::max<int64_t>(1, std::min<int64_t>(32, n_blocks / 256)); }
+
 }  // namespace vq
 
 using namespace vq;
@@ -332,6 +390,47 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
                        nchunks, n_voices, vmax, dlin, pos, nev, d_table, d_chan, d_event);
     VQ_CHECK_LAUNCH("embed_pos_bwd_reduce");
     return VQCPC_OK;
+}
+
+int vqcpc_block_table_gather(const float* table, const int64_t* tokens, float* out, int64_t M, int L, int vmax, int C,
+                             void* stream) {
+    VQ_REQUIRE(table && tokens && out && M >= 0 && L >= 1 && vmax >= 1 && C >= 4 && C % 4 == 0 && M % L == 0,
+               "block_table_gather: bad arguments");
+    VQ_REQUIRE(aligned16(table) && aligned16(out), "block_table_gather: buffers must be 16-byte aligned");
+    if (M == 0) return VQCPC_OK;
+    const int blocks = (int)std::min<int64_t>(ceil_div(M * (C / 4), 256), 16384);
+    hipLaunchKernelGGL(block_table_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, tokens, out, M, L,
+                       C / 4);
+    VQ_CHECK_LAUNCH("block_table_gather");
+    return VQCPC_OK;
+}
+
+int64_t vqcpc_block_table_segsum_workspace(int64_t M, int L, int vmax, int C) {
+    return (int64_t)segsum_chunks(std::max<int64_t>(M, 1) / std::max(L, 1)) * vmax * L * C * (int64_t)sizeof(float);
+}
+
+int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(g && tokens && d_table && workspace && M >= 1 && L >= 1 && vmax >= 1 && C >= 1 && M % L == 0,
+               "block_table_segsum: bad arguments");
+    const size_t lds = (size_t)vmax * 256 * sizeof(float);
+    VQ_REQUIRE(lds <= 160 * 1024, "block_table_segsum: vocabulary of %d tokens does not fit the LDS accumulator", vmax);
+    if (workspace_bytes < vqcpc_block_table_segsum_workspace(M, L, vmax, C)) {
+        set_error("block_table_segsum: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    const int64_t n_blocks = M / L;
+    const int chunks = segsum_chunks(n_blocks);
+    const int bpc = (int)ceil_div(n_blocks, chunks);
+    const int nchunk = (int)ceil_div(n_blocks, bpc);
+    hipStream_t s = (hipStream_t)stream;
+    if (lds > 64 * 1024)
+        (void)hipFuncSetAttribute((const void*)block_table_segsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(block_table_segsum_kernel, dim3(nchunk, L, (unsigned)ceil_div(C, 256)), dim3(256), lds, s, g, tokens,
+                       (float*)workspace, n_blocks, bpc, L, vmax, C);
+    VQ_CHECK_LAUNCH("block_table_segsum");
+    const int64_t total = (int64_t)vmax * L * C;
+    return launch_reduce_splits((const float*)workspace, total, nchunk, d_table, total, 0, s);
 }
 
 int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,

@@ -51,15 +51,18 @@ class RelativeTransformerDownscaler(Downscaler):
         self.transformers = nn.ModuleList(transformers)
 
     # ---- hot path ---------------------------------------------------------------------------------------------
-    def _stacks(self, x):
+    table_lookup_min_ratio = 4       # use the first-layer QKV table when tokens >= ratio * (vmax * L) table rows
+
+    def _stacks(self, x, first_qkv=None):
         """x (blocks * L0, d) -> (blocks, d): run the stacks, subsampling by stride between them."""
         L = self.sequence_length
         d = x.shape[1]
-        for transfo, factor in zip(self.transformers, self.downscale_factors):
+        for si, (transfo, factor) in enumerate(zip(self.transformers, self.downscale_factors)):
+            fq = first_qkv if si == 0 else None
             if _sub_supported(L, factor, self.d_model // transfo.layers[0].nhead):
-                x, _ = transfo.forward_rows(x, out_stride=factor)      # last layer only evaluates the kept rows
+                x, _ = transfo.forward_rows(x, out_stride=factor, first_qkv=fq)   # last layer only evaluates the kept rows
             else:
-                x, _ = transfo.forward_rows(x)
+                x, _ = transfo.forward_rows(x, first_qkv=fq)
                 x = x.view(-1, d)[::factor]      # keep positions 0, f, 2f, ... of every block: a row stride
             L //= factor
         assert L == 1
@@ -72,10 +75,30 @@ class RelativeTransformerDownscaler(Downscaler):
         tables = data_processor.stacked_tables()                                    # (nv, vmax, emb)
         # lookup(E_v)[tok] @ W_in^T + b  ==  lookup(E_v @ W_in^T + b)[tok]
         table = torch.matmul(tables, self.input_linear.weight.t()) + self.input_linear.bias
-        x = ops.EmbedPosFn.apply(tokens.reshape(-1).contiguous(), table, self.target_channel_embeddings.view(self.num_channels, -1),
-                                 self.events_positioning_embeddings.view(self.num_events, -1), self.sequence_length)
-        x = self._stacks(x)
+        flat_tokens = tokens.reshape(-1).contiguous()
+        chan = self.target_channel_embeddings.view(self.num_channels, -1)
+        event = self.events_positioning_embeddings.view(self.num_events, -1)
+        x = ops.EmbedPosFn.apply(flat_tokens, table, chan, event, self.sequence_length)
+        x = self._stacks(x, first_qkv=self._first_layer_qkv(flat_tokens, table, chan, event))
         return ops.linear(x, self.output_linear.weight, self.output_linear.bias).view(*lead, self.output_dim)
+
+    def _first_layer_qkv(self, flat_tokens, table, chan, event):
+        """in_proj of the FIRST layer as a block-table lookup: its input row depends only on (token id, position in the
+        block), i.e. vmax * L distinct rows, so the projection runs on those rows (a 912 x 768 x 256 GEMM at C1 instead of
+        557 056 x 768 x 256) and every token looks its row up; autograd sends the per-table-row sums of d qkv back through
+        the same small GEMM.  Not used when the first layer is also the query-subsampled last layer of its stack."""
+        stack = self.transformers[0]
+        if len(stack.layers) < 2 and _sub_supported(self.sequence_length, self.downscale_factors[0],
+                                                    self.d_model // stack.layers[0].nhead):
+            return None
+        L, vmax = self.sequence_length, table.shape[1]
+        if flat_tokens.numel() < self.table_lookup_min_ratio * vmax * L:    # tiny inputs: the plain projection is cheaper
+            return None
+        syn = torch.arange(vmax, device=flat_tokens.device).repeat_interleave(L)       # row t * L + p holds token t
+        x_table = ops.EmbedPosFn.apply(syn, table, chan, event, L)                     # (vmax * L, d)
+        attn = stack.layers[0].self_attn
+        qkv_table = ops.linear(x_table, attn.in_proj_weight, attn.in_proj_bias)        # (vmax * L, 3d)
+        return ops.BlockTableGatherFn.apply(qkv_table, flat_tokens, L)
 
     # ---- API-compatible path ----------------------------------------------------------------------------------
     def forward(self, embedded_seq):

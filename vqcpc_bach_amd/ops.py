@@ -105,6 +105,34 @@ class EmbedPosFn(torch.autograd.Function):
         return None, d_table, d_chan, d_event, None
 
 
+class BlockTableGatherFn(torch.autograd.Function):
+    """out[r] = table[tokens[r] * L + r % L]  (table (vmax * L, C)); backward = deterministic segment sum."""
+
+    @staticmethod
+    def forward(ctx, table, tokens, L):
+        table = _f32(table).contiguous()
+        rows, C = table.shape
+        vmax = rows // L
+        M = tokens.numel()
+        out = torch.empty(M, C, dtype=torch.float32, device=table.device)
+        hip.call('vqcpc_block_table_gather', table, tokens, out, M, L, vmax, C)
+        ctx.save_for_backward(tokens)
+        ctx.meta = (L, vmax, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (tokens,) = ctx.saved_tensors
+        L, vmax, C = ctx.meta
+        g = g.contiguous()
+        M = tokens.numel()
+        d_table = torch.empty(vmax * L, C, dtype=torch.float32, device=g.device)
+        nbytes = hip.query('vqcpc_block_table_segsum_workspace', M, L, vmax, C)
+        ws = hip.workspace(nbytes, g.device)
+        hip.call('vqcpc_block_table_segsum', g, tokens, d_table, M, L, vmax, C, ws, nbytes)
+        return d_table, None, None
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # plain linear (output_linear, upscaler)
 # ------------------------------------------------------------------------------------------------------------------
@@ -156,7 +184,9 @@ class EncoderLayerFn(torch.autograd.Function):
     Identical results, ~60 % fewer FLOPs in that layer."""
 
     @staticmethod
-    def forward(ctx, x, L, H, drop_p, seed, qstride, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1, g2, be2):
+    def forward(ctx, x, L, H, drop_p, seed, qstride, qkv_in, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1, g2, be2):
+        # qkv_in: the (M, 3d) projection computed elsewhere (first layer: block-table lookup); then wqkv / bqkv are
+        # not used here and the gradient of the projection is handed back through qkv_in
         x, ldx = _rows(_f32(x))
         M, d = x.shape
         hd = d // H
@@ -167,13 +197,13 @@ class EncoderLayerFn(torch.autograd.Function):
         s = [int(seed) + 0x1000 * i for i in range(4)]     # attention probs, dropout1, ffn dropout, dropout2
         if f == 1:
             Mq, xs, ldxs = M, x, ldx
-            qkv = gemm_nt(x, wqkv, bias=bqkv)
+            qkv = gemm_nt(x, wqkv, bias=bqkv) if qkv_in is None else _f32(qkv_in).contiguous()
             att = torch.empty(M, d, dtype=torch.float32, device=dev)
             probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
             hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
             qproj = qkv
         else:
-            assert L % f == 0
+            assert L % f == 0 and qkv_in is None
             Mq = M // f
             xs, ldxs = _rows(x[::f])                                       # query / residual rows: a stride, not a copy
             qkv = gemm_nt(x, wqkv[d:], bias=bqkv[d:])                      # k | v for every token   (M, 2d)
@@ -194,7 +224,7 @@ class EncoderLayerFn(torch.autograd.Function):
         hip.call('vqcpc_add_layernorm_fwd', x1, d, ff, g2, be2, y, mean2, rstd2, Mq, d, 1e-5, p, s[3])
         ctx.save_for_backward(x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
-        ctx.meta = (L, H, p, s, f)
+        ctx.meta = (L, H, p, s, f, qkv_in is not None)
         ctx.mark_non_differentiable(probs)
         return y, probs
 
@@ -202,7 +232,7 @@ class EncoderLayerFn(torch.autograd.Function):
     def backward(ctx, dy, _dprobs):
         (x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
          g2) = ctx.saved_tensors
-        L, H, p, s, f = ctx.meta
+        L, H, p, s, f, ext_qkv = ctx.meta
         x, ldx = _rows(x)
         M, d = x.shape
         hd, nblk, dev = d // H, M // L, x.device
@@ -240,6 +270,9 @@ class EncoderLayerFn(torch.autograd.Function):
             ws = hip.workspace(nbytes, dev)
             hip.call('vqcpc_relattn_bwd', datt, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd, p, s[0],
                      ws, nbytes)
+            if ext_qkv:          # projection lives outside: its gradient leaves through qkv_in, x keeps the residual path
+                return (ds1 if need_dx else None, None, None, None, None, None, dqkv, None, None, dwo, dbo, de1, de2, dw1,
+                        db1, dw2, db2, dg1, dbe1, dg2, dbe2)
             dwqkv, dbqkv = gemm_tn(dqkv, x)
             dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if need_dx else None
         else:
@@ -258,7 +291,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 dx = gemm_nt(dkv, wt[:, d:])                               # every row: keys / values path
                 dxs = dx[::f]                                              # kept rows also get the query + residual paths
                 gemm_nt(dq, wt[:, :d], add=ds1, add2=dxs, out=dxs)
-        return (dx, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1, dg2,
+        return (dx, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1, dg2,
                 dbe2)
 
 

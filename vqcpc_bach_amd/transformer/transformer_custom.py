@@ -38,11 +38,12 @@ class TransformerEncoderLayerCustom(nn.Module):
                 self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm1.weight,
                 self.norm1.bias, self.norm2.weight, self.norm2.bias)
 
-    def forward_rows(self, x, qstride=1):
+    def forward_rows(self, x, qstride=1, qkv=None):
         """x: (blocks * L, d) block-major rows (may be row-strided) -> (y (blocks * L / qstride, d), probs).
-        qstride = f > 1 evaluates only the output rows 0, f, 2f, ... (what `output[::f]` would keep)."""
+        qstride = f > 1 evaluates only the output rows 0, f, 2f, ... (what `output[::f]` would keep).
+        qkv: the in_proj output (rows, 3d) when the caller already has it (block-table lookup of the first layer)."""
         p = self.p if self.training else 0.0
-        return ops.EncoderLayerFn.apply(x, self.seq_len, self.nhead, p, SEEDS.next() if p > 0 else 0, qstride,
+        return ops.EncoderLayerFn.apply(x, self.seq_len, self.nhead, p, SEEDS.next() if p > 0 else 0, qstride, qkv,
                                         *self._params())
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
@@ -61,13 +62,14 @@ class TransformerEncoderCustom(nn.Module):
         self.num_layers = num_layers
         self.norm = norm
 
-    def forward_rows(self, x, out_stride=1):
+    def forward_rows(self, x, out_stride=1, first_qkv=None):
         """Runs the stack on block-major rows; `out_stride` = f returns only rows 0, f, 2f, ... of the stack output
-        (the downscaler's `output[::f]`), which lets the last layer skip the dropped rows."""
+        (the downscaler's `output[::f]`), which lets the last layer skip the dropped rows.  `first_qkv`: in_proj output
+        of the first layer when the caller computed it by table lookup."""
         attentions = []
         for li, layer in enumerate(self.layers):
             last = li == len(self.layers) - 1
-            x, probs = layer.forward_rows(x, qstride=out_stride if last else 1)
+            x, probs = layer.forward_rows(x, qstride=out_stride if last else 1, qkv=first_qkv if li == 0 else None)
             attentions.append(dict(a_self_encoder=probs))
         return x, attentions
 

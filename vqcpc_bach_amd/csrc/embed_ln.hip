@@ -40,6 +40,7 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __res
 // event sums are further split per event in a second small array).
 // =====================================================================================================================
 constexpr int kEmbRowsPerChunk = 2048;   // rows of ALL voices per chunk
+constexpr int kEmbU = 16;
 
 __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __restrict__ tokens, int64_t n_rows, int tpb,
                                                             int nv, int vmax, int dlin, int pos, int has_ev,
@@ -59,20 +60,23 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     const int64_t row1 = min(row0 + kEmbRowsPerChunk, n_rows);
     // rows of this voice: row % tpb % nv == v.  kEmbRowsPerChunk is a multiple of tpb (checked on the host).
     for (int col = threadIdx.x; col < d; col += blockDim.x) {
-        // 8 rows in flight per lane: issue the loads first, then the (ordered) LDS read-modify-writes
-        for (int64_t base = row0 + v; base < row1; base += (int64_t)nv * 8) {
-            float gv[8];
-            int tk[8], evi[8];
+        // kEmbU rows in flight per lane, branch-free (the tail re-reads the last row of the voice and adds zero): issue
+        // the loads first, then the (ordered) LDS read-modify-writes
+        const int64_t last = row0 + v + (row1 - 1 - row0 - v) / nv * nv;         // last row of this voice in the chunk
+        for (int64_t base = row0 + v; base < row1; base += (int64_t)nv * kEmbU) {
+            float gv[kEmbU];
+            int tk[kEmbU], evi[kEmbU];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int64_t row = base + (int64_t)u * nv;
-                const bool ok = row < row1;
-                gv[u] = ok ? g[row * d + col] : 0.0f;
-                tk[u] = (ok && col < dlin) ? (int)tokens[row] : 0;
-                evi[u] = ok ? (int)(row % tpb) / nv : 0;
+            for (int u = 0; u < kEmbU; ++u) {
+                const int64_t want = base + (int64_t)u * nv;
+                const int64_t row = min(want, last);
+                const float x = g[row * d + col];
+                gv[u] = want < row1 ? x : 0.0f;
+                tk[u] = (int)tokens[row];
+                evi[u] = (int)(row % tpb) / nv;
             }
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < kEmbU; ++u) {
                 if (col < dlin) tab[tk[u] * dlin + col] += gv[u];
                 else if (col < dlin + pos) csum[col - dlin] += gv[u];
                 else esum[evi[u] * pos + (col - dlin - pos)] += gv[u];
@@ -301,7 +305,10 @@ __global__ __launch_bounds__(256) void block_table_gather_kernel(const float* __
 // grid = (chunks, L, column tiles of 256).  Workgroup (chunk, p, ct): lane owns one column of an LDS accumulator
 // [vmax][256]; it walks the rows of position p of its chunk of blocks in ascending order, kSegU rows in flight -> the
 // read-modify-writes of a cell are ordered: deterministic, no atomics.  Partials ws[chunk][vmax][L][C].
-constexpr int kSegU = 16;
+// Measured at C1 (557 056 x 768 floats, tools/bench_segsum.py): 0.58 ms = 3.0 TB/s with 32 rows in flight per lane; a
+// probe without the LDS update streams at 3.3 TB/s, so the LDS read-modify-write is not the limiter (and ds_add_f32
+// atomics are 3x slower than the plain RMW here).
+constexpr int kSegU = 32;
 
 __global__ __launch_bounds__(256) void block_table_segsum_kernel(const float* __restrict__ g,
                                                                  const int64_t* __restrict__ tokens,
@@ -315,19 +322,21 @@ __global__ __launch_bounds__(256) void block_table_segsum_kernel(const float* __
     const bool cok = col < C;
     const int64_t b0 = (int64_t)blockIdx.x * blocks_per_chunk;
     const int64_t b1 = min(b0 + blocks_per_chunk, n_blocks);
+    const float* gp = g + (cok ? col : 0);
+    float* mine = acc + threadIdx.x;
     for (int64_t b = b0; b < b1; b += kSegU) {
         float v[kSegU];
         int tk[kSegU];
 #pragma unroll
-        for (int u = 0; u < kSegU; ++u) {
-            const int64_t row = (b + u) * L + p;
-            const bool ok = b + u < b1;
-            v[u] = (ok && cok) ? g[row * C + col] : 0.0f;
-            tk[u] = ok ? (int)tokens[row] : 0;
+        for (int u = 0; u < kSegU; ++u) {                                // branch-free: the tail re-reads the last row ...
+            const int64_t row = min(b + u, b1 - 1) * L + p;
+            v[u] = b + u < b1 ? gp[row * C] : 0.0f;                      // ... and adds zero
+            tk[u] = (int)tokens[row];
         }
 #pragma unroll
-        for (int u = 0; u < kSegU; ++u) acc[tk[u] * 256 + threadIdx.x] += v[u];
+        for (int u = 0; u < kSegU; ++u) mine[tk[u] * 256] += v[u];       // one lane per cell, rows in ascending order
     }
+    __syncthreads();
     if (cok) {
         float* dst = ws + (int64_t)blockIdx.x * vmax * L * C;
         for (int t = 0; t < vmax; ++t) dst[((int64_t)t * L + p) * C + col] = acc[t * 256 + threadIdx.x];

@@ -52,19 +52,46 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
     return out
 
 
-def gemm_tn(a, b, want_bias=True):
-    """dW[N,K] = a[M,N]^T @ b[M,K], db[N] = column sums of a."""
+def gemm_tn(a, b, want_bias=True, into=None):
+    """dW[N,K] = a[M,N]^T @ b[M,K], db[N] = column sums of a.  `into` = (dW, db) accumulates into existing buffers."""
     a, lda = _rows(_f32(a))
     b, ldb = _rows(_f32(b))
     M, N = a.shape
     K = b.shape[1]
     assert b.shape[0] == M
-    dw = torch.empty(N, K, dtype=torch.float32, device=a.device)
-    db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
+    if into is not None:
+        dw, db = into
+        assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or (db.shape == (N,) and db.is_contiguous()))
+    else:
+        dw = torch.empty(N, K, dtype=torch.float32, device=a.device)
+        db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
     nbytes = hip.query('vqcpc_gemm_tn_workspace', M, N, K)
     ws = hip.workspace(nbytes, a.device)
-    hip.call('vqcpc_gemm_tn', a, lda, b, ldb, dw, db, M, N, K, 0, ws, nbytes)
+    hip.call('vqcpc_gemm_tn', a, lda, b, ldb, dw, db, M, N, K, 0 if into is None else 1, ws, nbytes)
     return dw, db
+
+
+def _live_grad(t):
+    """The gradient buffer of a leaf parameter whose `.grad` already exists (parallel.FlatParameters installs views
+    into the flat all-reduce bucket), else None."""
+    if t is None or not t.is_leaf or not t.requires_grad:
+        return None
+    g = t.grad
+    return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32) else None
+
+
+def wgrad(g, x, weight, bias, rows=None):
+    """Weight / bias gradient of y = x W^T + b.  When the parameter already owns a gradient buffer the TN GEMM's final
+    reduction ACCUMULATES straight into it and (None, None) is returned to autograd -- no temporary, no extra
+    `grad += dW` pass per parameter; otherwise (dW, db) are returned as usual.  `rows` = slice of output features when
+    only a row block of the parameter is differentiated (q | k,v halves of in_proj)."""
+    wg, bg = _live_grad(weight), _live_grad(bias)
+    if wg is not None and (bias is None or bg is not None):
+        if rows is not None:
+            wg, bg = wg[rows], (bg[rows] if bg is not None else None)
+        gemm_tn(g, x, into=(wg, bg))
+        return None, None
+    return gemm_tn(g, x, want_bias=bias is not None)
 
 
 def transpose(w):
@@ -140,7 +167,7 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
-        ctx.has_bias = bias is not None
+        ctx.bias = bias
         return gemm_nt(x, weight, bias=bias)
 
     @staticmethod
@@ -148,7 +175,7 @@ class LinearFn(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = g.contiguous()
         dx = gemm_nt(g, transpose(weight)) if ctx.needs_input_grad[0] else None
-        dw, db = gemm_tn(g, x, want_bias=ctx.has_bias)
+        dw, db = wgrad(g, x, weight, ctx.bias)
         return dx, dw, db
 
 
@@ -225,6 +252,7 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
+        ctx.biases = (bqkv, bo, b1, b2)
         ctx.mark_non_differentiable(probs)
         return y, probs
 
@@ -233,6 +261,7 @@ class EncoderLayerFn(torch.autograd.Function):
         (x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
          g2) = ctx.saved_tensors
         L, H, p, s, f, ext_qkv = ctx.meta
+        bqkv, bo, b1, b2 = ctx.biases
         x, ldx = _rows(x)
         M, d = x.shape
         hd, nblk, dev = d // H, M // L, x.device
@@ -254,12 +283,12 @@ class EncoderLayerFn(torch.autograd.Function):
         ds2, df, dg2, dbe2 = ln_bwd(dy, x1, d, ff, g2, mean2, rstd2, s[3])
         # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
         da = gemm_nt(df, transpose(w2), gate=h2, gate_scale=1.0 / (1.0 - p))
-        dw2, db2 = gemm_tn(df, h2)
-        dw1, db1 = gemm_tn(da, x1)
+        dw2, db2 = wgrad(df, h2, w2, b2)
+        dw1, db1 = wgrad(da, x1, w1, b1)
         dx1 = gemm_nt(da, transpose(w1), add=ds2)
         del da, df, ds2
         ds1, dA, dg1, dbe1 = ln_bwd(dx1, xs, ldxs, a, g1, mean1, rstd1, s[1])
-        dwo, dbo = gemm_tn(dA, att)
+        dwo, dbo = wgrad(dA, att, wo, bo)
         datt = gemm_nt(dA, transpose(wo))
         de1 = torch.empty_like(e1)
         de2 = torch.empty_like(e2)
@@ -273,7 +302,7 @@ class EncoderLayerFn(torch.autograd.Function):
             if ext_qkv:          # projection lives outside: its gradient leaves through qkv_in, x keeps the residual path
                 return (ds1 if need_dx else None, None, None, None, None, None, dqkv, None, None, dwo, dbo, de1, de2, dw1,
                         db1, dw2, db2, dg1, dbe1, dg2, dbe2)
-            dwqkv, dbqkv = gemm_tn(dqkv, x)
+            dwqkv, dbqkv = wgrad(dqkv, x, wqkv, bqkv)
             dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if need_dx else None
         else:
             dq = torch.empty(Mq, d, dtype=torch.float32, device=dev)
@@ -282,9 +311,12 @@ class EncoderLayerFn(torch.autograd.Function):
             ws = hip.workspace(nbytes, dev)
             hip.call('vqcpc_relattn_sub_bwd', datt, d, qproj, d, qkv, 2 * d, probs, e1, e2, dq, d, dkv, 2 * d, de1, de2, nblk,
                      L, f, H, hd, p, s[0], ws, nbytes)
-            dwq, dbq = gemm_tn(dq, xs)
-            dwkv, dbkv = gemm_tn(dkv, x)
-            dwqkv, dbqkv = torch.cat([dwq, dwkv], dim=0), torch.cat([dbq, dbkv], dim=0)
+            dwq, dbq = wgrad(dq, xs, wqkv, bqkv, rows=slice(0, d))
+            dwkv, dbkv = wgrad(dkv, x, wqkv, bqkv, rows=slice(d, 3 * d))
+            if dwq is None:
+                dwqkv = dbqkv = None                                       # accumulated in place into in_proj's gradient
+            else:
+                dwqkv, dbqkv = torch.cat([dwq, dwkv], dim=0), torch.cat([dbq, dbkv], dim=0)
             dx = None
             if need_dx:
                 wt = transpose(wqkv)                                       # (d, 3d): columns q | k | v
@@ -393,6 +425,7 @@ class GRULayerFn(torch.autograd.Function):
             hip.call('vqcpc_gru_cell_fwd', gi[sl], gh[sl], h[sl], h[(t + 1) * B:(t + 2) * B],
                      None if y is None else y[sl], B, H, p, int(seed), t * B * H)
         ctx.save_for_backward(x, w_ih, w_hh, gi, gh, h)
+        ctx.biases = (b_ih, b_hh)
         ctx.meta = (T, B, H, p, int(seed), bool(last_only))
         return h[T * B:].clone() if last_only else y
 
@@ -413,8 +446,9 @@ class GRULayerFn(torch.autograd.Function):
             hip.call('vqcpc_gru_cell_bwd', gi[sl], gh[sl], h[sl], d_y, dh, dgi[sl], dgh[sl], dhp, B, H, p, seed, t * B * H)
             if t > 0:
                 dh = gemm_nt(dgh[sl], whh_t, add=dhp)                        # d h_{t-1} = dgh W_hh + dh * u
-        dw_hh, db_hh = gemm_tn(dgh, h[:T * B])                               # step 0 multiplies the zero rows h_{-1}
-        dw_ih, db_ih = gemm_tn(dgi, x)
+        b_ih, b_hh = ctx.biases
+        dw_hh, db_hh = wgrad(dgh, h[:T * B], w_hh, b_hh)                     # step 0 multiplies the zero rows h_{-1}
+        dw_ih, db_ih = wgrad(dgi, x, w_ih, b_ih)
         dx = gemm_nt(dgi, transpose(w_ih)) if ctx.needs_input_grad[0] else None
         return dx, dw_ih, dw_hh, db_ih, db_hh, None, None, None, None
 

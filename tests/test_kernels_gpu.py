@@ -677,3 +677,97 @@ def test_flat_adam_with_clip(ops, scale):
     assert abs(opt.grad_norm() - float(total)) < 1e-5 * float(total)
     assert (scale > 100) == (float(total) > 5.0)
     assert rel_err(pd.cpu(), P['w']) < 1e-6
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# student-step kernels
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('R,V', [(8, 56), (3, 5), (100, 130), (1, 1)])
+def test_softmax_ce_hard_and_soft_targets(ops, R, V):
+    gen = torch.Generator().manual_seed(R + V)
+    logits = (torch.randn(R, V, generator=gen) * 3)
+    teacher = torch.randn(R, V, generator=gen) * 2
+    target = torch.randint(0, V, (R,), generator=gen)
+    w = torch.randn(R, generator=gen)
+    for soft in (False, True):
+        lc = logits.clone().requires_grad_(True)
+        lp = torch.log_softmax(lc, dim=1)
+        ref = -(torch.softmax(teacher, 1) * lp).sum(1) if soft else -lp.gather(1, target.view(-1, 1)).squeeze(1)
+        (ref * w).sum().backward()
+        ld = dev(logits).requires_grad_(True)
+        out = ops.SoftmaxCEFn.apply(ld, None if soft else target.cuda(), dev(teacher) if soft else None)
+        assert rel_err(out.cpu(), ref.detach()) < FWD_TOL
+        (out * w.cuda()).sum().backward()
+        assert rel_err(ld.grad.cpu(), lc.grad) < GRAD_TOL
+    # strided logit rows (the masked event of a (B, E, V) tensor)
+    big = torch.randn(R, 7, V, generator=gen)
+    out = ops.SoftmaxCEFn.apply(dev(big)[:, 3], target.cuda(), None)
+    ref = -torch.log_softmax(big[:, 3], 1).gather(1, target.view(-1, 1)).squeeze(1)
+    assert rel_err(out.cpu(), ref) < FWD_TOL
+
+
+@pytest.mark.parametrize('rows,f,d', [(24, 4, 512), (7, 3, 32), (1000, 8, 64), (1, 1, 4)])
+def test_upscale(ops, rows, f, d):
+    gen = torch.Generator().manual_seed(rows + f)
+    x, emb, g = torch.randn(rows, d, generator=gen), torch.randn(f, d, generator=gen), torch.randn(rows * f, d, generator=gen)
+    xd, ed = dev(x).requires_grad_(True), dev(emb).requires_grad_(True)
+    out = ops.UpscaleFn.apply(xd, ed)
+    ref = (x.unsqueeze(1) + emb.unsqueeze(0)).reshape(rows * f, d)            # repeat_interleave + tiled embeddings
+    assert torch.equal(out.cpu(), ref)
+    out.backward(dev(g))
+    assert rel_err(xd.grad.cpu(), g.view(rows, f, d).sum(1)) < 1e-6
+    assert rel_err(ed.grad.cpu(), g.view(rows, f, d).double().sum(0)) < 1e-5
+
+
+def test_embed_pos_without_event_part(ops):
+    """Teacher input rows: [table(voice, token) | channel embedding] (teacher_relative.py:63-75)."""
+    gen = torch.Generator().manual_seed(9)
+    nv, vmax, dlin, pos, rows = 4, 13, 24, 8, 4 * 50
+    table = torch.randn(nv, vmax, dlin, generator=gen)
+    chan = torch.randn(nv, pos, generator=gen)
+    tokens = torch.randint(0, vmax, (rows,), generator=gen)
+    g = torch.randn(rows, dlin + pos, generator=gen)
+    td, cd = dev(table).requires_grad_(True), dev(chan).requires_grad_(True)
+    out = ops.EmbedPosFn.apply(tokens.cuda(), td, cd, None, nv)
+    v = torch.arange(rows) % nv
+    tr, cr = table.clone().requires_grad_(True), chan.clone().requires_grad_(True)
+    ref = torch.cat([tr[v, tokens], cr[v]], dim=1)
+    assert torch.equal(out.cpu(), ref.detach())
+    out.backward(dev(g))
+    ref.backward(g)
+    assert rel_err(td.grad.cpu(), tr.grad) < 1e-5 and rel_err(cd.grad.cpu(), cr.grad) < 1e-5
+
+
+def test_empty_inputs_are_no_ops(ops):
+    """Zero rows / zero blocks: every forward entry point returns success without touching memory."""
+    from vqcpc_bach_amd import hip
+    z = torch.empty(0, 16, device='cuda')
+    w = torch.randn(8, 16, device='cuda')
+    assert ops.gemm_nt(z, w).shape == (0, 8)
+    cb = torch.randn(1, 4, 16, device='cuda')
+    hip.call('vqcpc_vq_fwd', z, cb, 0, 1, 4, 16, 0.25, 1, 1, torch.empty(0, 1, dtype=torch.int64, device='cuda'),
+             torch.empty(0, 16, device='cuda'), torch.empty(0, device='cuda'))
+    e = torch.randn(2 * 16, 8, device='cuda')
+    hip.call('vqcpc_relattn_fwd', torch.empty(0, 48, device='cuda'), 48, e, e, torch.empty(0, 16, device='cuda'), 16,
+             torch.empty(0, 2, 16, 16, device='cuda'), 0, 16, 2, 8, 0.0, 0)
+    hip.call('vqcpc_softmax_ce', torch.empty(0, 5, device='cuda'), 5, torch.empty(0, dtype=torch.int64, device='cuda'), None, 0,
+             torch.empty(0, device='cuda'), torch.empty(0, 5, device='cuda'), 0, 5)
+    tok = torch.empty(0, dtype=torch.int64, device='cuda')
+    hip.call('vqcpc_same_sequence_negatives', tok, tok, tok, 0, 2, 2, 16)
+    torch.cuda.synchronize()
+
+
+def test_bad_arguments_raise_with_the_library_message(ops):
+    from vqcpc_bach_amd import hip
+    a = torch.randn(4, 6, device='cuda')                   # K = 6 is not a multiple of 4
+    with pytest.raises(hip.VqcpcHipError, match='gemm_nt'):
+        hip.call('vqcpc_gemm_nt', a, 6, a, 6, torch.empty(4, 4, device='cuda'), 4, 4, 4, 6, None, 0, 0.0, 0, None, 0, 1.0, None,
+                 0, None, 0)
+    e = torch.randn(2 * 2000, 16, device='cuda')
+    with pytest.raises(hip.VqcpcHipError, match='unsupported L'):
+        hip.call('vqcpc_relattn_fwd', torch.empty(2000, 96, device='cuda'), 96, e, e, torch.empty(2000, 32, device='cuda'), 32,
+                 torch.empty(1, device='cuda'), 1, 2000, 2, 16, 0.0, 0)
+    with pytest.raises(hip.VqcpcHipError, match='upscale'):
+        g = torch.randn(9 * 4, 8, device='cuda')
+        hip.call('vqcpc_upscale_bwd', g, torch.empty(4, 8, device='cuda'), torch.empty(9, 8, device='cuda'), 4, 9, 8,
+                 torch.empty(16, device='cuda'), 16)

@@ -353,12 +353,12 @@ extern "C" {
 
 int vqcpc_embed_pos_fwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, const float* table,
                         int vmax, int dlin, const float* chan, const float* event, int pos, float* out, void* stream) {
+    if (n_rows == 0) return VQCPC_OK;
     VQ_REQUIRE(tokens && table && chan && out, "embed_pos_fwd: null pointer");
     VQ_REQUIRE(n_rows >= 0 && tokens_per_block > 0 && n_voices > 0 && tokens_per_block % n_voices == 0 && vmax > 0,
                "embed_pos_fwd: bad shape");
     VQ_REQUIRE(dlin % 4 == 0 && pos % 4 == 0 && dlin > 0, "embed_pos_fwd: dlin and pos must be multiples of 4");
     VQ_REQUIRE(n_rows % tokens_per_block == 0, "embed_pos_fwd: n_rows must be a whole number of blocks");
-    if (n_rows == 0) return VQCPC_OK;
     const int64_t total = n_rows * ((dlin + (event ? 2 : 1) * pos) / 4);
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 8192);
     hipLaunchKernelGGL(embed_pos_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tokens, n_rows,
@@ -403,10 +403,10 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
 
 int vqcpc_block_table_gather(const float* table, const int64_t* tokens, float* out, int64_t M, int L, int vmax, int C,
                              void* stream) {
+    if (M == 0) return VQCPC_OK;
     VQ_REQUIRE(table && tokens && out && M >= 0 && L >= 1 && vmax >= 1 && C >= 4 && C % 4 == 0 && M % L == 0,
                "block_table_gather: bad arguments");
     VQ_REQUIRE(aligned16(table) && aligned16(out), "block_table_gather: buffers must be 16-byte aligned");
-    if (M == 0) return VQCPC_OK;
     const int blocks = (int)std::min<int64_t>(ceil_div(M * (C / 4), 256), 16384);
     hipLaunchKernelGGL(block_table_gather_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, table, tokens, out, M, L,
                        C / 4);
@@ -445,10 +445,10 @@ int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_tab
 int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
                             float* mean, float* rstd, int64_t M, int d, float eps, float drop_p, uint64_t seed,
                             void* stream) {
+    if (M == 0) return VQCPC_OK;
     VQ_REQUIRE(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
     VQ_REQUIRE(M >= 0 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_fwd: bad shape");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "add_layernorm_fwd: bad dropout probability");
-    if (M == 0) return VQCPC_OK;
     hipStream_t s = (hipStream_t)stream;
     const uint32_t thr = drop_threshold(drop_p);
     const float ik = 1.0f / (1.0f - drop_p);

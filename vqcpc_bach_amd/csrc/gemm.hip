@@ -1010,6 +1010,7 @@ int vqcpc_gemm_get_mode(void) { return gemm_mode(); }
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                   float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream) {
+    if (M == 0) return VQCPC_OK;
     VQ_REQUIRE(A && B && C, "gemm_nt: null pointer");
     VQ_REQUIRE(M >= 0 && N >= 1 && K >= 4 && K % 4 == 0, "gemm_nt: bad shape M=%lld N=%d K=%d (K %% 4 == 0 required)",
                (long long)M, N, K);
@@ -1020,7 +1021,6 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     VQ_REQUIRE(ldc < (1 << 22) && ldgate < (1 << 22) && ldadd < (1 << 22), "gemm_nt: leading dimension too large");
     VQ_REQUIRE((!gate || ldgate >= N) && (!add || ldadd >= N) && (!add2 || (add && ldadd2 >= N)),
                "gemm_nt: bad gate/add strides (add2 needs add)");
-    if (M == 0) return VQCPC_OK;
     const int tiles_n = (int)ceil_div(N, BN);
     const int64_t tiles = ceil_div(M, BM) * tiles_n;
     VQ_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");

@@ -68,9 +68,9 @@ extern "C" {
 
 int vqcpc_gru_cell_fwd(const float* gi, const float* gh, const float* h_prev, float* h_out, float* y_out, int64_t B, int H,
                        float drop_p, uint64_t seed, uint64_t idx_base, void* stream) {
+    if (B == 0) return VQCPC_OK;
     VQ_REQUIRE(gi && gh && h_out && B >= 0 && H >= 1, "gru_cell_fwd: bad arguments");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gru_cell_fwd: bad dropout probability");
-    if (B == 0) return VQCPC_OK;
     hipLaunchKernelGGL(gru_cell_fwd_kernel, dim3((unsigned)ceil_div(B * H, 256)), dim3(256), 0, (hipStream_t)stream, gi, gh,
                        h_prev, h_out, y_out, B, H, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, idx_base);
     VQ_CHECK_LAUNCH("gru_cell_fwd");
@@ -80,9 +80,9 @@ int vqcpc_gru_cell_fwd(const float* gi, const float* gh, const float* h_prev, fl
 int vqcpc_gru_cell_bwd(const float* gi, const float* gh, const float* h_prev, const float* d_y, const float* d_h, float* d_gi,
                        float* d_gh, float* d_hprev, int64_t B, int H, float drop_p, uint64_t seed, uint64_t idx_base,
                        void* stream) {
+    if (B == 0) return VQCPC_OK;
     VQ_REQUIRE(gi && gh && d_gi && d_gh && d_hprev && (d_y || d_h) && B >= 0 && H >= 1, "gru_cell_bwd: bad arguments");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gru_cell_bwd: bad dropout probability");
-    if (B == 0) return VQCPC_OK;
     hipLaunchKernelGGL(gru_cell_bwd_kernel, dim3((unsigned)ceil_div(B * H, 256)), dim3(256), 0, (hipStream_t)stream, gi, gh,
                        h_prev, d_y, d_h, d_gi, d_gh, d_hprev, B, H, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed,
                        idx_base);

@@ -397,13 +397,13 @@ int vqcpc_relattn_force_general(int on) {
 
 int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
                       float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* stream) {
+    if (n_blocks == 0) return VQCPC_OK;
     VQ_REQUIRE(qkv && e1 && e2 && ctx && probs, "relattn_fwd: null pointer");
     const bool small = att_supported(L, H, hd);
     VQ_REQUIRE(small || relattn_gen_supported(L, H, hd), "relattn_fwd: unsupported L=%d H=%d hd=%d (L <= 1024, hd in {16,32,64})",
                L, H, hd);
     VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= 3 * H * hd && ldo >= H * hd && n_blocks >= 0, "relattn_fwd: bad strides");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_fwd: bad dropout probability");
-    if (n_blocks == 0) return VQCPC_OK;
     hipStream_t s = (hipStream_t)stream;
     if (!small) {
         VQ_REQUIRE(aligned16(qkv) && aligned16(e1) && aligned16(e2), "relattn_fwd: qkv / e1 / e2 must be 16-byte aligned");

@@ -678,13 +678,13 @@ extern "C" {
 int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
                           float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd,
                           float drop_p, uint64_t seed, void* stream) {
+    if (n_blocks == 0) return VQCPC_OK;
     VQ_REQUIRE(q && kv && e1 && e2 && ctx && probs, "relattn_sub_fwd: null pointer");
     VQ_REQUIRE(sub_supported(L, F, H, hd), "relattn_sub_fwd: unsupported L=%d F=%d H=%d hd=%d", L, F, H, hd);
     VQ_REQUIRE(ldq % 4 == 0 && ldkv % 4 == 0 && ldo % 4 == 0 && ldq >= H * hd && ldkv >= 2 * H * hd && ldo >= H * hd &&
                    n_blocks >= 0,
                "relattn_sub_fwd: bad strides");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_sub_fwd: bad dropout probability");
-    if (n_blocks == 0) return VQCPC_OK;
     hipStream_t s = (hipStream_t)stream;
     if (L == 16 && (4 % H == 0 || H % 4 == 0)) {
         if (hd == 16) return sub16_launch_fwd<16>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);

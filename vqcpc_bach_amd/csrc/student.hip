@@ -139,10 +139,10 @@ extern "C" {
 
 int vqcpc_softmax_ce(const float* logits, int64_t ld, const int64_t* target, const float* target_logits, int64_t ldt,
                      float* loss, float* grad, int64_t R, int V, void* stream) {
+    if (R == 0) return VQCPC_OK;
     VQ_REQUIRE(logits && loss && grad && ((target != nullptr) != (target_logits != nullptr)),
                "softmax_ce: need logits, loss, grad and exactly one of target / target_logits");
     VQ_REQUIRE(R >= 0 && V >= 1 && ld >= V && (!target_logits || ldt >= V), "softmax_ce: bad shape");
-    if (R == 0) return VQCPC_OK;
     hipLaunchKernelGGL(softmax_ce_kernel, dim3((unsigned)ceil_div(R, 4)), dim3(256), 0, (hipStream_t)stream, logits, ld,
                        target, target_logits, ldt, loss, grad, R, V);
     VQ_CHECK_LAUNCH("softmax_ce");
@@ -151,11 +151,11 @@ int vqcpc_softmax_ce(const float* logits, int64_t ld, const int64_t* target, con
 
 int vqcpc_same_sequence_negatives(const int64_t* first, const int64_t* second, int64_t* out, int64_t B, int blocks_first,
                                   int blocks_second, int tokens_per_block, void* stream) {
+    if (B == 0) return VQCPC_OK;
     VQ_REQUIRE(first && second && out && B >= 0 && blocks_first >= 0 && blocks_second >= 1 && tokens_per_block >= 1 &&
                    blocks_first + blocks_second >= 2,
                "same_sequence_negatives: bad arguments");
     const int64_t total = B * (blocks_first + blocks_second - 1) * blocks_second * tokens_per_block;
-    if (total == 0) return VQCPC_OK;
     const int grid = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
     hipLaunchKernelGGL(same_seq_negatives_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, first, second, out, B,
                        blocks_first, blocks_second, tokens_per_block);
@@ -164,8 +164,8 @@ int vqcpc_same_sequence_negatives(const int64_t* first, const int64_t* second, i
 }
 
 int vqcpc_scale_rows(const float* in, const float* g, float* out, int64_t R, int V, void* stream) {
-    VQ_REQUIRE(in && g && out && R >= 0 && V >= 1, "scale_rows: bad arguments");
     if (R == 0) return VQCPC_OK;
+    VQ_REQUIRE(in && g && out && R >= 0 && V >= 1, "scale_rows: bad arguments");
     hipLaunchKernelGGL(scale_rows_kernel, dim3((unsigned)ceil_div(R * V, 256)), dim3(256), 0, (hipStream_t)stream, in, g,
                        out, R, V);
     VQ_CHECK_LAUNCH("scale_rows");
@@ -173,9 +173,9 @@ int vqcpc_scale_rows(const float* in, const float* g, float* out, int64_t R, int
 }
 
 int vqcpc_upscale_fwd(const float* x, const float* emb, float* out, int64_t rows, int f, int d, void* stream) {
+    if (rows == 0) return VQCPC_OK;
     VQ_REQUIRE(x && emb && out && rows >= 0 && f >= 1 && d >= 4 && d % 4 == 0, "upscale_fwd: bad arguments");
     VQ_REQUIRE(aligned16(x) && aligned16(emb) && aligned16(out), "upscale_fwd: buffers must be 16-byte aligned");
-    if (rows == 0) return VQCPC_OK;
     const int64_t total = rows * f * (d / 4);
     const int blocks = (int)std::min<int64_t>(ceil_div(total, 256), 4096);
     hipLaunchKernelGGL(upscale_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, emb, out, rows, f, d / 4);

@@ -185,8 +185,8 @@ int vqcpc_abi_version(void) { return VQCPC_ABI_VERSION; }
 const char* vqcpc_last_error(void) { return vq::g_err; }
 
 int vqcpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream) {
-    VQ_REQUIRE(mask != nullptr && n >= 0 && p >= 0.f && p < 1.f, "dropout_mask: bad arguments");
     if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(mask != nullptr && n >= 0 && p >= 0.f && p < 1.f, "dropout_mask: bad arguments");
     int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
     hipLaunchKernelGGL(dropout_mask_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, mask, n, drop_threshold(p),
                        seed);
@@ -203,8 +203,8 @@ int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream) {
 }
 
 int vqcpc_dropout_selu_fwd(const float* h, float* out, int64_t n, float drop_p, uint64_t seed, void* stream) {
-    VQ_REQUIRE(h && out && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_selu_fwd: bad arguments");
     if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(h && out && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_selu_fwd: bad arguments");
     int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
     hipLaunchKernelGGL(dropout_selu_fwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, out, n,
                        drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
@@ -214,8 +214,8 @@ int vqcpc_dropout_selu_fwd(const float* h, float* out, int64_t n, float drop_p, 
 
 int vqcpc_dropout_selu_bwd(const float* h, const float* g_out, float* g_h, int64_t n, float drop_p, uint64_t seed,
                            void* stream) {
-    VQ_REQUIRE(h && g_out && g_h && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_selu_bwd: bad arguments");
     if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(h && g_out && g_h && n >= 0 && drop_p >= 0.f && drop_p < 1.f, "dropout_selu_bwd: bad arguments");
     int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
     hipLaunchKernelGGL(dropout_selu_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, h, g_out, g_h, n,
                        drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);

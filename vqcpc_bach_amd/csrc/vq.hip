@@ -148,12 +148,12 @@ extern "C" {
 
 int vqcpc_vq_fwd(const float* z, const float* codebooks, int64_t R, int ncb, int K, int dsub, float beta, int squared,
                  int assign, int64_t* idx, float* zq_sg, float* loss, void* stream) {
+    if (R == 0) return VQCPC_OK;
     VQ_REQUIRE(z && codebooks && idx && ((zq_sg != nullptr) == (loss != nullptr)), "vq_fwd: null pointer");
     VQ_REQUIRE(zq_sg || assign, "vq_fwd: index-only mode (zq_sg == loss == NULL) needs assign = 1");
     VQ_REQUIRE(R >= 0 && ncb >= 1 && K >= 1 && dsub >= 1, "vq_fwd: bad shape R=%lld ncb=%d K=%d dsub=%d", (long long)R, ncb,
                K, dsub);
     VQ_REQUIRE((int64_t)K * dsub <= kVqLdsFloats, "vq_fwd: codebook of %d x %d floats does not fit the LDS", K, dsub);
-    if (R == 0) return VQCPC_OK;
     const dim3 grid((unsigned)ceil_div(R, kVqThreads)), block(kVqThreads);
     const size_t lds = (size_t)K * dsub * sizeof(float);
     hipStream_t s = (hipStream_t)stream;

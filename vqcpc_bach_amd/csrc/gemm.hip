@@ -317,22 +317,20 @@ template <int EPI>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ B, int64_t ldb,
                                                                       float* __restrict__ C, int64_t ldc, int64_t M, int N,
-                                                                      int K, int tiles_n, EpiParams ep) {
+                                                                      int K, int tiles_n, int tiles, EpiParams ep) {
+    // PERSISTENT: one workgroup per CU walks tiles t = blockIdx.x, + gridDim.x, ...  The first two K tiles of the NEXT
+    // output tile are requested before the epilogue of the current one, so the pipeline-fill latency and the workgroup
+    // relaunch disappear behind the stores (K = 256 means only 16 K tiles per output tile: fill / drain was ~30 %).
     extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, kh = lane >> 5;
-    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
-    const int64_t m0 = (int64_t)(t / tiles_n) * kT2;
-    const int n0 = (t % tiles_n) * kT2;
+    int t_lin = blockIdx.x;
+    int t = xcd_swizzle(t_lin, tiles);
+    int64_t m0 = (int64_t)(t / tiles_n) * kT2;
+    int n0 = (t % tiles_n) * kT2;
 
     floatx16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
     // staging: thread -> (row = tid >> 2 (+128), 4 consecutive k); 2 float4 of A and 2 of B per K tile
     const int ld_row = tid >> 2, ld_c4 = (tid & 3) * 4;
@@ -387,6 +385,13 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
     // sched_barrier pins "issue loads -> MFMAs -> split/store" (hipcc otherwise hoists the split above the MFMAs).
     T2_LOAD(x, 0)
     T2_LOAD(y, kT2BK)
+  for (;;) {
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
     T2_STORE(x, buf0)
     __syncthreads();
     for (int k0 = 0; k0 < K - 2 * kT2BK; k0 += 2 * kT2BK) {
@@ -406,21 +411,30 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
     T2_STORE(y, buf1)
     __syncthreads();
     T2_COMPUTE(buf1)
-#undef T2_TERM
-#undef T2_COMPUTE
-#undef T2_LOAD
-#undef T2_ST1
-#undef T2_STORE
+    // next output tile of this workgroup: request its first two K tiles now, store the current tile meanwhile
+    const int64_t m0_cur = m0;
+    const int n0_cur = n0;
+    t_lin += gridDim.x;
+    const bool has_next = t_lin < tiles;
+    if (has_next) {
+        t = xcd_swizzle(t_lin, tiles);
+        m0 = (int64_t)(t / tiles_n) * kT2;
+        n0 = (t % tiles_n) * kT2;
+        a_src = A + (m0 + ld_row) * lda + ld_c4;
+        b_src = B + (int64_t)(n0 + ld_row) * ldb + ld_c4;
+        T2_LOAD(x, 0)
+        T2_LOAD(y, kT2BK)
+    }
 
     // epilogue (buffer addressing); gate / add operands are fetched one 32x32 tile ahead
     constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;
-    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ldc + n0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0_cur * ldc + n0_cur), 0, 0x7FFFFFFF, 0x00020000);
     const int ldci = (int)ldc;
     const int voff_c = ((wm * 128 + 4 * kh) * ldci + wn * 64 + li) * 4;
     const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;
     const int ldxi = (int)((EPI & E_GATE) ? ep.ldgate : ep.ldadd);
     const __amdgpu_buffer_rsrc_t rx =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_AUX ? xsrc + m0 * (int64_t)ldxi + n0 : C), 0, 0x7FFFFFFF, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)(HAS_AUX ? xsrc + m0_cur * (int64_t)ldxi + n0_cur : C), 0, 0x7FFFFFFF, 0x00020000);
     const int voff_x = ((wm * 128 + 4 * kh) * ldxi + wn * 64 + li) * 4;
     float aux[2][16];
     if (HAS_AUX) {
@@ -429,8 +443,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
             aux[0][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
                 rx, voff_x, (((r & 3) + 8 * (r >> 2)) * ldxi) * 4, 0));
     }
-    const int64_t row_base = m0 + wm * 128 + 4 * kh;
-    const int col_base = n0 + wn * 64 + li;
+    const int64_t row_base = m0_cur + wm * 128 + 4 * kh;
+    const int col_base = n0_cur + wn * 64 + li;
 #pragma unroll
     for (int tile = 0; tile < 8; ++tile) {
         const int mt = tile >> 1, nt = tile & 1;
@@ -455,6 +469,200 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
                                                   ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);
         }
     }
+    if (!has_next) break;
+  }
+#undef T2_TERM
+#undef T2_COMPUTE
+#undef T2_LOAD
+#undef T2_ST1
+#undef T2_STORE
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PING-PONG variant of the 256 x 256 x 16 bf16x6 NT kernel.  With one workgroup-wide barrier per K tile the two waves
+// that share a SIMD run in lockstep: both wait for LDS / global data at the same time and both want the MFMA pipe at
+// the same time (measured: MFMA busy 57 %, 32 % of the wave time parked at waitcnt / barrier).  Here the K-tile stream
+// of the (persistent) workgroup is cut into a MEMORY phase (request K tile s+2, read the fragments of tile s, split and
+// store tile s+1) and an MFMA phase (48 MFMAs), each closed by a barrier, and wave group 1 (waves 4-7, the lower 128
+// rows) runs ONE PHASE BEHIND group 0 (one extra barrier up front, one extra for group 0 at the end): while one wave of
+// a SIMD issues its MFMAs the other one does its memory phase.  The epilogue of an output tile is part of the memory
+// phase that follows its last MFMA phase, so it also runs under the other group's MFMAs.
+//   LDS hazards: tile s+1 is written (by both groups) one full phase pair before anyone reads it; the buffer it
+//   replaces (tile s-1) was last read two barriers earlier by either group.
+template <int EPI>
+__global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
+                                                                     const float* __restrict__ B, int64_t ldb,
+                                                                     float* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                                     int K, int tiles_n, int tiles, EpiParams ep) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem2[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;           // wm = wave group: 0 leads, 1 runs one phase behind
+    const int li = lane & 31, kh = lane >> 5;
+    const int T = K / kT2BK;                            // K tiles per output tile (even: K % 32 == 0)
+    const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * T;                         // length of this workgroup's K-tile stream
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // ---- load cursor (runs two K tiles ahead of the compute cursor) ----
+    // staging is GROUP-LOCAL: group g stages rows [128 g, 128 g + 128) of both operands.  Group 1's MFMA phase still reads
+    // A fragments (its own rows 128..255) of tile s-1 while group 0's memory phase already writes tile s+1 into the same
+    // buffer -- rows 0..127 only, so the two never touch the same bytes (B fragments are all read in the memory phase).
+    const int ld_row = (tid >> 8) * 128 + ((tid & 255) >> 2), ld_c4 = (tid & 3) * 4;
+    int ld_tile = blockIdx.x, ld_k = 0;
+    const float* a_src;
+    const float* b_src;
+#define PP_SET_SRC()                                                        \
+    {                                                                       \
+        const int t_ = xcd_swizzle(min(ld_tile, tiles - 1), tiles);         \
+        a_src = A + ((int64_t)(t_ / tiles_n) * kT2 + ld_row) * lda + ld_c4; \
+        b_src = B + ((int64_t)(t_ % tiles_n) * kT2 + ld_row) * ldb + ld_c4; \
+    }
+    PP_SET_SRC()
+    float4 xa0, xa1, xb0, xb1;
+#define PP_LOAD(S_)                                                                       \
+    S_##a0 = *reinterpret_cast<const float4*>(a_src + ld_k);                              \
+    S_##a1 = *reinterpret_cast<const float4*>(a_src + (int64_t)64 * lda + ld_k);          \
+    S_##b0 = *reinterpret_cast<const float4*>(b_src + ld_k);                              \
+    S_##b1 = *reinterpret_cast<const float4*>(b_src + (int64_t)64 * ldb + ld_k);          \
+    ld_k += kT2BK;                                                                        \
+    if (ld_k == K) {                                                                      \
+        ld_k = 0;                                                                         \
+        ld_tile += gridDim.x;            /* past the end: re-reads the last tile, never used */ \
+        PP_SET_SRC()                                                                      \
+    }
+#define PP_ST1(R, PLANE0, ROW, BUFP)                                                 \
+    {                                                                                \
+        uint2 h_, m_, l_;                                                            \
+        split3x4(R, h_, m_, l_);                                                     \
+        const int o_ = (ROW) * kT2Stride + ld_c4 * 2;                                \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 0) * kT2Plane + o_) = h_;     \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 1) * kT2Plane + o_) = m_;     \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 2) * kT2Plane + o_) = l_;     \
+    }
+#define PP_STORE(S_, BUFP) \
+    PP_ST1(S_##a0, 0, ld_row, BUFP) PP_ST1(S_##a1, 0, ld_row + 64, BUFP) PP_ST1(S_##b0, 3, ld_row, BUFP) PP_ST1(S_##b1, 3, ld_row + 64, BUFP)
+
+    const int a_off = (wm * 128 + li) * kT2Stride + kh * 16;
+    const int b_off = 3 * kT2Plane + (wn * 64 + li) * kT2Stride + kh * 16;
+    unsigned char* const buf0 = smem2;
+    unsigned char* const buf1 = smem2 + kT2Buf;
+    bf16x8 fb[3][2], fa[4][3];                          // all fragments of a K tile: 18 x ds_read_b128 in the memory phase
+#define PP_READ_FRAGS(BUFP)                                                                                          \
+    _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                               \
+        _Pragma("unroll") for (int tl = 0; tl < 2; ++tl)                                                             \
+            fb[pc][tl] = *reinterpret_cast<const bf16x8*>((BUFP) + b_off + pc * kT2Plane + tl * 32 * kT2Stride);     \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                             \
+            fa[mt][pc] = *reinterpret_cast<const bf16x8*>((BUFP) + a_off + pc * kT2Plane + mt * 32 * kT2Stride);     \
+    }
+#define PP_TERM(PA, PB)                                                                                              \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                               \
+        acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][PA], fb[PB][0], acc[mt][0], 0, 0, 0);            \
+        acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][PA], fb[PB][1], acc[mt][1], 0, 0, 0);            \
+    }
+#define PP_MFMA() PP_TERM(2, 0) PP_TERM(0, 2) PP_TERM(1, 1) PP_TERM(1, 0) PP_TERM(0, 1) PP_TERM(0, 0)
+#define PP_BARRIER()                          \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue of the output tile with linear index `ep_tile` (buffer addressing, operands one 32x32 tile ahead) ----
+    int ep_tile = blockIdx.x;
+    constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;
+    const int ldci = (int)ldc;
+    const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;
+    const int ldxi = (int)((EPI & E_GATE) ? ep.ldgate : ep.ldadd);
+#define PP_EPILOGUE()                                                                                                  \
+    {                                                                                                                  \
+        const int t_ = xcd_swizzle(ep_tile, tiles);                                                                    \
+        const int64_t m0 = (int64_t)(t_ / tiles_n) * kT2;                                                              \
+        const int n0 = (t_ % tiles_n) * kT2;                                                                           \
+        const __amdgpu_buffer_rsrc_t rc =                                                                              \
+            __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ldc + n0), 0, 0x7FFFFFFF, 0x00020000);                  \
+        const int voff_c = ((wm * 128 + 4 * kh) * ldci + wn * 64 + li) * 4;                                            \
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)(HAS_AUX ? xsrc + m0 * (int64_t)ldxi + n0 : C), 0, 0x7FFFFFFF, 0x00020000);                         \
+        const int voff_x = ((wm * 128 + 4 * kh) * ldxi + wn * 64 + li) * 4;                                            \
+        float aux[2][16];                                                                                              \
+        if (HAS_AUX) {                                                                                                 \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) aux[0][r] = __builtin_bit_cast(                             \
+                float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff_x, (((r & 3) + 8 * (r >> 2)) * ldxi) * 4, 0));    \
+        }                                                                                                              \
+        const int64_t row_base = m0 + wm * 128 + 4 * kh;                                                               \
+        const int col_base = n0 + wn * 64 + li;                                                                        \
+        _Pragma("unroll") for (int tile = 0; tile < 8; ++tile) {                                                       \
+            const int mt = tile >> 1, nt = tile & 1;                                                                   \
+            if (HAS_AUX && tile + 1 < 8) {                                                                             \
+                const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;                                                 \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) aux[(tile + 1) & 1][r] = __builtin_bit_cast(            \
+                    float, __builtin_amdgcn_raw_buffer_load_b32(                                                       \
+                               rx, voff_x, ((mt2 * 32 + (r & 3) + 8 * (r >> 2)) * ldxi + nt2 * 32) * 4, 0));           \
+            }                                                                                                          \
+            const int col = col_base + nt * 32;                                                                        \
+            const float bv = (EPI & E_BIAS) ? ep.bias[col] : 0.0f;                                                     \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
+                const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);                                       \
+                float v = acc[mt][nt][r] + bv;                                                                         \
+                if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
+                if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);              \
+                if (EPI & E_GATE) v *= (aux[tile & 1][r] > 0.0f ? ep.gate_scale : 0.0f);                               \
+                if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
+                                                      ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
+                acc[mt][nt][r] = 0.0f;                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        ep_tile += gridDim.x;                                                                                          \
+    }
+
+    // one phase pair for stream position s (RB_ = LDS buffer with K tile s, WB_ = buffer for tile s+1).  ONE raw-operand
+    // register set: tile s+1 (requested in the previous memory phase) is split and stored, then the same registers are
+    // reused for the request of tile s+2 -- a full MFMA phase + two barriers of latency cover.
+#define PP_PHASES(RB_, WB_)                                                       \
+    {                                                                             \
+        if (kt == 0 && s > 0) PP_EPILOGUE()                                       \
+        PP_READ_FRAGS(RB_)                                                        \
+        PP_STORE(x, WB_)                                                          \
+        PP_LOAD(x)                                                                \
+        PP_BARRIER()                                                              \
+        __builtin_amdgcn_s_setprio(1);                                            \
+        PP_MFMA()                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                            \
+        PP_BARRIER()                                                              \
+        ++s;                                                                      \
+        kt = (kt + 1 == T) ? 0 : kt + 1;                                          \
+    }
+
+    // prologue: K tile 0 split into buffer 0, tile 1 requested
+    PP_LOAD(x)
+    PP_STORE(x, buf0)
+    PP_LOAD(x)
+    PP_BARRIER()
+    if (wm == 1) { PP_BARRIER() }                        // group 1 falls one phase behind
+    int s = 0, kt = 0;
+#pragma unroll 1
+    while (s < S) {
+        PP_PHASES(buf0, buf1)
+        PP_PHASES(buf1, buf0)
+    }
+    if (wm == 0) { PP_BARRIER() }                        // pairs with group 1's last barrier
+    PP_EPILOGUE()
+#undef PP_PHASES
+#undef PP_EPILOGUE
+#undef PP_BARRIER
+#undef PP_MFMA
+#undef PP_TERM
+#undef PP_READ_FRAGS
+#undef PP_STORE
+#undef PP_ST1
+#undef PP_LOAD
+#undef PP_SET_SRC
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -888,6 +1096,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const flo
 // GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate).
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
 static std::atomic<int> g_gemm_mode{-1};
+static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups (A/B switch)
 static std::atomic<int> g_use_t2{1};   // bf16x6 NT: use the 256x256 tile kernel where shapes allow (A/B switch)
 static int gemm_mode() {
     int m = g_gemm_mode.load(std::memory_order_relaxed);
@@ -998,8 +1207,10 @@ extern "C" {
 
 int vqcpc_gemm_set_mode(int mode) {
     // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing)
-    VQ_REQUIRE(mode >= 0 && mode <= 3, "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6) [+2: 128-tile only]");
+    VQ_REQUIRE(mode >= 0 && mode <= 7,
+               "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong]");
     g_use_t2.store((mode & 2) ? 0 : 1, std::memory_order_relaxed);
+    g_use_pp.store((mode & 4) ? 0 : 1, std::memory_order_relaxed);
     mode &= 1;
     g_gemm_mode.store(mode, std::memory_order_relaxed);
     return VQCPC_OK;
@@ -1055,7 +1266,9 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     }
     if (t2_ok) {
         const int tn2 = N / kT2;
-        const dim3 grid2((unsigned)((M / kT2) * tn2)), block2(kT2Threads);
+        const int tiles2 = (int)((M / kT2) * tn2);
+        const dim3 grid2((unsigned)std::min(tiles2, kNumCU)), block2(kT2Threads);
+        const bool use_pp = g_use_pp.load(std::memory_order_relaxed) != 0;
         const size_t lds2 = 2 * kT2Buf;
 #define T2_LAUNCH(EPIV)                                                                                                    \
     {                                                                                                                      \
@@ -1065,7 +1278,16 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                                       (int)lds2);                                                                          \
             attr_done = true;                                                                                              \
         }                                                                                                                  \
-        hipLaunchKernelGGL((gemm_nt_x6_256_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, ep);  \
+        static bool attr_pp = false;                                                                                       \
+        if (!attr_pp) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      (int)lds2);                                                                          \
+            attr_pp = true;                                                                                                \
+        }                                                                                                                  \
+        if (use_pp)                                                                                                        \
+            hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
+        else                                                                                                               \
+            hipLaunchKernelGGL((gemm_nt_x6_256_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
         VQ_CHECK_LAUNCH("gemm_nt_x6_256");                                                                                 \
         return VQCPC_OK;                                                                                                   \
     }

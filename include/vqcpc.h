@@ -122,6 +122,18 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
                       const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
                       int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* First-layer variant: q | k | v are rows of the block table of vqcpc_block_table_gather (table [vmax * L][ldt], row of
+ * token r of a block = tokens[r] * L + r); the kernels read them through the token indirection from the L2-resident
+ * table instead of a gathered (n_blocks * L, 3d) copy.  d_qkv is still per token (its segment sum is the table gradient:
+ * vqcpc_block_table_segsum).  L in {16, 4} only; workspace = vqcpc_relattn_bwd_workspace. */
+int vqcpc_relattn_tab_fwd(const float* table, int64_t ldt, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
+                          int64_t ldo, float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed,
+                          void* stream);
+int vqcpc_relattn_tab_bwd(const float* d_ctx, int64_t ldo, const float* table, int64_t ldt, const int64_t* tokens,
+                          const float* probs, const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* d_e1,
+                          float* d_e2, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+
 /* Query-subsampled variant for the LAST layer of a stack: `output[::F]` (relative_transformer_downscaler.py:125) keeps
  * only positions 0, F, 2F.. and everything after the attention is per-token, so only those queries are evaluated
  * (keys / values still span the block).  q [n_blocks*L/F][ldq] (projected from x[::F], unscaled), kv [n_blocks*L][ldkv]

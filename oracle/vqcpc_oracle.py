@@ -433,9 +433,10 @@ def cpc_losses(batch, P, cfg, training=False, gen=None):
 
     c = gru_context(z_l, P, 'c_module.', cfg['gru_layers'], cfg['dropout'], training, gen)
     f_pos, f_neg = fks_scores(c, P['fks_module.W'], z_r, zq_n[:, :, :, 0, :])
+    margin = (f_pos - f_neg.max(2)[0]).detach()          # sign = hit; |margin| ~ ulp marks a rounding-level tie
     score = f_pos > f_neg.max(2)[0]
     contrastive = nce_loss(f_pos, f_neg)
-    score_b = None
+    score_b = margin_b = None
     if cfg['bidirectional']:                                                    # :277-296
         c_b = gru_context(z_r.flip(dims=[1]), P, 'c_module_back.', cfg['gru_layers'], cfg['dropout'], training, gen)
         # Reference quirk, kept for parity: unlike the forward direction (:245-255) the backward negatives are NOT
@@ -445,6 +446,7 @@ def cpc_losses(batch, P, cfg, training=False, gen=None):
         zb = zq_nb[:, :, :, 0, :]
         zb = zb.reshape(B * N, Kr, zb.shape[-1]).reshape(N, B, Kr, zb.shape[-1]).permute(1, 0, 2, 3)
         f_pos_b, f_neg_b = fks_scores(c_b, P['fks_module_back.W'], z_l, zb)
+        margin_b = (f_pos_b - f_neg_b.max(2)[0]).detach()
         score_b = f_pos_b > f_neg_b.max(2)[0]
         contrastive = contrastive + nce_loss(f_pos_b, f_neg_b)
     q_loss = quantization_loss(ql_l, ql_n, ql_r, ql_nb)
@@ -457,7 +459,7 @@ def cpc_losses(batch, P, cfg, training=False, gen=None):
     ncw_neg = len(torch.unique(merge_codes(idx_n, K)))
     return dict(loss=loss, loss_contrastive=contrastive, loss_quantize=q_loss, accuracy=acc,
                 num_codewords=ncw, num_codewords_negative=ncw_neg,
-                idx_left=idx_l, idx_right=idx_r, idx_negative=idx_n)
+                idx_left=idx_l, idx_right=idx_r, idx_negative=idx_n, margin=margin, margin_back=margin_b)
 
 
 def clip_grad_norm(grads, max_norm=5.0):

@@ -409,6 +409,39 @@ def test_relattn_general_kernels_match_small_L_kernels(ops, n, L, H, hd, p):
         hip.force_general_attention(False)
 
 
+@pytest.mark.parametrize('n,L,H,hd,p', [(300, 16, 8, 32, 0.1), (77, 4, 2, 16, 0.0), (50, 16, 4, 64, 0.0)])
+def test_relattn_table_indirection_is_bit_identical_to_gathered_qkv(ops, n, L, H, hd, p):
+    """First-layer variant: q | k | v read from the block table through the tokens == the plain kernels on the gathered
+    (n L, 3d) copy, bit for bit, forward and backward."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(n + L)
+    d, vmax, seed = H * hd, 13, 99
+    table = torch.randn(vmax * L, 3 * d, generator=gen).cuda()
+    tokens = torch.randint(0, vmax, (n * L,), generator=gen).cuda()
+    e1, e2 = torch.randn(H * L, hd, generator=gen).cuda(), torch.randn(H * L, hd, generator=gen).cuda()
+    dctx = torch.randn(n * L, d, generator=gen).cuda()
+    qkv = ops.BlockTableGatherFn.apply(table, tokens, L)
+    outs = []
+    for tab in (False, True):
+        ctx = torch.empty(n * L, d, device='cuda')
+        probs = torch.empty(n, H, L, L, device='cuda')
+        dqkv = torch.empty(n * L, 3 * d, device='cuda')
+        de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
+        nbytes = hip.query('vqcpc_relattn_bwd_workspace', n, L, H, hd)
+        ws = hip.workspace(nbytes, 'cuda')
+        if tab:
+            hip.call('vqcpc_relattn_tab_fwd', table, 3 * d, tokens, e1, e2, ctx, d, probs, n, L, H, hd, p, seed)
+            hip.call('vqcpc_relattn_tab_bwd', dctx, d, table, 3 * d, tokens, probs, e1, e2, dqkv, 3 * d, de1, de2, n, L, H, hd, p,
+                     seed, ws, nbytes)
+        else:
+            hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, ctx, d, probs, n, L, H, hd, p, seed)
+            hip.call('vqcpc_relattn_bwd', dctx, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, n, L, H, hd, p, seed, ws,
+                     nbytes)
+        outs.append((ctx, probs, dqkv, de1, de2))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def _relattn_case(ops, n, L, H, hd, p):
     from vqcpc_bach_amd import hip
     gen = torch.Generator().manual_seed(n + L + H)
@@ -516,7 +549,7 @@ def test_encoder_layer_query_stride_equals_full_then_select(ops, L, H, d, ff):
     (y_ref[:, ::4] * gy).sum().backward()
     params = [dev(sdl[k]).requires_grad_(True) for k in order]
     xd = dev(x.reshape(n * L, d)).requires_grad_(True)
-    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 4, None, *params)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 4, None, None, *params)
     assert y.shape == (n * L // 4, d)
     assert rel_err(y.detach().cpu(), y_ref.detach()[:, ::4].reshape(-1, d)) < FWD_TOL
     (y * dev(gy.reshape(-1, d))).sum().backward()
@@ -538,7 +571,7 @@ def test_encoder_layer_golden(ops, name, L):
     x = T(g['x']).transpose(0, 1).contiguous()                   # (n, L, d) block-major
     n, _, d = x.shape
     xd = dev(x.reshape(n * L, d)).requires_grad_(True)
-    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 1, None, *params)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 1, None, None, *params)
     y_ref = T(g['y']).transpose(0, 1).reshape(n * L, d)
     assert rel_err(y.detach().cpu(), y_ref) < FWD_TOL
     assert rel_err(probs.cpu(), g['attn']) < FWD_TOL

@@ -87,6 +87,17 @@ def test_encoder_forward_golden(name):
     assert rel_err(ql.cpu(), g['fwd_qloss']) < 2e-4
 
 
+def _near_tie_fraction(cfg, sd, batch, tol=1e-5):
+    """Per prediction step k: fraction of windows whose oracle margin f_pos - max f_neg is below `tol` in magnitude
+    (averaged over the two directions of the bidirectional model, like the accuracy itself)."""
+    with torch.no_grad():
+        out = O.cpc_losses(batch, sd, cfg)
+    ties = (out['margin'].abs() < tol).float().mean(0)
+    if out['margin_back'] is not None:
+        ties = (ties + (out['margin_back'].abs() < tol).float().mean(0)) / 2
+    return ties.numpy()
+
+
 @pytest.fixture(params=['plain_qkv', 'table_qkv'])
 def first_layer_path(request):
     """The first layer's in_proj either as a GEMM over every token or as the block-table lookup (forced on here: the
@@ -111,8 +122,12 @@ def test_epoch_golden(name, first_layer_path):
         assert abs(ev[k] - float(g[f'eval/{k}'])) < FWD_TOL * max(1.0, abs(float(g[f'eval/{k}']))), k
     assert ev['num_codewords'] == float(g['eval/num_codewords'])
     assert ev['num_codewords_negative'] == float(g['eval/num_codewords_negative'])
-    assert np.allclose(np.asarray(ev['accuracy']), g['eval/accuracy'], atol=1e-6)
-    assert abs(ev['loss_monitor'] - float(g['eval/loss_monitor'])) < 1e-6
+    # accuracy is a count of strict wins `f_pos > max f_neg`; a positive and a negative block that fall on the same code
+    # give scores that differ by an ulp or not at all (the straight-through value z + (q - z) depends on z), so such
+    # windows may flip with any change of rounding: they are identified with the oracle and allowed either way
+    slack = _near_tie_fraction(cfg, sd, batch)
+    assert np.all(np.abs(np.asarray(ev['accuracy']) - g['eval/accuracy']) <= slack + 1e-6), (ev['accuracy'], slack)
+    assert abs(ev['loss_monitor'] - float(g['eval/loss_monitor'])) <= float(slack.mean()) + 1e-6
 
     # gradients BEFORE clipping: forward + backward only
     tr.train()

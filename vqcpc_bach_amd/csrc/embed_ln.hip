@@ -88,33 +88,6 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) dst[i] = lds[i];
 }
 
-// stage 2: sum partials over chunks (and over voices for the event table)
-__global__ __launch_bounds__(256) void embed_pos_bwd_reduce(const float* __restrict__ ws, int nchunks, int nv, int vmax,
-                                                            int dlin, int pos, int nev, float* __restrict__ d_table,
-                                                            float* __restrict__ d_chan, float* __restrict__ d_event) {
-    // nev == 0: no event part
-    const int lds_floats = vmax * dlin + pos + nev * pos;
-    const int n_tab = nv * vmax * dlin, n_chan = nv * pos, n_ev = nev * pos;
-    const int o = blockIdx.x * blockDim.x + threadIdx.x;
-    if (o < n_tab) {
-        const int v = o / (vmax * dlin), i = o % (vmax * dlin);
-        float acc = 0.0f;
-        for (int ch = 0; ch < nchunks; ++ch) acc += ws[((int64_t)ch * nv + v) * lds_floats + i];
-        d_table[o] = acc;
-    } else if (o < n_tab + n_chan) {
-        const int q = o - n_tab, v = q / pos, i = q % pos;
-        float acc = 0.0f;
-        for (int ch = 0; ch < nchunks; ++ch) acc += ws[((int64_t)ch * nv + v) * lds_floats + vmax * dlin + i];
-        d_chan[q] = acc;
-    } else if (o < n_tab + n_chan + n_ev) {
-        const int q = o - n_tab - n_chan;
-        float acc = 0.0f;
-        for (int ch = 0; ch < nchunks; ++ch)
-            for (int v = 0; v < nv; ++v) acc += ws[((int64_t)ch * nv + v) * lds_floats + vmax * dlin + pos + q];
-        d_event[q] = acc;
-    }
-}
-
 // =====================================================================================================================
 // residual + dropout + LayerNorm.  One wavefront per row, 4 rows per workgroup, lane owns columns lane*4 + 256*it.
 // =====================================================================================================================
@@ -394,10 +367,22 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
     hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(nchunks, n_voices), dim3(256), lds, s, tokens, n_rows,
                        tokens_per_block, n_voices, vmax, dlin, pos, d_event ? 1 : 0, g_out, (float*)workspace);
     VQ_CHECK_LAUNCH("embed_pos_bwd");
-    const int total = n_voices * vmax * dlin + n_voices * pos + nev * pos;
-    hipLaunchKernelGGL(embed_pos_bwd_reduce, dim3(ceil_div(total, 256)), dim3(256), 0, s, (const float*)workspace,
-                       nchunks, n_voices, vmax, dlin, pos, nev, d_table, d_chan, d_event);
-    VQ_CHECK_LAUNCH("embed_pos_bwd_reduce");
+    // stage 2: partials ws[chunk][voice][table | chan | event] -> parallel deterministic column reductions (a single
+    // thread per output walking 272 chunks was latency-bound: 140 us)
+    const float* wsf = (const float*)workspace;
+    const int64_t per = (int64_t)vmax * dlin + pos + (int64_t)nev * pos;
+    for (int v = 0; v < n_voices; ++v) {
+        int rc = launch_reduce_splits(wsf + v * per, (int64_t)n_voices * per, nchunks, d_table + (int64_t)v * vmax * dlin,
+                                      (int64_t)vmax * dlin, 0, s);
+        if (rc) return rc;
+        rc = launch_reduce_splits(wsf + v * per + (int64_t)vmax * dlin, (int64_t)n_voices * per, nchunks, d_chan + v * pos, pos,
+                                  0, s);
+        if (rc) return rc;
+    }
+    if (nev) {      // event sums also run over the voices: (chunk, voice) pairs are consecutive blocks of `per` floats
+        int rc = launch_reduce_splits(wsf + (int64_t)vmax * dlin + pos, per, nchunks * n_voices, d_event, (int64_t)nev * pos, 0, s);
+        if (rc) return rc;
+    }
     return VQCPC_OK;
 }
 

@@ -28,14 +28,19 @@ struct AttCfg {
     static constexpr int BWD_FLOATS = (4 * L + NE) * RS + 2 * L * (L + 1);
 };
 
-// cooperative copy of an L x HD matrix (row stride ld in global) into LDS (row stride RS) by the 4L lanes of a problem
+// cooperative copy of an L x HD matrix (row stride ld in global) into LDS (row stride RS) by the 4L lanes of a problem.
+// tok != nullptr: `src` is a block table [vmax * L][ld] and row r of the block is table row tok[r] * L + r (the first
+// layer's q | k | v are a function of (token id, position) only: they are read from the L2-resident table instead of a
+// gathered per-token copy in HBM).
 template <int L, int HD>
-__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, int64_t ld, int sl, float mul) {
+__device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__ src, int64_t ld, int sl, float mul,
+                                           const int64_t* __restrict__ tok = nullptr) {
     constexpr int LPP = 4 * L, RS = HD + kPad, V = HD / 4;
 #pragma unroll
     for (int e = sl; e < L * V; e += LPP) {
         const int row = e / V, c4 = e % V;
-        float4 v = *reinterpret_cast<const float4*>(src + row * ld + c4 * 4);
+        const int64_t grow = tok ? tok[row] * L + row : row;
+        float4 v = *reinterpret_cast<const float4*>(src + grow * ld + c4 * 4);
         v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
         *reinterpret_cast<float4*>(dst + row * RS + c4 * 4) = v;
     }
@@ -60,7 +65,8 @@ __global__ __launch_bounds__(kAttThreads) void relattn_fwd_kernel(const float* _
                                                                   const float* __restrict__ e2, float* __restrict__ ctx,
                                                                   int64_t ldo, float* __restrict__ probs,
                                                                   int64_t n_blocks, int H, float scale, uint32_t thr,
-                                                                  float inv_keep, uint64_t seed) {
+                                                                  float inv_keep, uint64_t seed,
+                                                                  const int64_t* __restrict__ tokens) {
     using C = AttCfg<L, HD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -80,10 +86,11 @@ __global__ __launch_bounds__(kAttThreads) void relattn_fwd_kernel(const float* _
     const int i = sl >> 2, jg = sl & 3;
 
     if (live) {
-        const float* qp = qkv + n * L * ldq + h * HD;
-        stage_rows<L, HD>(Qs, qp, ldq, sl, scale);
-        stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f);
-        stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f);
+        const int64_t* tk = tokens ? tokens + n * L : nullptr;
+        const float* qp = tokens ? qkv + h * HD : qkv + n * L * ldq + h * HD;
+        stage_rows<L, HD>(Qs, qp, ldq, sl, scale, tk);
+        stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f, tk);
+        stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f, tk);
         stage_erel<L, HD>(Er, e1, e2, h, sl);
     }
     __syncthreads();
@@ -158,7 +165,7 @@ __global__ __launch_bounds__(kAttThreads) void relattn_bwd_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ qkv, int64_t ldq,
     const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
     float* __restrict__ d_qkv, int64_t ldg, float* __restrict__ ws, int64_t n_blocks, int H, int blocks_per_wg,
-    float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    float scale, uint32_t thr, float inv_keep, uint64_t seed, const int64_t* __restrict__ tokens) {
     using C = AttCfg<L, HD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -198,10 +205,11 @@ __global__ __launch_bounds__(kAttThreads) void relattn_bwd_kernel(
         const int64_t prob = n * H + h;
         __syncthreads();
         if (live) {
-            const float* qp = qkv + n * L * ldq + h * HD;
-            stage_rows<L, HD>(Qs, qp, ldq, sl, scale);
-            stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f);
-            stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f);
+            const int64_t* tk = tokens ? tokens + n * L : nullptr;
+            const float* qp = tokens ? qkv + h * HD : qkv + n * L * ldq + h * HD;
+            stage_rows<L, HD>(Qs, qp, ldq, sl, scale, tk);
+            stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f, tk);
+            stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f, tk);
             stage_rows<L, HD>(Os, d_ctx + n * L * ldo + h * HD, ldo, sl, 1.0f);
         }
         __syncthreads();
@@ -330,14 +338,15 @@ static int att_blocks_per_wg(int64_t n_blocks, int slots, int H) {
 
 template <int L, int HD>
 static int launch_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
-                      float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
+                      float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s,
+                      const int64_t* tokens = nullptr) {
     using C = AttCfg<L, HD>;
     const size_t lds = (size_t)C::SLOTS * C::FWD_FLOATS * sizeof(float);
     auto kern = relattn_fwd_kernel<L, HD>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t grid = ceil_div(n_blocks * H, C::SLOTS);
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kAttThreads), lds, s, qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks,
-                       H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+                       H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, tokens);
     VQ_CHECK_LAUNCH("relattn_fwd");
     return VQCPC_OK;
 }
@@ -345,7 +354,7 @@ static int launch_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
 template <int L, int HD>
 static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
                       const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int H,
-                      float drop_p, uint64_t seed, float* ws, hipStream_t s) {
+                      float drop_p, uint64_t seed, float* ws, hipStream_t s, const int64_t* tokens = nullptr) {
     using C = AttCfg<L, HD>;
     const size_t lds = (size_t)C::SLOTS * C::BWD_FLOATS * sizeof(float);
     auto kern = relattn_bwd_kernel<L, HD>;
@@ -355,7 +364,7 @@ static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
     const int gy = C::SLOTS >= H ? 1 : H / C::SLOTS;
     const int NS = C::SLOTS >= H ? C::SLOTS / H : 1;
     hipLaunchKernelGGL(kern, dim3(chunks, gy), dim3(kAttThreads), lds, s, d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg,
-                       ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+                       ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, tokens);
     VQ_CHECK_LAUNCH("relattn_bwd");
     const int total = H * C::NE * HD;
     float* tot = ws + (int64_t)chunks * NS * total;            // tail of the workspace
@@ -446,6 +455,44 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
     }
 #define CALL(LL, DD) \
     launch_bwd<LL, DD>(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, H, drop_p, seed, (float*)workspace, s)
+    VQ_ATT_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+int vqcpc_relattn_tab_fwd(const float* table, int64_t ldt, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
+                          int64_t ldo, float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed,
+                          void* stream) {
+    if (n_blocks == 0) return VQCPC_OK;
+    VQ_REQUIRE(table && tokens && e1 && e2 && ctx && probs, "relattn_tab_fwd: null pointer");
+    VQ_REQUIRE(!g_force_general && att_supported(L, H, hd), "relattn_tab_fwd: unsupported L=%d H=%d hd=%d (L in {16,4})", L, H, hd);
+    VQ_REQUIRE(ldt % 4 == 0 && ldo % 4 == 0 && ldt >= 3 * H * hd && ldo >= H * hd, "relattn_tab_fwd: bad strides");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_tab_fwd: bad dropout probability");
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LL, DD) launch_fwd<LL, DD>(table, ldt, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s, tokens)
+    VQ_ATT_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+int vqcpc_relattn_tab_bwd(const float* d_ctx, int64_t ldo, const float* table, int64_t ldt, const int64_t* tokens,
+                          const float* probs, const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* d_e1,
+                          float* d_e2, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                          int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(d_ctx && table && tokens && probs && e1 && e2 && d_qkv && d_e1 && d_e2 && workspace,
+               "relattn_tab_bwd: null pointer");
+    VQ_REQUIRE(!g_force_general && att_supported(L, H, hd), "relattn_tab_bwd: unsupported L=%d H=%d hd=%d", L, H, hd);
+    VQ_REQUIRE(ldt % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldt >= 3 * H * hd && ldg >= 3 * H * hd && ldo >= H * hd &&
+                   n_blocks >= 1,
+               "relattn_tab_bwd: bad strides");
+    if (workspace_bytes < vqcpc_relattn_bwd_workspace(n_blocks, L, H, hd)) {
+        set_error("relattn_tab_bwd: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(LL, DD)                                                                                                   \
+    launch_bwd<LL, DD>(d_ctx, ldo, table, ldt, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, H, drop_p, seed,       \
+                       (float*)workspace, s, tokens)
     VQ_ATT_DISPATCH(CALL)
 #undef CALL
     return VQCPC_EINVAL;

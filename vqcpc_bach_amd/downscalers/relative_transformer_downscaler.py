@@ -74,7 +74,7 @@ class RelativeTransformerDownscaler(Downscaler):
         assert tokens.shape[-1] == self.sequence_length
         tables = data_processor.stacked_tables()                                    # (nv, vmax, emb)
         # lookup(E_v)[tok] @ W_in^T + b  ==  lookup(E_v @ W_in^T + b)[tok]
-        table = torch.matmul(tables, self.input_linear.weight.t()) + self.input_linear.bias
+        table = ops.linear(tables, self.input_linear.weight, self.input_linear.bias)      # (nv, vmax, dlin), own GEMM
         flat_tokens = tokens.reshape(-1).contiguous()
         chan = self.target_channel_embeddings.view(self.num_channels, -1)
         event = self.events_positioning_embeddings.view(self.num_events, -1)
@@ -85,8 +85,8 @@ class RelativeTransformerDownscaler(Downscaler):
     def _first_layer_qkv(self, flat_tokens, table, chan, event):
         """in_proj of the FIRST layer as a block-table lookup: its input row depends only on (token id, position in the
         block), i.e. vmax * L distinct rows, so the projection runs on those rows (a 912 x 768 x 256 GEMM at C1 instead of
-        557 056 x 768 x 256) and every token looks its row up; autograd sends the per-table-row sums of d qkv back through
-        the same small GEMM.  Not used when the first layer is also the query-subsampled last layer of its stack."""
+        557 056 x 768 x 256) and every token looks its row up (inside the attention kernels: the 2.8 MB table stays in L2);
+        the per-table-row sums of d qkv go back through the same small GEMM.  Not used when the first layer is also the query-subsampled last layer of its stack."""
         stack = self.transformers[0]
         if len(stack.layers) < 2 and _sub_supported(self.sequence_length, self.downscale_factors[0],
                                                     self.d_model // stack.layers[0].nhead):
@@ -98,6 +98,8 @@ class RelativeTransformerDownscaler(Downscaler):
         x_table = ops.EmbedPosFn.apply(syn, table, chan, event, L)                     # (vmax * L, d)
         attn = stack.layers[0].self_attn
         qkv_table = ops.linear(x_table, attn.in_proj_weight, attn.in_proj_bias)        # (vmax * L, 3d)
+        if L in (16, 4):
+            return qkv_table, flat_tokens                 # the L = 16 / 4 attention kernels read the table directly
         return ops.BlockTableGatherFn.apply(qkv_table, flat_tokens, L)
 
     # ---- API-compatible path ----------------------------------------------------------------------------------

@@ -55,7 +55,7 @@ class RelativeTransformerDownscalerLinear(Downscaler):
         lead = tokens.shape[:-1]
         assert tokens.shape[-1] == self.sequence_length
         tables = data_processor.stacked_tables()
-        table = torch.matmul(tables, self.input_linear.weight.t()) + self.input_linear.bias
+        table = ops.linear(tables, self.input_linear.weight, self.input_linear.bias)      # (nv, vmax, dlin), own GEMM
         x = ops.EmbedPosFn.apply(tokens.reshape(-1).contiguous(), table,
                                  self.target_channel_embeddings.view(self.num_channels, -1),
                                  self.events_positioning_embeddings.view(self.num_events, -1), self.sequence_length)

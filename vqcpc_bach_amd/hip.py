@@ -40,6 +40,10 @@ SIGNATURES = {
     'vqcpc_relattn_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int]),
     'vqcpc_relattn_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
                                   c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_relattn_tab_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_f32,
+                                      c_u64, c_ptr]),
+    'vqcpc_relattn_tab_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr,
+                                      c_i64, c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
     'vqcpc_relattn_sub_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int,
                                       c_int, c_int, c_f32, c_u64, c_ptr]),
     'vqcpc_relattn_sub_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int, c_int]),

@@ -211,9 +211,11 @@ class EncoderLayerFn(torch.autograd.Function):
     Identical results, ~60 % fewer FLOPs in that layer."""
 
     @staticmethod
-    def forward(ctx, x, L, H, drop_p, seed, qstride, qkv_in, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1, g2, be2):
-        # qkv_in: the (M, 3d) projection computed elsewhere (first layer: block-table lookup); then wqkv / bqkv are
-        # not used here and the gradient of the projection is handed back through qkv_in
+    def forward(ctx, x, L, H, drop_p, seed, qstride, qkv_in, qkv_tokens, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1,
+                g2, be2):
+        # qkv_in: the in_proj output computed elsewhere (first layer); wqkv / bqkv are then not used here and the gradient
+        # of the projection is handed back through qkv_in.  Either the per-token (M, 3d) tensor, or -- with qkv_tokens
+        # (M,) int64 -- the (vmax * L, 3d) block table, which the attention kernels read through the token indirection
         x, ldx = _rows(_f32(x))
         M, d = x.shape
         hd = d // H
@@ -227,7 +229,10 @@ class EncoderLayerFn(torch.autograd.Function):
             qkv = gemm_nt(x, wqkv, bias=bqkv) if qkv_in is None else _f32(qkv_in).contiguous()
             att = torch.empty(M, d, dtype=torch.float32, device=dev)
             probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
-            hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+            if qkv_tokens is not None:
+                hip.call('vqcpc_relattn_tab_fwd', qkv, 3 * d, qkv_tokens, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+            else:
+                hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
             qproj = qkv
         else:
             assert L % f == 0 and qkv_in is None
@@ -253,6 +258,7 @@ class EncoderLayerFn(torch.autograd.Function):
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
         ctx.biases = (bqkv, bo, b1, b2)
+        ctx.qkv_tokens = qkv_tokens
         ctx.mark_non_differentiable(probs)
         return y, probs
 
@@ -297,10 +303,21 @@ class EncoderLayerFn(torch.autograd.Function):
             dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
             nbytes = hip.query('vqcpc_relattn_bwd_workspace', nblk, L, H, hd)
             ws = hip.workspace(nbytes, dev)
-            hip.call('vqcpc_relattn_bwd', datt, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd, p, s[0],
-                     ws, nbytes)
+            tok = ctx.qkv_tokens
+            if tok is not None:
+                hip.call('vqcpc_relattn_tab_bwd', datt, d, qkv, 3 * d, tok, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd,
+                         p, s[0], ws, nbytes)
+                vmax = qkv.shape[0] // L                                  # table gradient = segment sum of d qkv
+                d_in = torch.empty_like(qkv)
+                nb2 = hip.query('vqcpc_block_table_segsum_workspace', M, L, vmax, 3 * d)
+                ws2 = hip.workspace(nb2, dev)
+                hip.call('vqcpc_block_table_segsum', dqkv, tok, d_in, M, L, vmax, 3 * d, ws2, nb2)
+            else:
+                hip.call('vqcpc_relattn_bwd', datt, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd, p, s[0],
+                         ws, nbytes)
+                d_in = dqkv
             if ext_qkv:          # projection lives outside: its gradient leaves through qkv_in, x keeps the residual path
-                return (ds1 if need_dx else None, None, None, None, None, None, dqkv, None, None, dwo, dbo, de1, de2, dw1,
+                return (ds1 if need_dx else None, None, None, None, None, None, d_in, None, None, None, dwo, dbo, de1, de2, dw1,
                         db1, dw2, db2, dg1, dbe1, dg2, dbe2)
             dwqkv, dbqkv = wgrad(dqkv, x, wqkv, bqkv)
             dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if need_dx else None
@@ -323,8 +340,8 @@ class EncoderLayerFn(torch.autograd.Function):
                 dx = gemm_nt(dkv, wt[:, d:])                               # every row: keys / values path
                 dxs = dx[::f]                                              # kept rows also get the query + residual paths
                 gemm_nt(dq, wt[:, :d], add=ds1, add2=dxs, out=dxs)
-        return (dx, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1, dg2,
-                dbe2)
+        return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1,
+                dg2, dbe2)
 
 
 # ------------------------------------------------------------------------------------------------------------------

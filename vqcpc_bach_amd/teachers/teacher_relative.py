@@ -40,7 +40,7 @@ class TeacherRelative(nn.Module):
         assert C == self.num_channels and E * C == self.num_tokens, 'the relative attention is built for num_tokens'
         tables = self.data_processor.stacked_tables()
         w = self.linear_to_input_transformer
-        table = torch.matmul(tables, w.weight.t()) + w.bias                 # lookup(E_c) W^T + b == lookup(E_c W^T + b)
+        table = ops.linear(tables, w.weight, w.bias)                        # lookup(E_c) W^T + b == lookup(E_c W^T + b)
         x = ops.EmbedPosFn.apply(tokens.reshape(-1).contiguous(), table, self.channel_embeddings.view(C, -1), None, C)
         x, _ = self.transformer.forward_rows(x)
         return x

@@ -41,9 +41,11 @@ class TransformerEncoderLayerCustom(nn.Module):
     def forward_rows(self, x, qstride=1, qkv=None):
         """x: (blocks * L, d) block-major rows (may be row-strided) -> (y (blocks * L / qstride, d), probs).
         qstride = f > 1 evaluates only the output rows 0, f, 2f, ... (what `output[::f]` would keep).
-        qkv: the in_proj output (rows, 3d) when the caller already has it (block-table lookup of the first layer)."""
+        qkv: the in_proj output when the caller already has it (first layer): a (rows, 3d) tensor, or a pair
+        (block table (vmax * L, 3d), tokens (rows,) int64) that the attention reads through the token indirection."""
         p = self.p if self.training else 0.0
-        return ops.EncoderLayerFn.apply(x, self.seq_len, self.nhead, p, SEEDS.next() if p > 0 else 0, qstride, qkv,
+        table, tokens = qkv if isinstance(qkv, tuple) else (qkv, None)
+        return ops.EncoderLayerFn.apply(x, self.seq_len, self.nhead, p, SEEDS.next() if p > 0 else 0, qstride, table, tokens,
                                         *self._params())
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):

@@ -68,6 +68,9 @@ __device__ __forceinline__ float wave_max(float v) {
 // deterministic reduction of `nsplit` partial arrays: out[i] = (accumulate ? out[i] : 0) + sum_s ws[s*stride + i]
 int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
                          hipStream_t stream);
+// same, two column segments in ONE launch: (ws, stride, out, count) and (ws2, stride2, out2, count2)
+int launch_reduce_splits2(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, const float* ws2,
+                          int64_t stride2, float* out2, int64_t count2, int accumulate, hipStream_t stream);
 
 // general-L relative attention (relattn_gen.hip); relattn.hip dispatches to it for L other than 16 / 4
 bool relattn_gen_supported(int L, int H, int hd);

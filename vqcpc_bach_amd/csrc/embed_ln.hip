@@ -472,9 +472,8 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
         hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
                            d_r, (float*)workspace, M, d, thr, ik, seed);
     VQ_CHECK_LAUNCH("add_layernorm_bwd");
-    int rc = launch_reduce_splits((const float*)workspace, (int64_t)2 * d, blocks, d_gamma, d, 0, s);
-    if (rc) return rc;
-    return launch_reduce_splits((const float*)workspace + d, (int64_t)2 * d, blocks, d_beta, d, 0, s);
+    return launch_reduce_splits2((const float*)workspace, (int64_t)2 * d, blocks, d_gamma, d, (const float*)workspace + d,
+                                 (int64_t)2 * d, d_beta, d, 0, s);
 }
 
 }  // extern "C"

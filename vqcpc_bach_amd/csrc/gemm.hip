@@ -1381,10 +1381,7 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N, K,
                            tiles_k, rows_per_split, ws, ws_bias);
     VQ_CHECK_LAUNCH("gemm_tn");
-    int rc = launch_reduce_splits(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, accumulate, s);
-    if (rc) return rc;
-    if (db) rc = launch_reduce_splits(ws_bias, N, splits, db, N, accumulate, s);
-    return rc;
+    return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
 }
 
 }  // extern "C"

@@ -1,6 +1,8 @@
 // Error plumbing, partial-sum reduction, dropout mask probe, transposes, upscaler activation, flat-buffer optimiser.
 #include <stdarg.h>
 
+#include <algorithm>
+
 #include "common.h"
 
 namespace vq {
@@ -19,13 +21,25 @@ void set_error(const char* fmt, ...) {
 // group partials are combined in a fixed order -> deterministic, and no lane walks more than nsplit/16 dependent loads.
 constexpr int kRedCols = 64, kRedGroups = 16;
 
+// Two column segments per launch (a weight gradient and its bias gradient share one launch): columns [0, count) come
+// from (ws, stride) and go to `out`, columns [count, count + count2) from (ws2, stride2) to `out2`.
 __global__ __launch_bounds__(kRedCols * kRedGroups) void reduce_splits_kernel(const float* __restrict__ ws,
                                                                               int64_t stride, int nsplit,
                                                                               float* __restrict__ out, int64_t count,
+                                                                              const float* __restrict__ ws2, int64_t stride2,
+                                                                              float* __restrict__ out2, int64_t count2,
                                                                               int accumulate) {
     __shared__ float part[kRedGroups][kRedCols];
     const int tx = threadIdx.x % kRedCols, ty = threadIdx.x / kRedCols;
-    const int64_t col = (int64_t)blockIdx.x * kRedCols + tx;
+    int64_t col = (int64_t)blockIdx.x * kRedCols + tx;
+    const int64_t first = (count + kRedCols - 1) / kRedCols * kRedCols;      // segment 2 starts on a workgroup boundary
+    if (col >= first) {
+        col -= first;
+        ws = ws2;
+        stride = stride2;
+        out = out2;
+        count = count2;
+    }
     float acc = 0.0f;
     if (col < count) {
         int s = ty;
@@ -48,14 +62,19 @@ __global__ __launch_bounds__(kRedCols * kRedGroups) void reduce_splits_kernel(co
     }
 }
 
-int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
-                         hipStream_t stream) {
-    if (count <= 0) return VQCPC_OK;
-    const int64_t blocks = ceil_div(count, kRedCols);
+int launch_reduce_splits2(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, const float* ws2,
+                          int64_t stride2, float* out2, int64_t count2, int accumulate, hipStream_t stream) {
+    if (count <= 0 && count2 <= 0) return VQCPC_OK;
+    const int64_t blocks = ceil_div(std::max<int64_t>(count, 0), kRedCols) + ceil_div(std::max<int64_t>(count2, 0), kRedCols);
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(kRedCols * kRedGroups), 0, stream, ws, stride,
-                       nsplit, out, count, accumulate);
+                       nsplit, out, std::max<int64_t>(count, 0), ws2, stride2, out2, std::max<int64_t>(count2, 0), accumulate);
     VQ_CHECK_LAUNCH("reduce_splits");
     return VQCPC_OK;
+}
+
+int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
+                         hipStream_t stream) {
+    return launch_reduce_splits2(ws, stride, nsplit, out, count, nullptr, 0, nullptr, 0, accumulate, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

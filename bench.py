@@ -10,9 +10,11 @@ configs[1] = C1: seq_len 256 = 8+8 blocks, B = 256 windows / GPU, 15 negatives, 
 0.1): forward of all 34 816 blocks, InfoNCE + quantisation loss, backward, RCCL all-reduce, global-norm clip, Adam.
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
 
-roofline  : the dominant kernel is the fp32 MFMA GEMM `gemm_nt` (forward + dgrad = 2/3 of the GEMM FLOPs); achieved =
+roofline  : the dominant kernel is the NT GEMM `gemm_nt` (forward + dgrad = 2/3 of the GEMM FLOPs); achieved =
             algorithmic FLOPs (2 M N K per launch) / launch durations measured with HIP events on the launch stream inside
-            the timed region; peak = 157.3 TFLOP/s (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md).
+            the timed region (every launch of every 4th timed step); peak = 416.7 TFLOP/s algorithmic for the default
+            bf16x6 arithmetic (2500 / 6, six bf16 MFMAs per fp32 product), 157.3 for --gemm-mode f32
+            (v_mfma_f32_32x32x2_f32, MI355X_MICROARCH.md).
 cpu_baseline: the CPU oracle (oracle/vqcpc_oracle.py, a port of the reference's path) timed on this host's cores on a
             bounded sample of the same workload (same model, smaller batch: windows/s is batch-normalised).
 """
@@ -68,7 +70,8 @@ class GemmTimer:
             e0.record()
             out = raw_nt(a, b, *args, **kw)
             e1.record()
-            timer.records['gemm_nt'].append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            timer.records['gemm_nt'].append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
+                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[0])))
             return out
 
         def gemm_tn(a, b, *args, **kw):
@@ -78,7 +81,8 @@ class GemmTimer:
             e0.record()
             out = raw_tn(a, b, *args, **kw)
             e1.record()
-            timer.records['gemm_tn'].append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1]))
+            timer.records['gemm_tn'].append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1],
+                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[1] * b.shape[1])))
             return out
 
         ops.gemm_nt, ops.gemm_tn = gemm_nt, gemm_tn
@@ -87,10 +91,10 @@ class GemmTimer:
         recs = self.records[name]
         if not recs:
             return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in recs)
-        flops = sum(f for _, _, f in recs)
+        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        flops = sum(r[2] for r in recs)
         return dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), tflops=flops / (ms * 1e-3) / 1e12,
-                    flops_per_launch=flops / len(recs))
+                    flops_per_launch=flops / len(recs), bytes_per_launch=sum(r[3] for r in recs) / len(recs))
 
 
 def hbm_traffic(kernel):
@@ -99,7 +103,7 @@ def hbm_traffic(kernel):
     for gfx950 -- calibrated on the QKV launch: WRITE_SIZE == M*N*4 exactly).  None when the file is absent."""
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')))
-        return {'hbm_bytes_per_launch': round(d[kernel]['hbm_bytes_per_launch']), 'source': 'profiles/r01_gemm_hbm_traffic.json'}
+        return round(d[kernel]['hbm_bytes_per_launch'])
     except Exception:
         return None
 
@@ -224,10 +228,12 @@ def main():
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
-    timer.enabled = True
     t0 = time.perf_counter()
     for i in range(args.steps):
+        # HIP events bracket the GEMM launches of every 4th timed step (all of them cost ~2 % of the step)
+        timer.enabled = (not args.no_kernel_timing) and (i % 4 == 0)
         out = trainer.train_step(pool[i % len(pool)], train=True)
+    t_enqueued = time.perf_counter() - t0          # host time to enqueue all steps (no sync inside a step)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -238,6 +244,7 @@ def main():
     last_loss = float(out['loss_encdec'] if student else out['loss'])
 
     seq_len = 384 if student else 16 * (dlg.num_blocks_left + dlg.num_blocks_right)
+    timed_steps = max(1, len(range(0, args.steps, 4)))
     if dp.rank == 0:
         value = B * dp.world_size * args.steps / dt
         nt, tn = timer.summary('gemm_nt'), timer.summary('gemm_tn')
@@ -250,9 +257,11 @@ def main():
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt_kernel<MODE=0> (fp32 v_mfma_f32_32x32x2_f32)'
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
                             frac=round(nt['tflops'] / peak, 4), traffic=hbm_traffic('gemm_nt'),
-                            launches_per_step=nt['launches'] // args.steps, avg_launch_us=round(nt['avg_us'], 1),
+                            traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_hbm_traffic.json)',
+                            algorithmic_bytes_per_launch=round(nt['bytes_per_launch']),
+                            launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),
                             flops_per_launch=nt['flops_per_launch'],
-                            share_of_step=round(nt['total_ms'] / (dt * 1e3), 3),
+                            share_of_step=round(nt['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
                             vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3))
         line = {
             'metric': 'encoder-train windows/sec (Bach 4-voice, seq=256)', 'value': round(value, 2), 'unit': 'windows/s',
@@ -268,8 +277,9 @@ def main():
                        'gemm': 'bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else 'fp32 MFMA'},
             'roofline': roofline,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
-                         'share_of_step': round(tn['total_ms'] / (dt * 1e3), 3)} if tn else None),
+                         'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3)} if tn else None),
             'final_loss': round(last_loss, 5),
+            'host_enqueue_ms_per_step': round(1e3 * t_enqueued / args.steps, 3),
         }
         if student:     # BASELINE configs[3]: an extra measurement, not the headline metric
             line['metric'], line['unit'] = 'student-train sequences/sec (Bach 4-voice, 24 beats = 384 tokens)', 'sequences/s'

@@ -81,4 +81,13 @@ int relattn_gen_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t l
                     const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
                     int hd, float drop_p, uint64_t seed, float* ws, hipStream_t s);
 
+// L = 16 attention on the fp32 matrix cores (relattn16.hip); tokens != nullptr = block-table indirection
+bool relattn16_supported(int H, int hd);
+int64_t relattn16_bwd_workspace(int64_t n_blocks, int H, int hd);
+int relattn16_fwd(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
+                  int64_t ldo, float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, hipStream_t s);
+int relattn16_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens, const float* probs,
+                  const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* ws, int64_t n_blocks, int H, int hd,
+                  float drop_p, uint64_t seed, hipStream_t s, int* nsplit);
+
 }  // namespace vq

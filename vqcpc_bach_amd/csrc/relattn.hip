@@ -9,6 +9,7 @@
 // f32 MFMA runs at the f32 VALU rate on gfx950, and the tile is 16x16x32, so this kernel is plain VALU + LDS and is
 // bound by HBM traffic (q, k, v in; ctx, probs out).
 #include "common.h"
+#include <stdlib.h>
 
 namespace vq {
 
@@ -376,6 +377,12 @@ static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
 }
 
 static int g_force_general = 0;   // tests: route L = 16 / 4 through the general-L kernels too
+// L = 16 runs on the matrix cores (relattn16.hip); VQCPC_RELATTN16_LDS=1 keeps the LDS-tiled VALU kernels (A/B, tests)
+static bool use_mfma16(int L, int H, int hd) {
+    static const bool lds_only = getenv("VQCPC_RELATTN16_LDS") && atoi(getenv("VQCPC_RELATTN16_LDS")) != 0;
+    return L == 16 && !lds_only && relattn16_supported(H, hd);
+}
+static int finish_de16(float* ws, int nsplit, int H, int hd, float* d_e1, float* d_e2, hipStream_t s);
 
 static bool att_supported(int L, int H, int hd) {
     if (g_force_general) return false;
@@ -383,6 +390,16 @@ static bool att_supported(int L, int H, int hd) {
     if (!(hd == 16 || hd == 32 || hd == 64)) return false;
     const int slots = 4 * (64 / (4 * L));
     return H >= 1 && ((slots % H) == 0 || (H % slots) == 0);
+}
+
+static int finish_de16(float* ws, int nsplit, int H, int hd, float* d_e1, float* d_e2, hipStream_t s) {
+    const int total = H * 31 * hd;
+    float* tot = ws + (int64_t)nsplit * total;
+    int rc = launch_reduce_splits(ws, total, nsplit, tot, total, 0, s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(relattn_de_split, dim3(ceil_div(total, 256)), dim3(256), 0, s, tot, H, 16, hd, d_e1, d_e2);
+    VQ_CHECK_LAUNCH("relattn_de_split");
+    return VQCPC_OK;
 }
 
 }  // namespace vq
@@ -419,6 +436,8 @@ int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
         VQ_REQUIRE(n_blocks * H * (int64_t)((L + 31) / 32) < (1ll << 31), "relattn_fwd: too many strips");
         return relattn_gen_fwd(qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks, L, H, hd, drop_p, seed, s);
     }
+    if (use_mfma16(L, H, hd) && aligned16(qkv) && aligned16(e1) && aligned16(e2) && aligned16(ctx))
+        return relattn16_fwd(qkv, ldq, nullptr, e1, e2, ctx, ldo, probs, n_blocks, H, hd, drop_p, seed, s);
 #define CALL(LL, DD) launch_fwd<LL, DD>(qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s)
     VQ_ATT_DISPATCH(CALL)
 #undef CALL
@@ -427,11 +446,12 @@ int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
 
 int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd) {
     if (!att_supported(L, H, hd)) return relattn_gen_bwd_workspace(std::max<int64_t>(n_blocks, 1), std::max(L, 1), std::max(H, 1), hd);
+    const int64_t w16 = use_mfma16(L, H, hd) ? relattn16_bwd_workspace(std::max<int64_t>(n_blocks, 1), H, hd) : 0;
     const int slots = 4 * (64 / (4 * std::max(L, 1)));
     const int bpw = att_blocks_per_wg(std::max<int64_t>(n_blocks, 1), slots, std::max(H, 1));
     const int64_t chunks = ceil_div(std::max<int64_t>(n_blocks, 1), bpw);
     const int NS = slots >= H ? slots / H : 1;
-    return (chunks * NS + 1) * H * (2 * L - 1) * hd * (int64_t)sizeof(float);
+    return std::max<int64_t>(w16, (chunks * NS + 1) * H * (2 * L - 1) * hd * (int64_t)sizeof(float));
 }
 
 int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
@@ -453,6 +473,12 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
         return relattn_gen_bwd(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, L, H, hd, drop_p, seed,
                                (float*)workspace, s);
     }
+    if (use_mfma16(L, H, hd) && aligned16(qkv) && aligned16(d_ctx) && aligned16(e1) && aligned16(e2) && aligned16(d_qkv)) {
+        int nsplit = 0;
+        int rc = relattn16_bwd(d_ctx, ldo, qkv, ldq, nullptr, probs, e1, e2, d_qkv, ldg, (float*)workspace, n_blocks, H, hd,
+                               drop_p, seed, s, &nsplit);
+        return rc ? rc : finish_de16((float*)workspace, nsplit, H, hd, d_e1, d_e2, s);
+    }
 #define CALL(LL, DD) \
     launch_bwd<LL, DD>(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, H, drop_p, seed, (float*)workspace, s)
     VQ_ATT_DISPATCH(CALL)
@@ -469,6 +495,8 @@ int vqcpc_relattn_tab_fwd(const float* table, int64_t ldt, const int64_t* tokens
     VQ_REQUIRE(ldt % 4 == 0 && ldo % 4 == 0 && ldt >= 3 * H * hd && ldo >= H * hd, "relattn_tab_fwd: bad strides");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_tab_fwd: bad dropout probability");
     hipStream_t s = (hipStream_t)stream;
+    if (use_mfma16(L, H, hd) && aligned16(table) && aligned16(e1) && aligned16(e2) && aligned16(ctx))
+        return relattn16_fwd(table, ldt, tokens, e1, e2, ctx, ldo, probs, n_blocks, H, hd, drop_p, seed, s);
 #define CALL(LL, DD) launch_fwd<LL, DD>(table, ldt, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s, tokens)
     VQ_ATT_DISPATCH(CALL)
 #undef CALL
@@ -490,6 +518,12 @@ int vqcpc_relattn_tab_bwd(const float* d_ctx, int64_t ldo, const float* table, i
         return VQCPC_EWORKSPACE;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (use_mfma16(L, H, hd) && aligned16(table) && aligned16(d_ctx) && aligned16(e1) && aligned16(e2) && aligned16(d_qkv)) {
+        int nsplit = 0;
+        int rc = relattn16_bwd(d_ctx, ldo, table, ldt, tokens, probs, e1, e2, d_qkv, ldg, (float*)workspace, n_blocks, H, hd,
+                               drop_p, seed, s, &nsplit);
+        return rc ? rc : finish_de16((float*)workspace, nsplit, H, hd, d_e1, d_e2, s);
+    }
 #define CALL(LL, DD)                                                                                                   \
     launch_bwd<LL, DD>(d_ctx, ldo, table, ldt, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, H, drop_p, seed,       \
                        (float*)workspace, s, tokens)

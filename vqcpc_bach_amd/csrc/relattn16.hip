@@ -1,0 +1,356 @@
+// L = 16 self-attention with the closed-form relative bias on the fp32 matrix cores (v_mfma_f32_16x16x4_f32).
+// One wavefront owns one (block, head) problem: the 16 x 16 score tile is ONE MFMA accumulator (4 registers per lane).
+// The LDS-tiled VALU kernels of relattn.hip read every operand of every FMA from LDS (~225 KB of LDS traffic per problem
+// in the backward: 0.9 ms of pure LDS time at C1); here the operands of the contractions over hd are float4 row loads
+// straight from global / L2 (the MFMA k index is a summation index, so lane group g takes the contiguous columns
+// [g hd/4, (g+1) hd/4) of its row) and only the two things that need a transposed or skewed view -- P for P.V / dS.K and
+// the relative term -- pass through a 16 x 33 float LDS tile per wave.
+//   MFMA layouts (l = lane, g = l >> 4, c = l & 15):  A[row c][k g]   B[k g][col c]   D[row 4g + r][col c], r = 0..3
+// Head columns are mapped to (column tile ct, lane c) as column = CT*c + ct (CT = hd/16 tiles): the CT values a lane
+// feeds to / receives from the CT column tiles are contiguous in memory -> one 8/16-byte access per lane, full 128-byte
+// lines per 16-lane group instead of CT half-line dword accesses.
+// Same semantics / buffers as relattn.hip (probs saved before dropout, dropout index ((prob*16 + i)*16 + j),
+// S[i][j] = qs_i.k_j + qs_i.Erel[j - i + 15], Erel[r] = e1[h][r] (r < 16) | e2[h][r - 15] (r >= 16)), optional token
+// indirection into the first layer's block table.
+#include "common.h"
+
+namespace vq {
+
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
+constexpr int kA16Waves = 4;
+constexpr int kA16RS = 33;              // LDS row stride of the per-wave 16 x 32 tile
+
+__device__ __forceinline__ const float* erel16(const float* __restrict__ e1, const float* __restrict__ e2, int h, int HD,
+                                               int x) {
+    x = min(x, 30);
+    return x < 16 ? e1 + ((int64_t)h * 16 + x) * HD : e2 + ((int64_t)h * 16 + (x - 15)) * HD;
+}
+
+// The LDS tile is private to a wavefront and LDS instructions of one wave execute in order, so a cross-lane exchange
+// needs no s_barrier: only the compiler must keep the program order of the accesses around this point.
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int N>
+__device__ __forceinline__ void load_f4(float (&dst)[N], const float* __restrict__ p, float mul) {
+#pragma unroll
+    for (int v = 0; v < N / 4; ++v) {
+        const float4 t = *reinterpret_cast<const float4*>(p + 4 * v);
+        dst[4 * v] = t.x * mul; dst[4 * v + 1] = t.y * mul; dst[4 * v + 2] = t.z * mul; dst[4 * v + 3] = t.w * mul;
+    }
+}
+
+template <int CT>
+__device__ __forceinline__ void load_ct(float (&dst)[CT], const float* __restrict__ p, float mul) {
+    if (CT == 4) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        dst[0] = t.x * mul; dst[1] = t.y * mul; dst[2 % CT] = t.z * mul; dst[3 % CT] = t.w * mul;
+    } else if (CT == 2) {
+        const float2 t = *reinterpret_cast<const float2*>(p);
+        dst[0] = t.x * mul; dst[1 % CT] = t.y * mul;
+    } else {
+        dst[0] = p[0] * mul;
+    }
+}
+template <int CT>
+__device__ __forceinline__ void store_ct(float* __restrict__ p, const float (&v)[CT]) {
+    if (CT == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1 % CT], v[2 % CT], v[3 % CT]);
+    else if (CT == 2) *reinterpret_cast<float2*>(p) = make_float2(v[0], v[1 % CT]);
+    else p[0] = v[0];
+}
+
+__device__ __forceinline__ float grp16_sum(float v) {
+    v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
+    return v;
+}
+__device__ __forceinline__ float grp16_max(float v) {
+    v = fmaxf(v, __shfl_xor(v, 1, 16)); v = fmaxf(v, __shfl_xor(v, 2, 16));
+    v = fmaxf(v, __shfl_xor(v, 4, 16)); v = fmaxf(v, __shfl_xor(v, 8, 16));
+    return v;
+}
+
+// =====================================================================================================================
+template <int HD>
+__global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const float* __restrict__ qkv, int64_t ldq,
+                                                                       const int64_t* __restrict__ tokens,
+                                                                       const float* __restrict__ e1,
+                                                                       const float* __restrict__ e2, float* __restrict__ ctx,
+                                                                       int64_t ldo, float* __restrict__ probs,
+                                                                       int64_t total, int H, float scale, uint32_t thr,
+                                                                       float inv_keep, uint64_t seed) {
+    constexpr int KH = HD / 4, CT = HD / 16;
+    __shared__ float lds[kA16Waves][16 * kA16RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    float* buf = lds[wave];
+    const int64_t prob = min((int64_t)blockIdx.x * kA16Waves + wave, total - 1);       // tail waves redo the last problem
+    const bool live = (int64_t)blockIdx.x * kA16Waves + wave < total;
+    const int64_t n = prob / H;
+    const int h = (int)(prob % H);
+    const int d = H * HD;
+    const int64_t tokv = tokens ? tokens[n * 16 + c] : 0;
+    const int64_t row_c = tokens ? tokv * 16 + c : n * 16 + c;                         // qkv / table row of token c
+    const float* rp = qkv + row_c * ldq + h * HD + g * KH;
+
+    float qa[KH], kb[KH];
+    load_f4<KH>(qa, rp, scale);
+    load_f4<KH>(kb, rp + d, 1.0f);
+    floatx4 s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < KH; ++k) s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[k], kb[k], s, 0, 0, 0);
+    // relative term: QE[i][x] = qs_i . Erel[x], x = 0..30 (two 16-column tiles), skewed into the scores through LDS
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        float eb[KH];
+        load_f4<KH>(eb, erel16(e1, e2, h, HD, 16 * t + c) + g * KH, 1.0f);
+        floatx4 qe = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KH; ++k) qe = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[k], eb[k], qe, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[(4 * g + r) * kA16RS + 16 * t + c] = qe[r];
+    }
+    wave_lds_fence();
+    float p[4], pd[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int i = 4 * g + r;
+        const float v = s[r] + buf[i * kA16RS + c - i + 15];
+        const float m = grp16_max(v);
+        const float e = __expf(v - m);
+        p[r] = e / grp16_sum(e);
+        const int64_t idx = (prob * 16 + i) * 16 + c;
+        if (live) probs[idx] = p[r];
+        pd[r] = p[r] * drop_scale(seed, (uint64_t)idx, thr, inv_keep);
+    }
+    wave_lds_fence();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) buf[(4 * g + r) * kA16RS + c] = pd[r];
+    wave_lds_fence();
+    // ctx = Pd . V :  A[row i = c][k j = 4g + s] = Pd[c][4g + s]   B[k j][col] = V[j][col]
+    floatx4 o[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) o[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int sidx = 0; sidx < 4; ++sidx) {
+        const int j = 4 * g + sidx;
+        const float pa = buf[c * kA16RS + j];
+        const int64_t tj = __shfl(tokv, j, 16);
+        const int64_t row_j = tokens ? tj * 16 + j : n * 16 + j;
+        float vb[CT];
+        load_ct<CT>(vb, qkv + row_j * ldq + 2 * d + h * HD + CT * c, 1.0f);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vb[ct], o[ct], 0, 0, 0);
+    }
+    if (live) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float v[CT];
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) v[ct] = o[ct][r];
+            store_ct<CT>(ctx + (n * 16 + 4 * g + r) * ldo + h * HD + CT * c, v);
+        }
+    }
+}
+
+// =====================================================================================================================
+// grid = (chunks, H).  Wave w of a workgroup walks the blocks chunk*bpc + w, + 4, ... of head blockIdx.y and keeps the
+// relative-embedding gradient of its head in registers; partials ws[(chunk*4 + w)][H][31][HD] (deterministic reduce).
+template <int HD>
+__global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
+    const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ qkv, int64_t ldq,
+    const int64_t* __restrict__ tokens, const float* __restrict__ probs, const float* __restrict__ e1,
+    const float* __restrict__ e2, float* __restrict__ d_qkv, int64_t ldg, float* __restrict__ ws, int64_t n_blocks, int H,
+    int blocks_per_chunk, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    constexpr int KH = HD / 4, CT = HD / 16;
+    __shared__ float lds[kA16Waves][16 * kA16RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    float* buf = lds[wave];
+    const int h = blockIdx.y;
+    const int d = H * HD;
+    floatx4 de[2][CT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) de[t][ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+    const int64_t b0 = (int64_t)blockIdx.x * blocks_per_chunk;
+    const int64_t b1 = min(b0 + blocks_per_chunk, n_blocks);
+    // every wave runs the same number of iterations (barriers inside); out-of-range waves redo block b1 - 1 without stores
+    const int iters = (int)((b1 - b0 + kA16Waves - 1) / kA16Waves);
+    for (int it = 0; it < iters; ++it) {
+        const int64_t want = b0 + (int64_t)it * kA16Waves + wave;
+        const bool live = want < b1;
+        const int64_t n = live ? want : b1 - 1;
+        const int64_t prob = n * H + h;
+        const int64_t tokv = tokens ? tokens[n * 16 + c] : 0;
+        const int64_t row_c = tokens ? tokv * 16 + c : n * 16 + c;
+        const float* rp = qkv + row_c * ldq + h * HD;
+        // dP = dO . V^T, softmax backward in the accumulator layout (rows 4g + r, column c)
+        float doa[KH], vb[KH];
+        load_f4<KH>(doa, d_ctx + (n * 16 + c) * ldo + h * HD + g * KH, 1.0f);
+        load_f4<KH>(vb, rp + 2 * d + g * KH, 1.0f);
+        floatx4 dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KH; ++k) dp = __builtin_amdgcn_mfma_f32_16x16x4f32(doa[k], vb[k], dp, 0, 0, 0);
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t idx = (prob * 16 + 4 * g + r) * 16 + c;
+            const float p = probs[idx];
+            const float mk = drop_scale(seed, (uint64_t)idx, thr, inv_keep);
+            const float dpm = dp[r] * mk;
+            pd[r] = p * mk;
+            ds[r] = p * (dpm - grp16_sum(dpm * p));
+        }
+        // rows 4g + s of token-dependent operands: their table rows
+        int64_t row_s[4];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j = 4 * g + sidx;
+            const int64_t tj = __shfl(tokv, j, 16);
+            row_s[sidx] = tokens ? tj * 16 + j : n * 16 + j;
+        }
+        // dV = Pd^T dO, dK = dS^T qs :  A[row j = c][k i = 4g + s] = X[4g + s][c] = this lane's register s
+        floatx4 dv[CT], dk[CT], dq[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) dv[ct] = dk[ct] = dq[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            float dob[CT], qb[CT];
+            load_ct<CT>(dob, d_ctx + (n * 16 + 4 * g + sidx) * ldo + h * HD + CT * c, 1.0f);
+            load_ct<CT>(qb, qkv + row_s[sidx] * ldq + h * HD + CT * c, scale);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                dv[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[sidx], dob[ct], dv[ct], 0, 0, 0);
+                dk[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[sidx], qb[ct], dk[ct], 0, 0, 0);
+            }
+        }
+        wave_lds_fence();                                  // previous iteration's LDS readers are done
+#pragma unroll
+        for (int r = 0; r < 4; ++r) buf[(4 * g + r) * kA16RS + c] = ds[r];
+        wave_lds_fence();
+        // dq = scale * (dS . K + skew(dS) . Erel):  A[row i = c][k] from the LDS tile
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const float a = buf[c * kA16RS + 4 * g + sidx];
+            float kb2[CT];
+            load_ct<CT>(kb2, qkv + row_s[sidx] * ldq + d + h * HD + CT * c, 1.0f);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) dq[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, kb2[ct], dq[ct], 0, 0, 0);
+        }
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx) {
+                const int x = 16 * xt + 4 * g + sidx;          // relative row
+                const int jj = x + c - 15;                     // key index seen from query c
+                const float a = (x <= 30 && jj >= 0 && jj < 16) ? buf[c * kA16RS + jj] : 0.0f;
+                float eb2[CT];
+                load_ct<CT>(eb2, erel16(e1, e2, h, HD, x) + CT * c, 1.0f);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) dq[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, eb2[ct], dq[ct], 0, 0, 0);
+            }
+        // dErel[x] += sum_i dS[i][x + i - 15] qs_i :  A[row x = 16 xt + c][k i = 4g + s]
+        if (live) {
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int i = 4 * g + sidx, x = 16 * xt + c;
+                    const int jj = x + i - 15;
+                    const float a = (x <= 30 && jj >= 0 && jj < 16) ? buf[i * kA16RS + jj] : 0.0f;
+                    float qb[CT];
+                    load_ct<CT>(qb, qkv + row_s[sidx] * ldq + h * HD + CT * c, scale);
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        de[xt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qb[ct], de[xt][ct], 0, 0, 0);
+                }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float vq[CT], vk[CT], vv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    vq[ct] = dq[ct][r] * scale;
+                    vk[ct] = dk[ct][r];
+                    vv[ct] = dv[ct][r];
+                }
+                float* gp = d_qkv + (n * 16 + 4 * g + r) * ldg + h * HD + CT * c;
+                store_ct<CT>(gp, vq);
+                store_ct<CT>(gp + d, vk);
+                store_ct<CT>(gp + 2 * d, vv);
+            }
+        }
+    }
+    float* dst = ws + (((int64_t)blockIdx.x * kA16Waves + wave) * H + h) * 31 * HD;
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = 16 * xt + 4 * g + r;
+                if (x <= 30) dst[x * HD + CT * c + ct] = de[xt][ct][r];
+            }
+}
+
+// ---- host side ------------------------------------------------------------------------------------------------------
+static int a16_blocks_per_chunk(int64_t n_blocks, int H) {
+    // ~8k wavefronts in flight: chunks * 4 waves * H ~ 8192
+    const int64_t chunks = std::max<int64_t>(1, std::min<int64_t>(ceil_div(n_blocks, kA16Waves), 2048 / std::max(H, 1)));
+    return (int)ceil_div(n_blocks, chunks);
+}
+
+bool relattn16_supported(int H, int hd) { return H >= 1 && (hd == 16 || hd == 32 || hd == 64); }
+
+int64_t relattn16_bwd_workspace(int64_t n_blocks, int H, int hd) {
+    const int bpc = a16_blocks_per_chunk(n_blocks, H);
+    const int64_t chunks = ceil_div(n_blocks, bpc);
+    return (chunks * kA16Waves + 1) * H * 31 * hd * (int64_t)sizeof(float);
+}
+
+template <int HD>
+static int a16_fwd_t(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
+                     int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
+    const int64_t total = n_blocks * H;
+    hipLaunchKernelGGL(relattn16_fwd_kernel<HD>, dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64), 0, s, qkv,
+                       ldq, tokens, e1, e2, ctx, ldo, probs, total, H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
+                       1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("relattn16_fwd");
+    return VQCPC_OK;
+}
+
+template <int HD>
+static int a16_bwd_t(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens,
+                     const float* probs, const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* ws,
+                     int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s, int* nsplit) {
+    const int bpc = a16_blocks_per_chunk(n_blocks, H);
+    const int chunks = (int)ceil_div(n_blocks, bpc);
+    hipLaunchKernelGGL(relattn16_bwd_kernel<HD>, dim3(chunks, H), dim3(kA16Waves * 64), 0, s, d_ctx, ldo, qkv, ldq, tokens,
+                       probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, bpc, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
+                       1.0f / (1.0f - drop_p), seed);
+    VQ_CHECK_LAUNCH("relattn16_bwd");
+    *nsplit = chunks * kA16Waves;
+    return VQCPC_OK;
+}
+
+int relattn16_fwd(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
+                  int64_t ldo, float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, hipStream_t s) {
+    if (hd == 16) return a16_fwd_t<16>(qkv, ldq, tokens, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
+    if (hd == 32) return a16_fwd_t<32>(qkv, ldq, tokens, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
+    return a16_fwd_t<64>(qkv, ldq, tokens, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
+}
+
+// writes per-wave partials to ws and returns their count; the caller reduces them (tail of ws) and splits into e1 / e2
+int relattn16_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens, const float* probs,
+                  const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* ws, int64_t n_blocks, int H, int hd,
+                  float drop_p, uint64_t seed, hipStream_t s, int* nsplit) {
+    if (hd == 16)
+        return a16_bwd_t<16>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+    if (hd == 32)
+        return a16_bwd_t<32>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+    return a16_bwd_t<64>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+}
+
+}  // namespace vq

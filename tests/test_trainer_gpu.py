@@ -260,3 +260,85 @@ def test_codebook_data_initialisation_and_epoch_contract():
     assert abs(tr.current_lr() - 1e-4 * (0.1 + 9e-5 * 3)) < 1e-12      # LambdaLR stepped once per training batch
     v = tr.epoch(gen_val, train=False, num_batches=1, corrupt_labels=False)
     assert np.isfinite(v['loss']) and tr.global_step == 3
+
+
+def test_three_step_trajectory_vs_oracle_with_lr_schedule():
+    """Three consecutive training steps (Adam bias correction at t = 1, 2, 3, LambdaLR stepped per batch): per-step
+    losses and the parameters after the third step follow the oracle's trajectory."""
+    cfg = O.make_cfg(emb=16, vocab=[30] * 4, d=64, H=4, layers=[2, 1], ff=128, D=16, K=16, ncb=1, zdim=16, up_hidden=32,
+                     cdim=16, gru_hidden=32, B=6, N=5, Kl=3, Kr=3)
+    sd = O.init_state(cfg, seed=13)
+    batches = [O.synthetic_batch(cfg, seed=40 + i) for i in range(3)]
+    st = {}
+    O.encoder_forward(batches[0]['x_left'], sd, cfg, stages=st)
+    sd['encoder.quantizer.embeddings.0'] = st['z'].reshape(-1, cfg['D'])[:cfg['K']].clone() + 0.01
+    otr = O.OracleTrainer(cfg, sd, lr=3e-3, schedule_lr=True)
+    tr = build_trainer(cfg, sd, lr=3e-3)
+    tr.schedule_lr = True
+    tr.train()
+    for i, b in enumerate(batches):
+        ref = otr.step(b, train=True)
+        assert abs(tr.current_lr() - 3e-3 * O.lr_lambda(i)) < 1e-12
+        out = tr.train_step(b, train=True)
+        # the trajectories separate slowly (different rounding, Adam's 1/sqrt(v) amplifies tiny gradients): 2e-4 per step
+        assert abs(float(out['loss']) - float(ref['loss'])) < 2e-4 * (i + 1) * max(1.0, abs(float(ref['loss']))), i
+    worst = max(float((p.detach().cpu() - otr.P[n].detach()).abs().max()) for n, p in tr.named_parameters())
+    assert worst < 3 * 3e-3 * 0.05, worst            # far below the 3 * lr a sign flip of every update would give
+
+
+def test_training_reduces_the_loss_on_a_fixed_batch():
+    """Sanity of the whole loop: 40 Adam steps on one batch lower the InfoNCE loss and raise the accuracy."""
+    cfg = O.make_cfg(emb=16, vocab=[30] * 4, d=64, H=4, layers=[2, 2], ff=128, D=16, K=32, ncb=1, zdim=16, up_hidden=32,
+                     cdim=16, gru_hidden=32, B=16, N=7, Kl=4, Kr=4)
+    sd = O.init_state(cfg, seed=21)
+    batch = O.synthetic_batch(cfg, seed=22)
+    st = {}
+    O.encoder_forward(batch['negative_samples'].reshape(-1, 4, 4), sd, cfg, stages=st)
+    sd['encoder.quantizer.embeddings.0'] = st['z'].reshape(-1, cfg['D'])[:cfg['K']].clone() + 0.01
+    tr = build_trainer(cfg, sd, lr=2e-3)
+    first = tr.epoch(iter([batch]), train=False, num_batches=1, corrupt_labels=False)
+    tr.epoch(iter([batch] * 40), train=True, num_batches=40, corrupt_labels=False)
+    last = tr.epoch(iter([batch]), train=False, num_batches=1, corrupt_labels=False)
+    assert last['loss_contrastive'] < 0.7 * first['loss_contrastive'], (first, last)
+    assert np.mean(last['accuracy']) > np.mean(first['accuracy']) + 0.2
+
+
+def test_full_size_c1_step_properties():
+    """BASELINE configs[1] at full size (B = 256, 34 816 blocks): size-independent properties.
+      * the product's code assignment on ITS OWN 34 816 x 32 encoder outputs == the oracle's canonical argmin, bit for bit;
+      * every window's loss only involves its own blocks: loss(batch) == mean(loss(first half), loss(second half));
+      * attention rows are probability distributions; one training step leaves a finite gradient bucket / parameters."""
+    from vqcpc_bach_amd import configs, getters, ops
+    from vqcpc_bach_amd.utils import SEEDS
+    config = configs.make_config('C1', dropout=0.0)
+    dlg = getters.get_dataloader_generator('bach', 'vqcpc', dict(config['dataloader_generator_kwargs'], device='cuda', seed=3))
+    enc = getters.get_encoder('/tmp/vqcpc_test_c1', dlg, config)
+    tr = getters.get_encoder_trainer('/tmp/vqcpc_test_c1', dlg, 'vqcpc', enc, config['auxiliary_networks_kwargs'])
+    tr.to('cuda')
+    tr.init_optimizers(lr=1e-4, schedule_lr=False)
+    batch = next(dlg.dataloaders(batch_size=256)[0])
+    tr.eval()
+    with torch.no_grad():
+        tr.compute_losses(batch)                                   # data-dependent codebook initialisation happens here
+        loss, out = tr.compute_losses(batch)
+        halves = [tr.compute_losses({k: v[s] for k, v in batch.items()})[0] for s in (slice(0, 128), slice(128, 256))]
+        assert abs(float(loss) - 0.5 * (float(halves[0]) + float(halves[1]))) < 2e-5 * abs(float(loss))
+        # index assignment at full size against the canonical CPU argmin on the SAME z
+        tokens = enc.data_processor.preprocess(batch['negative_samples'].reshape(-1, 4, 4))
+        z = enc.downscaler.forward_tokens(tokens.reshape(1, -1, 16), enc.data_processor)[0]
+        assert z.shape == (256 * 15 * 8, 32)
+        cb = torch.stack(list(enc.quantizer.embeddings))
+        idx = ops.vq_assign(z, cb)
+        ref = O.vq_assign(z.cpu(), [e.detach().cpu() for e in enc.quantizer.embeddings])
+        assert torch.equal(idx.cpu(), ref)
+        assert torch.equal(idx, out['idx_negative'].reshape(-1, 2))
+        # attention probabilities of the first layer
+        x = torch.randn(64 * 16, 256, device='cuda')
+        layer = enc.downscaler.transformers[0].layers[0]
+        _, probs = layer.forward_rows(x)
+        assert float((probs.sum(-1) - 1).abs().max()) < 1e-5 and float(probs.min()) >= 0.0
+    tr.train()
+    SEEDS.manual_seed(5)
+    tr.train_step(batch, train=True)
+    assert bool(torch.isfinite(tr.flat.flat_grad).all()) and bool(torch.isfinite(tr.flat.flat).all())
+    assert 0.0 < tr.optimizer.grad_norm() < 1e4

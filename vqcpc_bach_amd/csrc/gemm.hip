@@ -1268,7 +1268,9 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         const int tn2 = N / kT2;
         const int tiles2 = (int)((M / kT2) * tn2);
         const dim3 grid2((unsigned)std::min(tiles2, kNumCU)), block2(kT2Threads);
-        const bool use_pp = g_use_pp.load(std::memory_order_relaxed) != 0;
+        // the gate epilogue (relu / dropout backward: reads an M x N operand, N = 4 K) is HBM-bound; all eight waves storing
+        // together (lockstep kernel) keep more bytes in flight than one wave group at a time: 0.92 vs 1.21 ms at C1
+        const bool use_pp = g_use_pp.load(std::memory_order_relaxed) != 0 && flags != E_GATE;
         const size_t lds2 = 2 * kT2Buf;
 #define T2_LAUNCH(EPIV)                                                                                                    \
     {                                                                                                                      \

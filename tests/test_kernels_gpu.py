@@ -246,6 +246,33 @@ def test_gemm_nt_dropout_epilogue(ops):
     assert rel_err(out.cpu(), ref) < 1e-5
 
 
+@pytest.mark.parametrize('epi', ['bias_relu_drop', 'gate', 'add_in_place'])
+def test_gemm_nt_row_split_launch(ops, bf16x6, epi):
+    """300 row tiles x 1 column tile of 256 = 1.17 rounds of the 256-tile kernel: the launch is cut by rows into the full
+    round (256-tile kernel) and the remaining 44 tiles (128-tile kernel); epilogue operands, in-place residual and the
+    dropout element index must follow the row offset."""
+    gen = torch.Generator().manual_seed(8)
+    M, N, K, p, seed = 300 * 256, 256, 64, 0.25, 777
+    a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    prod = a.double() @ b.double().t()
+    if epi == 'bias_relu_drop':
+        out = ops.gemm_nt(dev(a), dev(b), bias=dev(bias), act=1, drop_p=p, seed=seed)
+        mask = ops.dropout_mask(M * N, p, seed, 'cuda').cpu().reshape(M, N)
+        ref = torch.relu(prod + bias.double()) * mask.double() / (1 - p)
+    elif epi == 'gate':
+        gate = torch.randn(M, N, generator=gen)
+        out = ops.gemm_nt(dev(a), dev(b), gate=dev(gate), gate_scale=1.5)
+        ref = prod * (gate > 0).double() * 1.5
+    else:
+        res = torch.randn(M, N, generator=gen)
+        out = dev(res)
+        ops.gemm_nt(dev(a), dev(b), add=out, out=out)
+        ref = prod + res.double()
+    err = (out.cpu().double() - ref).abs()
+    assert float(err.max()) < 1e-5 * float(ref.abs().max())
+    assert float(err[-44 * 256:].max()) < 1e-5 * float(ref.abs().max())        # the rows of the second launch
+
+
 @pytest.mark.parametrize('M,N,K', [(1000, 128, 128), (4097, 96, 36), (50000, 768, 256), (333, 4, 256), (20000, 32, 512)])
 def test_gemm_tn(ops, M, N, K):
     gen = torch.Generator().manual_seed(M + N)

@@ -35,6 +35,8 @@ struct EpiParams {
     int64_t ldadd;
     const float* add2;   // second residual (only honoured together with `add`)
     int64_t ldadd2;
+    int64_t row0;        // global row of the first row of this launch (a GEMM may be cut into two launches by rows): only
+                         // the dropout element index needs it
 };
 
 // epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)
@@ -282,7 +284,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
                 if (!FULL && row >= M) continue;
                 float v = acc[mt][nt][r] + bv;
                 if (relu) v = fmaxf(v, 0.0f);
-                if (drop) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);
+                if (drop) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * N + col, ep.thr, ep.inv_keep);
                 if (has_gate) {
                     const float gv = PREF ? aux[mt][nt][r] : ep.gate[row * ep.ldgate + col];
                     v *= (gv > 0.0f ? ep.gate_scale : 0.0f);
@@ -462,7 +464,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
             const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);
             float v = acc[mt][nt][r] + bv;
             if (EPI & E_RELU) v = fmaxf(v, 0.0f);
-            if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);
+            if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * N + col, ep.thr, ep.inv_keep);
             if (EPI & E_GATE) v *= (aux[tile & 1][r] > 0.0f ? ep.gate_scale : 0.0f);
             if (EPI & E_ADD) v += aux[tile & 1][r];
             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                 const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);                                       \
                 float v = acc[mt][nt][r] + bv;                                                                         \
                 if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
-                if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)row * N + col, ep.thr, ep.inv_keep);              \
+                if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * N + col, ep.thr, ep.inv_keep);              \
                 if (EPI & E_GATE) v *= (aux[tile & 1][r] > 0.0f ? ep.gate_scale : 0.0f);                               \
                 if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
@@ -1203,44 +1205,21 @@ static bool skinny_ok(int64_t M, int N, int K, int flags, int* nw) {
 
 using namespace vq;
 
-extern "C" {
-
-int vqcpc_gemm_set_mode(int mode) {
-    // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing)
-    VQ_REQUIRE(mode >= 0 && mode <= 7,
-               "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong]");
-    g_use_t2.store((mode & 2) ? 0 : 1, std::memory_order_relaxed);
-    g_use_pp.store((mode & 4) ? 0 : 1, std::memory_order_relaxed);
-    mode &= 1;
-    g_gemm_mode.store(mode, std::memory_order_relaxed);
-    return VQCPC_OK;
-}
-
-int vqcpc_gemm_get_mode(void) { return gemm_mode(); }
-
-int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
-                  const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
-                  float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream) {
-    if (M == 0) return VQCPC_OK;
-    VQ_REQUIRE(A && B && C, "gemm_nt: null pointer");
-    VQ_REQUIRE(M >= 0 && N >= 1 && K >= 4 && K % 4 == 0, "gemm_nt: bad shape M=%lld N=%d K=%d (K %% 4 == 0 required)",
-               (long long)M, N, K);
-    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N, "gemm_nt: bad leading dimensions");
-    VQ_REQUIRE(aligned16(A) && aligned16(B), "gemm_nt: A and B must be 16-byte aligned");
-    VQ_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (relu)");
-    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt: bad dropout probability");
-    VQ_REQUIRE(ldc < (1 << 22) && ldgate < (1 << 22) && ldadd < (1 << 22), "gemm_nt: leading dimension too large");
-    VQ_REQUIRE((!gate || ldgate >= N) && (!add || ldadd >= N) && (!add2 || (add && ldadd2 >= N)),
-               "gemm_nt: bad gate/add strides (add2 needs add)");
+static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                          int K, const EpiParams& ep_in, hipStream_t st, bool may_split) {
+    EpiParams ep = ep_in;
     const int tiles_n = (int)ceil_div(N, BN);
     const int64_t tiles = ceil_div(M, BM) * tiles_n;
     VQ_REQUIRE(tiles < (1ll << 31), "gemm_nt: too many tiles");
-    EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, add2, ldadd2};
+    const float* bias = ep.bias;
+    const float* gate = ep.gate;
+    const float* add = ep.add;
+    const float* add2 = ep.add2;
+    const int64_t ldadd = ep.ldadd;
     const bool full = (M % BM == 0) && (N % BN == 0) && (K % BK == 0);
-    const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (gate ? E_GATE : 0) |
+    const int flags = (bias ? E_BIAS : 0) | (ep.act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (gate ? E_GATE : 0) |
                       (add ? E_ADD : 0) | (add2 ? E_ADD2 : 0);
     const dim3 grid((unsigned)tiles), block(kGemmThreads);
-    hipStream_t st = (hipStream_t)stream;
     const int mode = gemm_mode();
     int nw = 0;
     if (skinny_ok(M, N, K, flags, &nw)) {
@@ -1259,7 +1238,32 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
     // more than the ~8 % it gains per tile over the 128-tile kernel (2 workgroups per CU, 4x more tiles)
     bool t2_ok = mode == 1 && g_use_t2.load(std::memory_order_relaxed) && (M % kT2 == 0) && (N % kT2 == 0) &&
                  (K % (2 * kT2BK) == 0) && !add2;
-    if (t2_ok) {
+    if (t2_ok && may_split) {
+        // cost model in units of one round of 256-tiles (256 workgroups): a round of the 128-tile kernel (512 workgroups)
+        // does half the work ~8 % less efficiently.  A partial last round wastes whole CUs, so a GEMM of 2.1 rounds is cut by
+        // rows into the full rounds (256-tile kernel) + the remaining rows (128-tile kernel).
+        const int64_t mt = M / kT2, tn = N / kT2, t256 = mt * tn;
+        const double c256 = ceil((double)t256 / kNumCU);
+        const double c128 = ceil((double)tiles / (2 * kNumCU)) * 0.54;
+        const int64_t main_mt = (t256 / kNumCU) * kNumCU / tn;          // row tiles that fill whole rounds
+        double csplit = 1e30;
+        if (main_mt > 0 && main_mt < mt) {
+            const int64_t rem_tiles128 = (mt - main_mt) * 2 * ceil_div(N, BN);
+            csplit = ceil((double)(main_mt * tn) / kNumCU) + ceil((double)rem_tiles128 / (2 * kNumCU)) * 0.54 + 0.03;
+        }
+        if (csplit < c256 && csplit < c128) {
+            const int64_t m_main = main_mt * kT2;
+            int rc = gemm_nt_launch(A, lda, B, ldb, C, ldc, m_main, N, K, ep, st, false);
+            if (rc) return rc;
+            EpiParams e2 = ep;
+            if (e2.gate) e2.gate += m_main * e2.ldgate;
+            if (e2.add) e2.add += m_main * e2.ldadd;
+            if (e2.add2) e2.add2 += m_main * e2.ldadd2;
+            e2.row0 = ep.row0 + m_main;
+            return gemm_nt_launch(A + m_main * lda, lda, B, ldb, C + m_main * ldc, ldc, M - m_main, N, K, e2, st, false);
+        }
+        t2_ok = c256 <= c128;
+    } else if (t2_ok) {
         const double r256 = (double)((M / kT2) * (N / kT2)) / kNumCU, r128 = (double)tiles / (2 * kNumCU);
         const double eff256 = r256 / ceil(r256), eff128 = r128 / ceil(r128);
         t2_ok = eff256 * 1.08 >= eff128;
@@ -1331,6 +1335,39 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 #undef NT_LAUNCH
     VQ_CHECK_LAUNCH("gemm_nt");
     return VQCPC_OK;
+}
+
+extern "C" {
+
+int vqcpc_gemm_set_mode(int mode) {
+    // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing)
+    VQ_REQUIRE(mode >= 0 && mode <= 7,
+               "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong]");
+    g_use_t2.store((mode & 2) ? 0 : 1, std::memory_order_relaxed);
+    g_use_pp.store((mode & 4) ? 0 : 1, std::memory_order_relaxed);
+    mode &= 1;
+    g_gemm_mode.store(mode, std::memory_order_relaxed);
+    return VQCPC_OK;
+}
+
+int vqcpc_gemm_get_mode(void) { return gemm_mode(); }
+
+int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                  const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
+                  float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream) {
+    if (M == 0) return VQCPC_OK;
+    VQ_REQUIRE(A && B && C, "gemm_nt: null pointer");
+    VQ_REQUIRE(M >= 0 && N >= 1 && K >= 4 && K % 4 == 0, "gemm_nt: bad shape M=%lld N=%d K=%d (K %% 4 == 0 required)",
+               (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N, "gemm_nt: bad leading dimensions");
+    VQ_REQUIRE(aligned16(A) && aligned16(B), "gemm_nt: A and B must be 16-byte aligned");
+    VQ_REQUIRE(act == 0 || act == 1, "gemm_nt: act must be 0 (none) or 1 (relu)");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt: bad dropout probability");
+    VQ_REQUIRE(ldc < (1 << 22) && ldgate < (1 << 22) && ldadd < (1 << 22), "gemm_nt: leading dimension too large");
+    VQ_REQUIRE((!gate || ldgate >= N) && (!add || ldadd >= N) && (!add2 || (add && ldadd2 >= N)),
+               "gemm_nt: bad gate/add strides (add2 needs add)");
+    EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, add2, ldadd2, 0};
+    return gemm_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, ep, (hipStream_t)stream, true);
 }
 
 int64_t vqcpc_gemm_tn_workspace(int64_t M, int N, int K) {

@@ -252,9 +252,11 @@ def main():
         if nt:
             if gemm_mode == 1:
                 # 6 bf16 MFMAs per fp32 product: the MFMA ceiling for ALGORITHMIC fp32 FLOPs is bf16 dense peak / 6
-                peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, 'gemm_nt_kernel<MODE=1> (bf16x6: exact 3-way bf16 split, 6x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate)'
+                peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, ('gemm_nt = every NT GEMM launch (gemm_nt_x6_pp_kernel / gemm_nt_x6_256_kernel 256-tile, '
+                               'gemm_nt_kernel<MODE=1> 128-tile, gemm_nt_skinny_kernel); bf16x6: exact 3-way bf16 split, '
+                               '6x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate')
             else:
-                peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt_kernel<MODE=0> (fp32 v_mfma_f32_32x32x2_f32)'
+                peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=0>, gemm_nt_skinny_kernel; fp32 v_mfma_f32_32x32x2_f32)'
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
                             frac=round(nt['tflops'] / peak, 4), traffic=hbm_traffic('gemm_nt'),
                             traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_hbm_traffic.json)',

@@ -162,11 +162,13 @@ class StudentEncoderTrainer(EncoderTrainer):
         return {'loss': loss, 'notes_to_be_predicted': notes, 'weights_per_category': logits, 'masked_event_index': m,
                 'monitored_quantities': {'loss_teacher': loss.detach()}}
 
-    def forward_encdec(self, x, weights_per_category_teacher, notes_to_be_predicted, masked_event_index=None):
-        """:186-218 with the teacher / student logits restricted to the masked event."""
-        m = self._last_masked_event if masked_event_index is None else masked_event_index
+    def _encode_decode(self, x, m):
+        """Encoder + auxiliary decoder up to the student logits of event m (independent of the teacher)."""
         z_quantized, encoding_indices, quantization_loss = self.encoder(x)
         logits = self.auxiliary_decoder.forward_events(z_quantized, m)
+        return encoding_indices, quantization_loss, logits
+
+    def _encdec_losses(self, encoding_indices, quantization_loss, logits, weights_per_category_teacher):
         rec = sum(ops.SoftmaxCEFn.apply(lg, None, t.detach()) for lg, t in zip(logits, weights_per_category_teacher))
         q_mean, rec_mean = quantization_loss.mean(), rec.mean()
         loss = self.quantization_weighting * q_mean + rec_mean
@@ -174,10 +176,36 @@ class StudentEncoderTrainer(EncoderTrainer):
                 'monitored_quantities': {'loss_quantization': q_mean.detach(), 'loss_reconstruction': rec_mean.detach(),
                                          'loss_encdec': loss.detach(), 'loss_monitor': rec_mean.detach()}}
 
+    def forward_encdec(self, x, weights_per_category_teacher, notes_to_be_predicted, masked_event_index=None):
+        """:186-218 with the teacher / student logits restricted to the masked event."""
+        m = self._last_masked_event if masked_event_index is None else masked_event_index
+        return self._encdec_losses(*self._encode_decode(x, m), weights_per_category_teacher)
+
+    overlap_streams = True      # teacher and encoder/decoder are independent graphs: run them on two HIP streams
+
     def compute_losses(self, tensor_dict, masked_event_index=None):
         x = self.teacher.data_processor.preprocess(tensor_dict['x'])
-        t = self.forward_teacher(x, masked_event_index)
-        e = self.forward_encdec(x, t['weights_per_category'], t['notes_to_be_predicted'], t['masked_event_index'])
+        m = self.draw_masked_event(x.shape[1]) if masked_event_index is None else int(masked_event_index)
+        if self.overlap_streams and x.is_cuda:
+            # at the reference's batch of 8 every GEMM has only 3072 rows and fills a fraction of the 256 CUs: the two
+            # independent halves of the step (teacher | encoder + decoder) run concurrently, forward and -- because
+            # autograd replays every node on the stream of its forward -- backward
+            main = torch.cuda.current_stream()
+            if getattr(self, '_side_stream', None) is None:
+                self._side_stream = torch.cuda.Stream()
+            side = self._side_stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                enc = self._encode_decode(x, m)
+            t = self.forward_teacher(x, m)
+            main.wait_stream(side)
+            for tensor in (enc[0], enc[1], *enc[2]):
+                if tensor is not None:
+                    tensor.record_stream(main)
+            e = self._encdec_losses(*enc, t['weights_per_category'])
+        else:
+            t = self.forward_teacher(x, m)
+            e = self.forward_encdec(x, t['weights_per_category'], t['notes_to_be_predicted'], m)
         out = dict(t['monitored_quantities'], **e['monitored_quantities'])
         out.update(masked_event_index=t['masked_event_index'], encoding_indices=e['encoding_indices'],
                    teacher_logits=t['weights_per_category'], student_logits=e['weights_per_category'])

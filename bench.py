@@ -43,7 +43,7 @@ def parse():
     ap.add_argument('--dropout', type=float, default=0.1)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=2)
+    ap.add_argument('--cpu-steps', type=int, default=12)
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', '0', '1'],
                     help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')

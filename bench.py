@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=12)
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--host-inputs', action='store_true',
+                    help='batches start in (pinned) host memory: the PCIe-inclusive rate quoted in DESIGN.md, never `value`')
     ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', '0', '1'],
                     help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
@@ -204,7 +206,7 @@ def main():
 
     config = configs.make_config(args.config, dropout=args.dropout)
     B = args.batch or config['batch_size']
-    dlg_kw = dict(config['dataloader_generator_kwargs'], seed=1234, rank=dp.rank, device=dev)
+    dlg_kw = dict(config['dataloader_generator_kwargs'], seed=1234, rank=dp.rank, device=None if args.host_inputs else dev)
     dlg = getters.get_dataloader_generator(config['dataset'], config['training_method'], dlg_kw)
     encoder = getters.get_encoder('/tmp/vqcpc_bench_model', dlg, config)
     trainer = getters.get_encoder_trainer('/tmp/vqcpc_bench_model', dlg, config['training_method'], encoder,
@@ -221,6 +223,8 @@ def main():
     # synthetic batches resident in HBM before the timed region (4 distinct batches, cycled)
     stream = dlg.dataloaders(batch_size=B)[0]
     pool = [next(stream) for _ in range(4)]
+    if args.host_inputs:
+        pool = [{k: v.pin_memory() for k, v in b.items()} for b in pool]
     torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -269,7 +273,8 @@ def main():
             'metric': 'encoder-train windows/sec (Bach 4-voice, seq=256)', 'value': round(value, 2), 'unit': 'windows/s',
             'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
+            'vs_baseline': None, 'dtype': 'f32',
+            'data': 'synthetic' + (' (host-resident inputs: PCIe-inclusive)' if args.host_inputs else ''),
             'config': {'workload': (f'encoder_cpc {args.config}: seq_len={seq_len}, '
                                     f'batch={B}/GPU, {getattr(dlg, "num_negative_samples", 0)} negatives, product-VQ '
                                     f'{config["quantizer_kwargs"]["num_codebooks"]}x{config["quantizer_kwargs"]["codebook_size"]}, '

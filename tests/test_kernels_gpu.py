@@ -153,6 +153,26 @@ def test_gemm_nt_bf16x6_has_fp32_class_accuracy(ops, bf16x6, M, N, K):
     assert err_el < max(2e-7, 3 * ref_el), (err_el, ref_el)
 
 
+def test_gemm_bf16x6_componentwise_bound_over_40_orders_of_magnitude(ops, bf16x6):
+    """The exact 3-way split keeps the fp32 componentwise error bound |C - AB^T| <= c K 2^-24 (|A| |B|^T) when rows are
+    scaled by 10^U(-10, 10) (a plain bf16 GEMM would be off by 2^-8 of that bound); NT (256- and 128-tile) and TN."""
+    gen = torch.Generator().manual_seed(31)
+    M, N, K = 1024, 512, 256
+    sa = 10.0 ** (torch.rand(M, 1, generator=gen) * 20 - 10)
+    sb = 10.0 ** (torch.rand(N, 1, generator=gen) * 20 - 10)
+    a, b = torch.randn(M, K, generator=gen) * sa, torch.randn(N, K, generator=gen) * sb
+    ref = a.double() @ b.double().t()
+    bound = a.double().abs() @ b.double().abs().t()
+    for rows in (M, 300):                                   # full 256-tiles / ragged 128-tile kernel
+        out = ops.gemm_nt(dev(a[:rows]), dev(b))
+        assert float(((out.cpu().double() - ref[:rows]).abs() / bound[:rows]).max()) < 4 * K * 2.0 ** -24
+    g = torch.randn(M, N, generator=gen) * sa               # TN: dW = g^T a, contraction over the scaled rows
+    dw, db = ops.gemm_tn(dev(g), dev(a))
+    ref_w, bound_w = g.double().t() @ a.double(), g.double().abs().t() @ a.double().abs()
+    assert float(((dw.cpu().double() - ref_w).abs() / bound_w).max()) < 4 * M * 2.0 ** -24
+    assert rel_err(db.cpu(), g.double().sum(0)) < 1e-5
+
+
 def test_gemm_nt_bf16x6_exact_on_bf16_representable_inputs(ops, bf16x6):
     """Inputs with <= 8 significant bits have m = l = 0: the result must equal the exact integer matmul."""
     n = 128

@@ -7,7 +7,8 @@ tests/golden/relbias_*.npz):
     bias[h, i, j] = q[h, i] . e1[h, L - 1 - (i - j)]   if j <= i
                   = q[h, i] . e2[h, j - i]             if j >  i
 
-which the fused attention kernel (csrc/relattn.hip) evaluates in registers; this module only owns e1 / e2."""
+which the fused attention kernels (csrc/relattn*.hip) evaluate in registers; this module owns e1 / e2 and offers the
+stand-alone `forward(q)` of the reference for API compatibility."""
 import torch
 from torch import nn
 
@@ -26,4 +27,18 @@ class SubsampledRelativeAttention(nn.Module):
         self.e2 = nn.Parameter(torch.randn(num_heads * seq_len_src, head_dim))
 
     def forward(self, q):
-        raise RuntimeError('the relative bias is fused into vqcpc_relattn_fwd; call MultiheadAttentionCustom instead')
+        """API-compatible stand-alone bias (the training path never calls it: the bias is fused into the attention
+        kernels).  q (batch * num_heads, L, head_dim), already scaled -> rel_attn (batch * num_heads, L, L).
+        Two GEMMs against e1 / e2 and the closed-form index selection that replaces the reference's pad / view skewing."""
+        from .. import ops
+        bh, L, hd = q.shape
+        assert bh % self.num_heads == 0 and L == self.seq_len_tgt and hd == self.head_dim
+        H = self.num_heads
+        qh = q.reshape(bh // H, H, L, hd)
+        a1 = torch.stack([ops.linear(qh[:, h], self.e1[h * L:(h + 1) * L]) for h in range(H)], dim=1)     # q . e1[h, m]
+        a2 = torch.stack([ops.linear(qh[:, h], self.e2[h * L:(h + 1) * L]) for h in range(H)], dim=1)
+        i = torch.arange(L, device=q.device).view(L, 1)
+        j = torch.arange(L, device=q.device).view(1, L)
+        m1 = (L - 1 - i + j).clamp(0, L - 1).expand(bh // H, H, L, L)
+        m2 = (j - i).clamp(0, L - 1).expand(bh // H, H, L, L)
+        return torch.where(j <= i, a1.gather(-1, m1), a2.gather(-1, m2)).reshape(bh, L, L)

@@ -123,3 +123,45 @@ def test_checkpoint_round_trip_with_optimizer_state(tmp_path):
     b_tr.train()
     b_tr.train_step(batches[2], train=True)
     assert torch.equal(b_tr.flat.flat, a.flat.flat)
+
+
+@pytest.mark.parametrize('method', ['vqcpc', 'student'])
+def test_train_model_loop_writes_the_reference_checkpoint_layout(tmp_path, method):
+    """EncoderTrainer.train_model (encoder.py:244-325) through the getters: epochs, validation, `overfitted` and
+    `early_stopped` checkpoints with the reference's file names, reloadable into a freshly built trainer."""
+    from vqcpc_bach_amd import configs, getters
+    import os
+    if method == 'vqcpc':
+        config = configs.make_config('C0', dropout=0.1)
+        config['dataloader_generator_kwargs']['device'] = 'cuda'
+        files = {'data_processor', 'downscaler', 'quantizer', 'upscaler', 'c_module', 'fks_module', 'optimizer'}
+    else:
+        config = configs.make_config('C3', dropout=0.1)
+        config['downscaler_kwargs'].update(d_model=64, n_head=2, list_of_num_layers=[1, 1], dim_feedforward=128)
+        aux = config['auxiliary_networks_kwargs']
+        aux['teacher_kwargs'].update(num_layers=2, d_model=64, n_head=2, dim_feedforward=128)
+        aux['auxiliary_decoder_kwargs'].update(d_model=64, n_head=2, dim_feedforward=128, list_of_num_layers=[1, 1])
+        config['dataloader_generator_kwargs'].update(sequences_size=8, device='cuda')
+        files = {'data_processor', 'downscaler', 'quantizer', 'decoder', 'teacher', 'optimizer'}
+    model_dir = str(tmp_path / 'model')
+
+    def build():
+        dlg = getters.get_dataloader_generator(config['dataset'], config['training_method'],
+                                               dict(config['dataloader_generator_kwargs']))
+        enc = getters.get_encoder(model_dir, dlg, config)
+        tr = getters.get_encoder_trainer(model_dir, dlg, config['training_method'], enc,
+                                         dict(config['auxiliary_networks_kwargs']))
+        tr.to('cuda')
+        return tr
+
+    tr = build()
+    hist = tr.train_model(batch_size=4, num_batches=2, num_epochs=2, lr=1e-4, corrupt_labels=False, schedule_lr=True,
+                          plot=False, num_workers=0)
+    assert len(hist) == 2 and all(np.isfinite(v) for v in (hist[-1][0]['loss_monitor'], hist[-1][1]['loss_monitor']))
+    for sub in ('overfitted', 'early_stopped'):
+        assert set(os.listdir(os.path.join(model_dir, sub))) == files, sub
+    tr2 = build()
+    tr2.load(early_stopped=False, device='cuda')
+    tr2.init_optimizers(lr=1e-4, schedule_lr=True)
+    assert tr2.global_step == tr.global_step == 4
+    assert torch.equal(tr2.flat.flat, tr.flat.flat)

@@ -543,25 +543,29 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     {                                                                                \
         uint2 h_, m_, l_;                                                            \
         split3x4(R, h_, m_, l_);                                                     \
-        const int o_ = (ROW) * kT2Stride + ld_c4 * 2;                                \
-        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 0) * kT2Plane + o_) = h_;     \
-        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 1) * kT2Plane + o_) = m_;     \
-        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 2) * kT2Plane + o_) = l_;     \
+        /* unpadded 32-byte rows, the two 16-byte chunks of a row XOR-swizzled by bit 3 of the row: fragment reads     \
+           (16 consecutive rows, one chunk each) and these stores (4 lanes = one row, rows consecutive) are conflict free */ \
+        const int o_ = (ROW) * 32 + ((((ld_c4 >> 3) ^ ((ROW) >> 3)) & 1) << 4) + (ld_c4 & 7) * 2; \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 0) * kPPPlane + o_) = h_;     \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 1) * kPPPlane + o_) = m_;     \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 2) * kPPPlane + o_) = l_;     \
     }
 #define PP_STORE(S_, BUFP) \
     PP_ST1(S_##a0, 0, ld_row, BUFP) PP_ST1(S_##a1, 0, ld_row + 64, BUFP) PP_ST1(S_##b0, 3, ld_row, BUFP) PP_ST1(S_##b1, 3, ld_row + 64, BUFP)
 
-    const int a_off = (wm * 128 + li) * kT2Stride + kh * 16;
-    const int b_off = 3 * kT2Plane + (wn * 64 + li) * kT2Stride + kh * 16;
+    constexpr int kPPPlane = kT2 * 32, kPPBuf = 6 * kPPPlane;      // 8 KB planes, 48 KB per buffer
+    const int swz = ((kh ^ (li >> 3)) & 1) << 4;                   // every fragment row is base + li with base % 16 == 0
+    const int a_off = (wm * 128 + li) * 32 + swz;
+    const int b_off = 3 * kPPPlane + (wn * 64 + li) * 32 + swz;
     unsigned char* const buf0 = smem2;
-    unsigned char* const buf1 = smem2 + kT2Buf;
+    unsigned char* const buf1 = smem2 + kPPBuf;
     bf16x8 fb[3][2], fa[4][3];                          // all fragments of a K tile: 18 x ds_read_b128 in the memory phase
 #define PP_READ_FRAGS(BUFP)                                                                                          \
     _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                               \
         _Pragma("unroll") for (int tl = 0; tl < 2; ++tl)                                                             \
-            fb[pc][tl] = *reinterpret_cast<const bf16x8*>((BUFP) + b_off + pc * kT2Plane + tl * 32 * kT2Stride);     \
+            fb[pc][tl] = *reinterpret_cast<const bf16x8*>((BUFP) + b_off + pc * kPPPlane + tl * 32 * 32);           \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                             \
-            fa[mt][pc] = *reinterpret_cast<const bf16x8*>((BUFP) + a_off + pc * kT2Plane + mt * 32 * kT2Stride);     \
+            fa[mt][pc] = *reinterpret_cast<const bf16x8*>((BUFP) + a_off + pc * kPPPlane + mt * 32 * 32);           \
     }
 #define PP_TERM(PA, PB)                                                                                              \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                               \
@@ -1276,6 +1280,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         // together (lockstep kernel) keep more bytes in flight than one wave group at a time: 0.92 vs 1.21 ms at C1
         const bool use_pp = g_use_pp.load(std::memory_order_relaxed) != 0 && flags != E_GATE;
         const size_t lds2 = 2 * kT2Buf;
+        const size_t lds_pp = 2 * 6 * kT2 * 32;          // ping-pong kernel: unpadded swizzled planes (96 KB)
 #define T2_LAUNCH(EPIV)                                                                                                    \
     {                                                                                                                      \
         static bool attr_done = false;                                                                                     \
@@ -1287,11 +1292,11 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         static bool attr_pp = false;                                                                                       \
         if (!attr_pp) {                                                                                                    \
             (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                      (int)lds2);                                                                          \
+                                      (int)lds_pp);                                                                        \
             attr_pp = true;                                                                                                \
         }                                                                                                                  \
         if (use_pp)                                                                                                        \
-            hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
+            hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
         else                                                                                                               \
             hipLaunchKernelGGL((gemm_nt_x6_256_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
         VQ_CHECK_LAUNCH("gemm_nt_x6_256");                                                                                 \

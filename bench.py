@@ -99,13 +99,15 @@ class GemmTimer:
                     flops_per_launch=flops / len(recs), bytes_per_launch=sum(r[3] for r in recs) / len(recs))
 
 
-def hbm_traffic(kernel):
+def hbm_traffic(kernel, calls_per_step):
     """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
     WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for gfx950 -- calibrated on the QKV launch: WRITE_SIZE == M*N*4 exactly).  None when the file is absent."""
     try:
         d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')))
-        return round(d[kernel]['hbm_bytes_per_launch'])
+        # the PMC passes count kernel launches (a row-split ops.gemm_nt call is two of them): normalise per step, then
+        # per call, so that `traffic` has the same unit as `achieved` / `algorithmic_bytes_per_launch`
+        return round(d[kernel]['hbm_bytes_per_step'] / calls_per_step)
     except Exception:
         return None
 
@@ -262,7 +264,7 @@ def main():
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=0>, gemm_nt_skinny_kernel; fp32 v_mfma_f32_32x32x2_f32)'
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
-                            frac=round(nt['tflops'] / peak, 4), traffic=hbm_traffic('gemm_nt'),
+                            frac=round(nt['tflops'] / peak, 4), traffic=hbm_traffic('gemm_nt', max(1, nt['launches'] // timed_steps)),
                             traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_hbm_traffic.json)',
                             algorithmic_bytes_per_launch=round(nt['bytes_per_launch']),
                             launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),

@@ -71,10 +71,29 @@ def gemm_tn(a, b, want_bias=True, into=None):
     return dw, db
 
 
+_DIRECT_WGRAD = False
+
+
+class direct_weight_gradients:
+    """Context manager used by the trainers around `loss.backward()`: inside it the weight-gradient GEMMs accumulate
+    straight into the parameters' existing `.grad` buffers (the flat all-reduce bucket) and hand `None` to autograd.
+    Outside it (plain `backward()`, `torch.autograd.grad`) gradients are returned to autograd as usual."""
+
+    def __enter__(self):
+        global _DIRECT_WGRAD
+        self.prev, _DIRECT_WGRAD = _DIRECT_WGRAD, True
+        return self
+
+    def __exit__(self, *exc):
+        global _DIRECT_WGRAD
+        _DIRECT_WGRAD = self.prev
+        return False
+
+
 def _live_grad(t):
     """The gradient buffer of a leaf parameter whose `.grad` already exists (parallel.FlatParameters installs views
     into the flat all-reduce bucket), else None."""
-    if t is None or not t.is_leaf or not t.requires_grad:
+    if not _DIRECT_WGRAD or t is None or not t.is_leaf or not t.requires_grad:
         return None
     g = t.grad
     return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32) else None

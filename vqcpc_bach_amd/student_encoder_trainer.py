@@ -216,7 +216,8 @@ class StudentEncoderTrainer(EncoderTrainer):
             loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, masked_event_index)
         if train:
             self.flat.zero_grad()
-            (loss_teacher + loss_encdec).backward()          # disjoint graphs: the teacher logits are detached
+            with ops.direct_weight_gradients():
+                (loss_teacher + loss_encdec).backward()      # disjoint graphs: the teacher logits are detached
             self.dp.all_reduce_sum_(self.flat.flat_grad)
             lr, scale = self.current_lr(), 1.0 / self.dp.world_size
             self.optimizer_teacher.step(lr=lr, grad_scale=scale)

@@ -206,7 +206,8 @@ class VQCPCEncoderTrainer(EncoderTrainer):
             loss, out = self.compute_losses(tensor_dict, corrupt_labels)
         if train:
             self.flat.zero_grad()
-            loss.backward()
+            with ops.direct_weight_gradients():
+                loss.backward()
             self.dp.all_reduce_sum_(self.flat.flat_grad)
             self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)
             self.global_step += 1

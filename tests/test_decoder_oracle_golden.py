@@ -1,0 +1,101 @@
+"""Pins oracle/decoder_oracle.py (CPU restatement of Decoder.epoch / Decoder.forward)
+against the fixtures tools/gen_golden_decoder.py produced by running the reference itself.  CPU only."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden, rel_err, sub_state
+from oracle import decoder_oracle as D
+
+T = torch.from_numpy
+FWD_TOL = 2e-5
+GRAD_TOL = 2e-4
+
+
+def decoder_state(g, tag='sd0'):
+    return dict(sub_state(g, tag))
+
+
+@pytest.mark.parametrize('name', ['relbias_cross_S3_T48', 'relbias_cross_S6_T12', 'relbias_cross_S40_T80'])
+def test_cross_relative_bias_closed_form(name):
+    """The pad / view / slice skewing of SubsampledRelativeAttention with seq_len_tgt = r * seq_len_src equals the
+    closed form in p = i // r; in particular its -100 fill values never reach a kept entry."""
+    g = load_golden(name)
+    q, e1, e2 = T(g['q']), T(g['e1']), T(g['e2'])
+    H, S = int(g['H']), int(g['S'])
+    n = q.shape[0] // H
+    got = D.relative_bias_cross(q.view(n, H, q.shape[1], q.shape[2]), e1, e2, S).reshape(g['bias'].shape)
+    assert rel_err(got, g['bias']) < 1e-6
+    assert float(np.abs(g['bias']).max()) < 50.0
+
+
+def test_masks_match_reference_generators():
+    g = load_golden('decoder_tiny')
+    S, Tn = g['mask/anticausal_S'].shape[0], g['mask/causal_T'].shape[0]
+    assert np.array_equal(D.additive_mask(D.CAUSAL, Tn, Tn).numpy(), g['mask/causal_T'])
+    assert np.array_equal(D.additive_mask(D.ANTICAUSAL, S, S).numpy(), g['mask/anticausal_S'])
+    assert np.array_equal(D.additive_mask(D.ANTICAUSAL, S, Tn).numpy(), g['mask/anticausal_ST'])
+
+
+def test_decoder_layer_forward_backward():
+    g = load_golden('decoder_layer_S3_T48')
+    P = {'l.' + k: v.clone().requires_grad_(True) for k, v in sub_state(g, 'sd').items()}
+    tgt = T(g['tgt']).transpose(0, 1).contiguous().requires_grad_(True)       # fixtures are time-first
+    mem = T(g['mem']).transpose(0, 1).contiguous().requires_grad_(True)
+    y, a_self, a_cross = D.target_layer(tgt, mem, P, 'l.', int(g['H']), D.ANTICAUSAL)
+    assert rel_err(y.transpose(0, 1), g['y']) < FWD_TOL
+    # per-head maps (bsz, H, T, S) (multihead_attention_custom.py:348-351: the 'average' comment there is stale)
+    assert rel_err(a_self, g['a_self']) < FWD_TOL
+    assert rel_err(a_cross, g['a_cross']) < FWD_TOL
+    (y * T(g['g']).transpose(0, 1)).sum().backward()
+    assert rel_err(tgt.grad.transpose(0, 1), g['d_tgt']) < GRAD_TOL
+    assert rel_err(mem.grad.transpose(0, 1), g['d_mem']) < GRAD_TOL
+    for k, p in P.items():
+        assert rel_err(p.grad, g['grad/' + k[2:]]) < GRAD_TOL, k
+
+
+@pytest.mark.parametrize('name', ['decoder_tiny', 'decoder_tiny_fullcross', 'decoder_tiny_clip'])
+def test_decoder_step(name):
+    g = load_golden(name)
+    cfg = D.make_cfg(**json.loads(str(g['cfg_json'])))
+    sd0 = decoder_state(g)
+    tr = D.DecoderOracleTrainer(cfg, sd0, lr=float(g['lr']))
+    x = T(g['batch/x'])
+    # frozen encoder: merged codes bit-exact
+    codes = D.encode_codes(x, tr.P, cfg)
+    assert torch.equal(codes, T(g['codes']))
+    assert torch.equal(codes, T(g['codes_raw'])[..., 0] + cfg['K'] * T(g['codes_raw'])[..., 1])
+    # eval forward
+    out = D.decoder_forward(codes, x, tr.P, cfg)
+    assert abs(float(out['loss']) - float(g['eval/loss'])) < 2e-5 * abs(float(g['eval/loss']))
+    for c, lg in enumerate(out['logits']):
+        assert rel_err(lg, g[f'eval_fwd/logits.{c}']) < FWD_TOL
+    assert rel_err(out['a_cross'], g['eval_fwd/a_cross_last']) < FWD_TOL
+    assert rel_err(out['a_self'], g['eval_fwd/a_self_last']) < FWD_TOL
+    assert rel_err(out['a_enc'], g['eval_fwd/a_enc_last']) < FWD_TOL
+    # train step: pre-clip gradients, total norm, parameters after one Adam step
+    res = tr.epoch(iter([{'x': x}]), train=True, num_batches=1)
+    assert abs(res['loss'] - float(g['train/loss'])) < 2e-5 * abs(float(g['train/loss']))
+    golden_grads = {k[5:]: v for k, v in g.items() if k.startswith('grad/')}
+    assert set(golden_grads) == set(tr.last_grads)
+    for k, v in golden_grads.items():
+        assert rel_err(tr.last_grads[k], v) < GRAD_TOL, k
+    assert abs(float(tr.last_grad_norm) - float(g['grad_total_norm'])) < 1e-4 * float(g['grad_total_norm'])
+    if name.endswith('clip'):
+        assert float(g['grad_total_norm']) > 5.0
+    sd1 = decoder_state(g, 'sd1')
+    for k, v in sd1.items():
+        if k.startswith('encoder.'):
+            assert torch.equal(tr.P[k], sd0[k]) and torch.equal(v, sd0[k]), k      # frozen
+        else:
+            # the first Adam step moves an element by lr * g / (|g| + 1e-8): where the gradient is rounding noise (the
+            # key bias of every attention: softmax is shift-invariant) its sign is noise too -> |diff| <= 2 lr there;
+            # elsewhere compare the updates, not the parameters
+            gr = T(golden_grads[k]).abs()
+            solid = gr > 1e-5 * gr.max()
+            mine, ref = tr.P[k].detach() - sd0[k], v - sd0[k]
+            if bool(solid.any()):
+                assert rel_err(mine[solid], ref[solid]) < 5e-3, k
+            assert float((mine - ref).abs().max()) <= 2.0001 * float(g['lr']), k

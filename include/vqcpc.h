@@ -73,6 +73,13 @@ int64_t vqcpc_block_table_segsum_workspace(int64_t M, int L, int vmax, int C);
 int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
                              void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Gradient of a plain row gather out[m] = table[idx[m]] (forward = vqcpc_block_table_gather with L = 1) for a table of
+ * any size V: the decoder's `source_embeddings(source)` on merged codes and its shifted target-token lookup
+ * (VQCPCB/decoders/decoder.py:212-215,439,474-480).  sorted_idx / perm = idx sorted ascending by a STABLE sort and the
+ * permutation that sorts it; d_table [V][C] is overwritten (rows no index refers to become 0); sums run in ascending m. */
+int vqcpc_embedding_bwd(const float* g, int64_t ldg, const int64_t* sorted_idx, const int64_t* perm, float* d_table, int64_t M,
+                        int64_t V, int C, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * fp32 MFMA GEMMs (v_mfma_f32_32x32x2_f32).  Replace every F.linear / nn.Linear on the path:
  * multihead_attention_custom.py:171,346 (in_proj / out_proj), transformer_custom.py:285 (linear1/linear2),
@@ -133,6 +140,27 @@ int vqcpc_relattn_tab_bwd(const float* d_ctx, int64_t ldo, const float* table, i
                           const float* probs, const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* d_e1,
                           float* d_e2, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* workspace,
                           int64_t workspace_bytes, void* stream);
+
+/* Rectangular, masked variant for the decoder training step (VQCPCB/decoders/decoder.py:431-543,
+ * transformer_custom.py:355-386): Lq = r * Lk queries over Lk keys, q / k / v from separate row-major buffers
+ * (self-attention: three column blocks of one in_proj output; cross-attention, multihead_attention_custom.py:173-196:
+ * q from the target rows, k | v from the memory rows).  With p = i / r,
+ *   bias[h,i,j] = q[h,i].e1[h, Lk-1-(p-j)] (j <= p) | q[h,i].e2[h, j-p] (j > p)
+ * (SubsampledRelativeAttention.forward with seq_len_tgt = r * seq_len_src, subsampled_relative_attention.py:30-122) and
+ * mask = 0 none | 1 causal (keep j <= p) | 2 anticausal (keep j >= p)  (decoder.py:292-308; masked probabilities are 0).
+ *   q [n_seq*Lq][ldq], k [n_seq*Lk][ldk], v [n_seq*Lk][ldv] (head h = columns [h*hd, (h+1)*hd), q UNSCALED),
+ *   e1, e2 [H*Lk][hd], ctx [n_seq*Lq][ldo], probs [n_seq][H][Lq][Lk] = softmax BEFORE dropout,
+ *   dropout element index = ((seq*H + h)*Lq + i)*Lk + j.   Lk <= 1024, hd in {16, 32, 64, 128}.
+ * bwd: d_q / d_k / d_v written in full (same layouts, own leading dimensions), d_e1 / d_e2 overwritten. */
+int vqcpc_relattn_x_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
+                        const float* e1, const float* e2, float* ctx, int64_t ldo, float* probs, int64_t n_seq, int Lq,
+                        int Lk, int H, int hd, int mask, float drop_p, uint64_t seed, void* stream);
+int64_t vqcpc_relattn_x_bwd_workspace(int64_t n_seq, int Lq, int Lk, int H, int hd);
+int vqcpc_relattn_x_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* k, int64_t ldk,
+                        const float* v, int64_t ldv, const float* probs, const float* e1, const float* e2, float* d_q,
+                        int64_t ldgq, float* d_k, int64_t ldgk, float* d_v, int64_t ldgv, float* d_e1, float* d_e2,
+                        int64_t n_seq, int Lq, int Lk, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                        int64_t workspace_bytes, void* stream);
 
 /* Query-subsampled variant for the LAST layer of a stack: `output[::F]` (relative_transformer_downscaler.py:125) keeps
  * only positions 0, F, 2F.. and everything after the attention is per-token, so only those queries are evaluated

@@ -3,7 +3,7 @@
 Module names mirror SonyCSLParis/vqcpc-bach's `VQCPCB` package for the hot path only
 (`encoder`, `vqcpc_encoder_trainer`, `student_encoder_trainer`, `vqcpc_helper`, `quantizer.vector_quantizer`,
 `downscalers.relative_transformer_downscaler[_linear]`, `transformer.*`, `data_processor.*`, `upscalers.mlp_upscaler`,
-`teachers.teacher_relative`, `auxiliary_decoders.auxiliary_decoder_relative`, `getters`), so `main_encoder.py` runs unchanged after `vqcpc_bach_amd.install_as_vqcpcb()`.
+`teachers.teacher_relative`, `auxiliary_decoders.auxiliary_decoder_relative`, `decoders.decoder` (training step only), `getters`), so `main_encoder.py` runs unchanged after `vqcpc_bach_amd.install_as_vqcpcb()`.
 All numerical work goes through libvqcpc_hip.so (include/vqcpc.h); there is no CPU fallback.
 """
 import sys
@@ -24,6 +24,6 @@ def install_as_vqcpcb():
                 'dataloaders.synthetic_cpc_dataloader', 'dataloaders.synthetic_student_dataloader',
                 'student_encoder_trainer', 'teachers', 'teachers.teacher_relative', 'auxiliary_decoders',
                 'auxiliary_decoders.auxiliary_decoder_relative', 'data_processor.bach_data_processor',
-                'downscalers.relative_transformer_downscaler_linear'):
+                'downscalers.relative_transformer_downscaler_linear', 'decoders', 'decoders.decoder'):
         sys.modules.setdefault('VQCPCB.' + sub, importlib.import_module(__name__ + '.' + sub))
     return pkg

@@ -316,6 +316,24 @@ __global__ __launch_bounds__(256) void block_table_segsum_kernel(const float* __
     }
 }
 
+// Gradient of a plain row gather out[m] = table[idx[m]] for tables of any size (the decoder's source-code and shifted
+// target-token embeddings: decoders/decoder.py:212-215,439,474-480).  The caller passes idx sorted (stable, so equal keys
+// keep ascending m) with the permutation; the workgroup at the first position of a run sums the run's rows in that
+// order -- deterministic, no atomics -- and rows nobody refers to keep the zero fill.
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restrict__ g, int64_t ldg,
+                                                            const int64_t* __restrict__ sorted_idx,
+                                                            const int64_t* __restrict__ perm, float* __restrict__ d_table,
+                                                            int64_t M, int C) {
+    const int64_t m = blockIdx.x;
+    const int64_t v = sorted_idx[m];
+    if (m > 0 && sorted_idx[m - 1] == v) return;
+    for (int col = threadIdx.x; col < C; col += 256) {
+        float acc = 0.0f;
+        for (int64_t mm = m; mm < M && sorted_idx[mm] == v; ++mm) acc += g[perm[mm] * ldg + col];
+        d_table[v * C + col] = acc;
+    }
+}
+
 static int segsum_chunks(int64_t n_blocks) { return (int)std::max<int64_t>(1, std::min<int64_t>(32, n_blocks / 256)); }
 
 }  // namespace vq
@@ -425,6 +443,21 @@ int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_tab
     VQ_CHECK_LAUNCH("block_table_segsum");
     const int64_t total = (int64_t)vmax * L * C;
     return launch_reduce_splits((const float*)workspace, total, nchunk, d_table, total, 0, s);
+}
+
+int vqcpc_embedding_bwd(const float* g, int64_t ldg, const int64_t* sorted_idx, const int64_t* perm, float* d_table, int64_t M,
+                        int64_t V, int C, void* stream) {
+    VQ_REQUIRE(d_table && V >= 1 && C >= 1 && M >= 0, "embedding_bwd: bad arguments");
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemsetAsync(d_table, 0, (size_t)V * C * sizeof(float), s) != hipSuccess) {
+        set_error("embedding_bwd: memset failed");
+        return VQCPC_ELAUNCH;
+    }
+    if (M == 0) return VQCPC_OK;
+    VQ_REQUIRE(g && sorted_idx && perm && ldg >= C && M < (int64_t)1 << 31, "embedding_bwd: bad arguments");
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)M), dim3(256), 0, s, g, ldg, sorted_idx, perm, d_table, M, C);
+    VQ_CHECK_LAUNCH("embedding_bwd");
+    return VQCPC_OK;
 }
 
 int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,

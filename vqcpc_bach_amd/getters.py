@@ -1,5 +1,6 @@
 """Factories with the reference's names and config schema (reference: VQCPCB/getters.py:24-45,48-175,221-270,431-514),
-restricted to the encoder branches (vqcpc, student) that `main_encoder.py` reaches."""
+restricted to the encoder branches (vqcpc, student) that `main_encoder.py` reaches, plus `get_decoder` (:274-392) for
+the relative decoder training step."""
 import numpy as np
 
 from .auxiliary_decoders.auxiliary_decoder_relative import AuxiliaryDecoderRelative
@@ -7,6 +8,7 @@ from .data_processor.bach_cpc_data_processor import BachCPCDataProcessor
 from .data_processor.bach_data_processor import BachDataProcessor
 from .dataloaders.synthetic_cpc_dataloader import SyntheticCPCDataloaderGenerator
 from .dataloaders.synthetic_student_dataloader import SyntheticStudentDataloaderGenerator
+from .decoders.decoder import Decoder
 from .downscalers.relative_transformer_downscaler import RelativeTransformerDownscaler
 from .downscalers.relative_transformer_downscaler_linear import RelativeTransformerDownscalerLinear
 from .encoder import Encoder
@@ -21,9 +23,9 @@ def get_dataloader_generator(dataset, training_method, dataloader_generator_kwar
     if dataset.lower() in ('bach', 'synthetic') and training_method.lower() == 'vqcpc':
         # the music21 Bach corpus is replaced by a synthetic generator with the same tensor contract
         return SyntheticCPCDataloaderGenerator(**dataloader_generator_kwargs)
-    if dataset.lower() in ('bach', 'synthetic') and training_method.lower() == 'student':
-        return SyntheticStudentDataloaderGenerator(**dataloader_generator_kwargs)
-    raise NotImplementedError('only the vqcpc and student training methods are on the path (decoder/prior: out of scope)')
+    if dataset.lower() in ('bach', 'synthetic') and training_method.lower() in ('student', 'decoder'):
+        return SyntheticStudentDataloaderGenerator(**dataloader_generator_kwargs)     # {'x': (B, events, voices)}
+    raise NotImplementedError('only the vqcpc, student and decoder training methods are on the path (prior: out of scope)')
 
 
 def get_downscaler(downscaler_type, downscaler_kwargs):
@@ -148,3 +150,25 @@ def get_encoder_trainer(model_dir, dataloader_generator, training_method, encode
                                      quantization_weighting=auxiliary_networks_kwargs['quantization_weighting'],
                                      num_events_masked=auxiliary_networks_kwargs['num_events_masked'])
     raise NotImplementedError(training_method)
+
+
+def get_decoder(model_dir, dataloader_generator, data_processor, encoder, decoder_type, decoder_kwargs):
+    """getters.py:274-392.  'transformer_relative' (anticausal source / anticausal cross / causal target) and
+    'transformer_relative_fullCross'; the absolute and diagonal variants are out of scope."""
+    kinds = {'transformer_relative': ('anticausal', 'anticausal'), 'transformer_relative_fullCross': ('anticausal', 'full')}
+    if decoder_type not in kinds:
+        raise NotImplementedError(f'decoder_type {decoder_type}: only the relative decoders {sorted(kinds)} are built')
+    num_channels_decoder = data_processor.num_channels
+    num_events_decoder = data_processor.num_events
+    num_channels_encoder = 1
+    num_events_encoder = int((num_events_decoder * num_channels_decoder)
+                             // (np.prod(encoder.downscaler.downscale_factors) * num_channels_encoder))
+    k = decoder_kwargs
+    return Decoder(model_dir=model_dir, dataloader_generator=dataloader_generator, data_processor=data_processor,
+                   encoder=encoder, transformer_type='relative', encoder_attention_type=kinds[decoder_type][0],
+                   cross_attention_type=kinds[decoder_type][1], d_model=k['d_model'],
+                   num_encoder_layers=k['num_encoder_layers'], num_decoder_layers=k['num_decoder_layers'],
+                   n_head=k['n_head'], dim_feedforward=k['dim_feedforward'], dropout=k['dropout'],
+                   positional_embedding_size=k['positional_embedding_size'], num_channels_encoder=num_channels_encoder,
+                   num_events_encoder=num_events_encoder, num_channels_decoder=num_channels_decoder,
+                   num_events_decoder=num_events_decoder)

@@ -364,6 +364,180 @@ class EncoderLayerFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# N4: building blocks of the decoder training step (decoders/decoder.py:431-543, transformer_custom.py:294-386)
+# ------------------------------------------------------------------------------------------------------------------
+MASK_NONE, MASK_CAUSAL, MASK_ANTICAUSAL = 0, 1, 2
+
+
+class AttnXFn(torch.autograd.Function):
+    """Masked, rectangular relative attention (vqcpc_relattn_x_fwd/bwd).  Self-attention: `qsrc` is the (n * L, 3d)
+    in_proj output and `kvsrc` None; cross-attention: `qsrc` (n * Lq, d) projected queries, `kvsrc` (n * Lk, 2d) k | v of
+    the memory.  Returns (ctx (n * Lq, d), probs (n, H, Lq, Lk)); the gradient comes back in the same packing."""
+
+    @staticmethod
+    def forward(ctx, qsrc, kvsrc, e1, e2, n, Lq, Lk, H, mask, drop_p, seed):
+        hd = e1.shape[1]
+        d = H * hd
+        qsrc = _f32(qsrc).contiguous()
+        if kvsrc is None:
+            assert qsrc.shape == (n * Lq, 3 * d) and Lq == Lk
+            q, k, v, ldq, ldk = qsrc, qsrc[:, d:], qsrc[:, 2 * d:], 3 * d, 3 * d
+        else:
+            kvsrc = _f32(kvsrc).contiguous()
+            assert qsrc.shape == (n * Lq, d) and kvsrc.shape == (n * Lk, 2 * d)
+            q, k, v, ldq, ldk = qsrc, kvsrc, kvsrc[:, d:], d, 2 * d
+        att = torch.empty(n * Lq, d, dtype=torch.float32, device=qsrc.device)
+        probs = torch.empty(n, H, Lq, Lk, dtype=torch.float32, device=qsrc.device)
+        hip.call('vqcpc_relattn_x_fwd', q, ldq, k, ldk, v, ldk, e1, e2, att, d, probs, n, Lq, Lk, H, hd, int(mask),
+                 float(drop_p), int(seed))
+        ctx.save_for_backward(qsrc, kvsrc, probs, e1, e2)
+        ctx.meta = (n, Lq, Lk, H, hd, float(drop_p), int(seed))
+        ctx.mark_non_differentiable(probs)
+        return att, probs
+
+    @staticmethod
+    def backward(ctx, datt, _dprobs):
+        qsrc, kvsrc, probs, e1, e2 = ctx.saved_tensors
+        n, Lq, Lk, H, hd, p, seed = ctx.meta
+        d = H * hd
+        dev = qsrc.device
+        datt = datt.contiguous()
+        de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
+        if kvsrc is None:
+            dqsrc, dkvsrc = torch.empty(n * Lq, 3 * d, dtype=torch.float32, device=dev), None
+            q, k, v, ldq, ldk = qsrc, qsrc[:, d:], qsrc[:, 2 * d:], 3 * d, 3 * d
+            dq, dk, dv = dqsrc, dqsrc[:, d:], dqsrc[:, 2 * d:]
+        else:
+            dqsrc = torch.empty(n * Lq, d, dtype=torch.float32, device=dev)
+            dkvsrc = torch.empty(n * Lk, 2 * d, dtype=torch.float32, device=dev)
+            q, k, v, ldq, ldk = qsrc, kvsrc, kvsrc[:, d:], d, 2 * d
+            dq, dk, dv = dqsrc, dkvsrc, dkvsrc[:, d:]
+        nbytes = hip.query('vqcpc_relattn_x_bwd_workspace', n, Lq, Lk, H, hd)
+        ws = hip.workspace(nbytes, dev)
+        hip.call('vqcpc_relattn_x_bwd', datt, d, q, ldq, k, ldk, v, ldk, probs, e1, e2, dq, ldq, dk, ldk, dv, ldk, de1, de2, n,
+                 Lq, Lk, H, hd, p, seed, ws, nbytes)
+        return dqsrc, dkvsrc, de1, de2, None, None, None, None, None, None, None
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """y = LayerNorm(x + dropout(r))  (transformer_custom.py:372-373,376-377,382-383)."""
+
+    @staticmethod
+    def forward(ctx, x, r, gamma, beta, drop_p, seed):
+        x, ldx = _rows(_f32(x))
+        r = _f32(r).contiguous()
+        M, d = x.shape
+        y = torch.empty(M, d, dtype=torch.float32, device=x.device)
+        mean = torch.empty(M, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(M, dtype=torch.float32, device=x.device)
+        hip.call('vqcpc_add_layernorm_fwd', x, ldx, r, gamma, beta, y, mean, rstd, M, d, 1e-5, float(drop_p), int(seed))
+        ctx.save_for_backward(x, r, gamma, mean, rstd)
+        ctx.meta = (float(drop_p), int(seed))
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, r, gamma, mean, rstd = ctx.saved_tensors
+        p, seed = ctx.meta
+        x, ldx = _rows(x)
+        M, d = x.shape
+        dev = x.device
+        ds = torch.empty(M, d, dtype=torch.float32, device=dev)
+        dr = torch.empty(M, d, dtype=torch.float32, device=dev) if p > 0 else None
+        dg = torch.empty(d, dtype=torch.float32, device=dev)
+        db = torch.empty(d, dtype=torch.float32, device=dev)
+        nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', M, d)
+        ws = hip.workspace(nbytes, dev)
+        hip.call('vqcpc_add_layernorm_bwd', dy.contiguous(), x, ldx, r, gamma, mean, rstd, ds, dr, dg, db, M, d, p, seed, ws,
+                 nbytes)
+        return ds, (dr if dr is not None else ds), dg, db, None, None
+
+
+class FFNFn(torch.autograd.Function):
+    """linear2(dropout(relu(linear1(x))))  (transformer_custom.py:379): ReLU + dropout in the first GEMM's epilogue, their
+    backward as the gate of the dgrad GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, drop_p, seed):
+        h = gemm_nt(x, w1, bias=b1, act=1, drop_p=float(drop_p), seed=int(seed))
+        y = gemm_nt(h, w2, bias=b2)
+        ctx.save_for_backward(x, h, w1, w2)
+        ctx.biases = (b1, b2)
+        ctx.p = float(drop_p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, h, w1, w2 = ctx.saved_tensors
+        b1, b2 = ctx.biases
+        dy = dy.contiguous()
+        da = gemm_nt(dy, transpose(w2), gate=h, gate_scale=1.0 / (1.0 - ctx.p))
+        dw2, db2 = wgrad(dy, h, w2, b2)
+        dw1, db1 = wgrad(da, x, w1, b1)
+        dx = gemm_nt(da, transpose(w1)) if ctx.needs_input_grad[0] else None
+        return dx, dw1, db1, dw2, db2, None, None
+
+
+class CrossProjFn(torch.autograd.Function):
+    """Encoder-decoder branch of in_proj (multihead_attention_custom.py:173-196): q = tgt W[:d]^T + b[:d],
+    k | v = mem W[d:]^T + b[d:].  One autograd node so that the two row blocks of in_proj's gradient are produced
+    together (or accumulated in place, ops.direct_weight_gradients)."""
+
+    @staticmethod
+    def forward(ctx, tgt, mem, w, b):
+        d = w.shape[1]
+        q = gemm_nt(tgt, w[:d], bias=b[:d])
+        kv = gemm_nt(mem, w[d:], bias=b[d:])
+        ctx.save_for_backward(tgt, mem, w)
+        ctx.b = b
+        return q, kv
+
+    @staticmethod
+    def backward(ctx, dq, dkv):
+        tgt, mem, w = ctx.saved_tensors
+        b = ctx.b
+        d = w.shape[1]
+        dq, dkv = dq.contiguous(), dkv.contiguous()
+        dwq, dbq = wgrad(dq, tgt, w, b, rows=slice(0, d))
+        dwkv, dbkv = wgrad(dkv, mem, w, b, rows=slice(d, 3 * d))
+        if dwq is None:
+            dw = db = None
+        else:
+            dw, db = torch.cat([dwq, dwkv], dim=0), torch.cat([dbq, dbkv], dim=0)
+        wt = transpose(w)
+        dtgt = gemm_nt(dq, wt[:, :d]) if ctx.needs_input_grad[0] else None
+        dmem = gemm_nt(dkv, wt[:, d:]) if ctx.needs_input_grad[1] else None
+        return dtgt, dmem, dw, db
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """out[m] = table[idx[m]] for a table of any size; backward = deterministic segment sum over a stable sort of the
+    indices (integer plumbing only) in vqcpc_embedding_bwd."""
+
+    @staticmethod
+    def forward(ctx, table, idx):
+        table = _f32(table).contiguous()
+        V, C = table.shape
+        idx = idx.reshape(-1).to(torch.int64).contiguous()
+        M = idx.numel()
+        out = torch.empty(M, C, dtype=torch.float32, device=table.device)
+        hip.call('vqcpc_block_table_gather', table, idx, out, M, 1, V, C)
+        ctx.save_for_backward(idx)
+        ctx.meta = (V, C)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        V, C = ctx.meta
+        g, ldg = _rows(_f32(g))
+        sorted_idx, perm = torch.sort(idx, stable=True)
+        d_table = torch.empty(V, C, dtype=torch.float32, device=g.device)
+        hip.call('vqcpc_embedding_bwd', g, ldg, sorted_idx, perm, d_table, idx.numel(), V, C)
+        return d_table, None
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # A9/A10: product vector quantiser
 # ------------------------------------------------------------------------------------------------------------------
 class VQFn(torch.autograd.Function):

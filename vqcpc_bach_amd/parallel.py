@@ -79,7 +79,7 @@ class FlatParameters:
     def __init__(self, modules):
         seen, self.params = set(), []
         for m in modules:
-            for p in m.parameters():
+            for p in (m.parameters() if hasattr(m, 'parameters') else [m]):     # a module or a bare Parameter
                 if id(p) not in seen:
                     seen.add(id(p))
                     self.params.append(p)

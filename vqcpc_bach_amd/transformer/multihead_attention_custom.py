@@ -1,6 +1,7 @@
 """Parameter container of the reference's MultiheadAttentionCustom
 (VQCPCB/transformer/multihead_attention_custom.py:8-120): in_proj_weight/bias, out_proj, attn_bias.{e1,e2}, same
-names, shapes and initialisation.  The arithmetic of its forward (:122-353) lives in ops.EncoderLayerFn."""
+names, shapes and initialisation.  The arithmetic of its forward (:122-353) lives in ops.EncoderLayerFn (encoder
+path) and, for the decoder's masked / cross attentions, in `forward_rows` below (ops.AttnXFn)."""
 import torch
 from torch import nn
 
@@ -26,6 +27,23 @@ class MultiheadAttentionCustom(nn.Module):
         self.attn_bias = SubsampledRelativeAttention(head_dim=self.head_dim, num_heads=num_heads,
                                                      seq_len_src=seq_len_src, seq_len_tgt=seq_len_tgt)
         self.seq_len = seq_len_tgt
+        self.seq_len_src = seq_len_src
         nn.init.xavier_uniform_(self.in_proj_weight)          # _reset_parameters, :106-120
         nn.init.constant_(self.in_proj_bias, 0.)
         nn.init.constant_(self.out_proj.bias, 0.)
+
+    def forward_rows(self, x, n, mask, memory=None, drop_p=0.0, seed=0):
+        """Masked attention on batch-major rows: x (n * T, d) queries; self-attention when `memory` is None, otherwise
+        encoder-decoder attention on memory (n * S, d) (:171-196).  mask: ops.MASK_NONE / MASK_CAUSAL / MASK_ANTICAUSAL
+        (the additive masks of decoders/decoder.py:292-308 as index rules).  -> (out (n * T, d), probs (n, H, T, S))."""
+        from .. import ops
+        T, S = self.seq_len, self.seq_len_src
+        e1, e2 = self.attn_bias.e1, self.attn_bias.e2
+        if memory is None:
+            assert T == S
+            qkv = ops.LinearFn.apply(x, self.in_proj_weight, self.in_proj_bias)
+            att, probs = ops.AttnXFn.apply(qkv, None, e1, e2, n, T, S, self.num_heads, mask, drop_p, seed)
+        else:
+            q, kv = ops.CrossProjFn.apply(x, memory, self.in_proj_weight, self.in_proj_bias)
+            att, probs = ops.AttnXFn.apply(q, kv, e1, e2, n, T, S, self.num_heads, mask, drop_p, seed)
+        return ops.LinearFn.apply(att, self.out_proj.weight, self.out_proj.bias), probs

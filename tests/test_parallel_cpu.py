@@ -170,3 +170,60 @@ def test_flat_parameters_range_of_rejects_interleaved_modules():
     assert ra == (0, 24) and rb == (24, 24 + 12 + 4)     # 15 + 5 -> padded 16 + 8; 10 + 2 -> 12 + 4
     both = torch.nn.ModuleList([a, b])
     assert flat.range_of(both) == (0, flat.numel)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# decoder step: frozen encoder outside the bucket, bare Parameters inside it
+# ----------------------------------------------------------------------------------------------------------------------
+def _decoder_worker(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    import json
+    from conftest import load_golden, sub_state
+    from oracle import decoder_oracle as D
+    from vqcpc_bach_amd.parallel import DataParallelContext, FlatParameters
+    dp = DataParallelContext(device='cpu')
+    g = load_golden('decoder_tiny')
+    cfg = D.make_cfg(**json.loads(str(g['cfg_json'])))
+    sd = sub_state(g, 'sd0')
+    gen = torch.Generator().manual_seed(17)
+    full = torch.cat([torch.randint(0, nv, (4, cfg['events'], 1), generator=gen) for nv in cfg['vocab']], dim=2)
+    lo, hi = rank * 4 // world, (rank + 1) * 4 // world
+    frozen = {k: v for k, v in sd.items() if k.startswith('encoder.')}
+    # the decoder's trainable set mixes modules and bare nn.Parameters (sos, positional embeddings)
+    bare = [k for k in sd if not k.startswith('encoder.') and '.' not in k]
+    holder = torch.nn.ParameterDict({k.replace('.', '/'): torch.nn.Parameter(v.clone() + float(rank))
+                                     for k, v in sd.items() if not k.startswith('encoder.') and k not in bare})
+    bare_params = {k: torch.nn.Parameter(sd[k].clone() + float(rank)) for k in bare}
+    flat = FlatParameters([holder] + list(bare_params.values()))
+    assert flat.check_views() and len(bare) == 3
+    dp.broadcast_(flat.flat, src=0)
+    P = dict(frozen)
+    P.update({k.replace('/', '.'): p for k, p in holder.items()})
+    P.update(bare_params)
+    for k in sd:
+        assert torch.equal(P[k].detach(), sd[k]), k
+    flat.zero_grad()
+    x = full[lo:hi]
+    loss = D.decoder_forward(D.encode_codes(x, P, cfg), x, P, cfg)['loss']
+    loss.backward()
+    assert flat.check_views() and all(v.grad is None for v in frozen.values())
+    dp.all_reduce_sum_(flat.flat_grad)
+    flat.flat_grad.mul_(1.0 / world)
+    ref = D.DecoderOracleTrainer(cfg, sd)
+    ref.step({'x': full}, train=True)
+    worst = max(float((P[k].grad - r).abs().max() / (r.abs().max() + 1e-5)) for k, r in ref.last_grads.items())
+    norm = float(flat.flat_grad.double().pow(2).sum().sqrt())
+    torch.save(dict(worst=worst, norm=norm, refn=float(ref.last_grad_norm)), os.path.join(out_dir, f'd{rank}.pt'))
+    dp.barrier()
+    dp.shutdown()
+
+
+def test_decoder_dp_gradient_mean_with_frozen_encoder(tmp_path):
+    world = 2
+    mp.spawn(_decoder_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        res = torch.load(tmp_path / f'd{r}.pt')
+        assert res['worst'] < 2e-4, res['worst']
+        assert abs(res['norm'] - res['refn']) < 1e-4 * res['refn']

@@ -40,7 +40,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=3)
     ap.add_argument('--config', default='C1')
     ap.add_argument('--batch', type=int, default=None, help='windows per GPU (default: the config\'s)')
-    ap.add_argument('--dropout', type=float, default=0.1)
+    ap.add_argument('--dropout', type=float, default=None, help='default: 0.1 (0.2 for --config DEC, as its reference config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-steps', type=int, default=12)
@@ -138,6 +138,10 @@ def cpu_baseline_worker(cfg_name, dropout, batch, steps):
         from oracle import student_oracle as O
         cfg = O.make_cfg('C3', dropout=dropout, B=batch)
         otr = O.StudentOracleTrainer(cfg, O.init_state(cfg, seed=0), lr=1e-5)
+    elif cfg_name == 'DEC':                               # decoder step: oracle/decoder_oracle.py
+        from oracle import decoder_oracle as O
+        cfg = O.make_cfg('DEC', dec_dropout=dropout, B=batch)
+        otr = O.DecoderOracleTrainer(cfg, O.init_state(cfg, seed=0), lr=1e-4)
     else:
         from oracle import vqcpc_oracle as O
         cfg = O.make_cfg(cfg_name, dropout=dropout, B=batch)
@@ -169,7 +173,7 @@ def cpu_baseline_worker(cfg_name, dropout, batch, steps):
         model = [l.split(':', 1)[1].strip() for l in open('/proc/cpuinfo') if l.startswith('model name')][0]
     except Exception:
         pass
-    unit = 'sequences/s' if cfg_name == 'C3' else 'windows/s'
+    unit = 'sequences/s' if cfg_name in ('C3', 'DEC') else 'windows/s'
     print(json.dumps(dict(value=round(batch * steps / dt, 3), unit=unit, cores=cores, kind='port',
                           sample=f'{cfg_name} model, B={batch} {unit[:-2]}/step, {steps} timed steps after 1 warm-up, fp32, '
                                  f'dropout {dropout}, torch {torch.__version__} CPU on {model} ({usable} usable cores, fastest of '
@@ -191,6 +195,8 @@ def cpu_baseline(cfg_name, dropout, batch, steps, timeout_s=240):
 
 def main():
     args = parse()
+    if args.dropout is None:
+        args.dropout = 0.2 if args.config == 'DEC' else 0.1
     if args.cpu_baseline_only:
         return cpu_baseline_worker(args.config, args.dropout, args.cpu_batch, args.cpu_steps)
     from vqcpc_bach_amd import configs, getters, hip, ops
@@ -210,9 +216,19 @@ def main():
     B = args.batch or config['batch_size']
     dlg_kw = dict(config['dataloader_generator_kwargs'], seed=1234, rank=dp.rank, device=None if args.host_inputs else dev)
     dlg = getters.get_dataloader_generator(config['dataset'], config['training_method'], dlg_kw)
-    encoder = getters.get_encoder('/tmp/vqcpc_bench_model', dlg, config)
-    trainer = getters.get_encoder_trainer('/tmp/vqcpc_bench_model', dlg, config['training_method'], encoder,
-                                          config['auxiliary_networks_kwargs'])
+    decoder_step = config['training_method'].lower() == 'decoder'
+    if decoder_step:                                               # frozen encoder + Decoder
+        enc_cfg = config['config_encoder']
+        enc_dlg = getters.get_dataloader_generator(enc_cfg['dataset'], enc_cfg['training_method'],
+                                                   dict(enc_cfg['dataloader_generator_kwargs'], seed=1234, rank=dp.rank, device=dev))
+        encoder = getters.get_encoder('/tmp/vqcpc_bench_model', enc_dlg, enc_cfg)
+        data_processor = getters.get_data_processor(dlg, config['data_processor_type'], config['data_processor_kwargs'])
+        trainer = getters.get_decoder('/tmp/vqcpc_bench_model', dlg, data_processor, encoder, config['decoder_type'],
+                                      config['decoder_kwargs'])
+    else:
+        encoder = getters.get_encoder('/tmp/vqcpc_bench_model', dlg, config)
+        trainer = getters.get_encoder_trainer('/tmp/vqcpc_bench_model', dlg, config['training_method'], encoder,
+                                              config['auxiliary_networks_kwargs'])
     trainer.to(dev)
     trainer.init_optimizers(lr=config['lr'], schedule_lr=config.get('schedule_lr', False), dp=dp)
     trainer.train()
@@ -247,9 +263,9 @@ def main():
     timer.enabled = False
     dt = dp.max_over_ranks(dt)
     student = config['training_method'].lower() == 'student'
-    last_loss = float(out['loss_encdec'] if student else out['loss'])
+    last_loss = float(out if decoder_step else (out['loss_encdec'] if student else out['loss']))
 
-    seq_len = 384 if student else 16 * (dlg.num_blocks_left + dlg.num_blocks_right)
+    seq_len = 384 if (student or decoder_step) else 16 * (dlg.num_blocks_left + dlg.num_blocks_right)
     timed_steps = max(1, len(range(0, args.steps, 4)))
     if dp.rank == 0:
         value = B * dp.world_size * args.steps / dt
@@ -264,7 +280,8 @@ def main():
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=0>, gemm_nt_skinny_kernel; fp32 v_mfma_f32_32x32x2_f32)'
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
-                            frac=round(nt['tflops'] / peak, 4), traffic=hbm_traffic('gemm_nt', max(1, nt['launches'] // timed_steps)),
+                            frac=round(nt['tflops'] / peak, 4),
+                            traffic=(hbm_traffic('gemm_nt', max(1, nt['launches'] // timed_steps)) if args.config == 'C1' and gemm_mode == 1 else None),
                             traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_hbm_traffic.json)',
                             algorithmic_bytes_per_launch=round(nt['bytes_per_launch']),
                             launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),
@@ -277,7 +294,8 @@ def main():
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32',
             'data': 'synthetic' + (' (host-resident inputs: PCIe-inclusive)' if args.host_inputs else ''),
-            'config': {'workload': (f'encoder_cpc {args.config}: seq_len={seq_len}, '
+            'config': {'workload': ('' if decoder_step else
+                                    f'encoder_cpc {args.config}: seq_len={seq_len}, '
                                     f'batch={B}/GPU, {getattr(dlg, "num_negative_samples", 0)} negatives, product-VQ '
                                     f'{config["quantizer_kwargs"]["num_codebooks"]}x{config["quantizer_kwargs"]["codebook_size"]}, '
                                     f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}'),
@@ -296,6 +314,16 @@ def main():
             line['config'] = {'workload': f'encoder_student C3: x (B, 96, 4), batch={B}/GPU, teacher {tk["num_layers"]} layers '
                                           f'L=384, encoder {dk["list_of_num_layers"]} layers (linear aggregation), decoder '
                                           f'L=24/96, d_model={dk["d_model"]}, VQ 1x32 dim 3, dropout={args.dropout}',
+                              'global_batch': B * dp.world_size, 'seq_len': 384, 'parallelism': f'dp{dp.world_size}',
+                              'params': n_params, 'gemm': line['config']['gemm']}
+        if decoder_step:   # an extra measurement, not the headline metric
+            line['metric'], line['unit'] = 'decoder-train sequences/sec (Bach 4-voice, 24 beats = 384 tokens)', 'sequences/s'
+            dk, ek = config['decoder_kwargs'], config['config_encoder']['downscaler_kwargs']
+            line['config'] = {'workload': f'decoder DEC: x (B, 96, 4) -> 24 codes (frozen transformer encoder d_model '
+                                          f'{ek["d_model"]}, {ek["list_of_num_layers"]} layers, 1x32 codes) -> relative seq2seq '
+                                          f'transformer {dk["num_encoder_layers"]}+{dk["num_decoder_layers"]} layers, d_model '
+                                          f'{dk["d_model"]}, {dk["n_head"]} heads, ff {dk["dim_feedforward"]}, anticausal source / '
+                                          f'anticausal cross / causal target, batch={B}/GPU, dropout={args.dropout}',
                               'global_batch': B * dp.world_size, 'seq_len': 384, 'parallelism': f'dp{dp.world_size}',
                               'params': n_params, 'gemm': line['config']['gemm']}
         if dp.world_size == 1 and not args.no_cpu_baseline:

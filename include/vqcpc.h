@@ -151,7 +151,8 @@ int vqcpc_relattn_tab_bwd(const float* d_ctx, int64_t ldo, const float* table, i
  *   q [n_seq*Lq][ldq], k [n_seq*Lk][ldk], v [n_seq*Lk][ldv] (head h = columns [h*hd, (h+1)*hd), q UNSCALED),
  *   e1, e2 [H*Lk][hd], ctx [n_seq*Lq][ldo], probs [n_seq][H][Lq][Lk] = softmax BEFORE dropout,
  *   dropout element index = ((seq*H + h)*Lq + i)*Lk + j.   Lk <= 1024, hd in {16, 32, 64, 128}.
- * bwd: d_q / d_k / d_v written in full (same layouts, own leading dimensions), d_e1 / d_e2 overwritten. */
+ * Key tiles a strip of queries cannot see under the mask are skipped (half of the causal self-attention).
+ * bwd: same mask as fwd; d_q / d_k / d_v written in full (same layouts, own leading dimensions), d_e1 / d_e2 overwritten. */
 int vqcpc_relattn_x_fwd(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv,
                         const float* e1, const float* e2, float* ctx, int64_t ldo, float* probs, int64_t n_seq, int Lq,
                         int Lk, int H, int hd, int mask, float drop_p, uint64_t seed, void* stream);
@@ -159,7 +160,7 @@ int64_t vqcpc_relattn_x_bwd_workspace(int64_t n_seq, int Lq, int Lk, int H, int 
 int vqcpc_relattn_x_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* k, int64_t ldk,
                         const float* v, int64_t ldv, const float* probs, const float* e1, const float* e2, float* d_q,
                         int64_t ldgq, float* d_k, int64_t ldgk, float* d_v, int64_t ldgv, float* d_e1, float* d_e2,
-                        int64_t n_seq, int Lq, int Lk, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                        int64_t n_seq, int Lq, int Lk, int H, int hd, int mask, float drop_p, uint64_t seed, void* workspace,
                         int64_t workspace_bytes, void* stream);
 
 /* Query-subsampled variant for the LAST layer of a stack: `output[::F]` (relative_transformer_downscaler.py:125) keeps

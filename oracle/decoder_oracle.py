@@ -24,13 +24,74 @@ MASKS = {'full': NONE, 'causal': CAUSAL, 'anticausal': ANTICAUSAL, None: NONE}
 
 
 def make_cfg(name=None, **over):
-    """Encoder keys as oracle/vqcpc_oracle.py; decoder keys dec_*."""
+    """Encoder keys as oracle/vqcpc_oracle.py; decoder keys dec_*.
+    'DEC' = the shipped relative decoder (configs/decoder_relative_AC_AC_C_random.py: 24 beats = 96 ticks = 384 target
+    tokens, d_model 512, 8 heads, 3 + 3 layers, ff 1024, batch 32) on the reference's own transformer encoder
+    (configs/encoder_random_transfo_config.py: d_model 512, 8 heads, [2, 2] layers, ff 2048, 1 x 32 codes of dim 3)."""
     cfg = O.make_cfg(name if name in O.CONFIGS else None)
     cfg.update(dict(events=48, dec_emb=32, dec_d=512, dec_H=4, dec_enc_layers=3, dec_dec_layers=3, dec_ff=1024, dec_pos=8,
                     enc_attn='anticausal', cross_attn='anticausal', dec_dropout=0.0))
-    # configs/decoder_relative_AC_AC_C_random.py: sequences_size=12 beats = 48 ticks, d_model 512, 4 heads, 3+3 layers
+    if name == 'DEC':
+        cfg.update(d=512, H=8, layers=[2, 2], ff=2048, D=3, K=32, ncb=1, events=96, dec_H=8, B=32)
     cfg.update(over)
     return cfg
+
+
+def init_state(cfg, seed=0):
+    """Random-init state dict with the reference's `Decoder.state_dict()` names / shapes and its initialisers
+    (decoder.py:87-232; TransformerCustom._reset_parameters xavier-initialises every matrix of the transformer,
+    e1 / e2 included, transformer_custom.py:113-118)."""
+    import math
+    g = torch.Generator().manual_seed(seed)
+    sd = {k: v for k, v in O.init_state(cfg, seed=seed + 1).items() if k.startswith('encoder.')}
+    nc = len(cfg['vocab'])
+    d, H, ff, pos = cfg['dec_d'], cfg['dec_H'], cfg['dec_ff'], cfg['dec_pos']
+    hd = d // H
+    T = cfg['events'] * nc
+    U = 1
+    for f in cfg['factors']:
+        U *= f
+    S = T // U
+    for v, nv in enumerate(cfg['vocab']):
+        sd[f'data_processor.embeddings.{v}.weight'] = torch.randn(nv + 1, cfg['dec_emb'], generator=g)
+    sd['target_channel_embeddings'] = torch.randn(1, nc, pos, generator=g)
+    sd['target_events_positioning_embeddings'] = torch.randn(1, U // nc, pos, generator=g)
+
+    def xav(r, c):
+        return O._xavier(g, r, c)
+
+    def attn(pre, Lk):
+        sd[pre + 'in_proj_weight'], sd[pre + 'in_proj_bias'] = xav(3 * d, d), torch.zeros(3 * d)
+        sd[pre + 'out_proj.weight'], sd[pre + 'out_proj.bias'] = xav(d, d), torch.zeros(d)
+        sd[pre + 'attn_bias.e1'], sd[pre + 'attn_bias.e2'] = xav(H * Lk, hd), xav(H * Lk, hd)
+
+    def ffn_norms(pre, norms):
+        sd[pre + 'linear1.weight'], sd[pre + 'linear1.bias'] = xav(ff, d), (torch.rand(ff, generator=g) * 2 - 1) / math.sqrt(d)
+        sd[pre + 'linear2.weight'], sd[pre + 'linear2.bias'] = xav(d, ff), (torch.rand(d, generator=g) * 2 - 1) / math.sqrt(ff)
+        for n in norms:
+            sd[pre + n + '.weight'], sd[pre + n + '.bias'] = torch.ones(d), torch.zeros(d)
+
+    for l in range(cfg['dec_enc_layers']):
+        pre = f'transformer.encoder.layers.{l}.'
+        attn(pre + 'self_attn.', S)
+        ffn_norms(pre, ('norm1', 'norm2'))
+    for l in range(cfg['dec_dec_layers']):
+        pre = f'transformer.decoder.layers.{l}.'
+        attn(pre + 'self_attn.', T)
+        attn(pre + 'multihead_attn.', S)
+        ffn_norms(pre, ('norm1', 'norm2', 'norm3'))
+    sd['linear_target.weight'], sd['linear_target.bias'] = O._linear_init(g, d, cfg['dec_emb'] + 2 * pos)
+    sd['sos'] = torch.randn(1, 1, d, generator=g)
+    sd['source_embeddings.weight'] = torch.randn(cfg['K'] ** cfg['ncb'], d, generator=g)
+    for c, nv in enumerate(cfg['vocab']):
+        sd[f'pre_softmaxes.{c}.weight'], sd[f'pre_softmaxes.{c}.bias'] = O._linear_init(g, nv, d)
+    return sd
+
+
+def synthetic_batch(cfg, seed=1234, B=None):
+    B = B or cfg['B']
+    g = torch.Generator().manual_seed(seed)
+    return {'x': torch.cat([torch.randint(0, nv, (B, cfg['events'], 1), generator=g) for nv in cfg['vocab']], dim=2)}
 
 
 def relative_bias_cross(q, e1, e2, S):

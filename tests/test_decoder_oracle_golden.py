@@ -99,3 +99,16 @@ def test_decoder_step(name):
             if bool(solid.any()):
                 assert rel_err(mine[solid], ref[solid]) < 5e-3, k
             assert float((mine - ref).abs().max()) <= 2.0001 * float(g['lr']), k
+
+
+def test_init_state_matches_reference_keys_and_shapes():
+    g = load_golden('decoder_tiny')
+    cfg = D.make_cfg(**json.loads(str(g['cfg_json'])))
+    ref = decoder_state(g)
+    mine = D.init_state(cfg)
+    assert set(mine) == set(ref)
+    for k in ref:
+        assert tuple(mine[k].shape) == tuple(ref[k].shape), k
+    tr = D.DecoderOracleTrainer(cfg, mine)
+    out = tr.step(D.synthetic_batch(cfg, B=2), train=True)
+    assert torch.isfinite(out['loss']) and all(torch.isfinite(v).all() for v in tr.last_grads.values())

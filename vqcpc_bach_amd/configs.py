@@ -42,9 +42,36 @@ def make_student_config(dropout=0.1, **over):
     return cfg
 
 
+def make_decoder_config(dropout=0.2, **over):
+    """VQCPCB/configs/decoder_relative_AC_AC_C_random.py:4-46 (24 beats = 96 ticks = 384
+    target tokens, d_model 512, 8 heads, 3 + 3 layers, ff 1024, dropout 0.2, batch 32, scheduled lr) on the frozen
+    transformer encoder of VQCPCB/configs/encoder_random_transfo_config.py:26-63 (d_model 512, 8 heads, [2, 2] layers,
+    ff 2048, 1 x 32 codes of dim 3) -- the shipped decoder configs point at LSTM-downscaler encoders, which are out of
+    scope."""
+    enc = make_config('C1', dropout=0.1)
+    enc['downscaler_kwargs'].update(d_model=512, n_head=8, list_of_num_layers=[2, 2], dim_feedforward=2048)
+    enc['quantizer_kwargs'].update(num_codebooks=1, codebook_size=32, codebook_dim=3, initialize=False)
+    cfg = {
+        'config_encoder': enc, 'training_method': 'decoder', 'dataset': 'bach',
+        'dataloader_generator_kwargs': dict(sequences_size=24),
+        'data_processor_type': 'bach', 'data_processor_kwargs': dict(embedding_size=32),
+        'decoder_type': 'transformer_relative',
+        'decoder_kwargs': dict(d_model=512, n_head=8, num_encoder_layers=3, num_decoder_layers=3, dim_feedforward=1024,
+                               positional_embedding_size=8, dropout=dropout),
+        'lr': 1e-4, 'schedule_lr': True, 'batch_size': 32, 'num_batches': 2048, 'num_epochs': 1, 'timestamp': None,
+        'savename': 'decoder_relative_AC_AC_C',
+    }
+    cfg = copy.deepcopy(cfg)
+    for k, v in over.items():
+        cfg[k] = v
+    return cfg
+
+
 def make_config(name='C1', dropout=0.1, **over):
     if name == 'C3':
         return make_student_config(dropout=dropout, **over)
+    if name == 'DEC':
+        return make_decoder_config(dropout=dropout, **over)
     d, H, layers, ff, D, K, ncb, B, Kl, Kr = _SIZES[name]
     cfg = {
         'training_method': 'vqcpc', 'dataset': 'bach',

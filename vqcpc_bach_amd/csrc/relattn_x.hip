@@ -74,6 +74,11 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
     const float* kbase = k + n * Lk * ldk + h * HD;
     const float* vbase = v + n * Lk * ldv + h * HD;
     const int pmax = (i0 + 31) / ratio;
+    // key tiles the strip can see: causal keeps j <= p <= pmax, anticausal keeps j >= p >= pmin; the other tiles have
+    // probability 0 and are never touched (half of the work of the causal target self-attention)
+    const int jt0 = mask == 2 ? (i0 / ratio) / 32 : 0;
+    const int KTe = mask == 1 ? min(KT, pmax / 32 + 1) : KT;
+    const int jlo = 32 * jt0, jhi = min(Lk, 32 * KTe);
 
     float qa[KH];
     {
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
     }
     // ---- phase 1: QE band  strip[ii][x] = qs_ii . Erel[rlo + x]
     const int rlo = Lk - 1 - pmax;
-    for (int t = 0; t <= KT; ++t) {
+    for (int t = jt0; t <= KTe; ++t) {
         float eb[KH];
         xload_row<KH>(eb, xerel_row(e1, e2, h, Lk, HD, rlo + 32 * t + l31) + g * KH, true, 1.0f);
         floatx16 acc = {0};
@@ -99,7 +104,7 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
     }
     __syncthreads();
     // ---- phase 2: scores, in place (tile jt reads columns [32jt, 32jt+62], writes [32jt, 32jt+31])
-    for (int jt = 0; jt < KT; ++jt) {
+    for (int jt = jt0; jt < KTe; ++jt) {
         const int j = 32 * jt + l31;
         float kb[KH];
         xload_row<KH>(kb, kbase + (int64_t)min(j, Lk - 1) * ldk + g * KH, j < Lk, 1.0f);
@@ -120,10 +125,10 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
     for (int ii = 0; ii < rows; ++ii) {
         float* row = strip + ii * SW;
         float m = kNegBigX;
-        for (int j = lane; j < Lk; j += 64) m = fmaxf(m, row[j]);
+        for (int j = jlo + lane; j < jhi; j += 64) m = fmaxf(m, row[j]);
         m = wave_max(m);
         float sum = 0.0f;
-        for (int j = lane; j < Lk; j += 64) {
+        for (int j = jlo + lane; j < jhi; j += 64) {
             const float e = __expf(row[j] - m);
             row[j] = e;
             sum += e;
@@ -134,7 +139,7 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
         for (int j = lane; j < 32 * KT; j += 64) {
             float pd = 0.0f;
             if (j < Lk) {
-                const float p = row[j] * inv;
+                const float p = (j >= jlo && j < jhi) ? row[j] * inv : 0.0f;
                 probs[pbase + j] = p;
                 pd = p * drop_scale(seed, (uint64_t)(pbase + j), thr, inv_keep);
             }
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
     floatx16 o[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) o[ct] = floatx16{0};
-    for (int jt = 0; jt < KT; ++jt) {
+    for (int jt = jt0; jt < KTe; ++jt) {
         float pa[16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -183,7 +188,7 @@ template <int HD>
 __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ k, int64_t ldk, const float* __restrict__ v,
     int64_t ldv, const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
-    float* __restrict__ d_q, int64_t ldgq, float* __restrict__ dSg, int Lq, int Lk, int ratio, int H, float scale,
+    float* __restrict__ d_q, int64_t ldgq, float* __restrict__ dSg, int Lq, int Lk, int ratio, int H, int mask, float scale,
     uint32_t thr, float inv_keep, uint64_t seed) {
     constexpr int KH = HD / 2, CT = (HD + 31) / 32, OFF = 32;
     extern __shared__ __attribute__((aligned(16))) float strip[];
@@ -196,6 +201,9 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
     const float* kbase = k + n * Lk * ldk + h * HD;
     const float* vbase = v + n * Lk * ldv + h * HD;
     const int pmax = (i0 + 31) / ratio;
+    // visible key tiles (see the forward kernel); dSg is only written there, its readers apply the same rule
+    const int jt0 = mask == 2 ? (i0 / ratio) / 32 : 0;
+    const int KTe = mask == 1 ? min(KT, pmax / 32 + 1) : KT;
 
     for (int e = lane; e < 32 * SW; e += 64) strip[e] = 0.0f;
     float doa[KH];
@@ -208,7 +216,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) rd[r] = 0.0f;
     // pass 1: dP = (dO . V^T) * dropout mask, row sums of dP * P
-    for (int jt = 0; jt < KT; ++jt) {
+    for (int jt = jt0; jt < KTe; ++jt) {
         const int j = 32 * jt + l31;
         float vb[KH];
         xload_row<KH>(vb, vbase + (int64_t)min(j, Lk - 1) * ldv + g * KH, j < Lk, 1.0f);
@@ -232,7 +240,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
         for (int o = 16; o > 0; o >>= 1) rd[r] += __shfl_xor(rd[r], o, 64);
     }
     // pass 2: dS = P (dP - rowsum); every lane revisits exactly the strip entries it wrote
-    for (int jt = 0; jt < KT; ++jt) {
+    for (int jt = jt0; jt < KTe; ++jt) {
         const int j = 32 * jt + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -250,7 +258,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = floatx16{0};
     // dS . K
-    for (int jt = 0; jt < KT; ++jt) {
+    for (int jt = jt0; jt < KTe; ++jt) {
         float pa[16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -271,7 +279,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
     // skew(dS) . Erel_band :  skew[ii][x] = dS[ii][x + p(ii) - pmax]  (zero padding on both sides of the strip)
     const int rlo = Lk - 1 - pmax;
     const int shift = (i0 + l31) / ratio - pmax;              // in [-31, 0]
-    for (int xt = 0; xt <= KT; ++xt) {
+    for (int xt = jt0; xt <= KTe; ++xt) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int x = 32 * xt + 16 * g + s;
@@ -302,7 +310,7 @@ template <int HD>
 __global__ __launch_bounds__(64) void relattn_x_bwd_dkv_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ q, int64_t ldq, const float* __restrict__ probs,
     const float* __restrict__ dSg, float* __restrict__ d_k, int64_t ldgk, float* __restrict__ d_v, int64_t ldgv, int Lq,
-    int Lk, int H, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    int Lk, int ratio, int H, int mask, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
     constexpr int CT = (HD + 31) / 32;
     const int lane = threadIdx.x, g = lane >> 5, l31 = lane & 31;
     const int QT = (Lq + 31) / 32, KT = (Lk + 31) / 32;
@@ -314,11 +322,14 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dkv_kernel(
     floatx16 dk[CT], dv[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) dk[ct] = dv[ct] = floatx16{0};
-    for (int it = 0; it < QT; ++it) {
+    // query tiles that can see this key tile: causal needs p(i) >= j0, anticausal p(i) <= j0 + 31
+    const int it0 = mask == 1 ? (int)(((int64_t)j0 * ratio) / 32) : 0;
+    const int itE = mask == 2 ? (int)min((int64_t)QT, (((int64_t)j0 + 32) * ratio - 1) / 32 + 1) : QT;
+    for (int it = it0; it < itE; ++it) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int i = 32 * it + 16 * g + s;
-            const bool ok = i < Lq && jA < Lk;
+            const bool ok = i < Lq && jA < Lk && x_keep(mask, jA, i / ratio);
             const int64_t idx = (prob * Lq + i) * Lk + jA;
             const float p = ok ? probs[idx] * drop_scale(seed, (uint64_t)idx, thr, inv_keep) : 0.0f;
             const float ds = ok ? dSg[idx] : 0.0f;
@@ -353,7 +364,7 @@ template <int HD>
 __global__ __launch_bounds__(64) void relattn_x_bwd_de_kernel(const float* __restrict__ q, int64_t ldq,
                                                               const float* __restrict__ dSg, float* __restrict__ ws,
                                                               int64_t n_seq, int seq_per_chunk, int Lq, int Lk, int ratio,
-                                                              int H, float scale) {
+                                                              int H, int mask, float scale) {
     constexpr int CT = (HD + 31) / 32;
     const int lane = threadIdx.x, g = lane >> 5, l31 = lane & 31;
     const int QT = (Lq + 31) / 32, NE = 2 * Lk - 1, RT = (NE + 31) / 32;
@@ -374,8 +385,9 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_de_kernel(const float* __res
 #pragma unroll
             for (int s = 0; s < 16; ++s) {
                 const int i = 32 * it + 16 * g + s;
-                const int j = rA + i / ratio - (Lk - 1);
-                const bool ok = i < Lq && j >= 0 && j < Lk && rA < NE;
+                const int pi = i / ratio;
+                const int j = rA + pi - (Lk - 1);
+                const bool ok = i < Lq && j >= 0 && j < Lk && rA < NE && x_keep(mask, j, pi);
                 const float a = ok ? dSg[(prob * Lq + i) * Lk + j] : 0.0f;
                 const int ic = min(i, Lq - 1);
 #pragma unroll
@@ -440,7 +452,7 @@ template <int HD>
 static int x_bwd_t(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v,
                    int64_t ldv, const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_k,
                    int64_t ldgk, float* d_v, int64_t ldgv, float* d_e1, float* d_e2, int64_t n_seq, int Lq, int Lk, int H,
-                   float drop_p, uint64_t seed, float* ws, hipStream_t s) {
+                   int mask, float drop_p, uint64_t seed, float* ws, hipStream_t s) {
     const float scale = 1.0f / sqrtf((float)HD), inv_keep = 1.0f / (1.0f - drop_p);
     const uint32_t thr = drop_threshold(drop_p);
     const int ratio = Lq / Lk;
@@ -452,18 +464,18 @@ static int x_bwd_t(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq,
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL(kern, dim3((unsigned)(n_seq * H * x_tiles(Lq))), dim3(64), lds, s, d_ctx, ldo, k, ldk, v, ldv,
-                           probs, e1, e2, d_q, ldgq, dSg, Lq, Lk, ratio, H, scale, thr, inv_keep, seed);
+                           probs, e1, e2, d_q, ldgq, dSg, Lq, Lk, ratio, H, mask, scale, thr, inv_keep, seed);
         VQ_CHECK_LAUNCH("relattn_x_bwd_dq");
     }
     hipLaunchKernelGGL(relattn_x_bwd_dkv_kernel<HD>, dim3((unsigned)(n_seq * H * x_tiles(Lk))), dim3(64), 0, s, d_ctx, ldo, q,
-                       ldq, probs, dSg, d_k, ldgk, d_v, ldgv, Lq, Lk, H, scale, thr, inv_keep, seed);
+                       ldq, probs, dSg, d_k, ldgk, d_v, ldgv, Lq, Lk, ratio, H, mask, scale, thr, inv_keep, seed);
     VQ_CHECK_LAUNCH("relattn_x_bwd_dkv");
     const int chunks = x_chunks(n_seq, Lk, H);
     const int spc = (int)ceil_div(n_seq, chunks);
     const int nchunk = (int)ceil_div(n_seq, spc);
     const int RT = (2 * Lk - 1 + 31) / 32;
     hipLaunchKernelGGL(relattn_x_bwd_de_kernel<HD>, dim3(H * RT, nchunk), dim3(64), 0, s, q, ldq, dSg, part, n_seq, spc, Lq,
-                       Lk, ratio, H, scale);
+                       Lk, ratio, H, mask, scale);
     VQ_CHECK_LAUNCH("relattn_x_bwd_de");
     const int total = H * (2 * Lk - 1) * HD;
     float* tot = part + (int64_t)chunks * total;
@@ -510,11 +522,12 @@ int64_t vqcpc_relattn_x_bwd_workspace(int64_t n_seq, int Lq, int Lk, int H, int 
 int vqcpc_relattn_x_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* k, int64_t ldk,
                         const float* v, int64_t ldv, const float* probs, const float* e1, const float* e2, float* d_q,
                         int64_t ldgq, float* d_k, int64_t ldgk, float* d_v, int64_t ldgv, float* d_e1, float* d_e2,
-                        int64_t n_seq, int Lq, int Lk, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                        int64_t n_seq, int Lq, int Lk, int H, int hd, int mask, float drop_p, uint64_t seed, void* workspace,
                         int64_t workspace_bytes, void* stream) {
     VQ_REQUIRE(d_ctx && q && k && v && probs && e1 && e2 && d_q && d_k && d_v && d_e1 && d_e2 && workspace,
                "relattn_x_bwd: null pointer");
     VQ_REQUIRE(x_supported(Lq, Lk, H, hd), "relattn_x_bwd: unsupported Lq=%d Lk=%d H=%d hd=%d", Lq, Lk, H, hd);
+    VQ_REQUIRE(mask >= 0 && mask <= 2, "relattn_x_bwd: mask must be 0 (none), 1 (causal) or 2 (anticausal)");
     VQ_REQUIRE(ldq % 4 == 0 && ldk % 4 == 0 && ldv % 4 == 0 && ldo % 4 == 0 && ldq >= H * hd && ldk >= H * hd &&
                    ldv >= H * hd && ldo >= H * hd && ldgq >= H * hd && ldgk >= H * hd && ldgv >= H * hd && n_seq >= 1 &&
                    aligned16(d_ctx) && aligned16(k) && aligned16(v),
@@ -527,7 +540,7 @@ int vqcpc_relattn_x_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t
     hipStream_t s = (hipStream_t)stream;
 #define CALL(DD)                                                                                                        \
     x_bwd_t<DD>(d_ctx, ldo, q, ldq, k, ldk, v, ldv, probs, e1, e2, d_q, ldgq, d_k, ldgk, d_v, ldgv, d_e1, d_e2, n_seq, Lq, Lk, \
-                H, drop_p, seed, (float*)workspace, s)
+                H, mask, drop_p, seed, (float*)workspace, s)
     if (hd == 16) return CALL(16);
     if (hd == 32) return CALL(32);
     if (hd == 64) return CALL(64);

@@ -54,7 +54,7 @@ SIGNATURES = {
                                     c_int, c_int, c_int, c_int, c_f32, c_u64, c_ptr]),
     'vqcpc_relattn_x_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int, c_int]),
     'vqcpc_relattn_x_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
-                                    c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_f32,
+                                    c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_f32,
                                     c_u64, c_ptr, c_i64, c_ptr]),
     'vqcpc_embedding_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_ptr]),
     'vqcpc_add_layernorm_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32,

@@ -391,14 +391,14 @@ class AttnXFn(torch.autograd.Function):
         hip.call('vqcpc_relattn_x_fwd', q, ldq, k, ldk, v, ldk, e1, e2, att, d, probs, n, Lq, Lk, H, hd, int(mask),
                  float(drop_p), int(seed))
         ctx.save_for_backward(qsrc, kvsrc, probs, e1, e2)
-        ctx.meta = (n, Lq, Lk, H, hd, float(drop_p), int(seed))
+        ctx.meta = (n, Lq, Lk, H, hd, int(mask), float(drop_p), int(seed))
         ctx.mark_non_differentiable(probs)
         return att, probs
 
     @staticmethod
     def backward(ctx, datt, _dprobs):
         qsrc, kvsrc, probs, e1, e2 = ctx.saved_tensors
-        n, Lq, Lk, H, hd, p, seed = ctx.meta
+        n, Lq, Lk, H, hd, mask, p, seed = ctx.meta
         d = H * hd
         dev = qsrc.device
         datt = datt.contiguous()
@@ -415,7 +415,7 @@ class AttnXFn(torch.autograd.Function):
         nbytes = hip.query('vqcpc_relattn_x_bwd_workspace', n, Lq, Lk, H, hd)
         ws = hip.workspace(nbytes, dev)
         hip.call('vqcpc_relattn_x_bwd', datt, d, q, ldq, k, ldk, v, ldk, probs, e1, e2, dq, ldq, dk, ldk, dv, ldk, de1, de2, n,
-                 Lq, Lk, H, hd, p, seed, ws, nbytes)
+                 Lq, Lk, H, hd, mask, p, seed, ws, nbytes)
         return dqsrc, dkvsrc, de1, de2, None, None, None, None, None, None, None
 
 

@@ -324,12 +324,25 @@ __global__ __launch_bounds__(256) void embedding_bwd_kernel(const float* __restr
                                                             const int64_t* __restrict__ sorted_idx,
                                                             const int64_t* __restrict__ perm, float* __restrict__ d_table,
                                                             int64_t M, int C) {
+    constexpr int U = 8;                                              // rows in flight per lane; added in ascending order
     const int64_t m = blockIdx.x;
     const int64_t v = sorted_idx[m];
     if (m > 0 && sorted_idx[m - 1] == v) return;
+    int64_t lo = m, hi = M;                                           // end of the run: first position whose key differs
+    while (lo + 1 < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (sorted_idx[mid] == v) lo = mid; else hi = mid;
+    }
+    const int64_t end = hi;
     for (int col = threadIdx.x; col < C; col += 256) {
         float acc = 0.0f;
-        for (int64_t mm = m; mm < M && sorted_idx[mm] == v; ++mm) acc += g[perm[mm] * ldg + col];
+        for (int64_t mm = m; mm < end; mm += U) {
+            float x[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) x[u] = mm + u < end ? g[perm[mm + u] * ldg + col] : 0.0f;
+#pragma unroll
+            for (int u = 0; u < U; ++u) acc += x[u];
+        }
         d_table[v * C + col] = acc;
     }
 }

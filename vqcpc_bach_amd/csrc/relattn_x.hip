@@ -25,6 +25,7 @@ namespace vq {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 
 constexpr int kXMaxLk = 1024;
+constexpr int kXWaves = 4;      // wavefronts per strip when the key range has at least that many 32-column tiles
 constexpr float kNegBigX = -1.0e30f;
 
 __device__ __forceinline__ int xrow(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
@@ -54,17 +55,21 @@ __device__ __forceinline__ const float* xerel_row(const float* __restrict__ e1, 
 __device__ __forceinline__ bool x_keep(int mask, int j, int p) { return mask == 0 || (mask == 1 ? j <= p : j >= p); }
 
 // =====================================================================================================================
-template <int HD>
-__global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restrict__ q, int64_t ldq,
-                                                           const float* __restrict__ k, int64_t ldk,
-                                                           const float* __restrict__ v, int64_t ldv,
-                                                           const float* __restrict__ e1, const float* __restrict__ e2,
-                                                           float* __restrict__ ctx, int64_t ldo, float* __restrict__ probs,
-                                                           int Lq, int Lk, int ratio, int H, int mask, float scale,
-                                                           uint32_t thr, float inv_keep, uint64_t seed) {
+// NW wavefronts share one strip (NW = 4 when there are >= 4 key tiles, else 1): band / score / P.V tiles and softmax rows
+// are dealt round-robin to the waves, the partial P.V products are summed through LDS in wave order (deterministic).
+// With one wave per 54 KB strip (L = 384) only 2 waves fit a CU; four waves per strip keep every SIMD busy.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void relattn_x_fwd_kernel(const float* __restrict__ q, int64_t ldq,
+                                                                const float* __restrict__ k, int64_t ldk,
+                                                                const float* __restrict__ v, int64_t ldv,
+                                                                const float* __restrict__ e1, const float* __restrict__ e2,
+                                                                float* __restrict__ ctx, int64_t ldo,
+                                                                float* __restrict__ probs, int Lq, int Lk, int ratio, int H,
+                                                                int mask, float scale, uint32_t thr, float inv_keep,
+                                                                uint64_t seed) {
     constexpr int KH = HD / 2, CT = (HD + 31) / 32;
     extern __shared__ __attribute__((aligned(16))) float strip[];
-    const int lane = threadIdx.x, g = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
     const int QT = (Lq + 31) / 32, KT = (Lk + 31) / 32, SW = 32 * (KT + 1) + 4;
     const int64_t prob = blockIdx.x / QT;
     const int i0 = (int)(blockIdx.x % QT) * 32;
@@ -93,7 +98,7 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
     }
     // ---- phase 1: QE band  strip[ii][x] = qs_ii . Erel[rlo + x]
     const int rlo = Lk - 1 - pmax;
-    for (int t = jt0; t <= KTe; ++t) {
+    for (int t = jt0 + wave; t <= KTe; t += NW) {
         float eb[KH];
         xload_row<KH>(eb, xerel_row(e1, e2, h, Lk, HD, rlo + 32 * t + l31) + g * KH, true, 1.0f);
         floatx16 acc = {0};
@@ -103,26 +108,33 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
         for (int r = 0; r < 16; ++r) strip[xrow(r, lane) * SW + 32 * t + l31] = acc[r];
     }
     __syncthreads();
-    // ---- phase 2: scores, in place (tile jt reads columns [32jt, 32jt+62], writes [32jt, 32jt+31])
-    for (int jt = jt0; jt < KTe; ++jt) {
+    // ---- phase 2: scores, in place.  Tile jt reads columns [32jt, 32jt+62] and writes [32jt, 32jt+31]: a round of NW
+    // consecutive tiles reads everything before anyone writes; later rounds only read columns no earlier round writes
+    for (int jb = jt0; jb < KTe; jb += NW) {
+        const int jt = jb + wave;
+        const bool act = jt < KTe;
         const int j = 32 * jt + l31;
-        float kb[KH];
-        xload_row<KH>(kb, kbase + (int64_t)min(j, Lk - 1) * ldk + g * KH, j < Lk, 1.0f);
-        floatx16 acc = {0};
-#pragma unroll
-        for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kb[s], acc, 0, 0, 0);
         float sv[16];
+        if (act) {
+            float kb[KH];
+            xload_row<KH>(kb, kbase + (int64_t)min(j, Lk - 1) * ldk + g * KH, j < Lk, 1.0f);
+            floatx16 acc = {0};
 #pragma unroll
-        for (int r = 0; r < 16; ++r) sv[r] = acc[r] + strip[xrow(r, lane) * SW + j + pofs[r]];
+            for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qa[s], kb[s], acc, 0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sv[r] = acc[r] + strip[xrow(r, lane) * SW + j + pofs[r]];
+        }
         __syncthreads();
+        if (act) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-            strip[xrow(r, lane) * SW + j] = (j < Lk && x_keep(mask, j, prow[r])) ? sv[r] : kNegBigX;
+            for (int r = 0; r < 16; ++r)
+                strip[xrow(r, lane) * SW + j] = (j < Lk && x_keep(mask, j, prow[r])) ? sv[r] : kNegBigX;
+        }
     }
     __syncthreads();
-    // ---- softmax, one row at a time by the whole wave; probs saved BEFORE dropout
+    // ---- softmax, one row at a time by a whole wave; probs saved BEFORE dropout
     const int rows = min(32, Lq - i0);
-    for (int ii = 0; ii < rows; ++ii) {
+    for (int ii = wave; ii < rows; ii += NW) {
         float* row = strip + ii * SW;
         float m = kNegBigX;
         for (int j = jlo + lane; j < jhi; j += 64) m = fmaxf(m, row[j]);
@@ -146,14 +158,14 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
             row[j] = pd;
         }
     }
-    for (int ii = rows; ii < 32; ++ii)
+    for (int ii = rows + wave; ii < 32; ii += NW)
         for (int j = lane; j < 32 * KT; j += 64) strip[ii * SW + j] = 0.0f;
     __syncthreads();
     // ---- ctx = Pd . V
     floatx16 o[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) o[ct] = floatx16{0};
-    for (int jt = jt0; jt < KTe; ++jt) {
+    for (int jt = jt0 + wave; jt < KTe; jt += NW) {
         float pa[16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -171,28 +183,48 @@ __global__ __launch_bounds__(64) void relattn_x_fwd_kernel(const float* __restri
             }
         }
     }
+    if (NW == 1) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int c = 32 * ct + l31;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = 32 * ct + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = i0 + xrow(r, lane);
-            if (i < Lq && c < HD) ctx[(n * Lq + i) * ldo + h * HD + c] = o[ct][r];
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + xrow(r, lane);
+                if (i < Lq && c < HD) ctx[(n * Lq + i) * ldo + h * HD + c] = o[ct][r];
+            }
+        }
+    } else {
+        __syncthreads();                           // the strip is dead: its memory takes the partial products [NW][32][HD]
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = 32 * ct + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (c < HD) strip[(wave * 32 + xrow(r, lane)) * HD + c] = o[ct][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * HD; e += 64 * NW) {
+            const int row = e / HD, c = e % HD;
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += strip[(w * 32 + row) * HD + c];
+            if (i0 + row < Lq) ctx[(n * Lq + i0 + row) * ldo + h * HD + c] = sum;
         }
     }
 }
 
 // =====================================================================================================================
-// dS strip + dq.  dS is also written to dSg [n][H][Lq][Lk] for the dkv / de kernels.
-template <int HD>
-__global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
+// dS strip + dq (same wave / tile assignment as the forward).  dS is also written to dSg [n][H][Lq][Lk] for the
+// dkv / de kernels.
+template <int HD, int NW>
+__global__ __launch_bounds__(64 * NW) void relattn_x_bwd_dq_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ k, int64_t ldk, const float* __restrict__ v,
     int64_t ldv, const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
     float* __restrict__ d_q, int64_t ldgq, float* __restrict__ dSg, int Lq, int Lk, int ratio, int H, int mask, float scale,
     uint32_t thr, float inv_keep, uint64_t seed) {
     constexpr int KH = HD / 2, CT = (HD + 31) / 32, OFF = 32;
     extern __shared__ __attribute__((aligned(16))) float strip[];
-    const int lane = threadIdx.x, g = lane >> 5, l31 = lane & 31;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, g = lane >> 5, l31 = lane & 31;
     const int QT = (Lq + 31) / 32, KT = (Lk + 31) / 32, SW = 32 * KT + 64 + 4;
     const int64_t prob = blockIdx.x / QT;
     const int i0 = (int)(blockIdx.x % QT) * 32;
@@ -204,8 +236,9 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
     // visible key tiles (see the forward kernel); dSg is only written there, its readers apply the same rule
     const int jt0 = mask == 2 ? (i0 / ratio) / 32 : 0;
     const int KTe = mask == 1 ? min(KT, pmax / 32 + 1) : KT;
+    float* rdbuf = strip + 32 * SW;                                  // [NW][32] row-sum partials
 
-    for (int e = lane; e < 32 * SW; e += 64) strip[e] = 0.0f;
+    for (int e = tid; e < 32 * SW; e += 64 * NW) strip[e] = 0.0f;
     float doa[KH];
     {
         const int i = i0 + l31;
@@ -216,7 +249,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
 #pragma unroll
     for (int r = 0; r < 16; ++r) rd[r] = 0.0f;
     // pass 1: dP = (dO . V^T) * dropout mask, row sums of dP * P
-    for (int jt = jt0; jt < KTe; ++jt) {
+    for (int jt = jt0 + wave; jt < KTe; jt += NW) {
         const int j = 32 * jt + l31;
         float vb[KH];
         xload_row<KH>(vb, vbase + (int64_t)min(j, Lk - 1) * ldv + g * KH, j < Lk, 1.0f);
@@ -239,8 +272,22 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
 #pragma unroll
         for (int o = 16; o > 0; o >>= 1) rd[r] += __shfl_xor(rd[r], o, 64);
     }
+    if (NW > 1) {                                                    // row sums across the waves, in wave order
+        if (l31 == 0) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) rdbuf[wave * 32 + xrow(r, lane)] = rd[r];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            float t = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) t += rdbuf[w * 32 + xrow(r, lane)];
+            rd[r] = t;
+        }
+    }
     // pass 2: dS = P (dP - rowsum); every lane revisits exactly the strip entries it wrote
-    for (int jt = jt0; jt < KTe; ++jt) {
+    for (int jt = jt0 + wave; jt < KTe; jt += NW) {
         const int j = 32 * jt + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -258,7 +305,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = floatx16{0};
     // dS . K
-    for (int jt = jt0; jt < KTe; ++jt) {
+    for (int jt = jt0 + wave; jt < KTe; jt += NW) {
         float pa[16];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -279,7 +326,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
     // skew(dS) . Erel_band :  skew[ii][x] = dS[ii][x + p(ii) - pmax]  (zero padding on both sides of the strip)
     const int rlo = Lk - 1 - pmax;
     const int shift = (i0 + l31) / ratio - pmax;              // in [-31, 0]
-    for (int xt = jt0; xt <= KTe; ++xt) {
+    for (int xt = jt0 + wave; xt <= KTe; xt += NW) {
 #pragma unroll
         for (int s = 0; s < 16; ++s) {
             const int x = 32 * xt + 16 * g + s;
@@ -293,13 +340,32 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dq_kernel(
             }
         }
     }
+    if (NW == 1) {
 #pragma unroll
-    for (int ct = 0; ct < CT; ++ct) {
-        const int c = 32 * ct + l31;
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = 32 * ct + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int i = i0 + xrow(r, lane);
-            if (i < Lq && c < HD) d_q[(n * Lq + i) * ldgq + h * HD + c] = acc[ct][r] * scale;
+            for (int r = 0; r < 16; ++r) {
+                const int i = i0 + xrow(r, lane);
+                if (i < Lq && c < HD) d_q[(n * Lq + i) * ldgq + h * HD + c] = acc[ct][r] * scale;
+            }
+        }
+    } else {
+        __syncthreads();                           // the strip is dead: its memory takes the partial products [NW][32][HD]
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int c = 32 * ct + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (c < HD) strip[(wave * 32 + xrow(r, lane)) * HD + c] = acc[ct][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * HD; e += 64 * NW) {
+            const int row = e / HD, c = e % HD;
+            float sum = 0.0f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) sum += strip[(w * 32 + row) * HD + c];
+            if (i0 + row < Lq) d_q[(n * Lq + i0 + row) * ldgq + h * HD + c] = sum * scale;
         }
     }
 }
@@ -375,7 +441,9 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_de_kernel(const float* __res
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = floatx16{0};
     const int64_t n_begin = (int64_t)blockIdx.y * seq_per_chunk;
-    const int64_t n_end = min(n_begin + seq_per_chunk, n_seq);
+    // relative rows x >= Lk (e2) pair keys j > p, rows x < Lk - 1 keys j < p: a causal / anticausal mask leaves them zero
+    const bool dead = (mask == 1 && r0 >= Lk) || (mask == 2 && r0 + 31 < Lk - 1);
+    const int64_t n_end = dead ? n_begin : min(n_begin + seq_per_chunk, n_seq);
     for (int64_t n = n_begin; n < n_end; ++n) {
         const int64_t prob = n * H + h;
         for (int it = 0; it < QT; ++it) {
@@ -426,7 +494,7 @@ __global__ __launch_bounds__(256) void relattn_x_de_split(const float* __restric
 // ---- host side ------------------------------------------------------------------------------------------------------
 static int x_chunks(int64_t n_seq, int Lk, int H) {
     const int RT = (2 * Lk - 1 + 31) / 32;
-    const int64_t want = std::max<int64_t>(1, 2048 / ((int64_t)H * RT));
+    const int64_t want = std::max<int64_t>(1, 8192 / ((int64_t)H * RT));
     return (int)std::min<int64_t>(n_seq, want);
 }
 
@@ -438,12 +506,20 @@ template <int HD>
 static int x_fwd_t(const float* q, int64_t ldq, const float* k, int64_t ldk, const float* v, int64_t ldv, const float* e1,
                    const float* e2, float* ctx, int64_t ldo, float* probs, int64_t n_seq, int Lq, int Lk, int H, int mask,
                    float drop_p, uint64_t seed, hipStream_t s) {
-    const size_t lds = (size_t)32 * x_sw_fwd(Lk) * sizeof(float);
-    auto kern = relattn_x_fwd_kernel<HD>;
-    if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int64_t grid = n_seq * H * x_tiles(Lq);
-    hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, q, ldq, k, ldk, v, ldv, e1, e2, ctx, ldo, probs, Lq, Lk,
-                       Lq / Lk, H, mask, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+    const float scale = 1.0f / sqrtf((float)HD), inv_keep = 1.0f / (1.0f - drop_p);
+    const uint32_t thr = drop_threshold(drop_p);
+    if (x_tiles(Lk) >= kXWaves) {
+        const size_t lds = sizeof(float) * std::max<size_t>((size_t)32 * x_sw_fwd(Lk), (size_t)kXWaves * 32 * HD);
+        auto kern = relattn_x_fwd_kernel<HD, kXWaves>;
+        if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64 * kXWaves), lds, s, q, ldq, k, ldk, v, ldv, e1, e2, ctx, ldo,
+                           probs, Lq, Lk, Lq / Lk, H, mask, scale, thr, inv_keep, seed);
+    } else {
+        const size_t lds = (size_t)32 * x_sw_fwd(Lk) * sizeof(float);
+        hipLaunchKernelGGL((relattn_x_fwd_kernel<HD, 1>), dim3((unsigned)grid), dim3(64), lds, s, q, ldq, k, ldk, v, ldv, e1,
+                           e2, ctx, ldo, probs, Lq, Lk, Lq / Lk, H, mask, scale, thr, inv_keep, seed);
+    }
     VQ_CHECK_LAUNCH("relattn_x_fwd");
     return VQCPC_OK;
 }
@@ -458,13 +534,18 @@ static int x_bwd_t(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq,
     const int ratio = Lq / Lk;
     float* dSg = ws;
     float* part = ws + round_up(n_seq * H * (int64_t)Lq * Lk, 64);
-    {
-        const size_t lds = (size_t)32 * x_sw_bwd(Lk) * sizeof(float);
-        auto kern = relattn_x_bwd_dq_kernel<HD>;
+    if (x_tiles(Lk) >= kXWaves) {
+        const size_t lds = sizeof(float) * std::max<size_t>((size_t)32 * x_sw_bwd(Lk) + kXWaves * 32, (size_t)kXWaves * 32 * HD);
+        auto kern = relattn_x_bwd_dq_kernel<HD, kXWaves>;
         if (lds > 64 * 1024)
             (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL(kern, dim3((unsigned)(n_seq * H * x_tiles(Lq))), dim3(64), lds, s, d_ctx, ldo, k, ldk, v, ldv,
-                           probs, e1, e2, d_q, ldgq, dSg, Lq, Lk, ratio, H, mask, scale, thr, inv_keep, seed);
+        hipLaunchKernelGGL(kern, dim3((unsigned)(n_seq * H * x_tiles(Lq))), dim3(64 * kXWaves), lds, s, d_ctx, ldo, k, ldk, v,
+                           ldv, probs, e1, e2, d_q, ldgq, dSg, Lq, Lk, ratio, H, mask, scale, thr, inv_keep, seed);
+        VQ_CHECK_LAUNCH("relattn_x_bwd_dq");
+    } else {
+        const size_t lds = ((size_t)32 * x_sw_bwd(Lk) + 32) * sizeof(float);
+        hipLaunchKernelGGL((relattn_x_bwd_dq_kernel<HD, 1>), dim3((unsigned)(n_seq * H * x_tiles(Lq))), dim3(64), lds, s, d_ctx,
+                           ldo, k, ldk, v, ldv, probs, e1, e2, d_q, ldgq, dSg, Lq, Lk, ratio, H, mask, scale, thr, inv_keep, seed);
         VQ_CHECK_LAUNCH("relattn_x_bwd_dq");
     }
     hipLaunchKernelGGL(relattn_x_bwd_dkv_kernel<HD>, dim3((unsigned)(n_seq * H * x_tiles(Lk))), dim3(64), 0, s, d_ctx, ldo, q,

@@ -193,6 +193,17 @@ def cpu_baseline(cfg_name, dropout, batch, steps, timeout_s=240):
                     sample=f'cpu baseline failed: {type(e).__name__}: {str(e)[:200]}')
 
 
+def flush_c_stdio():
+    """RCCL prints its version banner with printf; on a pipe that text sits in libc's buffer until exit and would land
+    AFTER the JSON line.  Flushing libc's streams on every rank before rank 0 prints keeps the JSON line last."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    sys.stdout.flush()
+
+
 def main():
     args = parse()
     if args.dropout is None:
@@ -262,6 +273,8 @@ def main():
     dt = time.perf_counter() - t0
     timer.enabled = False
     dt = dp.max_over_ranks(dt)
+    flush_c_stdio()
+    dp.barrier()                                    # every rank has emitted whatever its libraries had buffered
     student = config['training_method'].lower() == 'student'
     last_loss = float(out if decoder_step else (out['loss_encdec'] if student else out['loss']))
 

@@ -413,3 +413,62 @@ def test_decoder_learns_and_checkpoint_roundtrip(tmp_path, gemm_mode):
     assert abs(a - b) < 1e-6
     for (k, p), (_, p2) in zip(dec.named_parameters(), dec2.named_parameters()):
         assert torch.equal(p, p2), k                      # resumed run continues bit-identically
+
+
+def test_new_entry_points_reject_bad_arguments_and_accept_empty_inputs(gemm_mode):
+    if gemm_mode != 'f32':
+        pytest.skip('no GEMM')
+    from vqcpc_bach_amd import hip
+    d = 64
+    q = torch.randn(48, d, device='cuda')
+    kv = torch.randn(4, 2 * d, device='cuda')
+    e = torch.randn(2 * 4, 32, device='cuda')
+    ctx, probs = torch.empty(48, d, device='cuda'), torch.empty(1, 2, 48, 4, device='cuda')
+    hip.call('vqcpc_relattn_x_fwd', q, d, kv, 2 * d, kv[:, d:], 2 * d, e, e, ctx, d, probs, 0, 48, 4, 2, 32, 2, 0.0, 0)   # n_seq = 0
+    with pytest.raises(hip.VqcpcHipError, match='unsupported Lq'):          # Lq not a multiple of Lk
+        hip.call('vqcpc_relattn_x_fwd', q, d, kv, 2 * d, kv[:, d:], 2 * d, e, e, ctx, d, probs, 1, 46, 4, 2, 32, 2, 0.0, 0)
+    with pytest.raises(hip.VqcpcHipError, match='mask must be'):
+        hip.call('vqcpc_relattn_x_fwd', q, d, kv, 2 * d, kv[:, d:], 2 * d, e, e, ctx, d, probs, 1, 48, 4, 2, 32, 3, 0.0, 0)
+    with pytest.raises(hip.VqcpcHipError, match='workspace too small'):
+        hip.call('vqcpc_relattn_x_bwd', ctx, d, q, d, kv, 2 * d, kv[:, d:], 2 * d, probs, e, e, torch.empty_like(q), d,
+                 torch.empty_like(kv), 2 * d, torch.empty_like(kv)[:, d:], 2 * d, torch.empty_like(e), torch.empty_like(e), 1,
+                 48, 4, 2, 32, 2, 0.0, 0, torch.empty(16, device='cuda'), 16)
+    table = torch.zeros(5, 8, device='cuda').fill_(7.0)
+    idx = torch.empty(0, dtype=torch.int64, device='cuda')
+    hip.call('vqcpc_embedding_bwd', None, 8, idx, idx, table, 0, 5, 8)      # M = 0: the table gradient is all zeros
+    assert float(table.abs().max()) == 0.0
+    torch.cuda.synchronize()
+
+
+def _run_bench(args, env_extra):
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    env = dict(os.environ, **env_extra)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, capture_output=True, text=True, env=env,
+                         timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert sum(l.startswith('{') for l in lines) == 1, (out.stdout[-1500:], out.stderr[-1500:])   # exactly ONE JSON line ...
+    return json.loads(lines[-1])                    # ... and it is the last thing on stdout (after RCCL's printf banner)
+
+
+@pytest.mark.parametrize('config,batch', [('DEC', 4), ('C0', 8)])
+def test_bench_contract_through_single_rank_rccl(config, batch, gemm_mode):
+    """The N > 1 code path on one GPU: VQCPC_FORCE_DIST=1 makes the trainer create a one-rank RCCL group, so weights are
+    broadcast and the flat gradient is all-reduced exactly as with 8 ranks; bench.py must still print its one JSON line."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('the subprocess uses the default GEMM mode')
+    import socket
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    line = _run_bench(['--config', config, '--batch', str(batch), '--steps', '3', '--warmup', '1', '--no-cpu-baseline'],
+                      dict(VQCPC_FORCE_DIST='1', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK='0', WORLD_SIZE='1',
+                           LOCAL_RANK='0'))
+    for key in ('metric', 'value', 'unit', 'n_gpus', 'steps', 'warmup', 'ms_per_step', 'higher_is_better', 'scaling',
+                'vs_baseline', 'dtype', 'data', 'config', 'roofline', 'cpu_baseline'):
+        assert key in line, key
+    assert line['n_gpus'] == 1 and line['steps'] == 3 and line['value'] > 0 and np.isfinite(line['final_loss'])
+    assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1

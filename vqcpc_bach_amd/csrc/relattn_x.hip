@@ -52,7 +52,14 @@ __device__ __forceinline__ const float* xerel_row(const float* __restrict__ e1, 
     return x < Lk ? e1 + ((int64_t)h * Lk + x) * HD : e2 + ((int64_t)h * Lk + (x - Lk + 1)) * HD;
 }
 
-__device__ __forceinline__ bool x_keep(int mask, int j, int p) { return mask == 0 || (mask == 1 ? j <= p : j >= p); }
+__device__ __forceinline__ bool x_keep(int mask, int j, int p) {
+    return (mask == 0) | ((mask == 1) & (j <= p)) | ((mask == 2) & (j >= p));       // bitwise: no short-circuit branches
+}
+// drop_scale without its uniform early-out (thr == 0 keeps everything at inv_keep == 1): straight-line code, so that the
+// loads of a whole tile can be issued before the first MFMA (a branch per element serialises load -> wait -> MFMA)
+__device__ __forceinline__ float xdrop(uint64_t seed, uint64_t idx, uint32_t thr, float inv_keep) {
+    return rng_u24(seed, idx) >= thr ? inv_keep : 0.0f;
+}
 
 // =====================================================================================================================
 // NW wavefronts share one strip (NW = 4 when there are >= 4 key tiles, else 1): band / score / P.V tiles and softmax rows
@@ -256,13 +263,19 @@ __global__ __launch_bounds__(64 * NW) void relattn_x_bwd_dq_kernel(
         floatx16 acc = {0};
 #pragma unroll
         for (int s = 0; s < KH; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(doa[s], vb[s], acc, 0, 0, 0);
+        // P of the tile: 16 loads issued back to back (clamped addresses; `* okf` instead of a select keeps the compiler
+        // from sinking each load behind its own branch, which serialises load -> wait -> use per element)
+        float pl[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            pl[r] = probs[(prob * Lq + min(i0 + xrow(r, lane), Lq - 1)) * Lk + min(j, Lk - 1)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ii = xrow(r, lane), i = i0 + ii;
-            const bool ok = i < Lq && j < Lk;
-            const int64_t idx = (prob * Lq + i) * Lk + j;
-            const float p = ok ? probs[idx] : 0.0f;
-            const float dp = ok ? acc[r] * drop_scale(seed, (uint64_t)idx, thr, inv_keep) : 0.0f;
+            const float okf = (i < Lq && j < Lk) ? 1.0f : 0.0f;
+            const int64_t idx = (prob * Lq + min(i, Lq - 1)) * Lk + min(j, Lk - 1);
+            const float p = pl[r] * okf;
+            const float dp = acc[r] * xdrop(seed, (uint64_t)idx, thr, inv_keep) * okf;
             rd[r] += dp * p;
             strip[ii * SW + OFF + j] = dp;
         }
@@ -289,15 +302,17 @@ __global__ __launch_bounds__(64 * NW) void relattn_x_bwd_dq_kernel(
     // pass 2: dS = P (dP - rowsum); every lane revisits exactly the strip entries it wrote
     for (int jt = jt0 + wave; jt < KTe; jt += NW) {
         const int j = 32 * jt + l31;
+        float pl[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            pl[r] = probs[(prob * Lq + min(i0 + xrow(r, lane), Lq - 1)) * Lk + min(j, Lk - 1)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ii = xrow(r, lane), i = i0 + ii;
             const bool ok = i < Lq && j < Lk;
-            const int64_t idx = (prob * Lq + i) * Lk + j;
-            const float p = ok ? probs[idx] : 0.0f;
-            const float ds = p * (strip[ii * SW + OFF + j] - rd[r]);
+            const float ds = pl[r] * (ok ? 1.0f : 0.0f) * (strip[ii * SW + OFF + j] - rd[r]);
             strip[ii * SW + OFF + j] = ds;
-            if (ok) dSg[idx] = ds;
+            if (ok) dSg[(prob * Lq + i) * Lk + j] = ds;
         }
     }
     __syncthreads();
@@ -391,22 +406,38 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_dkv_kernel(
     // query tiles that can see this key tile: causal needs p(i) >= j0, anticausal p(i) <= j0 + 31
     const int it0 = mask == 1 ? (int)(((int64_t)j0 * ratio) / 32) : 0;
     const int itE = mask == 2 ? (int)min((int64_t)QT, (((int64_t)j0 + 32) * ratio - 1) / 32 + 1) : QT;
+    const int jc = min(jA, Lk - 1);
+    const int cc[2] = {min(l31, HD - 1), min(32 + l31, HD - 1)};      // clamped head columns (HD = 16: the upper lanes)
     for (int it = it0; it < itE; ++it) {
+        // all loads of a half tile first (clamped addresses, no branches), selects afterwards, then the MFMAs
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            const int i = 32 * it + 16 * g + s;
-            const bool ok = i < Lq && jA < Lk && x_keep(mask, jA, i / ratio);
-            const int64_t idx = (prob * Lq + i) * Lk + jA;
-            const float p = ok ? probs[idx] * drop_scale(seed, (uint64_t)idx, thr, inv_keep) : 0.0f;
-            const float ds = ok ? dSg[idx] : 0.0f;
-            const int ic = min(i, Lq - 1);
+        for (int hs = 0; hs < 16; hs += 8) {
+            float pv[8], dsv[8], dob[8][CT], qb[8][CT];
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) {
-                const int c = 32 * ct + l31;
-                const float dob = c < HD ? d_ctx[(n * Lq + ic) * ldo + h * HD + c] : 0.0f;
-                const float qb = c < HD ? q[(n * Lq + ic) * ldq + h * HD + c] * scale : 0.0f;
-                dv[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(p, dob, dv[ct], 0, 0, 0);
-                dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, qb, dk[ct], 0, 0, 0);
+            for (int u = 0; u < 8; ++u) {
+                const int ic = min(32 * it + 16 * g + hs + u, Lq - 1);
+                const int64_t idx = (prob * Lq + ic) * Lk + jc;
+                pv[u] = probs[idx];
+                dsv[u] = dSg[idx];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    dob[u][ct] = d_ctx[(n * Lq + ic) * ldo + h * HD + cc[ct & 1] + 64 * (ct >> 1)];
+                    qb[u][ct] = q[(n * Lq + ic) * ldq + h * HD + cc[ct & 1] + 64 * (ct >> 1)];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int i = 32 * it + 16 * g + hs + u;
+                const bool ok = i < Lq && jA < Lk && x_keep(mask, jA, i / ratio);
+                const int64_t idx = (prob * Lq + min(i, Lq - 1)) * Lk + jc;
+                const float p = ok ? pv[u] * xdrop(seed, (uint64_t)idx, thr, inv_keep) : 0.0f;
+                const float ds = ok ? dsv[u] : 0.0f;              // a select: unwritten (masked) dS entries may hold anything
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const bool cok = 32 * ct + l31 < HD;
+                    dv[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(p, cok ? dob[u][ct] : 0.0f, dv[ct], 0, 0, 0);
+                    dk[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(ds, cok ? qb[u][ct] * scale : 0.0f, dk[ct], 0, 0, 0);
+                }
             }
         }
     }
@@ -440,6 +471,7 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_de_kernel(const float* __res
     floatx16 acc[CT];
 #pragma unroll
     for (int ct = 0; ct < CT; ++ct) acc[ct] = floatx16{0};
+    const int cc[2] = {min(l31, HD - 1), min(32 + l31, HD - 1)};      // clamped head columns (HD = 16: the upper lanes)
     const int64_t n_begin = (int64_t)blockIdx.y * seq_per_chunk;
     // relative rows x >= Lk (e2) pair keys j > p, rows x < Lk - 1 keys j < p: a causal / anticausal mask leaves them zero
     const bool dead = (mask == 1 && r0 >= Lk) || (mask == 2 && r0 + 31 < Lk - 1);
@@ -450,19 +482,31 @@ __global__ __launch_bounds__(64) void relattn_x_bwd_de_kernel(const float* __res
             const int jlo = r0 + (32 * it) / ratio - (Lk - 1);              // key range this tile pair can touch
             const int jhi = r0 + 31 + (32 * it + 31) / ratio - (Lk - 1);
             if (jhi < 0 || jlo >= Lk) continue;
+            // loads of a half tile first (clamped addresses, no branches), selects afterwards, then the MFMAs
 #pragma unroll
-            for (int s = 0; s < 16; ++s) {
-                const int i = 32 * it + 16 * g + s;
-                const int pi = i / ratio;
-                const int j = rA + pi - (Lk - 1);
-                const bool ok = i < Lq && j >= 0 && j < Lk && rA < NE && x_keep(mask, j, pi);
-                const float a = ok ? dSg[(prob * Lq + i) * Lk + j] : 0.0f;
-                const int ic = min(i, Lq - 1);
+            for (int hs = 0; hs < 16; hs += 8) {
+                float av[8], qb[8][CT];
 #pragma unroll
-                for (int ct = 0; ct < CT; ++ct) {
-                    const int c = 32 * ct + l31;
-                    const float qb = c < HD ? q[(n * Lq + ic) * ldq + h * HD + c] * scale : 0.0f;
-                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, qb, acc[ct], 0, 0, 0);
+                for (int u = 0; u < 8; ++u) {
+                    const int ic = min(32 * it + 16 * g + hs + u, Lq - 1);
+                    const int jc = min(max(rA + ic / ratio - (Lk - 1), 0), Lk - 1);
+                    av[u] = dSg[(prob * Lq + ic) * Lk + jc];
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        qb[u][ct] = q[(n * Lq + ic) * ldq + h * HD + cc[ct & 1] + 64 * (ct >> 1)];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int i = 32 * it + 16 * g + hs + u;
+                    const int pi = i / ratio;
+                    const int j = rA + pi - (Lk - 1);
+                    const bool ok = i < Lq && j >= 0 && j < Lk && rA < NE && x_keep(mask, j, pi);
+                    const float a = ok ? av[u] : 0.0f;            // a select: unwritten (masked) dS entries may hold anything
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) {
+                        const bool cok = 32 * ct + l31 < HD;
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, cok ? qb[u][ct] * scale : 0.0f, acc[ct], 0, 0, 0);
+                    }
                 }
             }
         }

@@ -119,7 +119,7 @@ int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream);
  * bwd: d_qkv [n_blocks*L][ldg] (all 3d columns written), d_e1/d_e2 overwritten (deterministic partials in workspace).
  * ------------------------------------------------------------------------------------------------------------------ */
 /* L = 16 and L = 4 run the one-wavefront-per-block kernels; any other L <= 1024 (teacher_relative.py L = 384,
- * auxiliary_decoder_relative.py L = 24 / 96) runs the strip kernels of relattn_gen.hip with identical semantics.
+ * auxiliary_decoder_relative.py L = 24 / 96) runs the strip kernels of relattn_x.hip (Lq = Lk, no mask) with identical semantics.
  * vqcpc_relattn_force_general(1) routes every L through the latter (parity tests between the two). */
 int vqcpc_relattn_force_general(int on);
 int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,

@@ -72,15 +72,6 @@ int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out
 int launch_reduce_splits2(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, const float* ws2,
                           int64_t stride2, float* out2, int64_t count2, int accumulate, hipStream_t stream);
 
-// general-L relative attention (relattn_gen.hip); relattn.hip dispatches to it for L other than 16 / 4
-bool relattn_gen_supported(int L, int H, int hd);
-int64_t relattn_gen_bwd_workspace(int64_t n_blocks, int L, int H, int hd);
-int relattn_gen_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo, float* probs,
-                    int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, hipStream_t s);
-int relattn_gen_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
-                    const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L, int H,
-                    int hd, float drop_p, uint64_t seed, float* ws, hipStream_t s);
-
 // L = 16 attention on the fp32 matrix cores (relattn16.hip); tokens != nullptr = block-table indirection
 bool relattn16_supported(int H, int hd);
 int64_t relattn16_bwd_workspace(int64_t n_blocks, int H, int hd);

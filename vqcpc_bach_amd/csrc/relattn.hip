@@ -414,6 +414,10 @@ using namespace vq;
     if (L == 4 && hd == 32) return CALL(4, 32);                            \
     if (L == 4 && hd == 64) return CALL(4, 64);
 
+static bool strip_supported(int L, int H, int hd) {
+    return L >= 1 && L <= 1024 && H >= 1 && (hd == 16 || hd == 32 || hd == 64 || hd == 128);
+}
+
 extern "C" {
 
 int vqcpc_relattn_force_general(int on) {
@@ -426,15 +430,18 @@ int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
     if (n_blocks == 0) return VQCPC_OK;
     VQ_REQUIRE(qkv && e1 && e2 && ctx && probs, "relattn_fwd: null pointer");
     const bool small = att_supported(L, H, hd);
-    VQ_REQUIRE(small || relattn_gen_supported(L, H, hd), "relattn_fwd: unsupported L=%d H=%d hd=%d (L <= 1024, hd in {16,32,64})",
+    VQ_REQUIRE(small || strip_supported(L, H, hd), "relattn_fwd: unsupported L=%d H=%d hd=%d (L <= 1024, hd in {16,32,64,128})",
                L, H, hd);
     VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= 3 * H * hd && ldo >= H * hd && n_blocks >= 0, "relattn_fwd: bad strides");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_fwd: bad dropout probability");
     hipStream_t s = (hipStream_t)stream;
     if (!small) {
+        // any other L: the strip kernels of relattn_x.hip with Lq = Lk, no mask, q | k | v = column blocks of qkv
         VQ_REQUIRE(aligned16(qkv) && aligned16(e1) && aligned16(e2), "relattn_fwd: qkv / e1 / e2 must be 16-byte aligned");
         VQ_REQUIRE(n_blocks * H * (int64_t)((L + 31) / 32) < (1ll << 31), "relattn_fwd: too many strips");
-        return relattn_gen_fwd(qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks, L, H, hd, drop_p, seed, s);
+        const int d = H * hd;
+        return vqcpc_relattn_x_fwd(qkv, ldq, qkv + d, ldq, qkv + 2 * d, ldq, e1, e2, ctx, ldo, probs, n_blocks, L, L, H, hd, 0,
+                                   drop_p, seed, stream);
     }
     if (use_mfma16(L, H, hd) && aligned16(qkv) && aligned16(e1) && aligned16(e2) && aligned16(ctx))
         return relattn16_fwd(qkv, ldq, nullptr, e1, e2, ctx, ldo, probs, n_blocks, H, hd, drop_p, seed, s);
@@ -445,7 +452,7 @@ int vqcpc_relattn_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
 }
 
 int64_t vqcpc_relattn_bwd_workspace(int64_t n_blocks, int L, int H, int hd) {
-    if (!att_supported(L, H, hd)) return relattn_gen_bwd_workspace(std::max<int64_t>(n_blocks, 1), std::max(L, 1), std::max(H, 1), hd);
+    if (!att_supported(L, H, hd)) return vqcpc_relattn_x_bwd_workspace(n_blocks, std::max(L, 1), std::max(L, 1), std::max(H, 1), hd);
     const int64_t w16 = use_mfma16(L, H, hd) ? relattn16_bwd_workspace(std::max<int64_t>(n_blocks, 1), H, hd) : 0;
     const int slots = 4 * (64 / (4 * std::max(L, 1)));
     const int bpw = att_blocks_per_wg(std::max<int64_t>(n_blocks, 1), slots, std::max(H, 1));
@@ -459,7 +466,7 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
                       int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
     VQ_REQUIRE(d_ctx && qkv && probs && e1 && e2 && d_qkv && d_e1 && d_e2 && workspace, "relattn_bwd: null pointer");
     const bool small = att_supported(L, H, hd);
-    VQ_REQUIRE(small || relattn_gen_supported(L, H, hd), "relattn_bwd: unsupported L=%d H=%d hd=%d", L, H, hd);
+    VQ_REQUIRE(small || strip_supported(L, H, hd), "relattn_bwd: unsupported L=%d H=%d hd=%d", L, H, hd);
     VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldq >= 3 * H * hd && ldg >= 3 * H * hd && ldo >= H * hd &&
                    n_blocks >= 1,
                "relattn_bwd: bad strides");
@@ -470,8 +477,10 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
     hipStream_t s = (hipStream_t)stream;
     if (!small) {
         VQ_REQUIRE(aligned16(qkv) && aligned16(d_ctx) && aligned16(workspace), "relattn_bwd: buffers must be 16-byte aligned");
-        return relattn_gen_bwd(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, L, H, hd, drop_p, seed,
-                               (float*)workspace, s);
+        const int d = H * hd;
+        return vqcpc_relattn_x_bwd(d_ctx, ldo, qkv, ldq, qkv + d, ldq, qkv + 2 * d, ldq, probs, e1, e2, d_qkv, ldg, d_qkv + d, ldg,
+                                   d_qkv + 2 * d, ldg, d_e1, d_e2, n_blocks, L, L, H, hd, 0, drop_p, seed, workspace,
+                                   workspace_bytes, stream);
     }
     if (use_mfma16(L, H, hd) && aligned16(qkv) && aligned16(d_ctx) && aligned16(e1) && aligned16(e2) && aligned16(d_qkv)) {
         int nsplit = 0;

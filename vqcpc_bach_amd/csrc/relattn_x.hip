@@ -8,11 +8,13 @@
 // seq_len_tgt = r * seq_len_src.  With p(i) = i / r, the memory position query i is aligned with,
 //     S[i][j] = qs_i . k_j + qs_i . Erel[j - p(i) + Lk - 1],     qs = q / sqrt(hd),
 //     Erel[x] = e1[h][x] (x < Lk: j <= p) | e2[h][x - Lk + 1] (x >= Lk: j > p)
-// (its -100 pad values never land on a kept entry; r = 1 is the square form of relattn_gen.hip).  The additive masks of
+// (its -100 pad values never land on a kept entry; r = 1, p = i is the square form of the encoder path: relattn.hip routes
+// every L other than 16 / 4 here -- the teacher's L = 384 and the auxiliary decoder's L = 24 / 96 of the student step).  The additive masks of
 // decoder.py:292-308 are index rules in the same p:  causal = keep j <= p,  anticausal = keep j >= p; a masked logit is
 // -inf in the reference, so its probability -- and with it every gradient term through it -- is exactly 0.
 //
-// Mapping = relattn_gen.hip's: one wavefront owns a strip of 32 query rows of one (sequence, head) problem, walks the key
+// Mapping: one wavefront (four when the key range has >= 4 tiles) owns a strip of 32 query rows of one (sequence, head)
+// problem, walks the key
 // tiles with v_mfma_f32_32x32x2_f32 (exact fp32 products), operand fragments are float4 loads straight from global
 // memory (each lane half takes a contiguous half of the head dimension: the MFMA k index is a summation index), the
 // relative term is one extra GEMM per strip against the band of relative rows the strip can see (rows

@@ -141,30 +141,59 @@ __global__ __launch_bounds__(64 * NW) void relattn_x_fwd_kernel(const float* __r
         }
     }
     __syncthreads();
-    // ---- softmax, one row at a time by a whole wave; probs saved BEFORE dropout
+    // ---- softmax by whole waves, kSR rows of a wave in flight (independent max / sum chains hide the LDS and
+    // cross-lane latency of one row behind the others); probs saved BEFORE dropout
     const int rows = min(32, Lq - i0);
-    for (int ii = wave; ii < rows; ii += NW) {
-        float* row = strip + ii * SW;
-        float m = kNegBigX;
-        for (int j = jlo + lane; j < jhi; j += 64) m = fmaxf(m, row[j]);
-        m = wave_max(m);
-        float sum = 0.0f;
-        for (int j = jlo + lane; j < jhi; j += 64) {
-            const float e = __expf(row[j] - m);
-            row[j] = e;
-            sum += e;
+    constexpr int kSR = 4;
+    for (int k0 = 0; k0 < 32 / NW; k0 += kSR) {
+        float* row[kSR];
+        bool live[kSR];
+        float m[kSR], sum[kSR];
+#pragma unroll
+        for (int u = 0; u < kSR; ++u) {
+            const int ii = wave + (k0 + u) * NW;
+            live[u] = ii < rows;
+            row[u] = strip + min(ii, 31) * SW;
+            m[u] = kNegBigX;
+            sum[u] = 0.0f;
         }
-        sum = wave_sum(sum);
-        const float inv = 1.0f / sum;
-        const int64_t pbase = (prob * Lq + i0 + ii) * Lk;
-        for (int j = lane; j < 32 * KT; j += 64) {
-            float pd = 0.0f;
-            if (j < Lk) {
-                const float p = (j >= jlo && j < jhi) ? row[j] * inv : 0.0f;
-                probs[pbase + j] = p;
-                pd = p * drop_scale(seed, (uint64_t)(pbase + j), thr, inv_keep);
+        if (!live[0]) break;                                         // rows are dealt in ascending order
+        for (int j = jlo + lane; j < jhi; j += 64) {
+#pragma unroll
+            for (int u = 0; u < kSR; ++u) m[u] = fmaxf(m[u], row[u][j]);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < kSR; ++u) m[u] = fmaxf(m[u], __shfl_xor(m[u], o, 64));
+        }
+        for (int j = jlo + lane; j < jhi; j += 64) {
+#pragma unroll
+            for (int u = 0; u < kSR; ++u) {
+                const float e = __expf(row[u][j] - m[u]);
+                if (live[u]) row[u][j] = e;
+                sum[u] += e;
             }
-            row[j] = pd;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+#pragma unroll
+            for (int u = 0; u < kSR; ++u) sum[u] += __shfl_xor(sum[u], o, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < kSR; ++u) {
+            if (!live[u]) continue;
+            const float inv = 1.0f / sum[u];
+            const int64_t pbase = (prob * Lq + i0 + wave + (k0 + u) * NW) * Lk;
+            for (int j = lane; j < 32 * KT; j += 64) {
+                float pd = 0.0f;
+                if (j < Lk) {
+                    const float p = (j >= jlo && j < jhi) ? row[u][j] * inv : 0.0f;
+                    probs[pbase + j] = p;
+                    pd = p * drop_scale(seed, (uint64_t)(pbase + j), thr, inv_keep);
+                }
+                row[u][j] = pd;
+            }
         }
     }
     for (int ii = rows + wave; ii < 32; ii += NW)

@@ -302,7 +302,7 @@ def main():
                             share_of_step=round(nt['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
                             vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3))
         line = {
-            'metric': 'encoder-train windows/sec (Bach 4-voice, seq=256)', 'value': round(value, 2), 'unit': 'windows/s',
+            'metric': f'encoder-train windows/sec (Bach 4-voice, seq={seq_len})', 'value': round(value, 2), 'unit': 'windows/s',
             'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'f32',

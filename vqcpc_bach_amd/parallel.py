@@ -13,8 +13,10 @@ The reference has no distributed code at all.  Design for 
 """
 import os
 
-import torch
-import torch.distributed as dist
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # dmabuf IPC only on this platform (RCCL needs it)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
 
 
 class DataParallelContext:

@@ -69,7 +69,7 @@ def test_decoder_step(name):
     assert torch.equal(codes, T(g['codes_raw'])[..., 0] + cfg['K'] * T(g['codes_raw'])[..., 1])
     # eval forward
     out = D.decoder_forward(codes, x, tr.P, cfg)
-    assert abs(float(out['loss']) - float(g['eval/loss'])) < 2e-5 * abs(float(g['eval/loss']))
+    assert abs(float(out['loss'].detach()) - float(g['eval/loss'])) < 2e-5 * abs(float(g['eval/loss']))
     for c, lg in enumerate(out['logits']):
         assert rel_err(lg, g[f'eval_fwd/logits.{c}']) < FWD_TOL
     assert rel_err(out['a_cross'], g['eval_fwd/a_cross_last']) < FWD_TOL

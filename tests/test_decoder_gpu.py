@@ -473,3 +473,53 @@ def test_bench_contract_through_single_rank_rccl(config, batch, gemm_mode):
         assert key in line, key
     assert line['n_gpus'] == 1 and line['steps'] == 3 and line['value'] > 0 and np.isfinite(line['final_loss'])
     assert line['roofline']['bound'] == 'mfma' and 0 < line['roofline']['frac'] < 1
+
+
+def test_decoder_full_config_through_getters_vs_oracle(gemm_mode):
+    """The shipped configuration itself (configs.make_config('DEC'): 384 target tokens, 24 codes, d_model 512, 8 heads of
+    64 -> the four-waves-per-strip attention kernels, 3 + 3 layers, frozen d_model-512 encoder), built through the
+    getters exactly as bench.py does, at batch 4: codes bit-exact, loss / logits / gradients against the oracle."""
+    from vqcpc_bach_amd import configs, getters
+    config = configs.make_config('DEC', dropout=0.0)
+    torch.manual_seed(5)
+    dlg = getters.get_dataloader_generator(config['dataset'], config['training_method'],
+                                           dict(config['dataloader_generator_kwargs'], seed=7, device='cuda'))
+    enc_cfg = config['config_encoder']
+    enc_cfg['downscaler_kwargs']['dropout'] = 0.0
+    enc_dlg = getters.get_dataloader_generator(enc_cfg['dataset'], enc_cfg['training_method'],
+                                               dict(enc_cfg['dataloader_generator_kwargs'], seed=7, device='cuda'))
+    encoder = getters.get_encoder('/tmp/vqcpc_test_decoder_full', enc_dlg, enc_cfg)
+    dp = getters.get_data_processor(dlg, config['data_processor_type'], config['data_processor_kwargs'])
+    dec = getters.get_decoder('/tmp/vqcpc_test_decoder_full', dlg, dp, encoder, config['decoder_type'], config['decoder_kwargs'])
+    dec.cuda()
+    dec.init_optimizers(lr=config['lr'], schedule_lr=config['schedule_lr'])
+    sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    cfg = D.make_cfg('DEC', vocab=list(dlg.vocab), B=4)
+    assert set(D.init_state(cfg)) == set(sd)                       # the oracle's view of the model has the same keys
+    x = next(dlg.dataloaders(batch_size=4)[0])['x']
+    oracle = D.DecoderOracleTrainer(cfg, sd, lr=config['lr'])
+    ref = oracle.step({'x': x.cpu()}, train=True)
+    dec.eval()
+    codes = dec.encode(x)
+    assert torch.equal(codes.cpu(), ref['codes'])
+    dec.train()
+    loss, logits, _, _ = dec.compute_loss(codes, dec.data_processor.preprocess(x))
+    assert abs(float(loss.detach()) - float(ref['loss'].detach())) < FWD_TOL * float(ref['loss'].detach())
+    for c in range(4):
+        assert rel_err(logits[c].cpu(), ref['logits'][c]) < 2 * FWD_TOL
+    dec.flat.zero_grad()
+    loss.backward()
+    worst = 0.0
+    for k, p in dec.named_parameters():
+        if k.startswith('encoder.'):
+            continue
+        r = oracle.last_grads[k]
+        if float(r.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            worst = max(worst, rel_err(p.grad.cpu(), r))
+            assert rel_err(p.grad.cpu(), r) < 2 * GRAD_TOL, k
+    # one full training step through the epoch API, twice from the same state -> bit-identical (deterministic kernels)
+    a = dec.epoch(iter([{'x': x}]), train=False, num_batches=1)['loss']
+    b = dec.epoch(iter([{'x': x}]), train=False, num_batches=1)['loss']
+    assert a == b

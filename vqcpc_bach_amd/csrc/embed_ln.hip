@@ -49,9 +49,6 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     const int d = dlin + (has_ev ? 2 : 1) * pos;
     const int nev = has_ev ? tpb / nv : 0;
     // LDS: tab [vmax][dlin] | chan_sum [pos] | ev_sum [nev][pos]
-    float* tab = lds;
-    float* csum = tab + vmax * dlin;
-    float* esum = csum + pos;
     const int lds_floats = vmax * dlin + pos + nev * pos;
     for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) lds[i] = 0.0f;
     __syncthreads();
@@ -60,6 +57,9 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     const int64_t row1 = min(row0 + kEmbRowsPerChunk, n_rows);
     // rows of this voice: row % tpb % nv == v.  kEmbRowsPerChunk is a multiple of tpb (checked on the host).
     for (int col = threadIdx.x; col < d; col += blockDim.x) {
+        const int kind = col < dlin ? 0 : (col < dlin + pos ? 1 : 2);                 // table column | channel | event
+        const int cbase = kind == 0 ? col : (kind == 1 ? vmax * dlin + (col - dlin) : vmax * dlin + pos + (col - dlin - pos));
+        const int cmul = kind == 0 ? dlin : (kind == 2 ? pos : 0);
         // kEmbU rows in flight per lane, branch-free (the tail re-reads the last row of the voice and adds zero): issue
         // the loads first, then the (ordered) LDS read-modify-writes
         const int64_t last = row0 + v + (row1 - 1 - row0 - v) / nv * nv;         // last row of this voice in the chunk
@@ -75,12 +75,11 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
                 tk[u] = (int)tokens[row];
                 evi[u] = (int)(row % tpb) / nv;
             }
+            // tab | csum | esum are one contiguous LDS array: one branch-free cell index per lane (a per-element
+            // if / else-if / else made the wave that holds the 16 positional columns run all three arms for every row:
+            // 465 -> 324 us at C1; requesting the next batch before these read-modify-writes was slower again, 423 us)
 #pragma unroll
-            for (int u = 0; u < kEmbU; ++u) {
-                if (col < dlin) tab[tk[u] * dlin + col] += gv[u];
-                else if (col < dlin + pos) csum[col - dlin] += gv[u];
-                else esum[evi[u] * pos + (col - dlin - pos)] += gv[u];
-            }
+            for (int u = 0; u < kEmbU; ++u) lds[cbase + (kind == 2 ? evi[u] : tk[u]) * cmul] += gv[u];
         }
     }
     __syncthreads();

@@ -47,6 +47,38 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__
     }
 }
 
+// register-staged variant for the backward's block loop: `fetch_rows` issues the global loads of the NEXT block before the
+// current one is processed, `commit_rows` writes them to LDS after the barrier that retires the current block's readers
+template <int L, int HD>
+struct RowRegs {
+    static constexpr int N = HD / 16;            // float4 per lane: L * (HD / 4) elements over the 4 L lanes of a problem
+    float4 r[N];
+};
+
+template <int L, int HD>
+__device__ __forceinline__ void fetch_rows(RowRegs<L, HD>& t, const float* __restrict__ src, int64_t ld, int sl,
+                                           const int64_t* __restrict__ tok = nullptr) {
+    constexpr int LPP = 4 * L, V = HD / 4;
+#pragma unroll
+    for (int k = 0; k < RowRegs<L, HD>::N; ++k) {
+        const int e = sl + k * LPP, row = e / V, c4 = e % V;
+        const int64_t grow = tok ? tok[row] * L + row : row;
+        t.r[k] = *reinterpret_cast<const float4*>(src + grow * ld + c4 * 4);
+    }
+}
+
+template <int L, int HD>
+__device__ __forceinline__ void commit_rows(float* dst, const RowRegs<L, HD>& t, int sl, float mul) {
+    constexpr int LPP = 4 * L, RS = HD + kPad, V = HD / 4;
+#pragma unroll
+    for (int k = 0; k < RowRegs<L, HD>::N; ++k) {
+        const int e = sl + k * LPP, row = e / V, c4 = e % V;
+        float4 v = t.r[k];
+        v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+        *reinterpret_cast<float4*>(dst + row * RS + c4 * 4) = v;
+    }
+}
+
 template <int L, int HD>
 __device__ __forceinline__ void stage_erel(float* dst, const float* __restrict__ e1, const float* __restrict__ e2, int h,
                                            int sl) {
@@ -200,20 +232,45 @@ __global__ __launch_bounds__(kAttThreads) void relattn_bwd_kernel(
         for (int c = 0; c < C::CPL; ++c) de[a][c] = 0.0f;
 
     const int64_t n_begin = (int64_t)blockIdx.x * blocks_per_wg;
+    // software pipeline over the blocks: the operands of the slot's next block are in flight while this one is processed
+    // (the loop is barrier-lockstep, so nothing else hides the global-load round trip).  L = 4 only: at L = 16 (the
+    // fallback of the matrix-core kernel) and at head_dim 64 the staging registers cost occupancy
+    constexpr bool kPipe = HD <= 32 && L == 4;
+    RowRegs<L, HD> rq, rk, rv, ro;
+    auto prefetch = [&](int64_t nb) {
+        if constexpr (kPipe) {
+            const int64_t nc = min(nb, n_blocks - 1);                // past the end: re-read the last block, never used
+            const int64_t* tk = tokens ? tokens + nc * L : nullptr;
+            const float* qp = tokens ? qkv + h * HD : qkv + nc * L * ldq + h * HD;
+            fetch_rows<L, HD>(rq, qp, ldq, sl, tk);
+            fetch_rows<L, HD>(rk, qp + d, ldq, sl, tk);
+            fetch_rows<L, HD>(rv, qp + 2 * d, ldq, sl, tk);
+            fetch_rows<L, HD>(ro, d_ctx + nc * L * ldo + h * HD, ldo, sl);
+        }
+    };
+    prefetch(n_begin + nsub);
     for (int it = 0; it < blocks_per_wg; it += NS) {
         const int64_t n = n_begin + it + nsub;
         const bool live = (it + nsub < blocks_per_wg) && n < n_blocks;
         const int64_t prob = n * H + h;
         __syncthreads();
         if (live) {
-            const int64_t* tk = tokens ? tokens + n * L : nullptr;
-            const float* qp = tokens ? qkv + h * HD : qkv + n * L * ldq + h * HD;
-            stage_rows<L, HD>(Qs, qp, ldq, sl, scale, tk);
-            stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f, tk);
-            stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f, tk);
-            stage_rows<L, HD>(Os, d_ctx + n * L * ldo + h * HD, ldo, sl, 1.0f);
+            if constexpr (kPipe) {
+                commit_rows<L, HD>(Qs, rq, sl, scale);
+                commit_rows<L, HD>(Ks, rk, sl, 1.0f);
+                commit_rows<L, HD>(Vs, rv, sl, 1.0f);
+                commit_rows<L, HD>(Os, ro, sl, 1.0f);
+            } else {
+                const int64_t* tk = tokens ? tokens + n * L : nullptr;
+                const float* qp = tokens ? qkv + h * HD : qkv + n * L * ldq + h * HD;
+                stage_rows<L, HD>(Qs, qp, ldq, sl, scale, tk);
+                stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f, tk);
+                stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f, tk);
+                stage_rows<L, HD>(Os, d_ctx + n * L * ldo + h * HD, ldo, sl, 1.0f);
+            }
         }
         __syncthreads();
+        prefetch(n + NS);
         if (live) {
             // dPd[i][j] = dO_i . V_j ; softmax backward
             float dp[C::JPL], p[C::JPL];

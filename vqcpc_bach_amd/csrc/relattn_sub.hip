@@ -38,6 +38,37 @@ __device__ __forceinline__ void sub_stage(float* dst, const float* __restrict__ 
     }
 }
 
+// register-staged variant of sub_stage for the backward's block loop (see relattn.hip: fetch_rows / commit_rows)
+template <int ROWS, int HD, int LPP>
+struct SubRegs {
+    static constexpr int V = HD / 4, N = (ROWS * V + LPP - 1) / LPP;
+    float4 r[N];
+};
+
+template <int ROWS, int HD, int LPP>
+__device__ __forceinline__ void sub_fetch(SubRegs<ROWS, HD, LPP>& t, const float* __restrict__ src, int64_t ld, int sl) {
+    constexpr int V = HD / 4;
+#pragma unroll
+    for (int k = 0; k < SubRegs<ROWS, HD, LPP>::N; ++k) {
+        const int e = min(sl + k * LPP, ROWS * V - 1);                  // clamped: no branch around the load
+        t.r[k] = *reinterpret_cast<const float4*>(src + (e / V) * ld + (e % V) * 4);
+    }
+}
+
+template <int ROWS, int HD, int LPP>
+__device__ __forceinline__ void sub_commit(float* dst, const SubRegs<ROWS, HD, LPP>& t, int sl, float mul) {
+    constexpr int RS = HD + kSubPad, V = HD / 4;
+#pragma unroll
+    for (int k = 0; k < SubRegs<ROWS, HD, LPP>::N; ++k) {
+        const int e = sl + k * LPP;
+        if (e < ROWS * V) {
+            float4 v = t.r[k];
+            v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+            *reinterpret_cast<float4*>(dst + (e / V) * RS + (e % V) * 4) = v;
+        }
+    }
+}
+
 template <int L, int HD, int LPP>
 __device__ __forceinline__ void sub_stage_erel(float* dst, const float* __restrict__ e1, const float* __restrict__ e2,
                                                int h, int sl) {
@@ -182,18 +213,40 @@ __global__ __launch_bounds__(64) void relattn_sub_bwd_kernel(
         for (int c = 0; c < C::CPL; ++c) de[a][c] = 0.0f;
 
     const int64_t n_begin = (int64_t)blockIdx.x * blocks_per_wg;
+    // software pipeline over the blocks (barrier-lockstep loop): next block's operands in flight during this block
+    constexpr bool kPipe = HD <= 32 && L == 4;
+    SubRegs<C::LQ, HD, C::LPP> rq, ro;
+    SubRegs<L, HD, C::LPP> rk, rv;
+    auto prefetch = [&](int64_t nb) {
+        if constexpr (kPipe) {
+            const int64_t nc = min(nb, n_blocks - 1);                // past the end: re-read the last block, never used
+            sub_fetch<C::LQ, HD, C::LPP>(rq, q + nc * C::LQ * ldq + h * HD, ldq, sl);
+            sub_fetch<C::LQ, HD, C::LPP>(ro, d_ctx + nc * C::LQ * ldo + h * HD, ldo, sl);
+            sub_fetch<L, HD, C::LPP>(rk, kv + nc * L * ldkv + h * HD, ldkv, sl);
+            sub_fetch<L, HD, C::LPP>(rv, kv + nc * L * ldkv + d + h * HD, ldkv, sl);
+        }
+    };
+    prefetch(n_begin + nsub);
     for (int it = 0; it < blocks_per_wg; it += NS) {
         const int64_t n = n_begin + it + nsub;
         const bool live = n < n_blocks;
         const int64_t prob = n * H + h;
         __syncthreads();
         if (live) {
-            sub_stage<C::LQ, HD, C::LPP>(Qs, q + n * C::LQ * ldq + h * HD, ldq, sl, scale);
-            sub_stage<C::LQ, HD, C::LPP>(Os, d_ctx + n * C::LQ * ldo + h * HD, ldo, sl, 1.0f);
-            sub_stage<L, HD, C::LPP>(Ks, kv + n * L * ldkv + h * HD, ldkv, sl, 1.0f);
-            sub_stage<L, HD, C::LPP>(Vs, kv + n * L * ldkv + d + h * HD, ldkv, sl, 1.0f);
+            if constexpr (kPipe) {
+                sub_commit<C::LQ, HD, C::LPP>(Qs, rq, sl, scale);
+                sub_commit<C::LQ, HD, C::LPP>(Os, ro, sl, 1.0f);
+                sub_commit<L, HD, C::LPP>(Ks, rk, sl, 1.0f);
+                sub_commit<L, HD, C::LPP>(Vs, rv, sl, 1.0f);
+            } else {
+                sub_stage<C::LQ, HD, C::LPP>(Qs, q + n * C::LQ * ldq + h * HD, ldq, sl, scale);
+                sub_stage<C::LQ, HD, C::LPP>(Os, d_ctx + n * C::LQ * ldo + h * HD, ldo, sl, 1.0f);
+                sub_stage<L, HD, C::LPP>(Ks, kv + n * L * ldkv + h * HD, ldkv, sl, 1.0f);
+                sub_stage<L, HD, C::LPP>(Vs, kv + n * L * ldkv + d + h * HD, ldkv, sl, 1.0f);
+            }
         }
         __syncthreads();
+        prefetch(n + NS);
         if (live) {
             float dp[C::JPL], p[C::JPL];
 #pragma unroll
@@ -333,6 +386,38 @@ __device__ __forceinline__ void stage64(float* dst, const float* __restrict__ sr
     }
 }
 
+// register-staged variant for the block loops: `fetch64` issues the global loads of the NEXT block before the current one
+// is processed, `commit64` writes them to LDS after the barrier that retires the current block's readers
+template <int ROWS, int HD>
+struct Stage64Regs {
+    static constexpr int V = HD / 4, N = (ROWS * V + 63) / 64;
+    float4 r[N];
+};
+
+template <int ROWS, int HD>
+__device__ __forceinline__ void fetch64(Stage64Regs<ROWS, HD>& t, const float* __restrict__ src, int64_t ld, int lane) {
+    constexpr int V = HD / 4;
+#pragma unroll
+    for (int k = 0; k < Stage64Regs<ROWS, HD>::N; ++k) {
+        const int e = min(lane + 64 * k, ROWS * V - 1);              // clamped: no branch around the load
+        t.r[k] = *reinterpret_cast<const float4*>(src + (e / V) * ld + (e % V) * 4);
+    }
+}
+
+template <int ROWS, int HD>
+__device__ __forceinline__ void commit64(float* dst, const Stage64Regs<ROWS, HD>& t, int lane, float mul) {
+    constexpr int RS = HD + kSubPad, V = HD / 4;
+#pragma unroll
+    for (int k = 0; k < Stage64Regs<ROWS, HD>::N; ++k) {
+        const int e = lane + 64 * k;
+        if (e < ROWS * V) {
+            float4 v = t.r[k];
+            v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
+            *reinterpret_cast<float4*>(dst + (e / V) * RS + (e % V) * 4) = v;
+        }
+    }
+}
+
 template <int HD>
 __global__ __launch_bounds__(256) void relattn_sub16_fwd_kernel(const float* __restrict__ q, int64_t ldq,
                                                                 const float* __restrict__ kv, int64_t ldkv,
@@ -447,18 +532,41 @@ __global__ __launch_bounds__(256) void relattn_sub16_bwd_kernel(
         for (int c = 0; c < C::C4; ++c) de[a][c] = 0.0f;
 
     const int64_t n_begin = (int64_t)blockIdx.x * blocks_per_wg;
+    // software pipeline over the blocks (790 -> 580 us at C1): the operands of block it + NS are in flight while block it
+    // is processed.  Not at head_dim 64: its 24 extra staging registers would halve the occupancy
+    constexpr bool kPipe = HD <= 32;
+    Stage64Regs<C::LQ, HD> rq, ro;
+    Stage64Regs<C::L, HD> rk, rv;
+    auto prefetch = [&](int64_t nb) {
+        if constexpr (kPipe) {
+            const int64_t nc = min(nb, n_blocks - 1);                // past the end: re-read the last block, never used
+            fetch64<C::LQ, HD>(rq, q + nc * C::LQ * ldq + h * HD, ldq, lane);
+            fetch64<C::LQ, HD>(ro, d_ctx + nc * C::LQ * ldo + h * HD, ldo, lane);
+            fetch64<C::L, HD>(rk, kv + nc * C::L * ldkv + h * HD, ldkv, lane);
+            fetch64<C::L, HD>(rv, kv + nc * C::L * ldkv + d + h * HD, ldkv, lane);
+        }
+    };
+    prefetch(n_begin + nsub);
     for (int it = 0; it < blocks_per_wg; it += NS) {
         const int64_t n = n_begin + it + nsub;
         const bool live = n < n_blocks;
         const int64_t prob = n * H + h;
         __syncthreads();
         if (live) {
-            stage64<C::LQ, HD>(Qs, q + n * C::LQ * ldq + h * HD, ldq, lane, scale);
-            stage64<C::LQ, HD>(Os, d_ctx + n * C::LQ * ldo + h * HD, ldo, lane, 1.0f);
-            stage64<C::L, HD>(Ks, kv + n * C::L * ldkv + h * HD, ldkv, lane, 1.0f);
-            stage64<C::L, HD>(Vs, kv + n * C::L * ldkv + d + h * HD, ldkv, lane, 1.0f);
+            if constexpr (kPipe) {
+                commit64<C::LQ, HD>(Qs, rq, lane, scale);
+                commit64<C::LQ, HD>(Os, ro, lane, 1.0f);
+                commit64<C::L, HD>(Ks, rk, lane, 1.0f);
+                commit64<C::L, HD>(Vs, rv, lane, 1.0f);
+            } else {
+                stage64<C::LQ, HD>(Qs, q + n * C::LQ * ldq + h * HD, ldq, lane, scale);
+                stage64<C::LQ, HD>(Os, d_ctx + n * C::LQ * ldo + h * HD, ldo, lane, 1.0f);
+                stage64<C::L, HD>(Ks, kv + n * C::L * ldkv + h * HD, ldkv, lane, 1.0f);
+                stage64<C::L, HD>(Vs, kv + n * C::L * ldkv + d + h * HD, ldkv, lane, 1.0f);
+            }
         }
         __syncthreads();
+        prefetch(n + NS);
         if (live) {
             float dp = 0.0f;
 #pragma unroll

@@ -179,38 +179,63 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
     const int64_t b1 = min(b0 + blocks_per_chunk, n_blocks);
     // every wave runs the same number of iterations (barriers inside); out-of-range waves redo block b1 - 1 without stores
     const int iters = (int)((b1 - b0 + kA16Waves - 1) / kA16Waves);
+    // Software pipeline (head_dim <= 32): every global operand of block it + 1 is requested while block it is processed --
+    // a block is otherwise four dependent round trips (token ids -> operand rows -> probs -> second operand set) with two
+    // waves per SIMD to hide them.  The token ids run one block further ahead (they address the operand rows).
+    constexpr bool kPipe = HD <= 32;
+    struct Blk {
+        float doa[KH], vb[KH], p[4], dob[4][CT], qb[4][CT], kb[4][CT];
+    };
+    auto block_of = [&](int it) { return min(b0 + (int64_t)it * kA16Waves + wave, b1 - 1); };
+    auto load_tok = [&](int64_t n) -> int64_t { return tokens ? tokens[n * 16 + c] : 0; };
+    auto load_blk = [&](Blk& B, int64_t n, int64_t tokv) {
+        const int64_t prob = n * H + h;
+        const int64_t row_c = tokens ? tokv * 16 + c : n * 16 + c;
+        load_f4<KH>(B.doa, d_ctx + (n * 16 + c) * ldo + h * HD + g * KH, 1.0f);
+        load_f4<KH>(B.vb, qkv + row_c * ldq + h * HD + 2 * d + g * KH, 1.0f);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B.p[r] = probs[(prob * 16 + 4 * g + r) * 16 + c];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int j = 4 * g + sidx;
+            const int64_t tj = __shfl(tokv, j, 16);
+            const int64_t row = tokens ? tj * 16 + j : n * 16 + j;
+            load_ct<CT>(B.dob[sidx], d_ctx + (n * 16 + j) * ldo + h * HD + CT * c, 1.0f);
+            load_ct<CT>(B.qb[sidx], qkv + row * ldq + h * HD + CT * c, scale);
+            load_ct<CT>(B.kb[sidx], qkv + row * ldq + d + h * HD + CT * c, 1.0f);
+        }
+    };
+    Blk cur;
+    int64_t tok_n1 = 0;                                   // token ids of block it + 1
+    if (kPipe) {
+        load_blk(cur, block_of(0), load_tok(block_of(0)));
+        tok_n1 = load_tok(block_of(1));
+    }
     for (int it = 0; it < iters; ++it) {
         const int64_t want = b0 + (int64_t)it * kA16Waves + wave;
         const bool live = want < b1;
         const int64_t n = live ? want : b1 - 1;
         const int64_t prob = n * H + h;
-        const int64_t tokv = tokens ? tokens[n * 16 + c] : 0;
-        const int64_t row_c = tokens ? tokv * 16 + c : n * 16 + c;
-        const float* rp = qkv + row_c * ldq + h * HD;
+        Blk nxt;
+        if (kPipe) {
+            load_blk(nxt, block_of(it + 1), tok_n1);
+            tok_n1 = load_tok(block_of(it + 2));
+        } else {
+            load_blk(cur, n, load_tok(n));
+        }
         // dP = dO . V^T, softmax backward in the accumulator layout (rows 4g + r, column c)
-        float doa[KH], vb[KH];
-        load_f4<KH>(doa, d_ctx + (n * 16 + c) * ldo + h * HD + g * KH, 1.0f);
-        load_f4<KH>(vb, rp + 2 * d + g * KH, 1.0f);
         floatx4 dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int k = 0; k < KH; ++k) dp = __builtin_amdgcn_mfma_f32_16x16x4f32(doa[k], vb[k], dp, 0, 0, 0);
+        for (int k = 0; k < KH; ++k) dp = __builtin_amdgcn_mfma_f32_16x16x4f32(cur.doa[k], cur.vb[k], dp, 0, 0, 0);
         float pd[4], ds[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const int64_t idx = (prob * 16 + 4 * g + r) * 16 + c;
-            const float p = probs[idx];
+            const float p = cur.p[r];
             const float mk = drop_scale(seed, (uint64_t)idx, thr, inv_keep);
             const float dpm = dp[r] * mk;
             pd[r] = p * mk;
             ds[r] = p * (dpm - grp16_sum(dpm * p));
-        }
-        // rows 4g + s of token-dependent operands: their table rows
-        int64_t row_s[4];
-#pragma unroll
-        for (int sidx = 0; sidx < 4; ++sidx) {
-            const int j = 4 * g + sidx;
-            const int64_t tj = __shfl(tokv, j, 16);
-            row_s[sidx] = tokens ? tj * 16 + j : n * 16 + j;
         }
         // dV = Pd^T dO, dK = dS^T qs :  A[row j = c][k i = 4g + s] = X[4g + s][c] = this lane's register s
         floatx4 dv[CT], dk[CT], dq[CT];
@@ -218,13 +243,10 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
         for (int ct = 0; ct < CT; ++ct) dv[ct] = dk[ct] = dq[ct] = floatx4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
-            float dob[CT], qb[CT];
-            load_ct<CT>(dob, d_ctx + (n * 16 + 4 * g + sidx) * ldo + h * HD + CT * c, 1.0f);
-            load_ct<CT>(qb, qkv + row_s[sidx] * ldq + h * HD + CT * c, scale);
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
-                dv[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[sidx], dob[ct], dv[ct], 0, 0, 0);
-                dk[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[sidx], qb[ct], dk[ct], 0, 0, 0);
+                dv[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pd[sidx], cur.dob[sidx][ct], dv[ct], 0, 0, 0);
+                dk[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds[sidx], cur.qb[sidx][ct], dk[ct], 0, 0, 0);
             }
         }
         wave_lds_fence();                                  // previous iteration's LDS readers are done
@@ -235,10 +257,9 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
 #pragma unroll
         for (int sidx = 0; sidx < 4; ++sidx) {
             const float a = buf[c * kA16RS + 4 * g + sidx];
-            float kb2[CT];
-            load_ct<CT>(kb2, qkv + row_s[sidx] * ldq + d + h * HD + CT * c, 1.0f);
 #pragma unroll
-            for (int ct = 0; ct < CT; ++ct) dq[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, kb2[ct], dq[ct], 0, 0, 0);
+            for (int ct = 0; ct < CT; ++ct)
+                dq[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cur.kb[sidx][ct], dq[ct], 0, 0, 0);
         }
 #pragma unroll
         for (int xt = 0; xt < 2; ++xt)
@@ -261,11 +282,9 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
                     const int i = 4 * g + sidx, x = 16 * xt + c;
                     const int jj = x + i - 15;
                     const float a = (x <= 30 && jj >= 0 && jj < 16) ? buf[i * kA16RS + jj] : 0.0f;
-                    float qb[CT];
-                    load_ct<CT>(qb, qkv + row_s[sidx] * ldq + h * HD + CT * c, scale);
 #pragma unroll
                     for (int ct = 0; ct < CT; ++ct)
-                        de[xt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, qb[ct], de[xt][ct], 0, 0, 0);
+                        de[xt][ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, cur.qb[sidx][ct], de[xt][ct], 0, 0, 0);
                 }
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -282,6 +301,7 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
                 store_ct<CT>(gp + 2 * d, vv);
             }
         }
+        if (kPipe) cur = nxt;
     }
     float* dst = ws + (((int64_t)blockIdx.x * kA16Waves + wave) * H + h) * 31 * HD;
 #pragma unroll

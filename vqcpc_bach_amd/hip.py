@@ -134,11 +134,18 @@ def _check(rc, name):
         raise VqcpcHipError(f'{name} failed ({rc}): {load().vqcpc_last_error().decode()}')
 
 
+_TENSOR_TYPES = frozenset((torch.Tensor, torch.nn.Parameter))
+_FN = {}
+
+
 def call(name, *args):
-    """Invoke an int-returning entry point; tensors become device pointers, the stream is appended."""
-    lib = _lib if _lib is not None else load()
-    conv = [(_p(a) if isinstance(a, torch.Tensor) or a is None else a) for a in args]
-    rc = getattr(lib, name)(*conv, _stream())
+    """Invoke an int-returning entry point; tensors become device pointers, the stream is appended.
+    Hot path (hundreds of calls per training step): exact-type test instead of isinstance, bound function cached."""
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib if _lib is not None else load(), name)
+    rc = fn(*[a.data_ptr() if type(a) in _TENSOR_TYPES else a for a in args],
+            torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
     if rc != 0:
         _check(rc, name)
 

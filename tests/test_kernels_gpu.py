@@ -433,7 +433,8 @@ def _attn_ref(qkv, e1, e2, L, H, hd, mask=None):
 
 
 @pytest.mark.parametrize('n,L,H,hd,p', [(37, 16, 2, 16, 0.0), (64, 16, 8, 32, 0.0), (129, 4, 8, 32, 0.0), (40, 16, 8, 64, 0.0),
-                                        (33, 4, 4, 16, 0.0), (50, 16, 4, 32, 0.15), (70, 4, 2, 16, 0.15), (3000, 16, 8, 32, 0.0)])
+                                        (33, 4, 4, 16, 0.0), (50, 16, 4, 32, 0.15), (70, 4, 2, 16, 0.15), (3000, 16, 8, 32, 0.0),
+                                        (1, 16, 8, 32, 0.0), (2, 4, 8, 32, 0.1), (5, 16, 3, 32, 0.1), (1, 4, 2, 16, 0.0)])
 def test_relattn(ops, n, L, H, hd, p):
     _relattn_case(ops, n, L, H, hd, p)
 
@@ -524,7 +525,7 @@ def _relattn_case(ops, n, L, H, hd, p):
 
 @pytest.mark.parametrize('n,L,H,hd,p', [(37, 16, 2, 16, 0.0), (64, 16, 8, 32, 0.0), (129, 4, 8, 32, 0.0), (40, 16, 8, 64, 0.0),
                                         (33, 4, 4, 16, 0.0), (50, 16, 4, 32, 0.15), (70, 4, 2, 16, 0.15), (5000, 16, 8, 32, 0.0),
-                                        (4100, 4, 8, 32, 0.0)])
+                                        (4100, 4, 8, 32, 0.0), (1, 16, 8, 32, 0.0), (2, 4, 8, 32, 0.1), (3, 16, 2, 32, 0.1)])
 def test_relattn_query_subsampled(ops, n, L, H, hd, p):
     """Last-layer variant: only the queries at positions 0, 4, 8, .. -- must equal the full attention's rows [::4]."""
     from vqcpc_bach_amd import hip

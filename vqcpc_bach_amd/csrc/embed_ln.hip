@@ -92,6 +92,18 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
 // =====================================================================================================================
 constexpr int kLnMaxIt = 4;   // d <= 1024
 
+// streaming accesses of the LayerNorm kernels (every element is touched once): non-temporal loads / stores keep them out
+// of the way of the caches -- backward 225 -> 199 us per call at C1
+typedef float nt_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 nt_load4(const float* p) {
+    const nt_f4 v = __builtin_nontemporal_load(reinterpret_cast<const nt_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void nt_store4(float* p, const float4& v) {
+    nt_f4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
+}
+
 template <bool HAS_R>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ r, const float* __restrict__ gamma,
@@ -108,9 +120,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
         for (int it = 0; it < kLnMaxIt; ++it) {
             const int col = lane * 4 + it * 256;
             if (it < nit && col < d) {
-                float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + col);
+                float4 xv = nt_load4(x + row * ldx + col);
                 if (HAS_R) {
-                    const float4 rv = *reinterpret_cast<const float4*>(r + row * d + col);
+                    const float4 rv = nt_load4(r + row * d + col);
                     const uint64_t e = (uint64_t)row * d + col;
                     xv.x += rv.x * drop_scale(seed, e + 0, thr, inv_keep);
                     xv.y += rv.y * drop_scale(seed, e + 1, thr, inv_keep);
@@ -145,7 +157,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                 o.y = (s[it].y - mu) * rs * gm.y + bt.y;
                 o.z = (s[it].z - mu) * rs * gm.z + bt.z;
                 o.w = (s[it].w - mu) * rs * gm.w + bt.w;
-                *reinterpret_cast<float4*>(y + row * d + col) = o;
+                nt_store4(y + row * d + col, o);
             }
         }
         if (lane == 0) {
@@ -183,10 +195,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         for (int it = 0; it < kLnMaxIt; ++it) {
             const int col = lane * 4 + it * 256;
             if (it < nit && col < d) {
-                float4 xv = *reinterpret_cast<const float4*>(x + row * ldx + col);
+                float4 xv = nt_load4(x + row * ldx + col);
                 msk[it] = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (HAS_R) {
-                    const float4 rv = *reinterpret_cast<const float4*>(r + row * d + col);
+                    const float4 rv = nt_load4(r + row * d + col);
                     const uint64_t e = (uint64_t)row * d + col;
                     msk[it].x = drop_scale(seed, e + 0, thr, inv_keep);
                     msk[it].y = drop_scale(seed, e + 1, thr, inv_keep);
@@ -197,7 +209,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                     xv.z += rv.z * msk[it].z;
                     xv.w += rv.w * msk[it].w;
                 }
-                const float4 dv = *reinterpret_cast<const float4*>(dy + row * d + col);
+                const float4 dv = nt_load4(dy + row * d + col);
                 xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 gy[it] = make_float4(dv.x * gm[it].x, dv.y * gm[it].y, dv.z * gm[it].z, dv.w * gm[it].w);
                 s1 += (gy[it].x + gy[it].y) + (gy[it].z + gy[it].w);
@@ -222,13 +234,13 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                 o.y = rs * (gy[it].y - m1 - xh[it].y * m2);
                 o.z = rs * (gy[it].z - m1 - xh[it].z * m2);
                 o.w = rs * (gy[it].w - m1 - xh[it].w * m2);
-                *reinterpret_cast<float4*>(d_s + row * d + col) = o;
+                nt_store4(d_s + row * d + col, o);
                 if (HAS_R && d_r != nullptr) {
                     o.x *= msk[it].x;
                     o.y *= msk[it].y;
                     o.z *= msk[it].z;
                     o.w *= msk[it].w;
-                    *reinterpret_cast<float4*>(d_r + row * d + col) = o;
+                    nt_store4(d_r + row * d + col, o);
                 }
             }
         }

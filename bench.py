@@ -50,7 +50,7 @@ def parse():
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--host-inputs', action='store_true',
                     help='batches start in (pinned) host memory: the PCIe-inclusive rate quoted in DESIGN.md, never `value`')
-    ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', '0', '1'],
+    ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', 'bf16', '0', '1', '8'],
                     help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -218,8 +218,8 @@ def main():
     from vqcpc_bach_amd.utils import SEEDS
     assert torch.cuda.is_available(), 'bench.py measures the HIP path: it needs an MI355X'
     hip.load()
-    gemm_mode = 1 if args.gemm_mode in ('bf16x6', '1') else 0
-    hip.set_gemm_mode(gemm_mode)
+    gemm_mode = 2 if args.gemm_mode in ('bf16', '8') else (1 if args.gemm_mode in ('bf16x6', '1') else 0)
+    hip.set_gemm_mode(8 if gemm_mode == 2 else gemm_mode)
     dp = DataParallelContext()
     assert dp.world_size == args.gpus or dp.world_size == 1, f'--gpus {args.gpus} but WORLD_SIZE={dp.world_size}'
     dev = dp.device
@@ -293,6 +293,10 @@ def main():
                 peak, kname = PEAK_BF16_MFMA_TFLOPS / 6.0, ('gemm_nt = every NT GEMM launch (gemm_nt_x6_pp_kernel / gemm_nt_x6_256_kernel 256-tile, '
                                'gemm_nt_kernel<MODE=1> 128-tile, gemm_nt_skinny_kernel); bf16x6: exact 3-way bf16 split, '
                                '6x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate')
+            elif gemm_mode == 2:
+                # reduced precision (BASELINE configs[4] names bf16): NOT valid for the fp32 headline configuration
+                peak, kname = PEAK_BF16_MFMA_TFLOPS, ('gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=2> 128-tile: operands rounded '
+                               'to bf16, one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; gemm_nt_skinny_kernel in fp32)')
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=0>, gemm_nt_skinny_kernel; fp32 v_mfma_f32_32x32x2_f32)'
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
@@ -308,7 +312,7 @@ def main():
             'metric': f'encoder-train windows/sec (Bach 4-voice, seq={seq_len})', 'value': round(value, 2), 'unit': 'windows/s',
             'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
-            'vs_baseline': None, 'dtype': 'f32',
+            'vs_baseline': None, 'dtype': 'bf16' if gemm_mode == 2 else 'f32',
             'data': 'synthetic' + (' (host-resident inputs: PCIe-inclusive)' if args.host_inputs else ''),
             'config': {'workload': ('' if decoder_step else
                                     f'encoder_cpc {args.config}: seq_len={seq_len}, '
@@ -317,7 +321,8 @@ def main():
                                     f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}'),
                        'global_batch': B * dp.world_size, 'seq_len': seq_len,
                        'parallelism': f'dp{dp.world_size}', 'params': n_params,
-                       'gemm': 'bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else 'fp32 MFMA'},
+                       'gemm': ('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else
+                                'bf16 operands, fp32 accumulate (reduced precision)' if gemm_mode == 2 else 'fp32 MFMA')},
             'roofline': roofline,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
                          'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3)} if tn else None),

@@ -96,7 +96,9 @@ int vqcpc_embedding_bwd(const float* g, int64_t ldg, const int64_t* sorted_idx, 
 /* GEMM arithmetic: mode 0 = fp32 operands on v_mfma_f32_32x32x2_f32 (bit-exact fp32 fmaf chains);
  * mode 1 = "bf16x6": each fp32 operand is split exactly into 3 bf16 pieces and a product is evaluated with 6 bf16 MFMAs
  * (v_mfma_f32_32x32x16_bf16) and fp32 accumulation -- fp32-class accuracy at 2.67x the fp32 MFMA rate.
- * Process-wide; the initial value comes from the environment variable VQCPC_GEMM_MODE (default 0). */
+ * mode 8 = plain bf16: operands rounded to bf16 (nearest even), ONE bf16 MFMA per product, fp32 accumulation and epilogue
+ * (reduced precision; BASELINE configs[4] names it; 128 x 128 tile kernels).  vqcpc_gemm_get_mode returns 0 / 1 / 2.
+ * Process-wide; the initial value comes from the environment variable VQCPC_GEMM_MODE (0, 1, or 8; default 0). */
 int vqcpc_gemm_set_mode(int mode);
 int vqcpc_gemm_get_mode(void);
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,

@@ -127,6 +127,33 @@ def test_gemm_nt_skinny_shapes(ops, M, N, K, with_add, mode):
 
 
 @pytest.fixture()
+def bf16_mode(ops):
+    from vqcpc_bach_amd import hip
+    hip.set_gemm_mode(8)
+    assert hip.get_gemm_mode() == 2
+    yield
+    hip.set_gemm_mode(0)
+
+
+@pytest.mark.parametrize('M,N,K', [(2048, 256, 128), (4096, 768, 256), (1300, 96, 64), (513, 256, 1024), (2000, 44, 36)])
+def test_gemm_bf16_mode_is_a_bf16_product_with_fp32_accumulation(ops, bf16_mode, M, N, K):
+    """mode 8 (BASELINE configs[4] names bf16): operands rounded to bf16 (nearest even, as a torch cast), one bf16 MFMA per
+    product, fp32 accumulation, fp32 epilogue -> equals the product of the bf16-cast operands up to summation order."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    ar, br = a.bfloat16().double(), b.bfloat16().double()
+    out = ops.gemm_nt(dev(a), dev(b), bias=dev(bias), act=1)
+    ref = torch.relu(ar @ br.t() + bias.double())
+    assert rel_err(out.cpu(), ref) < 2e-6 * max(1, K ** 0.5)
+    assert rel_err(out.cpu(), torch.relu(a.double() @ b.double().t() + bias.double())) > 1e-4       # and it IS bf16
+    # weight gradient: dW = g^T x, db = column sums (exact fp32 sums of the unrounded g)
+    g = torch.randn(M, N, generator=gen)
+    dw, db = ops.gemm_tn(dev(g), dev(a))
+    assert rel_err(dw.cpu(), g.bfloat16().double().t() @ ar) < 2e-6 * max(1, M ** 0.5)
+    assert rel_err(db.cpu(), g.double().sum(0)) < 2e-6 * max(1, M ** 0.5)
+
+
+@pytest.fixture()
 def bf16x6(ops):
     from vqcpc_bach_amd import hip
     hip.set_gemm_mode(1)

@@ -342,3 +342,39 @@ def test_full_size_c1_step_properties():
     tr.train_step(batch, train=True)
     assert bool(torch.isfinite(tr.flat.flat_grad).all()) and bool(torch.isfinite(tr.flat.flat).all())
     assert 0.0 < tr.optimizer.grad_norm() < 1e4
+
+
+def test_bf16_gemm_mode_step_is_close_to_the_fp32_step(gemm_mode):
+    """Reduced-precision mode for BASELINE configs[4] (`bench.py --config C4 --gemm-mode bf16`): operands of every tiled GEMM
+    rounded to bf16, fp32 accumulation; everything else (attention, LayerNorm, VQ distances, GRU recurrence, losses, Adam)
+    stays fp32.  Against the fp32 oracle: losses within 2 %, almost every code identical, gradients within 10 % of the
+    largest entry.  (This mode is never used for the fp32 headline configuration.)"""
+    if gemm_mode != 'f32':
+        pytest.skip('sets its own GEMM mode')
+    from vqcpc_bach_amd import hip
+    cfg = O.make_cfg(emb=32, vocab=[56] * 4, d=128, H=4, layers=[2, 2], ff=256, D=32, K=64, ncb=2, zdim=32, up_hidden=64,
+                     cdim=32, gru_hidden=64, B=64, N=15, Kl=4, Kr=4)
+    sd = O.init_state(cfg, seed=3)
+    batch = O.synthetic_batch(cfg, seed=11)
+    O.encoder_forward(batch['negative_samples'].reshape(-1, 4, 4), sd, cfg, stages=(st := {}))
+    zp = st['z'].reshape(-1, cfg['D'])
+    for c in range(cfg['ncb']):
+        sd[f'encoder.quantizer.embeddings.{c}'] = zp[c * 7:c * 7 + cfg['K'], c * 16:(c + 1) * 16].clone() + 0.01
+    otr = O.OracleTrainer(cfg, sd, lr=1e-3)
+    ref = otr.step(batch, train=True)
+    tr = build_trainer(cfg, sd, lr=1e-3)
+    tr.train()
+    hip.set_gemm_mode(8)
+    try:
+        loss, out = tr.compute_losses(batch)
+        tr.flat.zero_grad()
+        loss.backward()
+    finally:
+        hip.set_gemm_mode(0)
+    same = sum(int((out[k].cpu().reshape(ref[k].shape) == ref[k]).sum()) for k in ('idx_left', 'idx_right', 'idx_negative'))
+    total = sum(ref[k].numel() for k in ('idx_left', 'idx_right', 'idx_negative'))
+    assert same / total > 0.97, same / total
+    for k in ('loss', 'loss_contrastive', 'loss_quantize'):
+        assert abs(float(out[k].detach()) - float(ref[k].detach())) < 2e-2 * max(1.0, abs(float(ref[k].detach()))), k
+    worst = max(rel_err(p.grad.cpu(), otr.last_grads[n]) for n, p in tr.named_parameters())
+    assert 1e-4 < worst < 0.1, worst                     # visibly bf16, still the same gradients

@@ -62,6 +62,14 @@ __device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32
 }
 // pack the high halves of two fp32 bit patterns into one dword (element 0 in the low half)
 __device__ __forceinline__ uint32_t pack_hi(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
+// MODE 2 ("bf16"): ONE bf16 piece per operand, round-to-nearest-even like a torch .bfloat16() cast (finite inputs)
+__device__ __forceinline__ uint32_t round_bf16(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
+}
+__device__ __forceinline__ uint2 round4_bf16(const float4& v) {
+    return make_uint2(pack_hi(round_bf16(v.x), round_bf16(v.y)), pack_hi(round_bf16(v.z), round_bf16(v.w)));
+}
 __device__ __forceinline__ void split3x4(const float4& v, uint2& h, uint2& m, uint2& l) {
     uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
     split3(v.x, h0, m0, l0);
@@ -134,7 +142,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
     NT_STORE1(ra0, rb0, 0, BUF) NT_STORE1(ra1, rb1, 1, BUF) NT_STORE1(ra2, rb2, 2, BUF) NT_STORE1(ra3, rb3, 3, BUF)
     // MODE 1: split into bf16 planes  A_h | A_m | A_l | B_h | B_m | B_l, each [128][kX6Stride] bf16
 #define X6_STORE1(RA, RB, I)                                                                           \
-    {                                                                                                  \
+    if (MODE == 2) {                                                                                   \
+        const int o_ = ((ld_row + 32 * (I)) * kX6Stride + ld_c4) * 2;                                  \
+        *reinterpret_cast<uint2*>(smem + 0 * kX6Plane + o_) = round4_bf16(RA);                         \
+        *reinterpret_cast<uint2*>(smem + 3 * kX6Plane + o_) = round4_bf16(RB);                         \
+    } else {                                                                                           \
         const int o_ = ((ld_row + 32 * (I)) * kX6Stride + ld_c4) * 2;                                  \
         uint2 h_, m_, l_;                                                                              \
         split3x4(RA, h_, m_, l_);                                                                      \
@@ -225,9 +237,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
             const unsigned char* bbase = smem + 3 * kX6Plane + ((wn * 64 + li) * kX6Stride + kh * 8) * 2;
 #pragma unroll
             for (int ks = 0; ks < BK / 16; ++ks) {
+                constexpr int NP = MODE == 2 ? 1 : 3;          // planes in use
                 bf16x8 a[3][2], b[3][2];
 #pragma unroll
-                for (int pc = 0; pc < 3; ++pc)
+                for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
                     for (int tl = 0; tl < 2; ++tl) {
                         a[pc][tl] = *reinterpret_cast<const bf16x8*>(abase + pc * kX6Plane + (tl * 32 * kX6Stride + ks * 16) * 2);
@@ -240,11 +253,13 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[0][1], 0, 0, 0);                \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[1][0], 0, 0, 0);                \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[1][1], 0, 0, 0);
-                X6_TERM(2, 0)   // l*h
-                X6_TERM(0, 2)   // h*l
-                X6_TERM(1, 1)   // m*m
-                X6_TERM(1, 0)   // m*h
-                X6_TERM(0, 1)   // h*m
+                if (MODE != 2) {
+                    X6_TERM(2, 0)   // l*h
+                    X6_TERM(0, 2)   // h*l
+                    X6_TERM(1, 1)   // m*m
+                    X6_TERM(1, 0)   // m*h
+                    X6_TERM(0, 1)   // h*m
+                }
                 X6_TERM(0, 0)   // h*h
 #undef X6_TERM
             }
@@ -808,7 +823,7 @@ __device__ __forceinline__ void split3_pair4(const float4& r0, const float4& r1,
 #undef TN_SPLIT_E
 }
 
-template <bool FULL>
+template <bool FULL, int MODE>
 __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float* __restrict__ A, int64_t lda,
                                                                     const float* __restrict__ B, int64_t ldb, int64_t M,
                                                                     int N, int K, int tiles_k, int64_t rows_per_split,
@@ -851,7 +866,11 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
         X6_LD(b11, B, ldb, k0, K, r1_ + 1)                     \
     }
 #define X6_ST(R0, R1, PLANE0, RP)                                                              \
-    {                                                                                          \
+    if (MODE == 2) {                                                                           \
+        const uint4 h_ = make_uint4(pack_hi(round_bf16(R0.x), round_bf16(R1.x)), pack_hi(round_bf16(R0.y), round_bf16(R1.y)), \
+                                    pack_hi(round_bf16(R0.z), round_bf16(R1.z)), pack_hi(round_bf16(R0.w), round_bf16(R1.w))); \
+        *reinterpret_cast<uint4*>(smem + (PLANE0) * kTnPlane + (RP) * kTnRS + c4 * 4) = h_;    \
+    } else {                                                                                   \
         uint4 h_, m_, l_;                                                                      \
         split3_pair4(R0, R1, h_, m_, l_);                                                      \
         const int o_ = (RP) * kTnRS + c4 * 4;                                                  \
@@ -881,9 +900,10 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
         if (more) { X6_LOAD(mm + TM) }
 #pragma unroll
         for (int ks = 0; ks < TM / 16; ++ks) {
+            constexpr int NP = MODE == 2 ? 1 : 3;              // planes in use
             bf16x8 a[3][2], b[3][2];
 #pragma unroll
-            for (int pc = 0; pc < 3; ++pc)
+            for (int pc = 0; pc < NP; ++pc)
 #pragma unroll
                 for (int tl = 0; tl < 2; ++tl) {
                     uint4 ua, ub;
@@ -905,7 +925,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
     acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][0], b[PB][1], acc[0][1], 0, 0, 0);                \
     acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][0], acc[1][0], 0, 0, 0);                \
     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[PA][1], b[PB][1], acc[1][1], 0, 0, 0);
-            X6_TERM(2, 0) X6_TERM(0, 2) X6_TERM(1, 1) X6_TERM(1, 0) X6_TERM(0, 1) X6_TERM(0, 0)
+            if (MODE != 2) { X6_TERM(2, 0) X6_TERM(0, 2) X6_TERM(1, 1) X6_TERM(1, 0) X6_TERM(0, 1) }
+            X6_TERM(0, 0)
 #undef X6_TERM
         }
         if (more) {
@@ -1099,7 +1120,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const flo
     }
 }
 
-// GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate).
+// GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate),
+// 2 = plain bf16 operands (one MFMA per product, fp32 accumulate; BASELINE configs[4] names bf16): 128-tile kernels only.
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
 static std::atomic<int> g_gemm_mode{-1};
 static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups (A/B switch)
@@ -1108,7 +1130,7 @@ static int gemm_mode() {
     int m = g_gemm_mode.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("VQCPC_GEMM_MODE");
-        m = (e && (e[0] == '1' || e[0] == 'x' || e[0] == 'b')) ? 1 : 0;
+        m = (e && (e[0] == '2' || e[0] == '8')) ? 2 : ((e && (e[0] == '1' || e[0] == 'x')) ? 1 : 0);
         g_gemm_mode.store(m, std::memory_order_relaxed);
     }
     return m;
@@ -1316,6 +1338,8 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
 #define NT_LAUNCH(FULLV, EPIV)                                                                                            \
     if (mode == 1)                                                                                                        \
         hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV, 1>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep); \
+    else if (mode == 2)                                                                                                   \
+        hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV, 2>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep); \
     else                                                                                                                  \
         hipLaunchKernelGGL((gemm_nt_kernel<FULLV, EPIV, 0>), grid, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tiles_n, ep)
 #define NT_CASE(EPIV)                       \
@@ -1345,9 +1369,14 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
 extern "C" {
 
 int vqcpc_gemm_set_mode(int mode) {
-    // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing)
-    VQ_REQUIRE(mode >= 0 && mode <= 7,
-               "gemm_set_mode: mode must be 0 (fp32 MFMA) or 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong]");
+    // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing);
+    // 8 = plain bf16 operands (one bf16 MFMA per product, fp32 accumulation)
+    VQ_REQUIRE((mode >= 0 && mode <= 7) || mode == 8,
+               "gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong] or 8 (bf16)");
+    if (mode == 8) {
+        g_gemm_mode.store(2, std::memory_order_relaxed);
+        return VQCPC_OK;
+    }
     g_use_t2.store((mode & 2) ? 0 : 1, std::memory_order_relaxed);
     g_use_pp.store((mode & 4) ? 0 : 1, std::memory_order_relaxed);
     mode &= 1;
@@ -1413,11 +1442,18 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                            ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
     } else if (gemm_mode() == 1) {
         if (full_tn)
-            hipLaunchKernelGGL(gemm_tn_x6_kernel<true>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N,
+            hipLaunchKernelGGL((gemm_tn_x6_kernel<true, 1>), dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N,
                                K, tiles_k, rows_per_split, ws, ws_bias);
         else
-            hipLaunchKernelGGL(gemm_tn_x6_kernel<false>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N,
+            hipLaunchKernelGGL((gemm_tn_x6_kernel<false, 1>), dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M,
+                               N, K, tiles_k, rows_per_split, ws, ws_bias);
+    } else if (gemm_mode() == 2) {
+        if (full_tn)
+            hipLaunchKernelGGL((gemm_tn_x6_kernel<true, 2>), dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N,
                                K, tiles_k, rows_per_split, ws, ws_bias);
+        else
+            hipLaunchKernelGGL((gemm_tn_x6_kernel<false, 2>), dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M,
+                               N, K, tiles_k, rows_per_split, ws, ws_bias);
     } else if (full_tn)
         hipLaunchKernelGGL(gemm_tn_kernel<true>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N, K,
                            tiles_k, rows_per_split, ws, ws_bias);

@@ -12,6 +12,8 @@
 #include <atomic>
 #include <stdlib.h>
 
+#include <string.h>
+
 #include "common.h"
 
 namespace vq {
@@ -1130,7 +1132,12 @@ static int gemm_mode() {
     int m = g_gemm_mode.load(std::memory_order_relaxed);
     if (m < 0) {
         const char* e = getenv("VQCPC_GEMM_MODE");
-        m = (e && (e[0] == '2' || e[0] == '8')) ? 2 : ((e && (e[0] == '1' || e[0] == 'x')) ? 1 : 0);
+        // "0" / "f32" -> 0;  "1" / "x6" / "bf16x6" -> 1;  "8" / "2" / "bf16" -> 2
+        m = 0;
+        if (e) {
+            if (!strcmp(e, "1") || !strcmp(e, "x6") || !strcmp(e, "bf16x6")) m = 1;
+            else if (!strcmp(e, "8") || !strcmp(e, "2") || !strcmp(e, "bf16")) m = 2;
+        }
         g_gemm_mode.store(m, std::memory_order_relaxed);
     }
     return m;

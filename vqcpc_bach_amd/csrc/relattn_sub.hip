@@ -386,6 +386,14 @@ __device__ __forceinline__ void stage64(float* dst, const float* __restrict__ sr
     }
 }
 
+// LDS regions private to one wavefront need no s_barrier: LDS instructions of a wave execute in order, only the compiler
+// must keep the program order of the accesses around the exchange
+__device__ __forceinline__ void sub_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // register-staged variant for the block loops: `fetch64` issues the global loads of the NEXT block before the current one
 // is processed, `commit64` writes them to LDS after the barrier that retires the current block's readers
 template <int ROWS, int HD>
@@ -425,6 +433,10 @@ __global__ __launch_bounds__(256) void relattn_sub16_fwd_kernel(const float* __r
                                                                 float* __restrict__ ctx, int64_t ldo,
                                                                 float* __restrict__ probs, int64_t n_blocks, int H,
                                                                 float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    // Persistent workgroups: wave w of the grid keeps head w % H (the host makes the wave count a multiple of H), so the 31
+    // relative rows -- 45 % of the bytes a problem stages -- go to LDS once, and the q / k / v rows of the wave's next block
+    // are fetched into registers while the current one is processed.  The LDS regions are private to a wavefront: only
+    // wave-level fences, no workgroup barrier (waves may run different trip counts).
     using C = Sub16<HD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -434,59 +446,70 @@ __global__ __launch_bounds__(256) void relattn_sub16_fwd_kernel(const float* __r
     float* Er = Vs + C::L * C::RS;
     float* Ps = Er + C::NE * C::RS;                // [4][17]
     const int d = H * HD;
-    const int64_t prob = (int64_t)blockIdx.x * 4 + wave;
-    const bool live = prob < n_blocks * H;
-    const int64_t n = live ? prob / H : 0;
-    const int h = live ? (int)(prob % H) : 0;
+    const int64_t nw = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
+    const int h = (int)(w % H);
+    const int64_t n0 = w / H, nstep = nw / H;
     const int iq = lane >> 4, j = lane & 15;
-
-    if (live) {
-        stage64<C::LQ, HD>(Qs, q + n * C::LQ * ldq + h * HD, ldq, lane, scale);
-        stage64<C::L, HD>(Ks, kv + n * C::L * ldkv + h * HD, ldkv, lane, 1.0f);
-        stage64<C::L, HD>(Vs, kv + n * C::L * ldkv + d + h * HD, ldkv, lane, 1.0f);
-        for (int e = lane; e < C::NE * (HD / 4); e += 64) {
-            const int r = e / (HD / 4), c4 = e % (HD / 4);
-            const float* src = r < C::L ? e1 + ((int64_t)h * C::L + r) * HD : e2 + ((int64_t)h * C::L + (r - C::L + 1)) * HD;
-            *reinterpret_cast<float4*>(Er + r * C::RS + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
-        }
+    if (n0 >= n_blocks) return;
+    for (int e = lane; e < C::NE * (HD / 4); e += 64) {
+        const int r = e / (HD / 4), c4 = e % (HD / 4);
+        const float* src = r < C::L ? e1 + ((int64_t)h * C::L + r) * HD : e2 + ((int64_t)h * C::L + (r - C::L + 1)) * HD;
+        *reinterpret_cast<float4*>(Er + r * C::RS + c4 * 4) = *reinterpret_cast<const float4*>(src + c4 * 4);
     }
-    __syncthreads();
-    if (live) {
-        const float* er = Er + (j - C::F * iq + C::L - 1) * C::RS;
-        float s = 0.0f;
+    Stage64Regs<C::LQ, HD> rq;
+    Stage64Regs<C::L, HD> rk, rv;
+    auto prefetch = [&](int64_t nb) {
+        const int64_t nc = min(nb, n_blocks - 1);                    // past the end: re-read the last block, never used
+        fetch64<C::LQ, HD>(rq, q + nc * C::LQ * ldq + h * HD, ldq, lane);
+        fetch64<C::L, HD>(rk, kv + nc * C::L * ldkv + h * HD, ldkv, lane);
+        fetch64<C::L, HD>(rv, kv + nc * C::L * ldkv + d + h * HD, ldkv, lane);
+    };
+    prefetch(n0);
+    for (int64_t n = n0; n < n_blocks; n += nstep) {
+        const int64_t prob = n * H + h;
+        sub_wave_fence();                                            // the previous block's LDS readers are done
+        commit64<C::LQ, HD>(Qs, rq, lane, scale);
+        commit64<C::L, HD>(Ks, rk, lane, 1.0f);
+        commit64<C::L, HD>(Vs, rv, lane, 1.0f);
+        sub_wave_fence();
+        prefetch(n + nstep);
+        {
+            const float* er = Er + (j - C::F * iq + C::L - 1) * C::RS;
+            float s = 0.0f;
 #pragma unroll
-        for (int c4 = 0; c4 < HD / 4; ++c4) {
-            const float4 qv = *reinterpret_cast<const float4*>(Qs + iq * C::RS + c4 * 4);
-            const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
-            const float4 e = *reinterpret_cast<const float4*>(er + c4 * 4);
-            s += qv.x * (k.x + e.x) + qv.y * (k.y + e.y) + qv.z * (k.z + e.z) + qv.w * (k.w + e.w);
+            for (int c4 = 0; c4 < HD / 4; ++c4) {
+                const float4 qv = *reinterpret_cast<const float4*>(Qs + iq * C::RS + c4 * 4);
+                const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
+                const float4 e = *reinterpret_cast<const float4*>(er + c4 * 4);
+                s += qv.x * (k.x + e.x) + qv.y * (k.y + e.y) + qv.z * (k.z + e.z) + qv.w * (k.w + e.w);
+            }
+            float m = s;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+            const float ex = __expf(s - m);
+            float sum = ex;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
+            const float p = ex / sum;
+            const int64_t pidx = prob * 64 + lane;                       // probs[prob][iq][j]: fully coalesced
+            probs[pidx] = p;
+            Ps[iq * (C::L + 1) + j] = p * drop_scale(seed, (uint64_t)pidx, thr, inv_keep);
         }
-        float m = s;
+        sub_wave_fence();
+        {
+            float o[C::C16];
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
-        const float ex = __expf(s - m);
-        float sum = ex;
+            for (int c = 0; c < C::C16; ++c) o[c] = 0.0f;
 #pragma unroll
-        for (int o = 1; o < 16; o <<= 1) sum += __shfl_xor(sum, o, 64);
-        const float p = ex / sum;
-        const int64_t pidx = prob * 64 + lane;                       // probs[prob][iq][j]: fully coalesced
-        probs[pidx] = p;
-        Ps[iq * (C::L + 1) + j] = p * drop_scale(seed, (uint64_t)pidx, thr, inv_keep);
-    }
-    __syncthreads();
-    if (live) {
-        float o[C::C16];
+            for (int jj = 0; jj < C::L; ++jj) {
+                const float p = Ps[iq * (C::L + 1) + jj];
 #pragma unroll
-        for (int c = 0; c < C::C16; ++c) o[c] = 0.0f;
+                for (int c = 0; c < C::C16; ++c) o[c] += p * Vs[jj * C::RS + j * C::C16 + c];
+            }
+            float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + j * C::C16;
 #pragma unroll
-        for (int jj = 0; jj < C::L; ++jj) {
-            const float p = Ps[iq * (C::L + 1) + jj];
-#pragma unroll
-            for (int c = 0; c < C::C16; ++c) o[c] += p * Vs[jj * C::RS + j * C::C16 + c];
+            for (int c = 0; c < C::C16; ++c) op[c] = o[c];
         }
-        float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + j * C::C16;
-#pragma unroll
-        for (int c = 0; c < C::C16; ++c) op[c] = o[c];
     }
 }
 
@@ -736,7 +759,12 @@ static int sub16_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_
     const size_t lds = (size_t)4 * C::FWD_FLOATS * sizeof(float);
     auto kern = relattn_sub16_fwd_kernel<HD>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int64_t grid = ceil_div(n_blocks * H, 4);
+    // persistent waves (about 4 resident workgroups per CU by LDS); the wave count must be a multiple of H
+    int64_t grid = std::min<int64_t>(ceil_div(n_blocks * H, 4), 2048);
+    int gcd = H, rem = 4;
+    while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+    const int64_t unit = H / gcd;
+    grid = ceil_div(grid, unit) * unit;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H,
                        1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
     VQ_CHECK_LAUNCH("relattn_sub16_fwd");

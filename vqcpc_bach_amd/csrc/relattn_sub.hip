@@ -38,6 +38,14 @@ __device__ __forceinline__ void sub_stage(float* dst, const float* __restrict__ 
     }
 }
 
+// LDS regions private to one wavefront need no s_barrier: LDS instructions of a wave execute in order, only the compiler
+// must keep the program order of the accesses around the exchange
+__device__ __forceinline__ void sub_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // register-staged variant of sub_stage for the backward's block loop (see relattn.hip: fetch_rows / commit_rows)
 template <int ROWS, int HD, int LPP>
 struct SubRegs {
@@ -88,6 +96,9 @@ __global__ __launch_bounds__(64) void relattn_sub_fwd_kernel(const float* __rest
                                                              float* __restrict__ ctx, int64_t ldo,
                                                              float* __restrict__ probs, int64_t n_blocks, int H,
                                                              float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    // Persistent slots: slot g of the grid keeps head g % H (the host makes the slot count a multiple of H) and walks the
+    // blocks g / H, + slots / H, ...: the relative rows are staged once, the q / k / v rows of the next block are fetched
+    // into registers while the current one is processed.  A slot's LDS region is private to its 4 LQ lanes of one wave.
     using C = SubCfg<L, HD, F>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
@@ -98,77 +109,91 @@ __global__ __launch_bounds__(64) void relattn_sub_fwd_kernel(const float* __rest
     float* Er = Vs + L * C::RS;
     float* Ps = Er + C::NE * C::RS;                 // [LQ][L+1]
     const int d = H * HD;
-    const int64_t total = n_blocks * H;
-    const int64_t prob = (int64_t)blockIdx.x * C::PPW + slot;
-    const bool live = prob < total;
-    const int64_t n = live ? prob / H : 0;
-    const int h = live ? (int)(prob % H) : 0;
+    const int64_t slots = (int64_t)gridDim.x * C::PPW, gs = (int64_t)blockIdx.x * C::PPW + slot;
+    const int h = (int)(gs % H);
+    const int64_t n0 = gs / H, nstep = slots / H;
     const int iq = sl >> 2, jg = sl & 3;
     const int i = iq * F;                           // absolute position of this query inside the block
-
-    if (live) {
-        sub_stage<C::LQ, HD, C::LPP>(Qs, q + n * C::LQ * ldq + h * HD, ldq, sl, scale);
-        sub_stage<L, HD, C::LPP>(Ks, kv + n * L * ldkv + h * HD, ldkv, sl, 1.0f);
-        sub_stage<L, HD, C::LPP>(Vs, kv + n * L * ldkv + d + h * HD, ldkv, sl, 1.0f);
-        sub_stage_erel<L, HD, C::LPP>(Er, e1, e2, h, sl);
-    }
-    __syncthreads();
-    if (live) {
-        float s[C::JPL];
+    sub_stage_erel<L, HD, C::LPP>(Er, e1, e2, h, sl);
+    SubRegs<C::LQ, HD, C::LPP> rq;
+    SubRegs<L, HD, C::LPP> rk, rv;
+    auto prefetch = [&](int64_t nb) {
+        const int64_t nc = min(nb, n_blocks - 1);                    // past the end: re-read the last block, never used
+        sub_fetch<C::LQ, HD, C::LPP>(rq, q + nc * C::LQ * ldq + h * HD, ldq, sl);
+        sub_fetch<L, HD, C::LPP>(rk, kv + nc * L * ldkv + h * HD, ldkv, sl);
+        sub_fetch<L, HD, C::LPP>(rv, kv + nc * L * ldkv + d + h * HD, ldkv, sl);
+    };
+    prefetch(n0);
+    const int64_t iters = (n_blocks + nstep - 1) / nstep;            // uniform trip count; slots past the end idle (live)
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t n = n0 + it * nstep;
+        const bool live = n < n_blocks;
+        const int64_t prob = n * H + h;
+        sub_wave_fence();                                            // the previous block's LDS readers are done
+        if (live) {
+            sub_commit<C::LQ, HD, C::LPP>(Qs, rq, sl, scale);
+            sub_commit<L, HD, C::LPP>(Ks, rk, sl, 1.0f);
+            sub_commit<L, HD, C::LPP>(Vs, rv, sl, 1.0f);
+        }
+        sub_wave_fence();
+        prefetch(n + nstep);
+        if (live) {
+            float s[C::JPL];
 #pragma unroll
-        for (int jj = 0; jj < C::JPL; ++jj) s[jj] = 0.0f;
+            for (int jj = 0; jj < C::JPL; ++jj) s[jj] = 0.0f;
 #pragma unroll
-        for (int c4 = 0; c4 < HD / 4; ++c4) {
-            const float4 qv = *reinterpret_cast<const float4*>(Qs + iq * C::RS + c4 * 4);
+            for (int c4 = 0; c4 < HD / 4; ++c4) {
+                const float4 qv = *reinterpret_cast<const float4*>(Qs + iq * C::RS + c4 * 4);
+#pragma unroll
+                for (int jj = 0; jj < C::JPL; ++jj) {
+                    const int j = jj * 4 + jg;
+                    const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
+                    const float4 e = *reinterpret_cast<const float4*>(Er + (j - i + L - 1) * C::RS + c4 * 4);
+                    s[jj] += qv.x * (k.x + e.x) + qv.y * (k.y + e.y) + qv.z * (k.z + e.z) + qv.w * (k.w + e.w);
+                }
+            }
+            float m = s[0];
+#pragma unroll
+            for (int jj = 1; jj < C::JPL; ++jj) m = fmaxf(m, s[jj]);
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) {
+                s[jj] = __expf(s[jj] - m);
+                sum += s[jj];
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            const float inv = 1.0f / sum;
+            const int64_t pbase = (prob * C::LQ + iq) * L;
 #pragma unroll
             for (int jj = 0; jj < C::JPL; ++jj) {
                 const int j = jj * 4 + jg;
-                const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
-                const float4 e = *reinterpret_cast<const float4*>(Er + (j - i + L - 1) * C::RS + c4 * 4);
-                s[jj] += qv.x * (k.x + e.x) + qv.y * (k.y + e.y) + qv.z * (k.z + e.z) + qv.w * (k.w + e.w);
+                const float p = s[jj] * inv;
+                probs[pbase + j] = p;
+                Ps[iq * (L + 1) + j] = p * drop_scale(seed, (uint64_t)(pbase + j), thr, inv_keep);
             }
         }
-        float m = s[0];
+        sub_wave_fence();
+        if (live) {
+            float o[C::CPL];
 #pragma unroll
-        for (int jj = 1; jj < C::JPL; ++jj) m = fmaxf(m, s[jj]);
-        m = fmaxf(m, __shfl_xor(m, 1, 64));
-        m = fmaxf(m, __shfl_xor(m, 2, 64));
-        float sum = 0.0f;
+            for (int c = 0; c < C::CPL; ++c) o[c] = 0.0f;
 #pragma unroll
-        for (int jj = 0; jj < C::JPL; ++jj) {
-            s[jj] = __expf(s[jj] - m);
-            sum += s[jj];
-        }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
-        const float inv = 1.0f / sum;
-        const int64_t pbase = (prob * C::LQ + iq) * L;
+            for (int j = 0; j < L; ++j) {
+                const float p = Ps[iq * (L + 1) + j];
 #pragma unroll
-        for (int jj = 0; jj < C::JPL; ++jj) {
-            const int j = jj * 4 + jg;
-            const float p = s[jj] * inv;
-            probs[pbase + j] = p;
-            Ps[iq * (L + 1) + j] = p * drop_scale(seed, (uint64_t)(pbase + j), thr, inv_keep);
-        }
-    }
-    __syncthreads();
-    if (live) {
-        float o[C::CPL];
-#pragma unroll
-        for (int c = 0; c < C::CPL; ++c) o[c] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            const float p = Ps[iq * (L + 1) + j];
-#pragma unroll
-            for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
-                const float4 v = *reinterpret_cast<const float4*>(Vs + j * C::RS + jg * C::CPL + c4 * 4);
-                o[c4 * 4 + 0] += p * v.x; o[c4 * 4 + 1] += p * v.y; o[c4 * 4 + 2] += p * v.z; o[c4 * 4 + 3] += p * v.w;
+                for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                    const float4 v = *reinterpret_cast<const float4*>(Vs + j * C::RS + jg * C::CPL + c4 * 4);
+                    o[c4 * 4 + 0] += p * v.x; o[c4 * 4 + 1] += p * v.y; o[c4 * 4 + 2] += p * v.z; o[c4 * 4 + 3] += p * v.w;
+                }
             }
-        }
-        float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + jg * C::CPL;
+            float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + jg * C::CPL;
 #pragma unroll
-        for (int c4 = 0; c4 < C::CPL / 4; ++c4)
-            *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+            for (int c4 = 0; c4 < C::CPL / 4; ++c4)
+                *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+        }
     }
 }
 
@@ -384,14 +409,6 @@ __device__ __forceinline__ void stage64(float* dst, const float* __restrict__ sr
         v.x *= mul; v.y *= mul; v.z *= mul; v.w *= mul;
         *reinterpret_cast<float4*>(dst + row * RS + c4 * 4) = v;
     }
-}
-
-// LDS regions private to one wavefront need no s_barrier: LDS instructions of a wave execute in order, only the compiler
-// must keep the program order of the accesses around the exchange
-__device__ __forceinline__ void sub_wave_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 // register-staged variant for the block loops: `fetch64` issues the global loads of the NEXT block before the current one
@@ -712,7 +729,12 @@ static int sub_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_t 
     const size_t lds = (size_t)C::PPW * C::FWD_FLOATS * sizeof(float);
     auto kern = relattn_sub_fwd_kernel<L, HD, F>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int64_t grid = ceil_div(n_blocks * H, C::PPW);
+    // persistent slots (8192 single-wave workgroups at most); the slot count must be a multiple of H
+    int64_t grid = std::min<int64_t>(ceil_div(n_blocks * H, C::PPW), 8192);
+    int gcd = H, rem = C::PPW;
+    while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+    const int64_t unit = H / gcd;
+    grid = ceil_div(grid, unit) * unit;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H,
                        1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
     VQ_CHECK_LAUNCH("relattn_sub_fwd");

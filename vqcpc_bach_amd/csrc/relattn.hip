@@ -47,6 +47,14 @@ __device__ __forceinline__ void stage_rows(float* dst, const float* __restrict__
     }
 }
 
+// LDS regions private to the lanes of one wavefront need no s_barrier: LDS instructions of a wave execute in order, only
+// the compiler must keep the program order of the accesses around the exchange
+__device__ __forceinline__ void att_wave_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // register-staged variant for the backward's block loop: `fetch_rows` issues the global loads of the NEXT block before the
 // current one is processed, `commit_rows` writes them to LDS after the barrier that retires the current block's readers
 template <int L, int HD>
@@ -100,6 +108,9 @@ __global__ __launch_bounds__(kAttThreads) void relattn_fwd_kernel(const float* _
                                                                   int64_t n_blocks, int H, float scale, uint32_t thr,
                                                                   float inv_keep, uint64_t seed,
                                                                   const int64_t* __restrict__ tokens) {
+    // Persistent slots: slot g of the grid keeps head g % H (the host makes the slot count a multiple of H) and walks the
+    // blocks g / H, + slots / H, ...: the relative rows are staged once, the q | k | v rows of the next block are fetched
+    // into registers while the current one is processed.  A slot's LDS region is private to its 4 L lanes of one wave.
     using C = AttCfg<L, HD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -111,81 +122,94 @@ __global__ __launch_bounds__(kAttThreads) void relattn_fwd_kernel(const float* _
     float* Er = Vs + L * C::RS;
     float* Ps = Er + C::NE * C::RS;                 // [L][L+1]
     const int d = H * HD;
-    const int64_t total = n_blocks * H;
-    const int64_t prob = (int64_t)blockIdx.x * C::SLOTS + slot;
-    const bool live = prob < total;
-    const int64_t n = live ? prob / H : 0;
-    const int h = live ? (int)(prob % H) : 0;
+    const int64_t slots = (int64_t)gridDim.x * C::SLOTS, gs = (int64_t)blockIdx.x * C::SLOTS + slot;
+    const int h = (int)(gs % H);
+    const int64_t n0 = gs / H, nstep = slots / H;
     const int i = sl >> 2, jg = sl & 3;
-
-    if (live) {
-        const int64_t* tk = tokens ? tokens + n * L : nullptr;
-        const float* qp = tokens ? qkv + h * HD : qkv + n * L * ldq + h * HD;
-        stage_rows<L, HD>(Qs, qp, ldq, sl, scale, tk);
-        stage_rows<L, HD>(Ks, qp + d, ldq, sl, 1.0f, tk);
-        stage_rows<L, HD>(Vs, qp + 2 * d, ldq, sl, 1.0f, tk);
-        stage_erel<L, HD>(Er, e1, e2, h, sl);
-    }
-    __syncthreads();
-    float s[C::JPL];
-    if (live) {
+    stage_erel<L, HD>(Er, e1, e2, h, sl);
+    RowRegs<L, HD> rq, rk, rv;
+    auto prefetch = [&](int64_t nb) {
+        const int64_t nc = min(nb, n_blocks - 1);                    // past the end: re-read the last block, never used
+        const int64_t* tk = tokens ? tokens + nc * L : nullptr;
+        const float* qp = tokens ? qkv + h * HD : qkv + nc * L * ldq + h * HD;
+        fetch_rows<L, HD>(rq, qp, ldq, sl, tk);
+        fetch_rows<L, HD>(rk, qp + d, ldq, sl, tk);
+        fetch_rows<L, HD>(rv, qp + 2 * d, ldq, sl, tk);
+    };
+    prefetch(n0);
+    const int64_t iters = (n_blocks + nstep - 1) / nstep;            // uniform trip count; slots past the end idle (live)
+    for (int64_t it = 0; it < iters; ++it) {
+        const int64_t n = n0 + it * nstep;
+        const bool live = n < n_blocks;
+        const int64_t prob = n * H + h;
+        att_wave_fence();                                            // the previous block's LDS readers are done
+        if (live) {
+            commit_rows<L, HD>(Qs, rq, sl, scale);
+            commit_rows<L, HD>(Ks, rk, sl, 1.0f);
+            commit_rows<L, HD>(Vs, rv, sl, 1.0f);
+        }
+        att_wave_fence();
+        prefetch(n + nstep);
+        if (live) {
+            float s[C::JPL];
 #pragma unroll
-        for (int jj = 0; jj < C::JPL; ++jj) s[jj] = 0.0f;
+            for (int jj = 0; jj < C::JPL; ++jj) s[jj] = 0.0f;
 #pragma unroll
-        for (int c4 = 0; c4 < HD / 4; ++c4) {
-            const float4 q = *reinterpret_cast<const float4*>(Qs + i * C::RS + c4 * 4);
+            for (int c4 = 0; c4 < HD / 4; ++c4) {
+                const float4 q = *reinterpret_cast<const float4*>(Qs + i * C::RS + c4 * 4);
+#pragma unroll
+                for (int jj = 0; jj < C::JPL; ++jj) {
+                    const int j = jj * 4 + jg;
+                    const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
+                    const float4 e = *reinterpret_cast<const float4*>(Er + (j - i + L - 1) * C::RS + c4 * 4);
+                    s[jj] += q.x * (k.x + e.x) + q.y * (k.y + e.y) + q.z * (k.z + e.z) + q.w * (k.w + e.w);
+                }
+            }
+            float m = s[0];
+#pragma unroll
+            for (int jj = 1; jj < C::JPL; ++jj) m = fmaxf(m, s[jj]);
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            float sum = 0.0f;
+#pragma unroll
+            for (int jj = 0; jj < C::JPL; ++jj) {
+                s[jj] = __expf(s[jj] - m);
+                sum += s[jj];
+            }
+            sum += __shfl_xor(sum, 1, 64);
+            sum += __shfl_xor(sum, 2, 64);
+            const float inv = 1.0f / sum;
+            float* pg = probs + prob * L * L + i * L;
 #pragma unroll
             for (int jj = 0; jj < C::JPL; ++jj) {
                 const int j = jj * 4 + jg;
-                const float4 k = *reinterpret_cast<const float4*>(Ks + j * C::RS + c4 * 4);
-                const float4 e = *reinterpret_cast<const float4*>(Er + (j - i + L - 1) * C::RS + c4 * 4);
-                s[jj] += q.x * (k.x + e.x) + q.y * (k.y + e.y) + q.z * (k.z + e.z) + q.w * (k.w + e.w);
+                const float p = s[jj] * inv;
+                pg[j] = p;                                                          // saved BEFORE dropout
+                Ps[i * (L + 1) + j] = p * drop_scale(seed, (uint64_t)(prob * L + i) * L + j, thr, inv_keep);
             }
         }
-        float m = s[0];
+        att_wave_fence();
+        if (live) {
+            float o[C::CPL];
 #pragma unroll
-        for (int jj = 1; jj < C::JPL; ++jj) m = fmaxf(m, s[jj]);
-        m = fmaxf(m, __shfl_xor(m, 1, 64));
-        m = fmaxf(m, __shfl_xor(m, 2, 64));
-        float sum = 0.0f;
+            for (int c = 0; c < C::CPL; ++c) o[c] = 0.0f;
 #pragma unroll
-        for (int jj = 0; jj < C::JPL; ++jj) {
-            s[jj] = __expf(s[jj] - m);
-            sum += s[jj];
-        }
-        sum += __shfl_xor(sum, 1, 64);
-        sum += __shfl_xor(sum, 2, 64);
-        const float inv = 1.0f / sum;
-        float* pg = probs + prob * L * L + i * L;
+            for (int j = 0; j < L; ++j) {
+                const float p = Ps[i * (L + 1) + j];
 #pragma unroll
-        for (int jj = 0; jj < C::JPL; ++jj) {
-            const int j = jj * 4 + jg;
-            const float p = s[jj] * inv;
-            pg[j] = p;                                                          // saved BEFORE dropout
-            Ps[i * (L + 1) + j] = p * drop_scale(seed, (uint64_t)(prob * L + i) * L + j, thr, inv_keep);
-        }
-    }
-    __syncthreads();
-    if (live) {
-        float o[C::CPL];
-#pragma unroll
-        for (int c = 0; c < C::CPL; ++c) o[c] = 0.0f;
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-            const float p = Ps[i * (L + 1) + j];
-#pragma unroll
-            for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
-                const float4 v = *reinterpret_cast<const float4*>(Vs + j * C::RS + jg * C::CPL + c4 * 4);
-                o[c4 * 4 + 0] += p * v.x;
-                o[c4 * 4 + 1] += p * v.y;
-                o[c4 * 4 + 2] += p * v.z;
-                o[c4 * 4 + 3] += p * v.w;
+                for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
+                    const float4 v = *reinterpret_cast<const float4*>(Vs + j * C::RS + jg * C::CPL + c4 * 4);
+                    o[c4 * 4 + 0] += p * v.x;
+                    o[c4 * 4 + 1] += p * v.y;
+                    o[c4 * 4 + 2] += p * v.z;
+                    o[c4 * 4 + 3] += p * v.w;
+                }
             }
-        }
-        float* op = ctx + (n * L + i) * ldo + h * HD + jg * C::CPL;
+            float* op = ctx + (n * L + i) * ldo + h * HD + jg * C::CPL;
 #pragma unroll
-        for (int c4 = 0; c4 < C::CPL / 4; ++c4)
-            *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+            for (int c4 = 0; c4 < C::CPL / 4; ++c4)
+                *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+        }
     }
 }
 
@@ -402,7 +426,12 @@ static int launch_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
     const size_t lds = (size_t)C::SLOTS * C::FWD_FLOATS * sizeof(float);
     auto kern = relattn_fwd_kernel<L, HD>;
     if (lds > 64 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    const int64_t grid = ceil_div(n_blocks * H, C::SLOTS);
+    // persistent slots (2048 workgroups at most); the slot count must be a multiple of H
+    int64_t grid = std::min<int64_t>(ceil_div(n_blocks * H, C::SLOTS), 2048);
+    int gcd = H, rem = C::SLOTS;
+    while (rem) { const int t = gcd % rem; gcd = rem; rem = t; }
+    const int64_t unit = H / gcd;
+    grid = ceil_div(grid, unit) * unit;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kAttThreads), lds, s, qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks,
                        H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, tokens);
     VQ_CHECK_LAUNCH("relattn_fwd");

@@ -38,7 +38,34 @@ __global__ __launch_bounds__(kVqThreads) void vq_fwd_kernel(const float* __restr
         }
         float best = 0.0f;
         int bi = assign ? 0 : (int)idx_out[r * ncb + c];   // assign == 0: indices are given (label corruption path)
-        for (int k = 0; k < (assign ? K : 0); ++k) {
+        int kstart = 0;
+        if (DSUB > 0 && assign) {
+            // four codes at a time: every distance is still the canonical chain (t ascending, separately rounded sub / mul /
+            // add), but the four chains are independent, so their latencies overlap (one row per lane leaves a single wave
+            // per SIMD with nothing else to issue); candidates are compared in code order with the same strict '<'
+            constexpr int KU = 4;
+            for (; kstart + KU <= K; kstart += KU) {
+                float dd[KU];
+#pragma unroll
+                for (int u = 0; u < KU; ++u) dd[u] = 0.0f;
+#pragma unroll
+                for (int t = 0; t < DSUB; ++t) {
+#pragma unroll
+                    for (int u = 0; u < KU; ++u) {
+                        const float df = __fsub_rn(x[t], lds[(kstart + u) * DSUB + t]);
+                        dd[u] = __fadd_rn(dd[u], __fmul_rn(df, df));
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < KU; ++u) {
+                    if ((kstart + u) == 0 || dd[u] < best) {
+                        best = dd[u];
+                        bi = kstart + u;
+                    }
+                }
+            }
+        }
+        for (int k = kstart; k < (assign ? K : 0); ++k) {
             const float* e = lds + k * dsub;
             float d = 0.0f;
             if (DSUB > 0) {

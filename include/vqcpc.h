@@ -44,6 +44,16 @@ const char* vqcpc_last_error(void);
 int vqcpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Token range check -- the `IndexError: index out of range in self` of nn.Embedding
+ * (VQCPCB/data_processor/data_processor.py:26-32 tables, looked up at bach_cpc_data_processor.py:55-63), made asynchronous:
+ *   clamped[i] = min(max(tokens[i], 0), limits[i % n_voices] - 1);  *flag |= 1 if any id was outside its table.
+ * `limits` is a HOST array of n_voices (<= 16) table sizes (V_c + 1 with the mask token); every kernel of this library
+ * that indexes by token id consumes the clamped copy, and the caller raises when it next reads `flag`.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_check_tokens(const int64_t* tokens, int64_t n, int n_voices, const int32_t* limits, int64_t* clamped, int32_t* flag,
+                       void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Fused per-voice embedding + input projection + positional concatenation.
  * Replaces BachCPCDataProcessor.embed (VQCPCB/data_processor/bach_cpc_data_processor.py:42-68) followed by
  * input_linear and the two positional concatenations of RelativeTransformerDownscaler.forward

@@ -1,0 +1,91 @@
+"""BASELINE.json configurations at their MODEL dimensions against the CPU oracle, at a batch the oracle finishes in
+seconds (every window is independent, so the per-window arithmetic is the configuration's own):
+
+  C1 (configs[1]): d_model 256, 8 heads, ff 1024, [2, 2] layers, product-VQ 2 x 512 codes of dim 16, 8 + 8 blocks
+  C4 (configs[4]): d_model 512, 8 heads of 64, ff 2048, [4, 4] layers, product-VQ 4 x 1024 codes of dim 16, 16 + 16 blocks
+
+fp32-class GEMM modes (exact fp32 MFMA and the bf16x6 split): codebook indices bit-exact, losses within 5e-5, every
+gradient within 5e-4 of the oracle's (relative to the tensor's largest entry).  Both first-layer paths (plain in_proj
+GEMM / block-table lookup) are covered at C1."""
+import pytest
+import torch
+
+from conftest import rel_err
+from oracle import vqcpc_oracle as O
+from test_trainer_gpu import FWD_TOL, GRAD_TOL, build_trainer, first_layer_path, gemm_mode  # noqa: F401  (fixtures)
+
+pytestmark = pytest.mark.gpu
+
+
+def _data_placed_codebooks(cfg, sd, batch):
+    """Codebooks on downscaler outputs of the batch (what `_initialize` does), so that many codes are in use."""
+    st = {}
+    with torch.no_grad():
+        O.encoder_forward(batch['negative_samples'].reshape(-1, 4, 4), sd, cfg, stages=st)
+    zp = st['z'].reshape(-1, cfg['D'])
+    assert zp.shape[0] >= cfg['K'] + 7 * cfg['ncb']
+    dsub = cfg['D'] // cfg['ncb']
+    for c in range(cfg['ncb']):
+        sd[f'encoder.quantizer.embeddings.{c}'] = zp[c * 7:c * 7 + cfg['K'], c * dsub:(c + 1) * dsub].clone() + 0.01
+
+
+_ORACLE_CACHE = {}       # the oracle step is the slow part (seconds): shared by the GEMM-mode / first-layer parametrisations
+
+
+def _oracle_step(cfg, seed):
+    key = (repr(sorted(cfg.items(), key=str)), seed)
+    if key not in _ORACLE_CACHE:
+        sd = O.init_state(cfg, seed=seed)
+        batch = O.synthetic_batch(cfg, seed=seed + 1)
+        _data_placed_codebooks(cfg, sd, batch)
+        otr = O.OracleTrainer(cfg, sd, lr=1e-4)
+        ref = otr.step(batch, train=True)
+        _ORACLE_CACHE[key] = (sd, batch, otr, ref)
+    return _ORACLE_CACHE[key]
+
+
+def _step_vs_oracle(cfg, seed):
+    sd, batch, otr, ref = _oracle_step(cfg, seed)
+    tr = build_trainer(cfg, sd, lr=1e-4)
+    tr.train()
+    loss, out = tr.compute_losses(batch)
+    tr.flat.zero_grad()
+    loss.backward()
+    for k in ('idx_left', 'idx_right', 'idx_negative'):
+        assert torch.equal(out[k].cpu().reshape(ref[k].shape), ref[k]), f'{k}: index assignment differs from the oracle'
+    used = torch.cat([ref[k].reshape(-1, cfg['ncb']) for k in ('idx_left', 'idx_right', 'idx_negative')]).unique().numel()
+    assert used > cfg['K'] // 4, f'only {used} codes in use: the index check would be vacuous'
+    for k in ('loss', 'loss_contrastive', 'loss_quantize'):
+        assert abs(float(out[k].detach()) - float(ref[k].detach())) < FWD_TOL * max(1.0, abs(float(ref[k].detach()))), k
+    worst = 0.0
+    for n, p in tr.named_parameters():
+        e = rel_err(p.grad.cpu(), otr.last_grads[n])
+        worst = max(worst, e)
+        assert e < GRAD_TOL, (n, e)
+    print(f'worst relative gradient error {worst:.2e}')
+    return tr, otr, batch
+
+
+def test_c1_model_dimensions_vs_oracle(first_layer_path):
+    cfg = O.make_cfg('C1', B=8)
+    _step_vs_oracle(cfg, seed=31)
+
+
+def test_c4_model_dimensions_vs_oracle():
+    """configs[4] at B = 4: 1088 blocks of 16 tokens through 4 + 4 layers at d_model 512, 4 x 1024 codes."""
+    cfg = O.make_cfg('C4', B=4)
+    assert cfg['d'] == 512 and cfg['layers'] == [4, 4] and cfg['ncb'] == 4 and cfg['K'] == 1024 and cfg['D'] == 64
+    _step_vs_oracle(cfg, seed=41)
+
+
+def test_c4_product_config_builds_the_same_model():
+    """configs.make_config('C4') (what `bench.py --config C4` runs) has the oracle's C4 parameter shapes."""
+    from vqcpc_bach_amd import configs, getters
+    config = configs.make_config('C4', dropout=0.0)
+    dlg = getters.get_dataloader_generator('bach', 'vqcpc', dict(config['dataloader_generator_kwargs'], device='cuda'))
+    enc = getters.get_encoder('/tmp/vqcpc_test_c4', dlg, config)
+    tr = getters.get_encoder_trainer('/tmp/vqcpc_test_c4', dlg, 'vqcpc', enc, config['auxiliary_networks_kwargs'])
+    ref = O.init_state(O.make_cfg('C4'))
+    got = {n: tuple(p.shape) for n, p in tr.named_parameters()}
+    assert got == {k: tuple(v.shape) for k, v in ref.items()}
+    assert dlg.num_blocks_left == 16 and dlg.num_blocks_right == 16 and config['batch_size'] == 256

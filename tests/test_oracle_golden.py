@@ -43,6 +43,28 @@ def test_vq_ties_pick_first_index():
     assert not (g['idx'] == 1).any()
 
 
+def test_vq_c1_shape_with_reference_data_init():
+    """The C1 quantiser shape (2 x 512 codes of dim 16, 4096 rows) run by the reference WITH its own data-dependent
+    initialisation (vector_quantizer.py:57-70) under torch.manual_seed(init_seed): the oracle's vq_data_init draws
+    the same rows from the global generator, and its canonical-order argmin equals torch's on all 8192 assignments."""
+    g = load_golden('vq_c1_init')
+    z = T(g['z'])
+    flat = z.reshape(-1, z.shape[-1])
+    K, dsub = g['codebooks'].shape[1:]
+    torch.manual_seed(int(g['init_seed']))
+    cbs = O.vq_data_init(flat, [torch.empty(K, dsub) for _ in range(g['codebooks'].shape[0])])
+    assert torch.equal(torch.stack(cbs), T(g['codebooks'])), 'data initialisation must select the reference\'s rows'
+    zq, idx, loss = O.vq_forward(z, cbs, beta=float(g['beta']), squared=True)
+    assert torch.equal(idx, T(g['idx'].astype(np.int64))), f'min top-2 gap in fixture {g["top2_gap"].min():.3e}'
+    assert rel_err(loss, g['loss']) < FWD_TOL
+    assert (T(g['idx'].astype(np.int64)).reshape(-1, 2).unique(dim=0).shape[0]) > 1000    # a non-degenerate assignment
+
+
+def test_epoch_acc_fixture_has_hits():
+    g = load_golden('epoch_tiny_acc')
+    assert (g['eval/accuracy'] > 0).all() and (g['eval/accuracy'] < 1).all(), 'this fixture pins the hit counting'
+
+
 @pytest.mark.parametrize('name', ['relbias_L16', 'relbias_L4'])
 def test_relative_bias_closed_form(name):
     g = load_golden(name)
@@ -101,7 +123,7 @@ def _trainer_from(g, prefix='sd0'):
     return cfg, sd
 
 
-@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir'])
+@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir', 'epoch_tiny_acc'])
 def test_encoder_forward_stages(name):
     g = load_golden(name)
     cfg, sd = _trainer_from(g)
@@ -116,7 +138,7 @@ def test_encoder_forward_stages(name):
     assert rel_err(z_up, g['fwd_zup']) < FWD_TOL
 
 
-@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir', 'epoch_tiny_clip'])
+@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir', 'epoch_tiny_clip', 'epoch_tiny_acc'])
 def test_epoch_eval_and_train(name):
     g = load_golden(name)
     cfg, sd = _trainer_from(g)

@@ -74,7 +74,7 @@ def golden_cfg_sd(g, prefix='sd0'):
     return cfg, sd
 
 
-@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir'])
+@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir', 'epoch_tiny_acc'])
 def test_encoder_forward_golden(name):
     g = load_golden(name)
     cfg, sd = golden_cfg_sd(g)
@@ -109,7 +109,7 @@ def first_layer_path(request):
     D.table_lookup_min_ratio = old
 
 
-@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir', 'epoch_tiny_clip'])
+@pytest.mark.parametrize('name', ['epoch_tiny', 'epoch_tiny_bidir', 'epoch_tiny_clip', 'epoch_tiny_acc'])
 def test_epoch_golden(name, first_layer_path):
     """epoch(train=False), then one training step, against the reference's VQCPCEncoderTrainer.epoch."""
     g = load_golden(name)

@@ -104,6 +104,30 @@ def gen_quantizer(name, R, nb, K, D, ncb, squared, seed, ties=False, scale=1.0):
 
 
 # ----------------------------------------------------------------------------------------------
+# 1b. ProductVectorQuantizer at the C1 quantiser shape (2 x 512 codes of dim 16), including the reference's own
+#     data-dependent initialisation (_initialize, vector_quantizer.py:57-70) under a fixed global seed.
+#     Slim fixture: inputs, the codebooks the reference initialised, indices (int16), loss, top-2 gaps.
+# ----------------------------------------------------------------------------------------------
+def gen_quantizer_init(name, R, K, D, ncb, seed, init_seed):
+    torch.manual_seed(seed)
+    q = ProductVectorQuantizer(codebook_size=K, codebook_dim=D, commitment_cost=0.25, num_codebooks=ncb,
+                               use_batch_norm=False, initialize=True, squared_l2_norm=True)
+    q.eval()
+    z = torch.randn(R, 1, D)
+    torch.manual_seed(init_seed)          # the permutations of _initialize come from the global CPU generator
+    zq, idx, loss = q(z, corrupt_labels=False)
+    assert not q.initialize
+    gaps = []
+    for xc, e in zip(z.view(-1, D).chunk(ncb, dim=1), q.embeddings):
+        d = ((xc.unsqueeze(1) - e.detach().unsqueeze(0)) ** 2).sum(2)
+        top2 = torch.topk(d, 2, dim=1, largest=False)[0]
+        gaps.append((top2[:, 1] - top2[:, 0]))
+    save(name, z=npy(z), codebooks=np.stack([npy(e) for e in q.embeddings]), idx=npy(idx).astype(np.int16),
+         loss=npy(loss), top2_gap=npy(torch.stack(gaps, 1)), init_seed=np.array(init_seed), squared=np.array(True),
+         beta=np.array(0.25))
+
+
+# ----------------------------------------------------------------------------------------------
 # 2. SubsampledRelativeAttention bias and one TransformerEncoderLayerCustom (eval mode)
 # ----------------------------------------------------------------------------------------------
 def gen_relbias(name, n, H, L, hd, seed):
@@ -305,3 +329,8 @@ if __name__ == '__main__':
     bidir = dict(tiny, bidirectional=True, Kl=3, Kr=3, B=4)   # reference needs Kl == Kr for the backward direction
     gen_encoder_and_epoch('epoch_tiny_bidir', bidir, seed=41)
     gen_encoder_and_epoch('epoch_tiny_clip', dict(tiny, qw=60.0, B=5), seed=42)   # global grad norm > 5: clip active
+    # round 2 additions (appended: every generator re-seeds, so the fixtures above are unchanged)
+    gen_quantizer_init('vq_c1_init', R=4096, K=512, D=32, ncb=2, seed=7, init_seed=1234)
+    acc = dict(emb=8, vocab=[11, 11, 11, 11], d=32, H=2, layers=[1, 1], ff=64, D=16, K=64, ncb=1, zdim=8, up_hidden=16,
+               cdim=8, gru_hidden=16, B=16, N=2, Kl=2, Kr=2)
+    gen_encoder_and_epoch('epoch_tiny_acc', acc, seed=43)     # accuracy is not all-zero: pins the hit counting

@@ -21,7 +21,7 @@ def make_student_config(dropout=0.1, **over):
                                   dim_feedforward=2048, attention_bias_type='relative_attention', dropout=dropout),
         'quantizer_type': 'commitment',
         'quantizer_kwargs': dict(num_codebooks=1, codebook_size=32, codebook_dim=3, commitment_cost=0.25,
-                                 use_batch_norm=False, squared_l2_norm=True),
+                                 use_batch_norm=False, squared_l2_norm=True, initialize=True),
         'upscaler_type': None,
         'auxiliary_networks_kwargs': {
             'quantization_weighting': 0.1, 'num_events_masked': 4, 'teacher_type': 'relative',

@@ -194,6 +194,29 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Token range check.  nn.Embedding raises on an id outside its table; the kernels of this library index tables (and an LDS
+// accumulator in the embedding backward) directly, so every token tensor passes through here once: the copy that the
+// kernels consume is clamped into [0, limit[voice]) and `flag` records that a clamp happened (the host raises on it at
+// its next synchronisation point).  voice = flat index % n_voices ((tick, voice) order, voices fastest).
+struct TokenLimits {
+    int v[16];
+};
+__global__ __launch_bounds__(256) void check_tokens_kernel(const int64_t* __restrict__ in, int64_t n, int nv,
+                                                           TokenLimits lim, int64_t* __restrict__ out,
+                                                           int* __restrict__ flag) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = in[i];
+        const int64_t hi = lim.v[(int)(i % nv)] - 1;
+        const int64_t c = t < 0 ? 0 : (t > hi ? hi : t);
+        bad |= c != t;
+        out[i] = c;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
 }  // namespace vq
 
 using namespace vq;
@@ -273,6 +296,21 @@ int vqcpc_adam_step(float* p, float* g, float* m, float* v, int64_t n, float lr,
     hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, (float)(lr / bc1),
                        beta1, beta2, eps, (float)(1.0 / sqrt(bc2)), grad_scale, max_norm, sumsq);
     VQ_CHECK_LAUNCH("adam_step");
+    return VQCPC_OK;
+}
+
+int vqcpc_check_tokens(const int64_t* tokens, int64_t n, int n_voices, const int32_t* limits, int64_t* clamped, int32_t* flag,
+                       void* stream) {
+    if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(tokens && limits && clamped && flag && n > 0 && n_voices >= 1 && n_voices <= 16,
+               "check_tokens: bad arguments (n_voices <= 16)");
+    TokenLimits lim;
+    for (int i = 0; i < 16; ++i) lim.v[i] = i < n_voices ? limits[i] : 1;
+    for (int i = 0; i < n_voices; ++i) VQ_REQUIRE(lim.v[i] >= 1, "check_tokens: empty vocabulary for voice %d", i);
+    int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 2048);
+    hipLaunchKernelGGL(check_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tokens, n, n_voices, lim,
+                       clamped, flag);
+    VQ_CHECK_LAUNCH("check_tokens");
     return VQCPC_OK;
 }
 

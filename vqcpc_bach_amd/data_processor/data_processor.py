@@ -1,4 +1,6 @@
 """Token pre-processing and embedding tables (reference: VQCPCB/data_processor/data_processor.py:7-104)."""
+import ctypes
+
 import torch
 from torch import nn
 
@@ -22,6 +24,36 @@ class DataProcessor(nn.Module):
 
     def preprocess(self, x):
         return cuda_variable(x.long())
+
+    # ---- token range check (nn.Embedding's IndexError, made asynchronous) ---------------------------------------
+    def checked(self, tokens):
+        """int64 device tokens in (..., voice-fastest) order -> a copy clamped into every voice's table range; an id
+        outside its table raises at the next `raise_if_bad_tokens()` (end of epoch()) instead of being used as an
+        address by the kernels (vqcpc_check_tokens)."""
+        from .. import hip
+        tokens = tokens.contiguous()
+        if getattr(self, '_token_flag', None) is None or self._token_flag.device != tokens.device:
+            self._token_flag = torch.zeros(1, dtype=torch.int32, device=tokens.device)
+            self._token_limits = (ctypes.c_int32 * self.num_channels)(*[e.weight.shape[0] for e in self.embeddings])
+        out = torch.empty_like(tokens)
+        hip.call('vqcpc_check_tokens', tokens, tokens.numel(), self.num_channels, self._token_limits, out,
+                 self._token_flag)
+        return out
+
+    def bad_token_flag(self):
+        """Device int32[1] (or None if nothing was checked yet): non-zero once any token id was out of range."""
+        return getattr(self, '_token_flag', None)
+
+    def raise_if_bad_tokens(self, flag_value=None):
+        flag = self.bad_token_flag()
+        if flag is None:
+            return
+        if flag_value is None:
+            flag_value = int(flag.item())
+        if flag_value:
+            flag.zero_()
+            raise IndexError(f'token id out of range: voice c takes ids in [0, {[e.weight.shape[0] for e in self.embeddings]}[c]) '
+                             '(nn.Embedding would have raised "index out of range in self")')
 
     def embed(self, x):
         """(..., num_channels) -> (..., num_channels, embedding_size)"""

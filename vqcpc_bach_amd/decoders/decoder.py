@@ -251,7 +251,7 @@ class Decoder(nn.Module):
 
     def forward(self, source, target):
         """API-compatible `Decoder.forward` (:431-543): source (B, S) merged codes, target (B, events, channels)."""
-        target = self.data_processor.preprocess(target)
+        target = self.data_processor.checked(self.data_processor.preprocess(target))
         loss, logits, att_dec, att_enc = self.compute_loss(source.to(target.device), target)
         return {'loss': loss, 'attentions_decoder': att_dec, 'attentions_encoder': att_enc,
                 'weights_per_category': logits, 'monitored_quantities': {'loss': loss.item()}}
@@ -261,7 +261,7 @@ class Decoder(nn.Module):
         return self.encoder.encode_indices(x, merged=True)
 
     def train_step(self, tensor_dict, train=True):
-        x = self.data_processor.preprocess(tensor_dict['x'])
+        x = self.data_processor.checked(self.data_processor.preprocess(tensor_dict['x']))
         codes = self.encode(tensor_dict['x'])
         with torch.set_grad_enabled(train):
             loss, _, _, _ = self.compute_loss(codes, x)
@@ -286,7 +286,10 @@ class Decoder(nn.Module):
         if self.dp.distributed:
             self.dp.all_reduce_sum_(total)
             total /= self.dp.world_size
-        return {'loss': float(total.item())}                     # the only host sync of the epoch
+        means = {'loss': float(total.item())}                    # the host sync of the epoch
+        self.data_processor.raise_if_bad_tokens()
+        self.encoder.data_processor.raise_if_bad_tokens()
+        return means
 
     def train_model(self, batch_size, num_batches, num_epochs, lr, schedule_lr, plot=False, num_workers=0, **kwargs):
         best_val = 1e8

@@ -42,6 +42,10 @@ class Encoder(nn.Module):
         self.quantizer.load_state_dict(torch.load(f'{model_dir}/quantizer', map_location=ml))
         if self.upscaler:
             self.upscaler.load_state_dict(torch.load(f'{model_dir}/upscaler', map_location=ml))
+        # loaded codebooks must never be overwritten by the data-dependent initialisation of the first batch
+        # (main_encoder.py:51 builds the quantizer with initialize = not load for the same reason)
+        if hasattr(self.quantizer, 'initialize'):
+            self.quantizer.initialize = False
 
     # ---- forward ---------------------------------------------------------------------------------------------
     def encode_many(self, xs, corrupt_flags=None):
@@ -58,6 +62,7 @@ class Encoder(nn.Module):
         toks = [t if t.shape[-1] == tpb else t.reshape(t.shape[0], -1, tpb) for t in toks]
         sizes = [t.shape[0] * t.shape[1] for t in toks]
         tokens = torch.cat([t.reshape(-1, tpb) for t in toks], dim=0) if len(toks) > 1 else toks[0].reshape(-1, tpb)
+        tokens = self.data_processor.checked(tokens)
         z = self.downscaler.forward_tokens(tokens.unsqueeze(0), self.data_processor)[0]        # (R, D)
         starts = [sum(sizes[:i]) for i in range(len(sizes))]
         corrupt_rows = None
@@ -97,6 +102,7 @@ class Encoder(nn.Module):
         tpb = self.downscaler.sequence_length
         t = self.data_processor.preprocess(x)
         t = t if t.shape[-1] == tpb else t.reshape(t.shape[0], -1, tpb)
+        t = self.data_processor.checked(t)
         z = self.downscaler.forward_tokens(t.unsqueeze(0), self.data_processor)[0]             # (batch, nb, D)
         q = self.quantizer
         assert not q.initialize, 'the codebooks are still waiting for their data-dependent initialisation'

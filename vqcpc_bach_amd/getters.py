@@ -111,7 +111,7 @@ def get_encoder(model_dir, dataloader_generator, config):
         quantizer = ProductVectorQuantizer(codebook_size=quantizer_kwargs['codebook_size'],
                                            num_codebooks=quantizer_kwargs['num_codebooks'],
                                            codebook_dim=quantizer_kwargs['codebook_dim'],
-                                           initialize=quantizer_kwargs.get('initialize', True),
+                                           initialize=quantizer_kwargs['initialize'],
                                            squared_l2_norm=quantizer_kwargs['squared_l2_norm'],
                                            use_batch_norm=quantizer_kwargs['use_batch_norm'],
                                            commitment_cost=quantizer_kwargs['commitment_cost'])

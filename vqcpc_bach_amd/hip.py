@@ -20,6 +20,7 @@ SIGNATURES = {
     'vqcpc_abi_version': (c_int, []),
     'vqcpc_last_error': (ctypes.c_char_p, []),
     'vqcpc_dropout_mask': (c_int, [c_ptr, c_i64, c_f32, c_u64, c_ptr]),
+    'vqcpc_check_tokens': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     'vqcpc_embed_pos_fwd': (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
     'vqcpc_embed_pos_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int, c_int, c_int]),
     'vqcpc_embed_pos_bwd': (c_int, [c_ptr, c_i64, c_int, c_int, c_int, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,

@@ -53,7 +53,9 @@ class ProductVectorQuantizer(VectorQuantizer):
             'not enough elements in a batch to initialise the clusters. You need to increase the batch dimension.'
         with torch.no_grad():
             for k, embedding in enumerate(self.embeddings):
-                perm = torch.randperm(flat_input.size(0), device=flat_input.device)[:embedding.size(0)]
+                # drawn from the global CPU generator like the reference's `torch.randperm(flat_input.size(0))` (:65),
+                # so `torch.manual_seed(s)` before the first batch selects the same rows as it does there
+                perm = torch.randperm(flat_input.size(0))[:embedding.size(0)].to(flat_input.device)
                 dsub = embedding.size(1)
                 embedding.copy_(flat_input[perm, k * dsub:(k + 1) * dsub])    # in place: parameters may be flat views
             if self.init_broadcast is not None:
@@ -72,7 +74,7 @@ class ProductVectorQuantizer(VectorQuantizer):
         given = None
         if self.training and corrupt_labels:                                      # :119-132
             with torch.no_grad():
-                _, idx, _ = ops.VQFn.apply(flat.detach(), codebooks.detach(), self._commitment_cost, self.squared_l2_norm)
+                idx = ops.vq_assign(flat.detach(), codebooks.detach())     # index-only search; the pass below is a lookup
                 rnd = torch.randint_like(idx, low=0, high=self.codebook_size)
                 keep = torch.rand(idx.shape, device=idx.device) > 0.05
                 if corrupt_rows is not None:

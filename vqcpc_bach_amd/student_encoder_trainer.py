@@ -184,7 +184,7 @@ class StudentEncoderTrainer(EncoderTrainer):
     overlap_streams = True      # teacher and encoder/decoder are independent graphs: run them on two HIP streams
 
     def compute_losses(self, tensor_dict, masked_event_index=None):
-        x = self.teacher.data_processor.preprocess(tensor_dict['x'])
+        x = self.teacher.data_processor.checked(self.teacher.data_processor.preprocess(tensor_dict['x']))
         m = self.draw_masked_event(x.shape[1]) if masked_event_index is None else int(masked_event_index)
         if self.overlap_streams and x.is_cuda:
             # at the reference's batch of 8 every GEMM has only 3072 rows and fills a fraction of the 256 CUs: the two
@@ -241,4 +241,7 @@ class StudentEncoderTrainer(EncoderTrainer):
         if self.dp.distributed:
             self.dp.all_reduce_sum_(sums)
             sums /= self.dp.world_size
-        return dict(zip(self.KEYS, sums.cpu().tolist()))      # the only host sync of the epoch
+        means = dict(zip(self.KEYS, sums.cpu().tolist()))     # the host sync of the epoch
+        self.teacher.data_processor.raise_if_bad_tokens()
+        self.encoder.data_processor.raise_if_bad_tokens()
+        return means

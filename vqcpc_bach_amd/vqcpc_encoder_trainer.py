@@ -194,8 +194,12 @@ class VQCPCEncoderTrainer(EncoderTrainer):
                           accuracy=accuracy, idx_left=idx_left, idx_right=idx_right, idx_negative=idx_neg)
 
     def _count_codewords(self, *idx_tensors):
-        """len(torch.unique(.)) without a host sync: sort + count boundaries, on merged product-codebook indices."""
-        K = self.encoder.quantizer.codebook_size
+        """len(torch.unique(.)) without a host sync: sort + count boundaries.  With a product quantiser
+        (num_codebooks > 1, which the reference's epoch() cannot run: SURVEY.md section 0 defect 1) the count is over
+        merged code tuples sum_c idx_c K^c -- the number of distinct product codes in use.  Without a quantiser
+        (NoQuantization returns encoding_indices None) the counters stay 0, as in the reference (:325)."""
+        if any(i is None for i in idx_tensors):
+            return torch.zeros((), dtype=torch.float32, device=self.flat.flat.device)
         merged = torch.cat([self.encoder.merge_codes(i.reshape(-1, i.shape[-1])) for i in idx_tensors])
         s = torch.sort(merged)[0]
         return (s[1:] != s[:-1]).sum().float() + 1.0
@@ -221,6 +225,7 @@ class VQCPCEncoderTrainer(EncoderTrainer):
         self.train() if train else self.eval()
         k_r = self.dataloader_generator.num_blocks_right
         sums = torch.zeros(5 + k_r, dtype=torch.float32, device=dev)   # loss, quantize, contrastive, ncw, ncw_neg, acc[k]
+        dproc = self.encoder.data_processor
         n = 0
         for tensor_dict in islice(data_loader, num_batches):
             out = self.train_step(tensor_dict, train=train, corrupt_labels=corrupt_labels)
@@ -233,7 +238,12 @@ class VQCPCEncoderTrainer(EncoderTrainer):
         if self.dp.distributed:                                       # metrics are means over ranks
             self.dp.all_reduce_sum_(sums)
             sums /= self.dp.world_size
+        flag = dproc.bad_token_flag()
+        if flag is not None:
+            sums = torch.cat([sums, flag.float()])
         host = sums.cpu().tolist()                                    # the only host sync of the epoch
+        if flag is not None:
+            dproc.raise_if_bad_tokens(host.pop())                     # nn.Embedding's IndexError, one epoch late at most
         means = dict(loss=host[0], accuracy=host[5:], loss_quantize=host[1], loss_contrastive=host[2],
                      num_codewords=host[3], num_codewords_negative=host[4])
         means['loss_monitor'] = -sum(means['accuracy']) / len(means['accuracy'])

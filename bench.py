@@ -5,7 +5,9 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-One "step" = one full iteration of VQCPCEncoderTrainer.epoch(train=True) on one synthetic batch per rank (BASELINE.json
+The timed region is `VQCPCEncoderTrainer.epoch(train=True, num_batches=steps)` itself (reference
+vqcpc_encoder_trainer.py:169-354): per-step codeword counts, metric accumulation and the
+end-of-epoch host read included.  One "step" = one iteration of it on one synthetic batch per rank (BASELINE.json
 configs[1] = C1: seq_len 256 = 8+8 blocks, B = 256 windows / GPU, 15 negatives, product-VQ 2x512, d_model 256, dropout
 0.1): forward of all 34 816 blocks, InfoNCE + quantisation loss, backward, RCCL all-reduce, global-norm clip, Adam.
 Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
@@ -39,8 +41,8 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0        # v_mfma_f32_32x32x16_bf16, dense
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=100)     # >= 50 timed steps after >= 10 warm-up
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--config', default='C1')
     ap.add_argument('--batch', type=int, default=None, help='windows per GPU (default: the config\'s)')
     ap.add_argument('--dropout', type=float, default=None, help='default: 0.1 (0.2 for --config DEC, as its reference config)')
@@ -259,17 +261,42 @@ def main():
         pool = [{k: v.pin_memory() for k, v in b.items()} for b in pool]
     torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        trainer.train_step(pool[i % len(pool)], train=True)
+    import contextlib
+
+    def batches(n, sample):
+        """n batches from the resident pool; HIP events bracket the GEMM launches of every 4th step when `sample`
+        (bracketing all of them costs ~2 % of the step)"""
+        for i in range(n):
+            timer.enabled = sample and (not args.no_kernel_timing) and (i % 4 == 0)
+            yield pool[i % len(pool)]
+        timer.enabled = False
+
+    def run_epoch(n, sample):
+        """THE METRIC: `trainer.epoch(train=True)` (vqcpc_encoder_trainer.py:169-354) over n batches -- forward, losses,
+        backward, all-reduce, clip, Adam, the per-step codeword counts / metric accumulation and the end-of-epoch
+        host read of the means.  Its `lr:` print goes to stderr so that the JSON line stays alone on stdout."""
+        kw = {} if decoder_step else dict(corrupt_labels=False)
+        with contextlib.redirect_stdout(sys.stderr):
+            return trainer.epoch(batches(n, sample), train=True, num_batches=n, **kw)
+
+    run_epoch(args.warmup, False)                   # includes the data-dependent codebook initialisation (step 0)
     torch.cuda.synchronize()
+    # (a) bare training steps, no metric bookkeeping: reported next to the metric when the two differ
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        # HIP events bracket the GEMM launches of every 4th timed step (all of them cost ~2 % of the step)
-        timer.enabled = (not args.no_kernel_timing) and (i % 4 == 0)
-        out = trainer.train_step(pool[i % len(pool)], train=True)
-    t_enqueued = time.perf_counter() - t0          # host time to enqueue all steps (no sync inside a step)
+    for b in batches(args.steps, False):
+        trainer.train_step(b, train=True)
+    t_enqueued = time.perf_counter() - t0          # host time to enqueue the steps (no sync inside a step)
+    torch.cuda.synchronize()
+    dp.barrier()
+    torch.cuda.synchronize()
+    dt_steps = dp.max_over_ranks(time.perf_counter() - t0)
+    # (b) the timed region of `value`: EXACTLY args.steps iterations of epoch(train=True)
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    means = run_epoch(args.steps, True)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
@@ -279,7 +306,7 @@ def main():
     flush_c_stdio()
     dp.barrier()                                    # every rank has emitted whatever its libraries had buffered
     student = config['training_method'].lower() == 'student'
-    last_loss = float(out if decoder_step else (out['loss_encdec'] if student else out['loss']))
+    last_loss = float(means['loss_encdec'] if student else means['loss'])
 
     seq_len = 384 if (student or decoder_step) else 16 * (dlg.num_blocks_left + dlg.num_blocks_right)
     timed_steps = max(1, len(range(0, args.steps, 4)))
@@ -327,7 +354,11 @@ def main():
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
                          'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3)} if tn else None),
             'final_loss': round(last_loss, 5),
-            'host_enqueue_ms_per_step': round(1e3 * t_enqueued / args.steps, 3),
+            'timed': 'trainer.epoch(train=True, num_batches=steps): steps + per-step metric bookkeeping + end-of-epoch host read',
+            'train_step_only': {'value': round(B * dp.world_size * args.steps / dt_steps, 2),
+                                'ms_per_step': round(1e3 * dt_steps / args.steps, 3),
+                                'host_enqueue_ms_per_step': round(1e3 * t_enqueued / args.steps, 3),
+                                'note': 'same steps without epoch()\'s metric bookkeeping; not the metric'},
         }
         if student:     # BASELINE configs[3]: an extra measurement, not the headline metric
             line['metric'], line['unit'] = 'student-train sequences/sec (Bach 4-voice, 24 beats = 384 tokens)', 'sequences/s'

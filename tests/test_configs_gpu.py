@@ -19,10 +19,13 @@ pytestmark = pytest.mark.gpu
 
 def _data_placed_codebooks(cfg, sd, batch):
     """Codebooks on downscaler outputs of the batch (what `_initialize` does), so that many codes are in use."""
-    st = {}
+    zs = []
     with torch.no_grad():
-        O.encoder_forward(batch['negative_samples'].reshape(-1, 4, 4), sd, cfg, stages=st)
-    zp = st['z'].reshape(-1, cfg['D'])
+        for x in (batch['negative_samples'].reshape(-1, 4, 4), batch['x_left'], batch['x_right']):
+            st = {}
+            O.encoder_forward(x, sd, cfg, stages=st)
+            zs.append(st['z'].reshape(-1, cfg['D']))
+    zp = torch.cat(zs)
     assert zp.shape[0] >= cfg['K'] + 7 * cfg['ncb']
     dsub = cfg['D'] // cfg['ncb']
     for c in range(cfg['ncb']):

@@ -1,0 +1,94 @@
+"""One rank of tests/test_multigpu_gpu.py (launched by torch.distributed.run, one process per GPU, RCCL).
+
+Every rank builds the same model from DIFFERENT seeds (so only the rank-0 broadcast can make them equal), trains 3 steps
+on its shard of a global batch and writes what it observed to <out_dir>/r<rank>.pt; the launching test asserts on it."""
+import hashlib
+import os
+import sys
+
+os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+
+import torch  # noqa: E402
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, 'tests'))
+
+from oracle import vqcpc_oracle as O  # noqa: E402
+
+
+def digest(t):
+    return hashlib.sha256(t.detach().cpu().contiguous().numpy().tobytes()).hexdigest()
+
+
+def main():
+    out_dir = sys.argv[1]
+    from test_trainer_gpu import build_trainer
+    from vqcpc_bach_amd import hip
+    from vqcpc_bach_amd.parallel import DataParallelContext
+    hip.load()
+    hip.set_gemm_mode(1)
+    dp = DataParallelContext()
+    rank, world = dp.rank, dp.world_size
+    per_rank = 4
+    cfg = O.make_cfg(emb=16, vocab=[30] * 4, d=64, H=4, layers=[2, 1], ff=128, D=16, K=32, ncb=2, zdim=16, up_hidden=32,
+                     cdim=16, gru_hidden=32, B=per_rank * world, N=5, Kl=3, Kr=3)
+    sd0 = O.init_state(cfg, seed=100)                       # the model every rank must end up with (rank 0's)
+    sd_mine = O.init_state(cfg, seed=100 + rank)            # what this rank starts from before the broadcast
+    full = O.synthetic_batch(cfg, seed=7)
+    shard = {k: v[rank * per_rank:(rank + 1) * per_rank] for k, v in full.items()}
+
+    torch.manual_seed(1234 + rank)                          # the data-init permutation differs per rank on purpose
+    tr = build_trainer(cfg, sd_mine, lr=1e-3)               # init_optimizers() broadcasts rank 0's flat parameter buffer
+    assert tr.dp.world_size == world and tr.dp.distributed == dp.distributed
+    names = [n for n, _ in tr.named_parameters()]
+    init_equal = all(torch.equal(p.detach().cpu(), sd0[n]) for n, p in tr.named_parameters())
+
+    # data-dependent codebook initialisation on the first forward: rank 0's codebooks everywhere
+    q = tr.encoder.quantizer
+    q.initialize = True
+    tr.eval()
+    with torch.no_grad():
+        tr.compute_losses(shard)
+    cb = torch.stack([e.detach() for e in q.embeddings]).contiguous()
+    gathered = [torch.empty_like(cb) for _ in range(world)]
+    if tr.dp.distributed:
+        torch.distributed.all_gather(gathered, cb)
+    else:
+        gathered = [cb]
+    codebook_equal = all(torch.equal(g, gathered[0]) for g in gathered) and not q.initialize
+
+    # gradient of the GLOBAL batch from the oracle (same codebooks), vs all-reduced mean of the shard gradients
+    sd_ref = {n: p.detach().cpu().clone() for n, p in tr.named_parameters()}
+    otr = O.OracleTrainer(cfg, sd_ref, lr=1e-3)
+    ref = otr.step(full, train=True)
+    tr.train()
+    loss, out = tr.compute_losses(shard)
+    tr.flat.zero_grad()
+    loss.backward()
+    tr.dp.all_reduce_sum_(tr.flat.flat_grad)
+    tr.flat.flat_grad.mul_(1.0 / world)
+    grad_worst = 0.0
+    for n, p in tr.named_parameters():
+        r = otr.last_grads[n]
+        grad_worst = max(grad_worst, float((p.grad.cpu() - r).abs().max() / (r.abs().max() + 1e-30)))
+    lo, hi = rank * per_rank, (rank + 1) * per_rank
+    idx_equal = (torch.equal(out['idx_left'].cpu(), ref['idx_left'][lo:hi]) and
+                 torch.equal(out['idx_right'].cpu(), ref['idx_right'][lo:hi]) and
+                 torch.equal(out['idx_negative'].cpu().reshape(per_rank, -1), ref['idx_negative'].reshape(cfg['B'], -1)[lo:hi]))
+
+    # three optimiser steps through the product's own train_step (all-reduce + grad_scale inside)
+    batches = [O.synthetic_batch(cfg, seed=20 + i) for i in range(3)]
+    for b in batches:
+        tr.train_step({k: v[lo:hi] for k, v in b.items()}, train=True)
+    m = tr.epoch(iter([{k: v[lo:hi] for k, v in full.items()}]), train=False, num_batches=1, corrupt_labels=False)
+    torch.cuda.synchronize()
+    torch.save(dict(rank=rank, world=world, init_equal=init_equal, codebook_equal=codebook_equal, grad_worst=grad_worst,
+                    idx_equal=idx_equal, param_digest=digest(tr.flat.flat), loss_global=m['loss'], names=len(names)),
+               os.path.join(out_dir, f'r{rank}.pt'))
+    dp.barrier()
+    dp.shutdown()
+
+
+if __name__ == '__main__':
+    main()

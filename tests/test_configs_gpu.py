@@ -5,7 +5,8 @@ seconds (every window is independent, so the per-window arithmetic is the config
   C4 (configs[4]): d_model 512, 8 heads of 64, ff 2048, [4, 4] layers, product-VQ 4 x 1024 codes of dim 16, 16 + 16 blocks
 
 fp32-class GEMM modes (exact fp32 MFMA and the bf16x6 split): codebook indices bit-exact, losses within 5e-5, every
-gradient within 5e-4 of the oracle's (relative to the tensor's largest entry).  Both first-layer paths (plain in_proj
+gradient within 5e-4 of the oracle's (relative to the tensor's largest entry) -- on parameters whose relu gates are not
+within rounding of zero (see _condition_relu_gates).  Both first-layer paths (plain in_proj
 GEMM / block-table lookup) are covered at C1."""
 import pytest
 import torch
@@ -32,6 +33,43 @@ def _data_placed_codebooks(cfg, sd, batch):
         sd[f'encoder.quantizer.embeddings.{c}'] = zp[c * 7:c * 7 + cfg['K'], c * dsub:(c + 1) * dsub].clone() + 0.01
 
 
+class _ReluProbe:
+    """Records the argument of every torch.relu call of the oracle (the FFN pre-activations, in call order)."""
+
+    def __enter__(self):
+        self.real, self.calls = torch.relu, []
+        torch.relu = lambda x: (self.calls.append(x.detach()), self.real(x))[1]
+        return self
+
+    def __exit__(self, *exc):
+        torch.relu = self.real
+
+
+def _condition_relu_gates(cfg, sd, batch, tau=5e-6, rounds=10):
+    """relu'(0) is a genuine discontinuity of the model: at these sizes (millions of hidden units per step) a handful of
+    FFN pre-activations land within fp32 rounding of zero, and whether such a unit's gate is open is decided by the last
+    ulp of a 256- or 512-term dot product -- two correct fp32 implementations (this product and the oracle, or the oracle
+    in fp32 and in fp64: tools/diag_grad_error.py) then differ by that unit's whole gradient contribution (measured:
+    up to 6e-3 of the largest entry of linear1.weight's gradient, 1e-4..1e-3 on everything below it).  To keep the
+    comparison well-posed the TEST PARAMETERS are chosen so that no pre-activation of the oracle lies within `tau` of
+    zero: the bias of an offending hidden unit is nudged by 4 tau (a different, equally arbitrary, random model)."""
+    names = [f'encoder.downscaler.transformers.{s}.layers.{l}.linear1.bias'
+             for s, nl in enumerate(cfg['layers']) for l in range(nl)]
+    for _ in range(rounds):
+        with _ReluProbe() as probe, torch.no_grad():
+            O.cpc_losses(batch, sd, cfg)
+        assert len(probe.calls) % len(names) == 0
+        dirty = 0
+        for i, pre in enumerate(probe.calls):
+            bad = (pre.abs() < tau).reshape(-1, pre.shape[-1]).any(0)
+            if bool(bad.any()):
+                sd[names[i % len(names)]][bad] += 4 * tau
+                dirty += int(bad.sum())
+        if not dirty:
+            return
+    raise AssertionError('could not move every FFN pre-activation away from zero')
+
+
 _ORACLE_CACHE = {}       # the oracle step is the slow part (seconds): shared by the GEMM-mode / first-layer parametrisations
 
 
@@ -41,6 +79,7 @@ def _oracle_step(cfg, seed):
         sd = O.init_state(cfg, seed=seed)
         batch = O.synthetic_batch(cfg, seed=seed + 1)
         _data_placed_codebooks(cfg, sd, batch)
+        _condition_relu_gates(cfg, sd, batch)
         otr = O.OracleTrainer(cfg, sd, lr=1e-4)
         ref = otr.step(batch, train=True)
         _ORACLE_CACHE[key] = (sd, batch, otr, ref)

@@ -233,6 +233,37 @@ def test_gemm_nt_bf16x6_epilogues(ops, bf16x6, M, N, K):
     assert float(dst[1::4].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('M,N,K', [(512, 256, 64), (1024, 768, 256), (256 * 300, 256, 128), (2048, 1024, 1024), (256 * 130, 512, 64)])
+def test_gemm_nt_bf16x6_dma_kernel_is_bit_identical_to_the_register_staged_kernel(ops, M, N, K):
+    """gemm_nt_x6_dma_kernel (operands global -> LDS by DMA, fragments split per wave) against gemm_nt_x6_pp_kernel
+    (global -> registers -> split -> LDS): same exact split, same MFMA order per K tile -> bitwise-equal outputs, for every
+    epilogue of the 256-tile path, with several output tiles per persistent workgroup (300 / 260 tiles on 256 CUs) and
+    strided operand / output rows; and against the fp64 product."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    gate, add = torch.randn(M, N, generator=gen), torch.randn(M, N, generator=gen)
+    ad, bd, biasd, gated, addd = dev(a), dev(b), dev(bias), dev(gate), dev(add)
+    big = dev(torch.randn(2 * M, K, generator=gen))
+    outs = {}
+    try:
+        for mode in (17, 1):                      # 17: LDS-DMA kernel, 1: register-staged ping-pong kernel
+            hip.set_gemm_mode(mode)
+            dst = torch.zeros(2 * M, N, device='cuda')
+            ops.gemm_nt(big[::2], bd, bias=biasd, out=dst[::2])
+            outs[mode] = [ops.gemm_nt(ad, bd), ops.gemm_nt(ad, bd, bias=biasd), ops.gemm_nt(ad, bd, bias=biasd, act=1),
+                          ops.gemm_nt(ad, bd, bias=biasd, act=1, drop_p=0.25, seed=5),
+                          ops.gemm_nt(ad, bd, gate=gated, gate_scale=1.5), ops.gemm_nt(ad, bd, add=addd), dst]
+    finally:
+        hip.set_gemm_mode(0)
+    for x, y in zip(outs[1], outs[17]):
+        assert torch.equal(x, y)
+    ref = a.double() @ b.double().t()
+    assert rel_err(outs[17][0].cpu(), ref) < 2e-6 * max(1, K ** 0.5)
+    assert rel_err(outs[17][5].cpu(), ref + add.double()) < 2e-6 * max(1, K ** 0.5)
+    assert float(outs[17][6][1::2].abs().max()) == 0.0
+
+
 def test_gemm_nt_bf16x6_256_tile_is_transpose_detecting(ops, bf16x6):
     n = 512
     a = torch.randint(-7, 8, (n, 64)).float()

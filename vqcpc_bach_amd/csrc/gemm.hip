@@ -14,74 +14,9 @@
 
 #include <string.h>
 
-#include "common.h"
+#include "gemm_common.h"
 
 namespace vq {
-
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-
-constexpr int BM = 128, BN = 128, BK = 32;
-constexpr int LDS_S = BK + 4;   // padded row stride (floats) of the NT operand tiles
-constexpr int kGemmThreads = 256;
-
-struct EpiParams {
-    const float* bias;
-    int act;
-    uint32_t thr;
-    float inv_keep;
-    uint64_t seed;
-    const float* gate;
-    int64_t ldgate;
-    float gate_scale;
-    const float* add;
-    int64_t ldadd;
-    const float* add2;   // second residual (only honoured together with `add`)
-    int64_t ldadd2;
-    int64_t row0;        // global row of the first row of this launch (a GEMM may be cut into two launches by rows): only
-                         // the dropout element index needs it
-};
-
-// epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)
-enum { E_BIAS = 1, E_RELU = 2, E_DROP = 4, E_GATE = 8, E_ADD = 16, E_RUNTIME = 32, E_ADD2 = 64 };
-
-// bijective XCD-aware remap: consecutive tiles (which share an A row panel) land on the same XCD / L2
-__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
-    const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, loc = bid / 8;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + loc;
-}
-
-// ---- bf16x6 helpers -------------------------------------------------------------------------------------------------
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-constexpr int kX6Stride = BK + 8;                    // bf16 per LDS row: 80 B -> conflict-free ds_read_b128 across 16 rows
-constexpr int kX6Plane = BM * kX6Stride * 2;         // bytes per plane (BM == BN)
-
-// exact 3-way split of an fp32 value into bf16 pieces by truncation: x == h + m + l (as fp32 values whose low 16 bits are 0)
-__device__ __forceinline__ void split3(float x, uint32_t& h, uint32_t& m, uint32_t& l) {
-    h = __float_as_uint(x) & 0xFFFF0000u;
-    const float r = x - __uint_as_float(h);
-    m = __float_as_uint(r) & 0xFFFF0000u;
-    l = __float_as_uint(r - __uint_as_float(m));     // at most 8 significant bits are left: truncation is exact
-}
-// pack the high halves of two fp32 bit patterns into one dword (element 0 in the low half)
-__device__ __forceinline__ uint32_t pack_hi(uint32_t e0, uint32_t e1) { return __builtin_amdgcn_perm(e1, e0, 0x07060302u); }
-// MODE 2 ("bf16"): ONE bf16 piece per operand, round-to-nearest-even like a torch .bfloat16() cast (finite inputs)
-__device__ __forceinline__ uint32_t round_bf16(float x) {
-    const uint32_t u = __float_as_uint(x);
-    return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
-}
-__device__ __forceinline__ uint2 round4_bf16(const float4& v) {
-    return make_uint2(pack_hi(round_bf16(v.x), round_bf16(v.y)), pack_hi(round_bf16(v.z), round_bf16(v.w)));
-}
-__device__ __forceinline__ void split3x4(const float4& v, uint2& h, uint2& m, uint2& l) {
-    uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;
-    split3(v.x, h0, m0, l0);
-    split3(v.y, h1, m1, l1);
-    split3(v.z, h2, m2, l2);
-    split3(v.w, h3, m3, l3);
-    h = make_uint2(pack_hi(h0, h1), pack_hi(h2, h3));
-    m = make_uint2(pack_hi(m0, m1), pack_hi(m2, m3));
-    l = make_uint2(pack_hi(l0, l1), pack_hi(l2, l3));
-}
 
 // FULL: M % 128 == 0, N % 128 == 0, K % 32 == 0 -> no bounds checks anywhere (all hot-path shapes).
 // Two LDS buffers: tile t+1 is staged (global -> registers -> other buffer) while tile t feeds the MFMAs; one barrier
@@ -1127,6 +1062,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const flo
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
 static std::atomic<int> g_gemm_mode{-1};
 static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups (A/B switch)
+static std::atomic<int> g_use_dma{0};  // bf16x6 NT 256-tile: LDS-DMA operand delivery (gemm_dma.hip) instead of register staging
 static std::atomic<int> g_use_t2{1};   // bf16x6 NT: use the 256x256 tile kernel where shapes allow (A/B switch)
 static int gemm_mode() {
     int m = g_gemm_mode.load(std::memory_order_relaxed);
@@ -1301,6 +1237,8 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         const double eff256 = r256 / ceil(r256), eff128 = r128 / ceil(r128);
         t2_ok = eff256 * 1.08 >= eff128;
     }
+    if (t2_ok && g_use_dma.load(std::memory_order_relaxed) && gemm_nt_dma_ok(M, N, K, flags))
+        return gemm_nt_dma_launch(A, lda, B, ldb, C, ldc, M, N, K, flags, ep, st);
     if (t2_ok) {
         const int tn2 = N / kT2;
         const int tiles2 = (int)((M / kT2) * tn2);
@@ -1378,8 +1316,13 @@ extern "C" {
 int vqcpc_gemm_set_mode(int mode) {
     // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing);
     // 8 = plain bf16 operands (one bf16 MFMA per product, fp32 accumulation)
+    // +16: 256-tile NT kernel with LDS-DMA operand delivery (gemm_dma.hip) instead of register staging (A/B switch; the
+    // register-staged ping-pong kernel is 3-5 % faster: an LDS-DMA instruction costs ~90 issue cycles on its SIMD)
+    const int use_dma = (mode >= 16 && mode < 32) ? 1 : 0;
+    if (use_dma) mode -= 16;
     VQ_REQUIRE((mode >= 0 && mode <= 7) || mode == 8,
-               "gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong] or 8 (bf16)");
+               "gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong, +16: LDS-DMA kernel] or 8 (bf16)");
+    g_use_dma.store(use_dma, std::memory_order_relaxed);
     if (mode == 8) {
         g_gemm_mode.store(2, std::memory_order_relaxed);
         return VQCPC_OK;

@@ -54,6 +54,7 @@ def parse():
                     help='batches start in (pinned) host memory: the PCIe-inclusive rate quoted in DESIGN.md, never `value`')
     ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', 'bf16', '0', '1', '8'],
                     help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')
+    ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM times of the sampled steps, to stderr')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
 
@@ -63,7 +64,7 @@ class GemmTimer:
     on: torch's current stream, which is the stream handle passed through the C ABI)."""
 
     def __init__(self):
-        self.records = {'gemm_nt': [], 'gemm_tn': []}
+        self.records = {'gemm_nt': [], 'gemm_tn': [], 'cast_bf16': []}
         self.enabled = False
 
     def install(self, ops):
@@ -77,8 +78,11 @@ class GemmTimer:
             e0.record()
             out = raw_nt(a, b, *args, **kw)
             e1.record()
+            epi = '+'.join(k for k in ('bias', 'act', 'drop_p', 'gate', 'add', 'add2')
+                           if kw.get(k) is not None and (torch.is_tensor(kw[k]) or kw[k] != 0)) or 'none'
             timer.records['gemm_nt'].append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
-                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[0])))
+                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[0]),
+                                             (a.shape[0], b.shape[0], a.shape[1], epi)))
             return out
 
         def gemm_tn(a, b, *args, **kw):
@@ -89,10 +93,66 @@ class GemmTimer:
             out = raw_tn(a, b, *args, **kw)
             e1.record()
             timer.records['gemm_tn'].append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1],
-                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[1] * b.shape[1])))
+                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[1] * b.shape[1]),
+                                             (a.shape[0], a.shape[1], b.shape[1], 'wgrad')))
             return out
 
-        ops.gemm_nt, ops.gemm_tn = gemm_nt, gemm_tn
+        raw_ntb, raw_cast, raw_tnb = ops.gemm_nt_bf16, ops.cast_bf16, ops.gemm_tn_bf16
+
+        def gemm_tn_bf16(a, b, *args, **kw):
+            if not timer.enabled:
+                return raw_tnb(a, b, *args, **kw)
+            a, b = cast_bf16(a), cast_bf16(b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = raw_tnb(a, b, *args, **kw)
+            e1.record()
+            timer.records['gemm_tn'].append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1],
+                                             2.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1]) + 4.0 * a.shape[1] * b.shape[1],
+                                             (a.shape[0], a.shape[1], b.shape[1], 'bf16:wgrad')))
+            return out
+
+        def gemm_nt_bf16(a, b, *args, **kw):
+            # bf16 path (configs[4]): counted as gemm_nt; operand casts are done (and timed) outside the bracket
+            if not timer.enabled:
+                return raw_ntb(a, b, *args, **kw)
+            a, b = cast_bf16(a), cast_bf16(b)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = raw_ntb(a, b, *args, **kw)
+            e1.record()
+            epi = 'bf16:' + ('+'.join(k for k in ('bias', 'act', 'drop_p', 'gate', 'gate_b', 'add', 'out_bf16')
+                                      if kw.get(k) is not None and (torch.is_tensor(kw[k]) or kw[k] not in (0, False))) or 'none')
+            timer.records['gemm_nt'].append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
+                                             2.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1]) + 4.0 * a.shape[0] * b.shape[0],
+                                             (a.shape[0], b.shape[0], a.shape[1], epi)))
+            return out
+
+        def cast_bf16(x):
+            if not timer.enabled or x.dtype == torch.bfloat16:
+                return raw_cast(x)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = raw_cast(x)
+            e1.record()
+            timer.records['cast_bf16'].append((e0, e1, 0.0, 6.0 * x.numel(), (x.shape[0], x.shape[1], 0, 'cast')))
+            return out
+
+        ops.gemm_nt, ops.gemm_tn, ops.gemm_nt_bf16, ops.cast_bf16 = gemm_nt, gemm_tn, gemm_nt_bf16, cast_bf16
+        ops.gemm_tn_bf16 = gemm_tn_bf16
+
+    def breakdown(self, name, steps):
+        agg = {}
+        for r in self.records[name]:
+            d = agg.setdefault(r[4], [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += r[0].elapsed_time(r[1])
+            d[2] += r[2]
+        rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
+        out = [f'{name}: per sampled step (M, N, K, epilogue): calls, ms, TFLOP/s']
+        for key, (n, ms, fl) in rows:
+            out.append(f'  {str(key):48s} {n / steps:5.1f} {ms / steps:8.3f} ms {fl / (ms * 1e-3) / 1e12:7.1f}')
+        return '\n'.join(out)
 
     def summary(self, name):
         recs = self.records[name]
@@ -310,6 +370,11 @@ def main():
 
     seq_len = 384 if (student or decoder_step) else 16 * (dlg.num_blocks_left + dlg.num_blocks_right)
     timed_steps = max(1, len(range(0, args.steps, 4)))
+    if dp.rank == 0 and args.gemm_breakdown:
+        print(timer.breakdown('gemm_nt', timed_steps), file=sys.stderr)
+        print(timer.breakdown('gemm_tn', timed_steps), file=sys.stderr)
+        if timer.records['cast_bf16']:
+            print(timer.breakdown('cast_bf16', timed_steps), file=sys.stderr)
     if dp.rank == 0:
         value = B * dp.world_size * args.steps / dt
         nt, tn = timer.summary('gemm_nt'), timer.summary('gemm_tn')
@@ -322,8 +387,9 @@ def main():
                                '6x v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate')
             elif gemm_mode == 2:
                 # reduced precision (BASELINE configs[4] names bf16): NOT valid for the fp32 headline configuration
-                peak, kname = PEAK_BF16_MFMA_TFLOPS, ('gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=2> 128-tile: operands rounded '
-                               'to bf16, one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate; gemm_nt_skinny_kernel in fp32)')
+                peak, kname = PEAK_BF16_MFMA_TFLOPS, ('gemm_nt = every NT GEMM launch (gemm_nt_bf16_kernel 256-tile on bf16 operands in HBM for the '
+                               'transformer layers; gemm_nt_kernel<MODE=2> 128-tile rounding fp32 operands for the rest; '
+                               'gemm_nt_skinny_kernel in fp32); one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate')
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=0>, gemm_nt_skinny_kernel; fp32 v_mfma_f32_32x32x2_f32)'
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
@@ -353,6 +419,9 @@ def main():
             'roofline': roofline,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
                          'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3)} if tn else None),
+            'cast_bf16': ({'ms_per_step': round(sum(r[0].elapsed_time(r[1]) for r in timer.records['cast_bf16']) / timed_steps, 3),
+                           'note': 'fp32 -> bf16 operand casts of the bf16 path (outside the gemm_nt bracket)'}
+                          if timer.records['cast_bf16'] else None),
             'final_loss': round(last_loss, 5),
             'timed': 'trainer.epoch(train=True, num_batches=steps): steps + per-step metric bookkeeping + end-of-epoch host read',
             'train_step_only': {'value': round(B * dp.world_size * args.steps / dt_steps, 2),

@@ -307,6 +307,31 @@ int64_t vqcpc_upscale_bwd_workspace(int64_t rows, int f, int d);
 int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int f, int d, void* workspace,
                       int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * bf16 GEMM path for BASELINE configs[4] (reduced precision; never used for the fp32 headline configuration).
+ * Operands are bf16 (uint16 bit patterns) IN HBM; fp32 accumulation; one v_mfma_f32_32x32x16_bf16 per product.
+ *   vqcpc_cast_bf16      out[r][c] = bf16_rne(in[r * ld_in + c])  (what torch's .bfloat16() does), dense [rows][cols]
+ *   vqcpc_gemm_nt_bf16   C / Cb = epilogue(A[M,K] . B[N,K]^T): replaces F.linear on bf16-cast operands
+ *                        (transformer_custom.py:282-289 FFN, multihead_attention_custom.py:171-196,338 projections).
+ *                        C (fp32) and / or Cb (bf16) receive the result; epilogue as vqcpc_gemm_nt (bias, act = 1 relu,
+ *                        dropout, gate: out *= gate > 0 ? gate_scale : 0 with an fp32 `gate` or a bf16 `gate_bf16` operand,
+ *                        add).  M, N multiples of 256, K of 64 (vqcpc_gemm_nt_bf16_supported); lda / ldb / ldcb / ldgate_bf16
+ *                        in bf16 elements.
+ *   vqcpc_gemm_tn_bf16   dW[N,K] (+)= A[M,N]^T . B[M,K], db[N] (+)= column sums of A: the weight / bias gradient of F.linear
+ *                        on bf16 operands (what autograd derives for the calls above); as vqcpc_gemm_tn.  M multiple of 128,
+ *                        N and K of 256 (vqcpc_gemm_tn_bf16_supported).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_cast_bf16(const float* in, int64_t ld_in, void* out, int64_t rows, int cols, void* stream);
+int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K);
+int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, void* Cb, int64_t ldcb,
+                       int64_t M, int N, int K, const float* bias, int act, float drop_p, uint64_t seed, const float* gate,
+                       int64_t ldgate, const void* gate_bf16, int64_t ldgate_bf16, float gate_scale, const float* add,
+                       int64_t ldadd, void* stream);
+int vqcpc_gemm_tn_bf16_supported(int64_t M, int N, int K);
+int64_t vqcpc_gemm_tn_bf16_workspace(int64_t M, int N, int K);
+int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
+                       int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -264,6 +264,101 @@ def test_gemm_nt_bf16x6_dma_kernel_is_bit_identical_to_the_register_staged_kerne
     assert float(outs[17][6][1::2].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize('M,N,K', [(512, 256, 64), (1024, 768, 512), (256 * 260, 256, 128), (2048, 512, 2048)])
+def test_gemm_nt_bf16_native_kernel(ops, M, N, K):
+    """vqcpc_gemm_nt_bf16 (bf16 operands in HBM, fp32 accumulation) against the fp64 product of the bf16-rounded operands:
+    every epilogue / output combination the training step uses, several output tiles per persistent workgroup."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b, bias = torch.randn(M, K, generator=gen), torch.randn(N, K, generator=gen), torch.randn(N, generator=gen)
+    gate, add = torch.randn(M, N, generator=gen), torch.randn(M, N, generator=gen)
+    ab, bb = ops.cast_bf16(dev(a)), ops.cast_bf16(dev(b))
+    assert ab.dtype == torch.bfloat16 and torch.equal(ab.cpu(), a.bfloat16()), 'cast == torch round-to-nearest-even'
+    big = torch.randn(2 * M, K, generator=gen)
+    assert torch.equal(ops.cast_bf16(dev(big)[::2]).cpu(), big[::2].bfloat16()), 'row-strided source'
+    ref = ab.cpu().double() @ bb.cpu().double().t()
+    tol = 2e-6 * max(1, K ** 0.5)
+    out = ops.gemm_nt_bf16(ab, bb)
+    assert rel_err(out.cpu(), ref) < tol
+    out = ops.gemm_nt_bf16(dev(a), dev(b), bias=dev(bias))                       # fp32 operands are cast on the way in
+    assert rel_err(out.cpu(), ref + bias.double()) < tol
+    p, seed = 0.25, 77
+    mask = ops.dropout_mask(M * N, p, seed, 'cuda').cpu().reshape(M, N).double()
+    h_ref = torch.relu(ref + bias.double()) * mask / (1 - p)
+    h32, h16 = ops.gemm_nt_bf16(ab, bb, bias=dev(bias), act=1, drop_p=p, seed=seed, out_f32=True, out_bf16=True)
+    assert rel_err(h32.cpu(), h_ref) < tol
+    assert h16.dtype == torch.bfloat16 and torch.equal(h16.cpu(), h32.cpu().bfloat16()), 'bf16 output = rounded fp32 output'
+    only16 = ops.gemm_nt_bf16(ab, bb, bias=dev(bias), act=1, out_f32=False, out_bf16=True)
+    assert torch.equal(only16.cpu(), ops.gemm_nt_bf16(ab, bb, bias=dev(bias), act=1).cpu().bfloat16())
+    g32 = ops.gemm_nt_bf16(ab, bb, gate=dev(gate), gate_scale=1.5)
+    assert rel_err(g32.cpu(), ref * (gate.double() > 0) * 1.5) < tol
+    gb = dev(gate).bfloat16()
+    d32, d16 = ops.gemm_nt_bf16(ab, bb, gate_b=gb, gate_scale=1.5, out_f32=True, out_bf16=True)
+    assert rel_err(d32.cpu(), ref * (gb.cpu().double() > 0) * 1.5) < tol and torch.equal(d16.cpu(), d32.cpu().bfloat16())
+    res = dev(add)
+    ops.gemm_nt_bf16(ab, bb, add=res, out=res)                                   # in-place residual
+    assert rel_err(res.cpu(), ref + add.double()) < tol
+    # transpose-detecting: A = I against an asymmetric B
+    n = 512
+    eye, bb2 = torch.eye(n), (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)
+    assert torch.equal(ops.gemm_nt_bf16(dev(eye), dev(bb2)).cpu(), bb2.t().contiguous())
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 256, 256), (4096, 512, 256), (128 * 700, 256, 768), (33280, 1024, 512)])
+def test_gemm_tn_bf16_native_kernel(ops, M, N, K):
+    """vqcpc_gemm_tn_bf16: dW = A^T B and db = column sums of A on bf16 operands, against fp64 on the rounded operands;
+    plain, accumulating into existing buffers, and A = I-like transpose detection."""
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
+    ab, bb = ops.cast_bf16(dev(a)), ops.cast_bf16(dev(b))
+    ref_w = ab.cpu().double().t() @ bb.cpu().double()
+    ref_b = ab.cpu().double().sum(0)
+    dw, db = ops.gemm_tn_bf16(ab, bb)
+    assert rel_err(dw.cpu(), ref_w) < 2e-6 * max(1, M ** 0.5)
+    assert rel_err(db.cpu(), ref_b) < 1e-5
+    dw2, db2 = torch.ones(N, K, device='cuda'), torch.ones(N, device='cuda')
+    ops.gemm_tn_bf16(dev(a), dev(b), into=(dw2, db2))                   # fp32 operands are cast on the way in; accumulate
+    assert rel_err(dw2.cpu(), ref_w + 1) < 2e-6 * max(1, M ** 0.5) and rel_err(db2.cpu(), ref_b + 1) < 1e-5
+    # exact and transpose-detecting: one-hot rows of A pick rows of an integer-valued B
+    sel = torch.zeros(M, N)
+    sel[torch.arange(N) * (M // N), torch.arange(N)] = 1.0
+    bi = (torch.arange(M * K, dtype=torch.float32).reshape(M, K) % 127) - 63
+    dw3, _ = ops.gemm_tn_bf16(dev(sel), dev(bi))
+    assert torch.equal(dw3.cpu(), bi[torch.arange(N) * (M // N)])
+
+
+def test_encoder_layer_bf16_native_path_matches_the_rounded_operand_path(ops):
+    """hip.set_gemm_mode(8): a layer whose shapes fit the 256-tile bf16 kernel takes bf16 operands from HBM (cast passes,
+    bf16 FFN hidden activation); a layer that does not fit rounds fp32 operands inside the 128-tile kernels.  Same
+    arithmetic (operands rounded to bf16, fp32 accumulation): outputs and gradients agree to fp32 summation order."""
+    from vqcpc_bach_amd import hip
+    from vqcpc_bach_amd.transformer.transformer_custom import TransformerEncoderLayerCustom
+    torch.manual_seed(3)
+    L, H, d, ff, nblk = 16, 8, 256, 512, 256      # M = 4096: enough tiles that the rounded-operand path is not the fp32 skinny kernel
+    layer = TransformerEncoderLayerCustom(d_model=d, nhead=H, attention_bias_type='relative_attention', num_channels=1,
+                                          num_events=L, dim_feedforward=ff, dropout=0.0).cuda()
+    x = torch.randn(nblk * L, d, device='cuda', requires_grad=True)
+    g = torch.randn(nblk * L, d, device='cuda')
+    res = {}
+    real = ops.bf16_native
+    try:
+        hip.set_gemm_mode(8)
+        for native in (True, False):
+            ops.bf16_native = real if native else (lambda *shapes: False)
+            assert ops.bf16_native((1024, 512, 256)) == native
+            for p_ in layer.parameters():
+                p_.grad = None
+            x.grad = None
+            y, _ = layer.forward_rows(x)
+            (y * g).sum().backward()
+            res[native] = [y.detach().clone(), x.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()]
+    finally:
+        ops.bf16_native = real
+        hip.set_gemm_mode(0)
+    for a_, b_ in zip(res[True], res[False]):
+        assert rel_err(a_, b_) < 5e-3, rel_err(a_, b_)          # bf16 roundings of near-identical fp32 values may flip
+    assert rel_err(res[True][0], res[False][0]) < 2e-4
+
+
 def test_gemm_nt_bf16x6_256_tile_is_transpose_detecting(ops, bf16x6):
     n = 512
     a = torch.randint(-7, 8, (n, 64)).float()

@@ -1,0 +1,565 @@
+// bf16 GEMMs for BASELINE configs[4] (reduced precision: bf16 operands, fp32 accumulation, one v_mfma_f32_32x32x16_bf16 per
+// product).  Unlike MODE 2 of the 128-tile kernels in gemm.hip (fp32 operands loaded from HBM and rounded while they are
+// staged), the operands here ARE bf16 in HBM: they go global -> VGPR -> LDS without conversion, and an output that only
+// feeds another GEMM (the FFN hidden activation, its gradient) is written as bf16 and never exists in fp32.
+//
+//   vqcpc_cast_bf16      fp32 (row stride) -> dense bf16, round-to-nearest-even like torch's .bfloat16()
+//   gemm_nt_bf16_kernel  C[M,N] = epi(A[M,K] . B[N,K]^T): 256 x 256 tile, 8 waves (2 x 4, wave tile 128 x 64), persistent
+//                        over tiles, K tiles of 32 (64-byte rows).  Ping-pong wave groups as gemm_nt_x6_pp_kernel: group 1
+//                        (rows 128..255) runs one phase behind group 0, so one wave of a SIMD issues its 16 MFMAs while the
+//                        other one reads fragments / stores the next K tile.  Without the three bf16 planes of the split
+//                        kernels there is room for TWO raw-operand register sets: a K tile is requested two phase pairs
+//                        before it is written to LDS.
+//                        LDS image of a K tile: A rows 0..255 then B rows 0..255, 64 bytes each, 16-byte chunk c of row r
+//                        at chunk position c ^ ((r >> 2) & 3): fragment reads (ds_read_b128, 16 rows per lane group) and
+//                        staging writes (ds_write_b128, 2 rows per 8-lane group) are conflict free.
+//                        Epilogue through a 4 KB LDS scratch per wave (see gemm_dma.hip): dwordx4 stores of fp32 and / or
+//                        dwordx2 stores of bf16.
+#include <stdlib.h>
+
+#include "gemm_common.h"
+
+namespace vq {
+
+typedef unsigned short bf16_t;
+typedef float fx4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kB = 256;                      // tile edge
+constexpr int kBBK = 32;                     // k (bf16 elements) per stage
+constexpr int kBRowB = kBBK * 2;             // 64 bytes per operand row per stage
+constexpr int kBOperand = kB * kBRowB;       // 16 KB
+constexpr int kBStage = 2 * kBOperand;       // 32 KB
+constexpr int kBThreads = 512;
+constexpr int kBLds = 2 * kBStage + 8 * 4096;   // two stages + a 4 KB epilogue scratch per wave = 96 KB
+
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict__ in, int64_t ld, bf16_t* __restrict__ out,
+                                                        int64_t rows, int cols) {
+    const int64_t n4 = rows * (cols / 4);
+    const int c4n = cols / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(in + r * ld + c);
+        *reinterpret_cast<uint2*>(out + r * cols + c) = round4_bf16(v);
+    }
+}
+
+// extra epilogue features of the bf16 kernel (on top of gemm_common.h's E_*)
+enum { B_OUT_F32 = 1, B_OUT_BF16 = 2, B_GATE_BF16 = 4 };
+
+struct Bf16Out {
+    float* c;            // fp32 output (B_OUT_F32)
+    int64_t ldc;
+    bf16_t* cb;          // bf16 output (B_OUT_BF16), dense or strided
+    int64_t ldcb;
+    const bf16_t* gate_b;   // bf16 gate operand (B_GATE_BF16): only its sign is used
+    int64_t ldgate_b;
+};
+
+template <int EPI, int OUT>
+__global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const bf16_t* __restrict__ B, int64_t ldb, Bf16Out o,
+                                                                   int64_t M, int N, int K, int tiles_n, int tiles,
+                                                                   EpiParams ep) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;                       // wm = wave group: 0 leads, 1 runs one phase behind
+    const int li = lane & 31, kh = lane >> 5;
+    const int T = K / kBBK;                                        // K tiles per output tile (K % 64 == 0: T even)
+    const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * T;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // ---- staging (group-local): group g moves rows [128 g, 128 g + 128) of both operands; thread -> 16-byte chunks q, q + 256
+    const int tg = tid & 255;
+    const int st_row0 = tg >> 2, st_c = tg & 3;                    // chunk q = tg: row tg >> 2, chunk tg & 3; q + 256: row + 64
+    int ld_tile = blockIdx.x, ld_k = 0;
+    const bf16_t* a_src;
+    const bf16_t* b_src;
+#define B_SET_SRC()                                                                              \
+    {                                                                                            \
+        const int t_ = xcd_swizzle(min(ld_tile, tiles - 1), tiles);                              \
+        a_src = A + ((int64_t)(t_ / tiles_n) * kB + wm * 128 + st_row0) * lda + st_c * 8;        \
+        b_src = B + ((int64_t)(t_ % tiles_n) * kB + wm * 128 + st_row0) * ldb + st_c * 8;        \
+    }
+    B_SET_SRC()
+    uint4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+#define B_LOAD(S_)                                                                        \
+    S_##a0 = *reinterpret_cast<const uint4*>(a_src + ld_k);                               \
+    S_##a1 = *reinterpret_cast<const uint4*>(a_src + (int64_t)64 * lda + ld_k);           \
+    S_##b0 = *reinterpret_cast<const uint4*>(b_src + ld_k);                               \
+    S_##b1 = *reinterpret_cast<const uint4*>(b_src + (int64_t)64 * ldb + ld_k);           \
+    ld_k += kBBK;                                                                         \
+    if (ld_k == K) {                                                                      \
+        ld_k = 0;                                                                         \
+        ld_tile += gridDim.x;            /* past the end: re-reads the last tile, never used */ \
+        B_SET_SRC()                                                                       \
+    }
+    // LDS position of chunk (row, c): row * 64 + ((c ^ ((row >> 2) & 3)) << 4); rows st_row0 and st_row0 + 64 share the swizzle
+    const int st_off = (wm * 128 + st_row0) * kBRowB + ((st_c ^ ((st_row0 >> 2) & 3)) << 4);
+#define B_STORE(S_, BUFP)                                                                 \
+    *reinterpret_cast<uint4*>((BUFP) + st_off) = S_##a0;                                  \
+    *reinterpret_cast<uint4*>((BUFP) + st_off + 64 * kBRowB) = S_##a1;                    \
+    *reinterpret_cast<uint4*>((BUFP) + kBOperand + st_off) = S_##b0;                      \
+    *reinterpret_cast<uint4*>((BUFP) + kBOperand + st_off + 64 * kBRowB) = S_##b1;
+
+    // ---- fragments: lane (row li, k group kh) of k16 step ks reads chunk 2 ks + kh of its row ----
+    const int fsw = (li >> 2) & 3;
+    const int f_off0 = li * kBRowB + (((0 + kh) ^ fsw) << 4);      // ks = 0
+    const int f_off1 = li * kBRowB + (((2 + kh) ^ fsw) << 4);      // ks = 1
+    const int a_base = (wm * 128) * kBRowB;
+    const int b_base = kBOperand + (wn * 64) * kBRowB;
+    bf16x8 fb[2][2], fa[2][4];                                     // [ks][tile]
+#define B_READ_FRAGS(BUFP)                                                                                   \
+    _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) {                                                       \
+        fb[0][tl] = *reinterpret_cast<const bf16x8*>((BUFP) + b_base + tl * 32 * kBRowB + f_off0);           \
+        fb[1][tl] = *reinterpret_cast<const bf16x8*>((BUFP) + b_base + tl * 32 * kBRowB + f_off1);           \
+    }                                                                                                        \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                       \
+        fa[0][mt] = *reinterpret_cast<const bf16x8*>((BUFP) + a_base + mt * 32 * kBRowB + f_off0);           \
+        fa[1][mt] = *reinterpret_cast<const bf16x8*>((BUFP) + a_base + mt * 32 * kBRowB + f_off1);           \
+    }
+#define B_MFMA()                                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                         \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                   \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt], fb[ks][0], acc[mt][0], 0, 0, 0); \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mt], fb[ks][1], acc[mt][1], 0, 0, 0); \
+        }
+#define B_BARRIER()                                                  \
+    __builtin_amdgcn_sched_barrier(0);                               \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue through the wave's LDS scratch (see gemm_dma.hip for the layout and for why stores are inline asm) ----
+    int ep_tile = blockIdx.x;
+    constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;
+    constexpr bool AUX_B16 = (OUT & B_GATE_BF16) != 0;             // gate operand is bf16 (sign only)
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const unsigned scr = lds0 + 2 * kBStage + wave * 4096;
+    const unsigned scr_w = scr + ((4 * kh) * 32 + li) * 4;
+    const unsigned scr_r = scr + ((lane >> 3) * 32 + (lane & 7) * 4) * 4;
+    const int e_row = wm * 128 + (lane >> 3), e_col = wn * 64 + 4 * (lane & 7);
+    const int ldci = (int)o.ldc, ldcbi = (int)o.ldcb;
+    const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;
+    const int ldxi = (int)(AUX_B16 ? o.ldgate_b : ((EPI & E_GATE) ? ep.ldgate : ep.ldadd));
+#define B_SCR_WRITE(MT, NT)                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                     \
+        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(scr_w), "v"(acc[MT][NT][r]), "i"(((r & 3) + 8 * (r >> 2)) * 128));
+#define B_SCR_READ(V)                                                                                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:0\n\tds_read_b128 %2, %1 offset:1024\n\tds_read_b128 %3, %1 offset:2048\n\t" \
+                 "ds_read_b128 %4, %1 offset:3072\n\ts_waitcnt lgkmcnt(0)"                                             \
+                 : "=&v"(V[0]), "+v"(scr_r_), "=&v"(V[1]), "=&v"(V[2]), "=&v"(V[3]));
+#define B_AUX_LOAD(DST, MT, NT)                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+        if (AUX_B16) {                                                                                                 \
+            const u32x2 g_ = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                           \
+                rx, voff_x, (((MT) * 32 + 8 * j) * ldxi + (NT) * 32) * 2, 0));                                         \
+            DST[j][0] = __uint_as_float(g_[0] << 16);                                                                  \
+            DST[j][1] = __uint_as_float(g_[0] & 0xFFFF0000u);                                                          \
+            DST[j][2] = __uint_as_float(g_[1] << 16);                                                                  \
+            DST[j][3] = __uint_as_float(g_[1] & 0xFFFF0000u);                                                          \
+        } else {                                                                                                       \
+            DST[j] = __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(                                    \
+                rx, voff_x, (((MT) * 32 + 8 * j) * ldxi + (NT) * 32) * 4, 0));                                         \
+        }                                                                                                              \
+    }
+#define B_EPI_TILE(V, AUX, MT, NT)                                                                                     \
+    {                                                                                                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
+            const int64_t row = m0 + e_row + (MT) * 32 + 8 * j;                                                        \
+            const int col = n0 + e_col + (NT) * 32;                                                                    \
+            fx4 ov;                                                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
+                float v = V[j][c];                                                                                     \
+                if (EPI & E_BIAS) v += bias4[NT][c];                                                                   \
+                if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
+                if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * N + col + c, ep.thr, ep.inv_keep); \
+                if (EPI & E_GATE) v *= (AUX[j][c] > 0.0f ? ep.gate_scale : 0.0f);                                      \
+                if (EPI & E_ADD) v += AUX[j][c];                                                                       \
+                ov[c] = v;                                                                                             \
+            }                                                                                                          \
+            if (OUT & B_OUT_F32)                                                                                       \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(ov), "v"(voff_c), \
+                             "s"(rc), "s"((((MT) * 32 + 8 * j) * ldci + (NT) * 32) * 4) : "memory");                   \
+            if (OUT & B_OUT_BF16) {                                                                                    \
+                u32x2 pk;                                                                                              \
+                pk[0] = pack_hi(round_bf16(ov[0]), round_bf16(ov[1]));                                                 \
+                pk[1] = pack_hi(round_bf16(ov[2]), round_bf16(ov[3]));                                                 \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(pk), "v"(voff_cb), \
+                             "s"(rcb), "s"((((MT) * 32 + 8 * j) * ldcbi + (NT) * 32) * 2) : "memory");                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[MT][NT][r] = 0.0f;                                          \
+    }
+#define B_EPILOGUE()                                                                                                   \
+    {                                                                                                                  \
+        const int t_ = xcd_swizzle(ep_tile, tiles);                                                                    \
+        const int64_t m0 = (int64_t)(t_ / tiles_n) * kB;                                                               \
+        const int n0 = (t_ % tiles_n) * kB;                                                                            \
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)((OUT & B_OUT_F32) ? o.c + m0 * o.ldc + n0 : (float*)smem), 0, 0x7FFFFFFF, 0x00020000);             \
+        const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(                                          \
+            (void*)((OUT & B_OUT_BF16) ? o.cb + m0 * o.ldcb + n0 : (bf16_t*)smem), 0, 0x7FFFFFFF, 0x00020000);         \
+        const int voff_c = (e_row * ldci + e_col) * 4;                                                                 \
+        const int voff_cb = (e_row * ldcbi + e_col) * 2;                                                               \
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)(!HAS_AUX ? (const void*)smem                                                                       \
+                             : AUX_B16 ? (const void*)(o.gate_b + m0 * (int64_t)ldxi + n0)                             \
+                                       : (const void*)(xsrc + m0 * (int64_t)ldxi + n0)),                               \
+            0, 0x7FFFFFFF, 0x00020000);                                                                                \
+        const int voff_x = (e_row * ldxi + e_col) * (AUX_B16 ? 2 : 4);                                                 \
+        fx4 bias4[2];                                                                                                  \
+        if (EPI & E_BIAS) {                                                                                            \
+            bias4[0] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col);                                            \
+            bias4[1] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col + 32);                                       \
+        }                                                                                                              \
+        fx4 va[4], xa[4];                                                                                              \
+        unsigned scr_r_ = scr_r;                                                                                       \
+        _Pragma("unroll") for (int tile = 0; tile < 8; ++tile) {                                                       \
+            const int mt = tile >> 1, nt = tile & 1;                                                                   \
+            if (HAS_AUX) { B_AUX_LOAD(xa, mt, nt) }                                                                    \
+            B_SCR_WRITE(mt, nt)                                                                                        \
+            B_SCR_READ(va)                                                                                             \
+            B_EPI_TILE(va, xa, mt, nt)                                                                                 \
+        }                                                                                                              \
+        ep_tile += gridDim.x;                                                                                          \
+    }
+
+    // one phase pair for stream position s: RB_ = LDS buffer with K tile s, WB_ = buffer for tile s+1; register set SET_
+    // holds tile s+1 (requested two phase pairs ago), is written to LDS and re-used for the request of tile s+3
+#define B_PHASES(RB_, WB_, SET_)                                                  \
+    {                                                                             \
+        if (kt == 0 && s > 0) B_EPILOGUE()                                        \
+        B_READ_FRAGS(RB_)                                                         \
+        B_STORE(SET_, WB_)                                                        \
+        B_LOAD(SET_)                                                              \
+        B_BARRIER()                                                               \
+        __builtin_amdgcn_s_setprio(1);                                            \
+        B_MFMA()                                                                  \
+        __builtin_amdgcn_s_setprio(0);                                            \
+        B_BARRIER()                                                               \
+        ++s;                                                                      \
+        kt = (kt + 1 == T) ? 0 : kt + 1;                                          \
+    }
+
+    unsigned char* const buf0 = smem;
+    unsigned char* const buf1 = smem + kBStage;
+    // prologue: K tile 0 in buffer 0, tiles 1 (set y) and 2 (set x) requested
+    B_LOAD(x)
+    B_LOAD(y)
+    B_STORE(x, buf0)
+    B_LOAD(x)
+    B_BARRIER()
+    if (wm == 1) { B_BARRIER() }                         // group 1 falls one phase behind
+    int s = 0, kt = 0;
+#pragma unroll 1
+    while (s < S) {
+        B_PHASES(buf0, buf1, y)                          // tile s+1 is in set y (s even), in set x (s odd)
+        B_PHASES(buf1, buf0, x)
+    }
+    if (wm == 0) { B_BARRIER() }                         // pairs with group 1's last barrier
+    B_EPILOGUE()
+#undef B_PHASES
+#undef B_EPILOGUE
+#undef B_EPI_TILE
+#undef B_AUX_LOAD
+#undef B_SCR_READ
+#undef B_SCR_WRITE
+#undef B_BARRIER
+#undef B_MFMA
+#undef B_READ_FRAGS
+#undef B_STORE
+#undef B_LOAD
+#undef B_SET_SRC
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// bf16 weight-gradient GEMM: dW[N,K] = A[M,N]^T . B[M,K], both operands bf16 in HBM, contraction over the rows M.
+// 256 x 256 output tile, 8 waves (2 x 4, wave tile 128 x 64), 32 rows of M per step (two register sets = two steps ahead), M split over blockIdx.y (one
+// workgroup per CU), deterministic reduction of the fp32 partials by the caller.  The contraction index is the ROW
+// index of both operands while the MFMA wants 8 consecutive contraction elements per lane, so -- as in gemm_tn_x6_256 --
+// staging interleaves row pairs into dwords (row 2r in the low half, 2r + 1 in the high half): LDS planes are
+// [row pair][256 columns] dwords and a fragment is 4 conflict-free ds_read_b32.  With bf16 sources the interleave is
+// 8 v_perm per 2 x 8 block and there is nothing else to compute.
+constexpr int kTBM = 32;                                   // contraction rows per step (64: two register sets spill)
+constexpr int kTBJ = kTBM / 32;                            // row pairs per thread, operand and step
+constexpr int kTBRS = kB * 4 + 16;                         // bytes per row pair (256 dwords + pad)
+constexpr int kTBPlane = (kTBM / 2) * kTBRS;               // 16 640 B per operand
+constexpr int kTBBuf = 2 * kTBPlane;                       // 33 280 B; two buffers = 66 560 B
+
+__global__ __launch_bounds__(kBThreads, 2) void gemm_tn_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                   const bf16_t* __restrict__ B, int64_t ldb, int64_t M,
+                                                                   int N, int K, int tiles_k, int64_t rows_per_split,
+                                                                   float* __restrict__ ws, float* __restrict__ ws_bias) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemt[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * kB, k0 = tk * kB;
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(m_begin + rows_per_split, M);          // (m_end - m_begin) % (2 kTBM) == 0 (host)
+    const bool want_bias = (ws_bias != nullptr) && tk == 0;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bsum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};         // column sums of A for this thread's 8 columns
+
+    // staging: thread = (column oct c8 of 32, row pair rp of 16); two row pairs (rp, rp + 16) per operand and step
+    const int c8 = (tid & 31) * 8, rp = tid >> 5;
+    const bf16_t* a_src = A + (m_begin + 2 * rp) * lda + n0 + c8;
+    const bf16_t* b_src = B + (m_begin + 2 * rp) * ldb + k0 + c8;
+    uint4 xa[2 * kTBJ], xb[2 * kTBJ], ya[2 * kTBJ], yb[2 * kTBJ];     // [pair j][row]: rows 2 rp (+ 32 j), + 1
+#define TB_LOAD(S, MM)                                                                          \
+    _Pragma("unroll") for (int j = 0; j < kTBJ; ++j) {                                             \
+        S##a[2 * j] = *reinterpret_cast<const uint4*>(a_src + (int64_t)((MM) + 32 * j) * lda);       \
+        S##a[2 * j + 1] = *reinterpret_cast<const uint4*>(a_src + (int64_t)((MM) + 32 * j + 1) * lda); \
+        S##b[2 * j] = *reinterpret_cast<const uint4*>(b_src + (int64_t)((MM) + 32 * j) * ldb);       \
+        S##b[2 * j + 1] = *reinterpret_cast<const uint4*>(b_src + (int64_t)((MM) + 32 * j + 1) * ldb); \
+    }
+    // dword c of the interleaved block = (row0[c] low half, row1[c] high half)
+#define TB_ILV(R0, R1, LO, HI)                                                                  \
+    LO = make_uint4(__builtin_amdgcn_perm(R1.x, R0.x, 0x05040100u), __builtin_amdgcn_perm(R1.x, R0.x, 0x07060302u), \
+                    __builtin_amdgcn_perm(R1.y, R0.y, 0x05040100u), __builtin_amdgcn_perm(R1.y, R0.y, 0x07060302u)); \
+    HI = make_uint4(__builtin_amdgcn_perm(R1.z, R0.z, 0x05040100u), __builtin_amdgcn_perm(R1.z, R0.z, 0x07060302u), \
+                    __builtin_amdgcn_perm(R1.w, R0.w, 0x05040100u), __builtin_amdgcn_perm(R1.w, R0.w, 0x07060302u));
+#define TB_BSUM(Q, U0, U1)                                                                      \
+    bsum[2 * (Q)] += __uint_as_float((U0) << 16) + __uint_as_float((U1) << 16);                 \
+    bsum[2 * (Q) + 1] += __uint_as_float((U0) & 0xFFFF0000u) + __uint_as_float((U1) & 0xFFFF0000u);
+#define TB_STORE(S, BUFP)                                                                       \
+    _Pragma("unroll") for (int j = 0; j < kTBJ; ++j) {                                             \
+        uint4 lo_, hi_;                                                                         \
+        const int o_ = (rp + 16 * j) * kTBRS + c8 * 4;                                          \
+        TB_ILV(S##a[2 * j], S##a[2 * j + 1], lo_, hi_)                                          \
+        *reinterpret_cast<uint4*>((BUFP) + o_) = lo_;                                           \
+        *reinterpret_cast<uint4*>((BUFP) + o_ + 16) = hi_;                                      \
+        if (want_bias) {                                                                        \
+            TB_BSUM(0, S##a[2 * j].x, S##a[2 * j + 1].x) TB_BSUM(1, S##a[2 * j].y, S##a[2 * j + 1].y)    \
+            TB_BSUM(2, S##a[2 * j].z, S##a[2 * j + 1].z) TB_BSUM(3, S##a[2 * j].w, S##a[2 * j + 1].w)    \
+        }                                                                                       \
+        TB_ILV(S##b[2 * j], S##b[2 * j + 1], lo_, hi_)                                          \
+        *reinterpret_cast<uint4*>((BUFP) + kTBPlane + o_) = lo_;                                \
+        *reinterpret_cast<uint4*>((BUFP) + kTBPlane + o_ + 16) = hi_;                           \
+    }
+#define TB_FRAG(DST, BASE)                                                               \
+    {                                                                                    \
+        uint4 u_;                                                                        \
+        u_.x = *reinterpret_cast<const uint32_t*>(BASE);                                 \
+        u_.y = *reinterpret_cast<const uint32_t*>((BASE) + kTBRS);                       \
+        u_.z = *reinterpret_cast<const uint32_t*>((BASE) + 2 * kTBRS);                   \
+        u_.w = *reinterpret_cast<const uint32_t*>((BASE) + 3 * kTBRS);                   \
+        DST = __builtin_bit_cast(bf16x8, u_);                                            \
+    }
+    // k16 step ks of the 64-row stage: row pairs 8 ks + 4 kh + 0..3
+#define TB_COMPUTE(BUFP)                                                                                                  \
+    _Pragma("unroll") for (int ks = 0; ks < kTBM / 16; ++ks) {                                                            \
+        const unsigned char* ab_ = (BUFP) + (8 * ks + 4 * kh) * kTBRS + (wm * 128 + li) * 4;                              \
+        const unsigned char* bb_ = (BUFP) + kTBPlane + (8 * ks + 4 * kh) * kTBRS + (wn * 64 + li) * 4;                    \
+        bf16x8 a_[4], b_[2];                                                                                              \
+        _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) TB_FRAG(b_[tl], bb_ + tl * 128)                                  \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) TB_FRAG(a_[mt], ab_ + mt * 128)                                  \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                                \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[mt], b_[0], acc[mt][0], 0, 0, 0);                     \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a_[mt], b_[1], acc[mt][1], 0, 0, 0);                     \
+        }                                                                                                                 \
+        if (ks & 1) __builtin_amdgcn_sched_barrier(0);     /* at most two k16 steps of fragments (48 VGPRs) in flight */  \
+    }
+
+    unsigned char* const buf0 = smemt;
+    unsigned char* const buf1 = smemt + kTBBuf;
+    const int64_t rows = m_end - m_begin;                     // multiple of 2 kTBM, >= 2 kTBM when non-empty
+    if (rows > 0) {
+        TB_LOAD(x, 0)
+        TB_LOAD(y, kTBM)
+        TB_STORE(x, buf0)
+        __syncthreads();
+        for (int64_t mm = 0; mm < rows - 2 * kTBM; mm += 2 * kTBM) {
+            TB_LOAD(x, mm + 2 * kTBM)
+            __builtin_amdgcn_sched_barrier(0);
+            TB_COMPUTE(buf0)
+            __builtin_amdgcn_sched_barrier(0);
+            TB_STORE(y, buf1)
+            __syncthreads();
+            TB_LOAD(y, mm + 3 * kTBM)
+            __builtin_amdgcn_sched_barrier(0);
+            TB_COMPUTE(buf1)
+            __builtin_amdgcn_sched_barrier(0);
+            TB_STORE(x, buf0)
+            __syncthreads();
+        }
+        TB_COMPUTE(buf0)
+        __builtin_amdgcn_sched_barrier(0);
+        TB_STORE(y, buf1)
+        __syncthreads();
+        TB_COMPUTE(buf1)
+    }
+#undef TB_LOAD
+#undef TB_ILV
+#undef TB_STORE
+#undef TB_BSUM
+#undef TB_FRAG
+#undef TB_COMPUTE
+
+    float* out = ws + (int64_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = k0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(int64_t)row * K + col] = acc[mt][nt][r];
+            }
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smemt);          // [16 row-pair groups][256 columns]
+#pragma unroll
+        for (int q = 0; q < 8; ++q) red[rp * kB + c8 + q] = bsum[q];
+        __syncthreads();
+        if (tid < kB) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 16; ++g) tot += red[g * kB + tid];
+            ws_bias[(int64_t)blockIdx.y * N + n0 + tid] = tot;
+        }
+    }
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+extern "C" {
+
+int vqcpc_cast_bf16(const float* in, int64_t ld_in, void* out, int64_t rows, int cols, void* stream) {
+    if (rows == 0) return VQCPC_OK;
+    VQ_REQUIRE(in && out && rows > 0 && cols > 0 && cols % 4 == 0 && ld_in >= cols && ld_in % 4 == 0,
+               "cast_bf16: bad arguments (cols, ld_in multiples of 4)");
+    VQ_REQUIRE(aligned16(in) && (reinterpret_cast<uintptr_t>(out) & 7u) == 0, "cast_bf16: alignment");
+    const int blocks = (int)std::min<int64_t>(ceil_div(rows * (cols / 4), 256), 8192);
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, in, ld_in, (bf16_t*)out, rows, cols);
+    VQ_CHECK_LAUNCH("cast_bf16");
+    return VQCPC_OK;
+}
+
+int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K) { return (M % kB == 0 && N % kB == 0 && K % (2 * kBBK) == 0) ? 1 : 0; }
+
+int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, void* Cb, int64_t ldcb,
+                       int64_t M, int N, int K, const float* bias, int act, float drop_p, uint64_t seed, const float* gate,
+                       int64_t ldgate, const void* gate_bf16, int64_t ldgate_bf16, float gate_scale, const float* add,
+                       int64_t ldadd, void* stream) {
+    if (M == 0) return VQCPC_OK;
+    VQ_REQUIRE(A && B && (C || Cb), "gemm_nt_bf16: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_nt_bf16_supported(M, N, K), "gemm_nt_bf16: M, N must be multiples of 256 and K of 64 (M=%lld N=%d K=%d)",
+               (long long)M, N, K);
+    VQ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= K && ldb >= K && (!C || ldc >= N) && (!Cb || (ldcb >= N && ldcb % 4 == 0)),
+               "gemm_nt_bf16: bad leading dimensions");
+    VQ_REQUIRE(aligned16(A) && aligned16(B) && (!C || aligned16(C)) && (reinterpret_cast<uintptr_t>(Cb) & 7u) == 0,
+               "gemm_nt_bf16: alignment");
+    VQ_REQUIRE(!(gate && gate_bf16), "gemm_nt_bf16: one gate operand only");
+    VQ_REQUIRE(act == 0 || act == 1, "gemm_nt_bf16: act must be 0 or 1");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt_bf16: bad dropout probability");
+    EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, nullptr, 0, 0};
+    Bf16Out o{C, ldc, (bf16_t*)Cb, ldcb, (const bf16_t*)gate_bf16, ldgate_bf16};
+    const bool has_gate = gate || gate_bf16;
+    const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (has_gate ? E_GATE : 0) |
+                      (add ? E_ADD : 0);
+    const int out = (C ? B_OUT_F32 : 0) | (Cb ? B_OUT_BF16 : 0) | (gate_bf16 ? B_GATE_BF16 : 0);
+    const int tn = N / kB;
+    const int tiles = (int)((M / kB) * tn);
+    const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kBThreads);
+    hipStream_t st = (hipStream_t)stream;
+#define BL(EPIV, OUTV)                                                                                                 \
+    if (flags == (EPIV) && out == (OUTV)) {                                                                            \
+        static bool attr_done = false;                                                                                 \
+        if (!attr_done) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_kernel<EPIV, OUTV>,                                    \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kBLds);                              \
+            attr_done = true;                                                                                          \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_nt_bf16_kernel<EPIV, OUTV>), grid, block, kBLds, st, (const bf16_t*)A, lda,           \
+                           (const bf16_t*)B, ldb, o, M, N, K, tn, tiles, ep);                                          \
+        VQ_CHECK_LAUNCH("gemm_nt_bf16");                                                                               \
+        return VQCPC_OK;                                                                                               \
+    }
+    // the combinations the training step uses
+    BL(0, B_OUT_F32)
+    BL(E_BIAS, B_OUT_F32)
+    BL(E_BIAS, B_OUT_F32 | B_OUT_BF16)
+    BL(E_BIAS | E_RELU, B_OUT_BF16)
+    BL(E_BIAS | E_RELU | E_DROP, B_OUT_BF16)
+    BL(E_BIAS | E_RELU, B_OUT_F32)
+    BL(E_BIAS | E_RELU, B_OUT_F32 | B_OUT_BF16)
+    BL(E_BIAS | E_RELU | E_DROP, B_OUT_F32 | B_OUT_BF16)
+    BL(E_GATE, B_OUT_F32 | B_OUT_BF16 | B_GATE_BF16)
+    BL(E_BIAS | E_RELU | E_DROP, B_OUT_F32)
+    BL(E_GATE, B_OUT_F32)
+    BL(E_GATE, B_OUT_BF16 | B_GATE_BF16)
+    BL(E_GATE, B_OUT_F32 | B_GATE_BF16)
+    BL(E_ADD, B_OUT_F32)
+    BL(0, B_OUT_BF16)
+#undef BL
+    set_error("gemm_nt_bf16: unsupported epilogue / output combination (flags %d, out %d)", flags, out);
+    return VQCPC_EINVAL;
+}
+
+int vqcpc_gemm_tn_bf16_supported(int64_t M, int N, int K) { return (M % 128 == 0 && N % kB == 0 && K % kB == 0) ? 1 : 0; }
+
+static int tn_bf16_splits(int64_t M, int N, int K) {
+    const int64_t tiles = (int64_t)(N / kB) * (K / kB);
+    int64_t s = std::max<int64_t>(1, kNumCU / tiles);
+    return (int)std::min<int64_t>(s, std::max<int64_t>(1, M / 512));
+}
+
+int64_t vqcpc_gemm_tn_bf16_workspace(int64_t M, int N, int K) {
+    return (int64_t)tn_bf16_splits(std::max<int64_t>(M, 1), N, K) * ((int64_t)N * K + N) * (int64_t)sizeof(float);
+}
+
+int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
+                       int accumulate, void* workspace, int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(A && B && dW && workspace, "gemm_tn_bf16: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_tn_bf16_supported(M, N, K), "gemm_tn_bf16: M must be a multiple of 128, N and K of 256");
+    VQ_REQUIRE(lda % 8 == 0 && ldb % 8 == 0 && lda >= N && ldb >= K && aligned16(A) && aligned16(B),
+               "gemm_tn_bf16: bad leading dimensions / alignment");
+    if (workspace_bytes < vqcpc_gemm_tn_bf16_workspace(M, N, K)) {
+        set_error("gemm_tn_bf16: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    const int splits = tn_bf16_splits(M, N, K);
+    const int64_t rows_per_split = round_up(ceil_div(M, splits), 2 * kTBM);
+    float* ws = (float*)workspace;
+    float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTBBuf);
+        attr_done = true;
+    }
+    const int tk2 = K / kB;
+    hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((N / kB) * tk2, splits), dim3(kBThreads), 2 * kTBBuf, s, (const bf16_t*)A, lda,
+                       (const bf16_t*)B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
+    VQ_CHECK_LAUNCH("gemm_tn_bf16");
+    return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
+}
+
+}  // extern "C"

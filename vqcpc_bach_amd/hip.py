@@ -30,6 +30,13 @@ SIGNATURES = {
     'vqcpc_block_table_segsum': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_nt': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64,
                               c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_cast_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr]),
+    'vqcpc_gemm_nt_bf16_supported': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_nt_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int,
+                                   c_f32, c_u64, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr]),
+    'vqcpc_gemm_tn_bf16_supported': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_tn_bf16_workspace': (c_i64, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_tn_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_set_mode': (c_int, [c_int]),
     'vqcpc_gemm_get_mode': (c_int, []),
     'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
@@ -160,8 +167,10 @@ def set_gemm_mode(mode):
     """0 = fp32 MFMA (exact), 1 = bf16x6 split MFMA (fp32-class accuracy, faster); +2: 128-tile kernels only,
     +4: 256-tile NT kernel without the ping-pong wave groups, +16: LDS-DMA 256-tile NT kernel (A/B switches); 8 = plain bf16 operands (one bf16 MFMA per
     product, fp32 accumulation: reduced precision, for BASELINE configs[4] only).  get_gemm_mode() returns 0 / 1 / 2."""
+    global _gemm_mode
     rc = load().vqcpc_gemm_set_mode(int(mode))
     _check(rc, 'vqcpc_gemm_set_mode')
+    _gemm_mode = None
 
 
 def force_general_attention(on):
@@ -169,8 +178,15 @@ def force_general_attention(on):
     _check(load().vqcpc_relattn_force_general(int(bool(on))), 'vqcpc_relattn_force_general')
 
 
+_gemm_mode = None
+
+
 def get_gemm_mode():
-    return int(load().vqcpc_gemm_get_mode())
+    """0 fp32 MFMA, 1 bf16x6, 2 bf16 (cached: asked on every GEMM of the bf16 path)."""
+    global _gemm_mode
+    if _gemm_mode is None:
+        _gemm_mode = int(load().vqcpc_gemm_get_mode())
+    return _gemm_mode
 
 
 def workspace(nbytes, device):

@@ -71,6 +71,70 @@ def gemm_tn(a, b, want_bias=True, into=None):
     return dw, db
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# bf16 path (BASELINE configs[4]: hip.set_gemm_mode(8)): operands are bf16 IN HBM (vqcpc_gemm_nt_bf16), fp32 accumulate
+# ------------------------------------------------------------------------------------------------------------------
+def cast_bf16(x):
+    """fp32 (rows, cols), rows possibly strided -> dense torch.bfloat16 (round to nearest even, like .bfloat16())."""
+    if x.dtype == torch.bfloat16:
+        return x if x.is_contiguous() else x.contiguous()
+    x, ld = _rows(_f32(x))
+    out = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    hip.call('vqcpc_cast_bf16', x, ld, out, x.shape[0], x.shape[1])
+    return out
+
+
+def bf16_native(*shapes):
+    """True when the bf16 mode is on and every (M, N, K) fits the 256-tile bf16 kernel."""
+    return hip.get_gemm_mode() == 2 and all(hip.query('vqcpc_gemm_nt_bf16_supported', m, n, k) for m, n, k in shapes)
+
+
+def gemm_nt_bf16(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_b=None, gate_scale=1.0, add=None, out=None,
+                 out_f32=True, out_bf16=False):
+    """epilogue(a[M,K] @ b[N,K]^T) on bf16 operands (fp32 tensors are cast first).  Returns the fp32 result, the bf16
+    result, or (fp32, bf16) when both are requested."""
+    a, b = cast_bf16(a), cast_bf16(b)
+    M, K = a.shape
+    N = b.shape[0]
+    assert b.shape[1] == K
+    c = cb = None
+    ldc = ldcb = 0
+    if out_f32:
+        c = out if out is not None else torch.empty(M, N, dtype=torch.float32, device=a.device)
+        c, ldc = _rows(c)
+    if out_bf16:
+        cb, ldcb = torch.empty(M, N, dtype=torch.bfloat16, device=a.device), N
+    ldg = ldgb = lda_ = 0
+    if gate is not None:
+        gate, ldg = _rows(gate)
+    if gate_b is not None:
+        assert gate_b.dtype == torch.bfloat16 and gate_b.is_contiguous()
+        ldgb = gate_b.shape[1]
+    if add is not None:
+        add, lda_ = _rows(add)
+    hip.call('vqcpc_gemm_nt_bf16', a, K, b, K, c, ldc, cb, ldcb, M, N, K, bias, int(act), float(drop_p), int(seed), gate, ldg,
+             gate_b, ldgb, float(gate_scale), add, lda_)
+    return (c, cb) if (out_f32 and out_bf16) else (c if out_f32 else cb)
+
+
+def gemm_tn_bf16(a, b, want_bias=True, into=None):
+    """dW[N,K] = a[M,N]^T @ b[M,K], db[N] = column sums of a, on bf16 operands (fp32 tensors are cast first)."""
+    a, b = cast_bf16(a), cast_bf16(b)
+    M, N = a.shape
+    K = b.shape[1]
+    assert b.shape[0] == M
+    if into is not None:
+        dw, db = into
+        assert dw.shape == (N, K) and dw.is_contiguous() and (db is None or (db.shape == (N,) and db.is_contiguous()))
+    else:
+        dw = torch.empty(N, K, dtype=torch.float32, device=a.device)
+        db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
+    nbytes = hip.query('vqcpc_gemm_tn_bf16_workspace', M, N, K)
+    ws = hip.workspace(nbytes, a.device)
+    hip.call('vqcpc_gemm_tn_bf16', a, N, b, K, dw, db, M, N, K, 0 if into is None else 1, ws, nbytes)
+    return dw, db
+
+
 _DIRECT_WGRAD = False
 
 
@@ -105,12 +169,16 @@ def wgrad(g, x, weight, bias, rows=None):
     `grad += dW` pass per parameter; otherwise (dW, db) are returned as usual.  `rows` = slice of output features when
     only a row block of the parameter is differentiated (q | k,v halves of in_proj)."""
     wg, bg = _live_grad(weight), _live_grad(bias)
+    tn = gemm_tn
+    if g.dtype == torch.bfloat16 or x.dtype == torch.bfloat16:       # bf16 path: operands already bf16 in HBM
+        assert hip.query('vqcpc_gemm_tn_bf16_supported', g.shape[0], g.shape[1], x.shape[1])
+        tn = gemm_tn_bf16
     if wg is not None and (bias is None or bg is not None):
         if rows is not None:
             wg, bg = wg[rows], (bg[rows] if bg is not None else None)
-        gemm_tn(g, x, into=(wg, bg))
+        tn(g, x, into=(wg, bg))
         return None, None
-    return gemm_tn(g, x, want_bias=bias is not None)
+    return tn(g, x, want_bias=bias is not None)
 
 
 def transpose(w):
@@ -243,9 +311,18 @@ class EncoderLayerFn(torch.autograd.Function):
         p = float(drop_p)
         f = int(qstride)
         s = [int(seed) + 0x1000 * i for i in range(4)]     # attention probs, dropout1, ffn dropout, dropout2
+        ffd = w1.shape[0]
+        Mq_ = M // f
+        # bf16 mode (configs[4]): the layer's GEMMs take bf16 operands from HBM; activations that only feed GEMMs get a bf16
+        # copy from the producing epilogue (FFN hidden) or from a cast pass (x, attention output, LayerNorm output)
+        nat = bf16_native((M, 2 * d, d), (Mq_, d, d), (Mq_, ffd, d), (Mq_, d, ffd)) and \
+            hip.query('vqcpc_gemm_tn_bf16_supported', Mq_, d, d)
+        lin = gemm_nt_bf16 if nat else gemm_nt
+        xb = cast_bf16(x) if (nat and (qkv_in is None or f > 1)) else None     # bf16 copies: GEMM operands now, wgrad later
+        xsb = None
         if f == 1:
             Mq, xs, ldxs = M, x, ldx
-            qkv = gemm_nt(x, wqkv, bias=bqkv) if qkv_in is None else _f32(qkv_in).contiguous()
+            qkv = lin(xb if nat else x, wqkv, bias=bqkv) if qkv_in is None else _f32(qkv_in).contiguous()
             att = torch.empty(M, d, dtype=torch.float32, device=dev)
             probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
             if qkv_tokens is not None:
@@ -257,18 +334,27 @@ class EncoderLayerFn(torch.autograd.Function):
             assert L % f == 0 and qkv_in is None
             Mq = M // f
             xs, ldxs = _rows(x[::f])                                       # query / residual rows: a stride, not a copy
-            qkv = gemm_nt(x, wqkv[d:], bias=bqkv[d:])                      # k | v for every token   (M, 2d)
-            qproj = gemm_nt(xs, wqkv[:d], bias=bqkv[:d])                   # q for the kept rows     (Mq, d)
+            xsb = cast_bf16(xs) if nat else None
+            qkv = lin(xb if nat else x, wqkv[d:], bias=bqkv[d:])           # k | v for every token   (M, 2d)
+            qproj = lin(xsb if nat else xs, wqkv[:d], bias=bqkv[:d])       # q for the kept rows     (Mq, d)
             att = torch.empty(Mq, d, dtype=torch.float32, device=dev)
             probs = torch.empty(nblk, H, L // f, L, dtype=torch.float32, device=dev)
             hip.call('vqcpc_relattn_sub_fwd', qproj, d, qkv, 2 * d, e1, e2, att, d, probs, nblk, L, f, H, hd, p, s[0])
-        a = gemm_nt(att, wo, bias=bo)
+        attb = cast_bf16(att) if nat else None
+        a = lin(attb if nat else att, wo, bias=bo)
         x1 = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         hip.call('vqcpc_add_layernorm_fwd', xs, ldxs, a, g1, be1, x1, mean1, rstd1, Mq, d, 1e-5, p, s[1])
-        h2 = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2])
-        ff = gemm_nt(h2, w2, bias=b2)
+        h2b = x1b = None
+        if nat:     # the FFN hidden activation exists in bf16 only: FFN2, the backward gate and the weight gradient read it
+            x1b = cast_bf16(x1)
+            h2b = gemm_nt_bf16(x1b, w1, bias=b1, act=1, drop_p=p, seed=s[2], out_f32=False, out_bf16=True)
+            ff = gemm_nt_bf16(h2b, w2, bias=b2)
+            h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
+        else:
+            h2 = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2])
+            ff = gemm_nt(h2, w2, bias=b2)
         y = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
@@ -276,6 +362,7 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.save_for_backward(x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
+        ctx.bf16 = (xb, xsb, attb, x1b, h2b) if nat else None
         ctx.biases = (bqkv, bo, b1, b2)
         ctx.qkv_tokens = qkv_tokens
         ctx.mark_non_differentiable(probs)
@@ -306,15 +393,31 @@ class EncoderLayerFn(torch.autograd.Function):
             return ds, (dr if dr is not None else ds), dg, db
 
         ds2, df, dg2, dbe2 = ln_bwd(dy, x1, d, ff, g2, mean2, rstd2, s[3])
-        # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
-        da = gemm_nt(df, transpose(w2), gate=h2, gate_scale=1.0 / (1.0 - p))
-        dw2, db2 = wgrad(df, h2, w2, b2)
-        dw1, db1 = wgrad(da, x1, w1, b1)
-        dx1 = gemm_nt(da, transpose(w1), add=ds2)
+        nat = ctx.bf16 is not None
+        lin = gemm_nt_bf16 if nat else gemm_nt
+        if nat:
+            xb, xsb, attb, x1b, h2b = ctx.bf16
+            dfb = cast_bf16(df)
+            # FFN: da = (df @ W2) * [h2 > 0] / (1 - p), bf16 only (it feeds two GEMMs and nothing else)
+            da = gemm_nt_bf16(dfb, transpose(w2), gate_b=h2b, gate_scale=1.0 / (1.0 - p), out_f32=False, out_bf16=True)
+            dw2, db2 = wgrad(dfb, h2b, w2, b2)
+            dw1, db1 = wgrad(da, x1b, w1, b1)
+            dx1 = gemm_nt_bf16(da, transpose(w1), add=ds2)
+        else:
+            # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
+            da = gemm_nt(df, transpose(w2), gate=h2, gate_scale=1.0 / (1.0 - p))
+            dw2, db2 = wgrad(df, h2, w2, b2)
+            dw1, db1 = wgrad(da, x1, w1, b1)
+            dx1 = gemm_nt(da, transpose(w1), add=ds2)
         del da, df, ds2
         ds1, dA, dg1, dbe1 = ln_bwd(dx1, xs, ldxs, a, g1, mean1, rstd1, s[1])
-        dwo, dbo = wgrad(dA, att, wo, bo)
-        datt = gemm_nt(dA, transpose(wo))
+        if nat:
+            dAb = cast_bf16(dA)
+            dwo, dbo = wgrad(dAb, attb, wo, bo)
+            datt = gemm_nt_bf16(dAb, transpose(wo))
+        else:
+            dwo, dbo = wgrad(dA, att, wo, bo)
+            datt = gemm_nt(dA, transpose(wo))
         de1 = torch.empty_like(e1)
         de2 = torch.empty_like(e2)
         need_dx = ctx.needs_input_grad[0]
@@ -338,8 +441,13 @@ class EncoderLayerFn(torch.autograd.Function):
             if ext_qkv:          # projection lives outside: its gradient leaves through qkv_in, x keeps the residual path
                 return (ds1 if need_dx else None, None, None, None, None, None, d_in, None, None, None, dwo, dbo, de1, de2, dw1,
                         db1, dw2, db2, dg1, dbe1, dg2, dbe2)
-            dwqkv, dbqkv = wgrad(dqkv, x, wqkv, bqkv)
-            dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if need_dx else None
+            if nat:
+                dqkvb = cast_bf16(dqkv)
+                dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
+                dx = gemm_nt_bf16(dqkvb, transpose(wqkv), add=ds1) if need_dx else None
+            else:
+                dwqkv, dbqkv = wgrad(dqkv, x, wqkv, bqkv)
+                dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if need_dx else None
         else:
             dq = torch.empty(Mq, d, dtype=torch.float32, device=dev)
             dkv = torch.empty(M, 2 * d, dtype=torch.float32, device=dev)
@@ -347,8 +455,13 @@ class EncoderLayerFn(torch.autograd.Function):
             ws = hip.workspace(nbytes, dev)
             hip.call('vqcpc_relattn_sub_bwd', datt, d, qproj, d, qkv, 2 * d, probs, e1, e2, dq, d, dkv, 2 * d, de1, de2, nblk,
                      L, f, H, hd, p, s[0], ws, nbytes)
-            dwq, dbq = wgrad(dq, xs, wqkv, bqkv, rows=slice(0, d))
-            dwkv, dbkv = wgrad(dkv, x, wqkv, bqkv, rows=slice(d, 3 * d))
+            if nat:
+                dkv = cast_bf16(dkv)
+                dwq, dbq = wgrad(cast_bf16(dq), xsb, wqkv, bqkv, rows=slice(0, d))
+                dwkv, dbkv = wgrad(dkv, xb, wqkv, bqkv, rows=slice(d, 3 * d))
+            else:
+                dwq, dbq = wgrad(dq, xs, wqkv, bqkv, rows=slice(0, d))
+                dwkv, dbkv = wgrad(dkv, x, wqkv, bqkv, rows=slice(d, 3 * d))
             if dwq is None:
                 dwqkv = dbqkv = None                                       # accumulated in place into in_proj's gradient
             else:
@@ -356,7 +469,7 @@ class EncoderLayerFn(torch.autograd.Function):
             dx = None
             if need_dx:
                 wt = transpose(wqkv)                                       # (d, 3d): columns q | k | v
-                dx = gemm_nt(dkv, wt[:, d:])                               # every row: keys / values path
+                dx = lin(dkv, wt[:, d:])                                   # every row: keys / values path
                 dxs = dx[::f]                                              # kept rows also get the query + residual paths
                 gemm_nt(dq, wt[:, :d], add=ds1, add2=dxs, out=dxs)
         return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1,

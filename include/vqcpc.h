@@ -205,6 +205,15 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
                             const float* mean, const float* rstd, float* d_s, float* d_r, float* d_gamma, float* d_beta,
                             int64_t M, int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes,
                             void* stream);
+/* the same two kernels with an extra bf16 copy of the output that feeds GEMMs in the bf16 path (configs[4]):
+ * y_bf16 [M][d] = bf16(y); d_r_bf16 [M][d] = bf16(d_r) (bf16(d_s) when drop_p == 0, where d_r == d_s).  NULL = no copy. */
+int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
+                                void* y_bf16, float* mean, float* rstd, int64_t M, int d, float eps, float drop_p,
+                                uint64_t seed, void* stream);
+int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
+                                const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
+                                float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
+                                int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Product vector quantiser: nearest code per sub-vector + straight-through output + commitment/codebook loss.

@@ -1,5 +1,6 @@
 // Wavefront-primitive kernels: fused embedding-table gather + positional concat, fused residual + dropout + LayerNorm.
 #include "common.h"
+#include "gemm_common.h"   // round4_bf16 (bf16 copies of LayerNorm outputs for the bf16 GEMM path)
 
 namespace vq {
 
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                                                          const float* __restrict__ r, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
                                                          float* __restrict__ mean, float* __restrict__ rstd, int64_t M,
-                                                         int d, float eps, uint32_t thr, float inv_keep, uint64_t seed) {
+                                                         int d, float eps, uint32_t thr, float inv_keep, uint64_t seed,
+                                                         unsigned short* __restrict__ y_b16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nit = (d + 255) >> 8;
     const float inv_d = 1.0f / (float)d;
@@ -158,6 +160,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                 o.z = (s[it].z - mu) * rs * gm.z + bt.z;
                 o.w = (s[it].w - mu) * rs * gm.w + bt.w;
                 nt_store4(y + row * d + col, o);
+                if (y_b16) *reinterpret_cast<uint2*>(y_b16 + row * d + col) = round4_bf16(o);   // GEMM operand copy
             }
         }
         if (lane == 0) {
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float* __restrict__ d_s,
                                                          float* __restrict__ d_r, float* __restrict__ ws, int64_t M, int d,
-                                                         uint32_t thr, float inv_keep, uint64_t seed) {
+                                                         uint32_t thr, float inv_keep, uint64_t seed,
+                                                         unsigned short* __restrict__ dr_b16) {
     __shared__ float red[4 * 2 * 1024];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int nit = (d + 255) >> 8;
@@ -242,6 +246,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                     o.w *= msk[it].w;
                     nt_store4(d_r + row * d + col, o);
                 }
+                // bf16 copy of the gradient of the sub-layer output r (= d_s when there is no dropout): GEMM operand
+                if (dr_b16) *reinterpret_cast<uint2*>(dr_b16 + row * d + col) = round4_bf16(o);
             }
         }
     }
@@ -487,6 +493,12 @@ int vqcpc_embedding_bwd(const float* g, int64_t ldg, const int64_t* sorted_idx, 
 int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
                             float* mean, float* rstd, int64_t M, int d, float eps, float drop_p, uint64_t seed,
                             void* stream) {
+    return vqcpc_add_layernorm_fwd_b16(x, ldx, r, gamma, beta, y, nullptr, mean, rstd, M, d, eps, drop_p, seed, stream);
+}
+
+int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
+                                void* y_bf16, float* mean, float* rstd, int64_t M, int d, float eps, float drop_p,
+                                uint64_t seed, void* stream) {
     if (M == 0) return VQCPC_OK;
     VQ_REQUIRE(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
     VQ_REQUIRE(M >= 0 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_fwd: bad shape");
@@ -496,10 +508,10 @@ int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const f
     const float ik = 1.0f / (1.0f - drop_p);
     if (r)
         hipLaunchKernelGGL(add_ln_fwd_kernel<true>, dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean,
-                           rstd, M, d, eps, thr, ik, seed);
+                           rstd, M, d, eps, thr, ik, seed, (unsigned short*)y_bf16);
     else
         hipLaunchKernelGGL(add_ln_fwd_kernel<false>, dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean,
-                           rstd, M, d, eps, thr, ik, seed);
+                           rstd, M, d, eps, thr, ik, seed, (unsigned short*)y_bf16);
     VQ_CHECK_LAUNCH("add_layernorm_fwd");
     return VQCPC_OK;
 }
@@ -512,6 +524,14 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
                             const float* mean, const float* rstd, float* d_s, float* d_r, float* d_gamma, float* d_beta,
                             int64_t M, int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes,
                             void* stream) {
+    return vqcpc_add_layernorm_bwd_b16(dy, x, ldx, r, gamma, mean, rstd, d_s, d_r, nullptr, d_gamma, d_beta, M, d, drop_p, seed,
+                                       workspace, workspace_bytes, stream);
+}
+
+int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
+                                const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
+                                float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
     VQ_REQUIRE(dy && x && gamma && mean && rstd && d_s && d_gamma && d_beta && workspace, "add_layernorm_bwd: null pointer");
     VQ_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_bwd: bad shape");
     if (workspace_bytes < vqcpc_add_layernorm_bwd_workspace(M, d)) {
@@ -524,10 +544,10 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
     const int blocks = ln_blocks(M);
     if (r)
         hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
-                           d_r, (float*)workspace, M, d, thr, ik, seed);
+                           d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
     else
         hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
-                           d_r, (float*)workspace, M, d, thr, ik, seed);
+                           d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
     VQ_CHECK_LAUNCH("add_layernorm_bwd");
     return launch_reduce_splits2((const float*)workspace, (int64_t)2 * d, blocks, d_gamma, d, (const float*)workspace + d,
                                  (int64_t)2 * d, d_beta, d, 0, s);

@@ -84,6 +84,17 @@ def cast_bf16(x):
     return out
 
 
+_BF16_OF = [None]      # (data_ptr, shape, bf16 copy) of the most recent layer output: the next layer's GEMM operand
+
+
+def _bf16_copy_of(x):
+    """The bf16 copy that the producing kernel wrote next to the fp32 tensor `x` (same values, rounded), if any."""
+    ent, _BF16_OF[0] = _BF16_OF[0], None                 # consumed at most once, by the very next layer
+    if ent is not None and ent[0] == x.data_ptr() and ent[1] == tuple(x.shape) and x.is_contiguous():
+        return ent[2]
+    return None
+
+
 def bf16_native(*shapes):
     """True when the bf16 mode is on and every (M, N, K) fits the 256-tile bf16 kernel."""
     return hip.get_gemm_mode() == 2 and all(hip.query('vqcpc_gemm_nt_bf16_supported', m, n, k) for m, n, k in shapes)
@@ -318,7 +329,11 @@ class EncoderLayerFn(torch.autograd.Function):
         nat = bf16_native((M, 2 * d, d), (Mq_, d, d), (Mq_, ffd, d), (Mq_, d, ffd)) and \
             hip.query('vqcpc_gemm_tn_bf16_supported', Mq_, d, d)
         lin = gemm_nt_bf16 if nat else gemm_nt
-        xb = cast_bf16(x) if (nat and (qkv_in is None or f > 1)) else None     # bf16 copies: GEMM operands now, wgrad later
+        xb = None                                       # bf16 copies: GEMM operands now, weight-gradient operands later
+        if nat and (qkv_in is None or f > 1):
+            xb = _bf16_copy_of(x)                       # written by the previous layer's LayerNorm kernel
+            if xb is None:
+                xb = cast_bf16(x)
         xsb = None
         if f == 1:
             Mq, xs, ldxs = M, x, ldx
@@ -334,7 +349,7 @@ class EncoderLayerFn(torch.autograd.Function):
             assert L % f == 0 and qkv_in is None
             Mq = M // f
             xs, ldxs = _rows(x[::f])                                       # query / residual rows: a stride, not a copy
-            xsb = cast_bf16(xs) if nat else None
+            xsb = xb[::f].contiguous() if nat else None
             qkv = lin(xb if nat else x, wqkv[d:], bias=bqkv[d:])           # k | v for every token   (M, 2d)
             qproj = lin(xsb if nat else xs, wqkv[:d], bias=bqkv[:d])       # q for the kept rows     (Mq, d)
             att = torch.empty(Mq, d, dtype=torch.float32, device=dev)
@@ -345,10 +360,10 @@ class EncoderLayerFn(torch.autograd.Function):
         x1 = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd1 = torch.empty(Mq, dtype=torch.float32, device=dev)
-        hip.call('vqcpc_add_layernorm_fwd', xs, ldxs, a, g1, be1, x1, mean1, rstd1, Mq, d, 1e-5, p, s[1])
-        h2b = x1b = None
+        x1b = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
+        hip.call('vqcpc_add_layernorm_fwd_b16', xs, ldxs, a, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5, p, s[1])
+        h2b = None
         if nat:     # the FFN hidden activation exists in bf16 only: FFN2, the backward gate and the weight gradient read it
-            x1b = cast_bf16(x1)
             h2b = gemm_nt_bf16(x1b, w1, bias=b1, act=1, drop_p=p, seed=s[2], out_f32=False, out_bf16=True)
             ff = gemm_nt_bf16(h2b, w2, bias=b2)
             h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
@@ -358,7 +373,9 @@ class EncoderLayerFn(torch.autograd.Function):
         y = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
-        hip.call('vqcpc_add_layernorm_fwd', x1, d, ff, g2, be2, y, mean2, rstd2, Mq, d, 1e-5, p, s[3])
+        yb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
+        hip.call('vqcpc_add_layernorm_fwd_b16', x1, d, ff, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, p, s[3])
+        _BF16_OF[0] = (y.data_ptr(), (Mq, d), yb) if nat else None
         ctx.save_for_backward(x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
@@ -381,23 +398,24 @@ class EncoderLayerFn(torch.autograd.Function):
         xs, ldxs = (x, ldx) if f == 1 else _rows(x[::f])
         dy = dy.contiguous()
 
+        nat = ctx.bf16 is not None
+
         def ln_bwd(dyv, xin, ldxin, r, gamma, mean, rstd, seed):
             ds = torch.empty(Mq, d, dtype=torch.float32, device=dev)
             dr = torch.empty(Mq, d, dtype=torch.float32, device=dev) if p > 0 else None
+            drb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None    # GEMM-operand copy of dr
             dg = torch.empty(d, dtype=torch.float32, device=dev)
             db = torch.empty(d, dtype=torch.float32, device=dev)
             nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', Mq, d)
             ws = hip.workspace(nbytes, dev)
-            hip.call('vqcpc_add_layernorm_bwd', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, dg, db, Mq, d, p, seed, ws,
-                     nbytes)
-            return ds, (dr if dr is not None else ds), dg, db
+            hip.call('vqcpc_add_layernorm_bwd_b16', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed,
+                     ws, nbytes)
+            return ds, (dr if dr is not None else ds), dg, db, drb
 
-        ds2, df, dg2, dbe2 = ln_bwd(dy, x1, d, ff, g2, mean2, rstd2, s[3])
-        nat = ctx.bf16 is not None
+        ds2, df, dg2, dbe2, dfb = ln_bwd(dy, x1, d, ff, g2, mean2, rstd2, s[3])
         lin = gemm_nt_bf16 if nat else gemm_nt
         if nat:
             xb, xsb, attb, x1b, h2b = ctx.bf16
-            dfb = cast_bf16(df)
             # FFN: da = (df @ W2) * [h2 > 0] / (1 - p), bf16 only (it feeds two GEMMs and nothing else)
             da = gemm_nt_bf16(dfb, transpose(w2), gate_b=h2b, gate_scale=1.0 / (1.0 - p), out_f32=False, out_bf16=True)
             dw2, db2 = wgrad(dfb, h2b, w2, b2)
@@ -410,9 +428,8 @@ class EncoderLayerFn(torch.autograd.Function):
             dw1, db1 = wgrad(da, x1, w1, b1)
             dx1 = gemm_nt(da, transpose(w1), add=ds2)
         del da, df, ds2
-        ds1, dA, dg1, dbe1 = ln_bwd(dx1, xs, ldxs, a, g1, mean1, rstd1, s[1])
+        ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, xs, ldxs, a, g1, mean1, rstd1, s[1])
         if nat:
-            dAb = cast_bf16(dA)
             dwo, dbo = wgrad(dAb, attb, wo, bo)
             datt = gemm_nt_bf16(dAb, transpose(wo))
         else:

@@ -54,6 +54,9 @@ def parse():
                     help='batches start in (pinned) host memory: the PCIe-inclusive rate quoted in DESIGN.md, never `value`')
     ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', 'bf16', '0', '1', '8'],
                     help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')
+    ap.add_argument('--graph', dest='graph', action='store_true', default=True,
+                    help='replay the training step from a HIP graph (vqcpc_bach_amd/graphs.py); single-rank runs only')
+    ap.add_argument('--no-graph', dest='graph', action='store_false')
     ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM times of the sampled steps, to stderr')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -309,6 +312,8 @@ def main():
     trainer.init_optimizers(lr=config['lr'], schedule_lr=config.get('schedule_lr', False), dp=dp)
     trainer.train()
     n_params = trainer.flat.numel
+    # per-launch HIP events cannot be recorded inside a replayed graph: the kernel-timing samples come from eager steps
+    use_graph = bool(args.graph) and dp.world_size == 1
 
     timer = GemmTimer()
     if not args.no_kernel_timing:
@@ -323,11 +328,11 @@ def main():
 
     import contextlib
 
-    def batches(n, sample):
+    def batches(n, sample, every=4):
         """n batches from the resident pool; HIP events bracket the GEMM launches of every 4th step when `sample`
         (bracketing all of them costs ~2 % of the step)"""
         for i in range(n):
-            timer.enabled = sample and (not args.no_kernel_timing) and (i % 4 == 0)
+            timer.enabled = sample and (not args.no_kernel_timing) and (i % every == 0)
             yield pool[i % len(pool)]
         timer.enabled = False
 
@@ -339,7 +344,12 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):
             return trainer.epoch(batches(n, sample), train=True, num_batches=n, **kw)
 
+    if use_graph:                                   # 2 eager steps, then one capture, then replays: all inside the warm-up
+        assert args.warmup >= 3, 'graph replay needs --warmup >= 3 (2 eager steps + the capture); or pass --no-graph'
+        trainer.enable_step_graph(True)
     run_epoch(args.warmup, False)                   # includes the data-dependent codebook initialisation (step 0)
+    if use_graph and hasattr(trainer, 'precapture_step_graphs'):
+        trainer.precapture_step_graphs(pool[0])     # student step: one graph per masked event index (96 at C3)
     torch.cuda.synchronize()
     # (a) bare training steps, no metric bookkeeping: reported next to the metric when the two differ
     dp.barrier()
@@ -356,20 +366,33 @@ def main():
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    means = run_epoch(args.steps, True)
+    means = run_epoch(args.steps, not use_graph)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     timer.enabled = False
     dt = dp.max_over_ranks(dt)
+    timed_steps = max(1, len(range(0, args.steps, 4)))
+    graph_replays = None
+    if use_graph:
+        # individual launches of a replayed graph cannot be bracketed with events from the host: the per-kernel samples
+        # of the roofline object come from eager steps run right AFTER the timed region (same kernels, same shapes, same
+        # launch order; the rocprofv3 kernel trace of this command under profiles/ covers the replayed launches)
+        g = getattr(trainer, '_graph', None)
+        graph_replays = g.replays if g is not None else 0
+        trainer.enable_step_graph(False)
+        timed_steps = 0 if args.no_kernel_timing else min(args.steps, 12)
+        for b in batches(timed_steps, True, every=1):
+            trainer.train_step(b, train=True)
+        torch.cuda.synchronize()
+        timed_steps = max(1, timed_steps)
     flush_c_stdio()
     dp.barrier()                                    # every rank has emitted whatever its libraries had buffered
     student = config['training_method'].lower() == 'student'
     last_loss = float(means['loss_encdec'] if student else means['loss'])
 
     seq_len = 384 if (student or decoder_step) else 16 * (dlg.num_blocks_left + dlg.num_blocks_right)
-    timed_steps = max(1, len(range(0, args.steps, 4)))
     if dp.rank == 0 and args.gemm_breakdown:
         print(timer.breakdown('gemm_nt', timed_steps), file=sys.stderr)
         print(timer.breakdown('gemm_tn', timed_steps), file=sys.stderr)
@@ -400,7 +423,10 @@ def main():
                             launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),
                             flops_per_launch=nt['flops_per_launch'],
                             share_of_step=round(nt['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
-                            vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3))
+                            vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3),
+                            sampled=(f'HIP events around every GEMM launch of {timed_steps} eager steps run right after the timed '
+                                     'region (the timed steps are graph replays)' if use_graph else
+                                     'HIP events around every GEMM launch of every 4th step of the timed region'))
         line = {
             'metric': f'encoder-train windows/sec (Bach 4-voice, seq={seq_len})', 'value': round(value, 2), 'unit': 'windows/s',
             'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
@@ -424,6 +450,8 @@ def main():
                           if timer.records['cast_bf16'] else None),
             'final_loss': round(last_loss, 5),
             'timed': 'trainer.epoch(train=True, num_batches=steps): steps + per-step metric bookkeeping + end-of-epoch host read',
+            'step_graph': ({'replays_in_run': graph_replays, 'note': 'each training step is one HIP-graph replay '
+                            '(vqcpc_bach_amd/graphs.py); --no-graph runs the same launches eagerly'} if use_graph else None),
             'train_step_only': {'value': round(B * dp.world_size * args.steps / dt_steps, 2),
                                 'ms_per_step': round(1e3 * dt_steps / args.steps, 3),
                                 'host_enqueue_ms_per_step': round(1e3 * t_enqueued / args.steps, 3),

@@ -341,6 +341,21 @@ int64_t vqcpc_gemm_tn_bf16_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
                        int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * Whole-step HIP-graph replay (vqcpc_bach_amd/graphs.py).  A captured step freezes its kernel ARGUMENTS, so the values
+ * that must change every step live on the device:
+ *   - dropout: every seed is XOR-ed with a step salt (0 outside graph replay).  vqcpc_rng_salt_advance is the first node
+ *     of a captured step: counter[0] += 1, salt = splitmix64(base ^ counter[0]); vqcpc_rng_salt_set writes it directly
+ *     (value 0 restores eager behaviour).  This is the ONE piece of library state: a process-wide device value.
+ *   - Adam (vqcpc_adam_step_dev = vqcpc_adam_step with lr read from lr_dev[0] and the step count t -- the bias
+ *     corrections 1 - beta^t -- from step_dev[0], the counter that vqcpc_rng_salt_advance increments).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_rng_salt_set(uint64_t value, void* stream);
+int vqcpc_rng_salt_advance(uint64_t* counter, uint64_t base, void* stream);
+int vqcpc_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                        float eps, const uint64_t* step_dev, float grad_scale, float max_norm, const double* sumsq,
+                        void* stream);
+
 #ifdef __cplusplus
 }
 #endif

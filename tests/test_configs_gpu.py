@@ -131,3 +131,82 @@ def test_c4_product_config_builds_the_same_model():
     got = {n: tuple(p.shape) for n, p in tr.named_parameters()}
     assert got == {k: tuple(v.shape) for k, v in ref.items()}
     assert dlg.num_blocks_left == 16 and dlg.num_blocks_right == 16 and config['batch_size'] == 256
+
+
+class _Bf16Linear(torch.autograd.Function):
+    """F.linear whose three GEMMs (forward, input gradient, weight gradient) take bf16-rounded operands and accumulate in
+    fp32 -- the arithmetic of the product's bf16 mode (hip.set_gemm_mode(8)), restated for the oracle."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        xb, wb = x.bfloat16().float(), w.bfloat16().float()
+        ctx.save_for_backward(xb, wb)
+        ctx.has_bias = b is not None
+        y = xb @ wb.t()
+        return y if b is None else y + b
+
+    @staticmethod
+    def backward(ctx, g):
+        xb, wb = ctx.saved_tensors
+        gb = g.bfloat16().float()
+        g2, x2 = gb.reshape(-1, gb.shape[-1]), xb.reshape(-1, xb.shape[-1])
+        return gb @ wb, g2.t() @ x2, (g.reshape(-1, g.shape[-1]).sum(0) if ctx.has_bias else None)
+
+
+def test_c4_bf16_mode_vs_bf16_cast_oracle(gemm_mode):
+    """configs[4] in the precision BASELINE names for it: the product in bf16 mode (bf16 operands in HBM, bf16 FFN hidden
+    activation, fp32 accumulation, everything else fp32) against the oracle with every linear layer's operands cast to
+    bf16.  Same roundings, different summation orders -- and bf16 roundings of near-equal fp32 values do flip, so the
+    agreement is statistical: >= 99 % of the code assignments, losses within 1 % (0.5 % with the oracle's assignment
+    forced), gradients in the bf16-cast oracle's neighbourhood (see the end of the test)."""
+    if gemm_mode != 'f32':
+        pytest.skip('sets its own GEMM mode')
+    from vqcpc_bach_amd import hip
+    cfg = O.make_cfg('C4', B=4)
+    sd, batch, otr32, ref32 = _oracle_step(cfg, seed=41)
+    real = O.linear
+    O.linear = lambda x, w, b=None: _Bf16Linear.apply(x, w, b)
+    try:
+        otr = O.OracleTrainer(cfg, sd, lr=1e-4)
+        ref = otr.step(batch, train=True)
+    finally:
+        O.linear = real
+    from vqcpc_bach_amd import ops
+    tr = build_trainer(cfg, sd, lr=1e-4)
+    tr.train()
+    keys = ('idx_left', 'idx_right', 'idx_negative')
+    hip.set_gemm_mode(8)
+    real_vq = ops.VQFn.apply
+    try:
+        loss, out = tr.compute_losses(batch)                      # free-running: the product's own code assignment
+        # second pass with the ORACLE's assignment forced (rows in the order of Encoder.encode_many: negatives, left,
+        # right): a code that flips changes z_q, the InfoNCE scores and every gradient behind them by O(1), which would
+        # hide the bf16-level agreement of everything else
+        given = torch.cat([ref[k].reshape(-1, cfg['ncb']) for k in ('idx_negative', 'idx_left', 'idx_right')]).cuda()
+        ops.VQFn.apply = lambda z, cb, beta, sq, g=None: real_vq(z, cb, beta, sq, given)
+        loss_f, out_f = tr.compute_losses(batch)
+        tr.flat.zero_grad()
+        loss_f.backward()
+    finally:
+        ops.VQFn.apply = real_vq
+        hip.set_gemm_mode(0)
+    same = sum(int((out[k].cpu().reshape(ref[k].shape) == ref[k]).sum()) for k in keys)
+    total = sum(ref[k].numel() for k in keys)
+    assert same / total > 0.99, same / total
+    for k in ('loss', 'loss_contrastive', 'loss_quantize'):
+        assert abs(float(out[k].detach()) - float(ref[k].detach())) < 1e-2 * max(1.0, abs(float(ref[k].detach()))), k
+        assert abs(float(out_f[k].detach()) - float(ref[k].detach())) < 5e-3 * max(1.0, abs(float(ref[k].detach()))), k
+    errs = {n: (rel_err(p.grad.cpu(), otr.last_grads[n]), rel_err(otr.last_grads[n], otr32.last_grads[n]))
+            for n, p in tr.named_parameters()}
+    top = sorted(errs.items(), key=lambda kv: -kv[1][0])[:6]
+    print('largest gradient errors (vs bf16-cast oracle, bf16-cast oracle vs fp32 oracle):')
+    for n, (e, e32) in top:
+        print(f'  {n:70s} {e:.3e} {e32:.3e}')
+    # bf16 noise in the FFN pre-activations flips relu gates by the hundred, so single tensors still differ by ~10 % of
+    # their largest entry; what the test pins is that the product sits in the bf16-cast oracle's neighbourhood: every
+    # gradient within 25 %, and closer to the bf16-cast oracle than that oracle is to the fp32 one for most tensors
+    import statistics
+    assert top[0][1][0] < 0.25, top[0]
+    closer = sum(1 for e, e32 in errs.values() if e < e32)
+    assert closer > 0.7 * len(errs), (closer, len(errs))
+    assert statistics.median(e for e, _ in errs.values()) < 0.6 * statistics.median(e32 for _, e32 in errs.values())

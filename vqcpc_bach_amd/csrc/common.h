@@ -36,7 +36,31 @@ constexpr int kNumCU = 256;   // MI355X
 
 // ---- dropout RNG: stateless, one 32-bit integer mix per element (8 VALU ops; a 64-bit splitmix cost ~25 and doubled the
 // instruction count of the K = 256 GEMM epilogues).  The element index enters modulo 2^32 (tensors of the path stay below).
-__host__ __device__ __forceinline__ uint32_t rng_u24(uint64_t seed, uint64_t idx) {
+// Step salt: every seed is XOR-ed with g_rng_salt before use.  It is 0 in eager execution (a fresh seed per dropout site and
+// step arrives as a kernel argument); when a whole training step is replayed from a HIP graph the seed ARGUMENTS are frozen
+// in the graph, so its first node (vqcpc_rng_salt_advance) draws a new salt per replay and the masks still change every
+// step.  One copy per translation unit (no relocatable device code); util.hip keeps the registry of their addresses.
+// __constant__: read-only inside a kernel, so the load is a hoistable scalar load; written between kernels only.
+__attribute__((used)) static __constant__ uint64_t g_rng_salt = 0;
+typedef uint64_t* (*SaltAddrFn)();
+void register_rng_salt(SaltAddrFn fn);
+namespace {
+inline uint64_t* rng_salt_addr_of_this_unit() {
+    uint64_t* p = nullptr;
+    if (hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(g_rng_salt)) != hipSuccess) {
+        (void)hipGetLastError();
+        p = nullptr;
+    }
+    return p;
+}
+struct RngSaltRegistrar {
+    RngSaltRegistrar() { register_rng_salt(&rng_salt_addr_of_this_unit); }
+};
+static RngSaltRegistrar g_rng_salt_registrar;
+}  // namespace
+
+__device__ __forceinline__ uint32_t rng_u24(uint64_t seed, uint64_t idx) {
+    seed ^= g_rng_salt;
     uint32_t x = static_cast<uint32_t>(idx) * 0x9E3779B1u + static_cast<uint32_t>(seed);
     x ^= static_cast<uint32_t>(seed >> 32);
     x ^= x >> 16;

@@ -196,6 +196,82 @@ __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, float*
 
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Step salt registry (see common.h): addresses of every translation unit's g_rng_salt, resolved lazily (the HIP runtime
+// must be up), and the kernels that write them.
+static SaltAddrFn g_salt_fns[32];
+static int g_salt_nfn = 0;
+void register_rng_salt(SaltAddrFn fn) {
+    if (g_salt_nfn < 32) g_salt_fns[g_salt_nfn++] = fn;
+}
+struct SaltAddrs {
+    uint64_t* p[32];
+    int n;
+};
+static SaltAddrs salt_addrs() {
+    static SaltAddrs a = [] {
+        SaltAddrs r{};
+        for (int i = 0; i < g_salt_nfn; ++i) {
+            uint64_t* q = g_salt_fns[i]();
+            if (q) r.p[r.n++] = q;
+        }
+        return r;
+    }();
+    return a;
+}
+__device__ __forceinline__ uint64_t splitmix64(uint64_t x) {
+    x += 0x9E3779B97F4A7C15ull;
+    x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+    x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+    return x ^ (x >> 31);
+}
+__global__ void rng_salt_set_kernel(SaltAddrs a, uint64_t value) {
+    if (threadIdx.x < a.n) *a.p[threadIdx.x] = value;
+}
+// counter[0] += 1; salt = splitmix64(base ^ counter[0]) (never 0): ONE thread decides, then every copy is written
+__global__ void rng_salt_advance_kernel(SaltAddrs a, uint64_t* counter, uint64_t base) {
+    __shared__ uint64_t salt;
+    if (threadIdx.x == 0) {
+        const uint64_t c = counter[0] + 1;
+        counter[0] = c;
+        const uint64_t v = splitmix64(base ^ c);
+        salt = v ? v : 1;
+    }
+    __syncthreads();
+    if (threadIdx.x < a.n) *a.p[threadIdx.x] = salt;
+}
+
+// Adam with its per-step scalars on the device: lr from lr_dev[0], step count t from step_dev[0] (graph replay)
+__global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                                       float* __restrict__ v, int64_t n, const float* __restrict__ lr_dev,
+                                                       float beta1, float beta2, float eps,
+                                                       const uint64_t* __restrict__ step_dev, float grad_scale,
+                                                       float max_norm, const double* __restrict__ sumsq) {
+    __shared__ float sh[2];
+    if (threadIdx.x == 0) {
+        const double t = (double)step_dev[0];
+        const double bc1 = 1.0 - pow((double)beta1, t), bc2 = 1.0 - pow((double)beta2, t);
+        sh[0] = (float)((double)lr_dev[0] / bc1);
+        sh[1] = (float)(1.0 / sqrt(bc2));
+    }
+    __syncthreads();
+    const float lr_over_bc1 = sh[0], inv_sqrt_bc2 = sh[1];
+    float coef = grad_scale;
+    if (sumsq != nullptr) {
+        const float total = (float)sqrt(sumsq[0]);
+        coef *= fminf(1.0f, max_norm / (total + 1e-6f));
+    }
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * coef;
+        const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+        const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+        m[i] = mi;
+        v[i] = vi;
+        g[i] = gi;   // gradients are left clipped in place, as clip_grad_norm_ does
+        p[i] -= lr_over_bc1 * (mi / (sqrtf(vi) * inv_sqrt_bc2 + eps));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Token range check.  nn.Embedding raises on an id outside its table; the kernels of this library index tables (and an LDS
 // accumulator in the embedding backward) directly, so every token tensor passes through here once: the copy that the
 // kernels consume is clamped into [0, limit[voice]) and `flag` records that a clamp happened (the host raises on it at
@@ -311,6 +387,32 @@ int vqcpc_check_tokens(const int64_t* tokens, int64_t n, int n_voices, const int
     hipLaunchKernelGGL(check_tokens_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tokens, n, n_voices, lim,
                        clamped, flag);
     VQ_CHECK_LAUNCH("check_tokens");
+    return VQCPC_OK;
+}
+
+int vqcpc_rng_salt_set(uint64_t value, void* stream) {
+    const SaltAddrs a = salt_addrs();
+    hipLaunchKernelGGL(rng_salt_set_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, value);
+    VQ_CHECK_LAUNCH("rng_salt_set");
+    return VQCPC_OK;
+}
+
+int vqcpc_rng_salt_advance(uint64_t* counter, uint64_t base, void* stream) {
+    VQ_REQUIRE(counter != nullptr, "rng_salt_advance: null counter");
+    const SaltAddrs a = salt_addrs();
+    hipLaunchKernelGGL(rng_salt_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, counter, base);
+    VQ_CHECK_LAUNCH("rng_salt_advance");
+    return VQCPC_OK;
+}
+
+int vqcpc_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                        float eps, const uint64_t* step_dev, float grad_scale, float max_norm, const double* sumsq,
+                        void* stream) {
+    VQ_REQUIRE(p && g && m && v && lr_dev && step_dev && n > 0, "adam_step_dev: bad arguments");
+    int blocks = (int)std::min<int64_t>(ceil_div(n, 256), 4096);
+    hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_dev, beta1, beta2,
+                       eps, step_dev, grad_scale, max_norm, sumsq);
+    VQ_CHECK_LAUNCH("adam_step_dev");
     return VQCPC_OK;
 }
 

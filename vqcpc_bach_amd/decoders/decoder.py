@@ -27,6 +27,7 @@ import torch
 from torch import nn
 
 from .. import ops
+from ..graphs import GraphedTraining
 from ..parallel import DataParallelContext, FlatParameters
 from ..transformer.transformer_custom import (TransformerCustom, TransformerDecoderCustom, TransformerDecoderLayerCustom,
                                               TransformerEncoderCustom, TransformerEncoderLayerCustom, mask_code)
@@ -70,7 +71,7 @@ class HeadsFn(torch.autograd.Function):
         return (d_out, None, *d_params)
 
 
-class Decoder(nn.Module):
+class Decoder(GraphedTraining, nn.Module):
     def __init__(self, model_dir, dataloader_generator, data_processor, encoder, transformer_type, encoder_attention_type,
                  cross_attention_type, d_model, num_encoder_layers, num_decoder_layers, n_head, dim_feedforward,
                  positional_embedding_size, num_channels_encoder, num_events_encoder, num_channels_decoder,
@@ -260,19 +261,31 @@ class Decoder(nn.Module):
         """:327-336 + the merge the reference forgot: frozen encoder, inference only -> merged codes (B, S)."""
         return self.encoder.encode_indices(x, merged=True)
 
-    def train_step(self, tensor_dict, train=True):
+    def _train_step_body(self, tensor_dict):
         x = self.data_processor.checked(self.data_processor.preprocess(tensor_dict['x']))
         codes = self.encode(tensor_dict['x'])
-        with torch.set_grad_enabled(train):
-            loss, _, _, _ = self.compute_loss(codes, x)
-        if train:
-            self.flat.zero_grad()
-            with ops.direct_weight_gradients():
-                loss.backward()
-            self.dp.all_reduce_sum_(self.flat.flat_grad)
-            self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)   # clip 5 + Adam (:345-346)
-            self.global_step += 1
+        loss, _, _, _ = self.compute_loss(codes, x)
+        self.flat.zero_grad()
+        with ops.direct_weight_gradients():
+            loss.backward()
+        self.dp.all_reduce_sum_(self.flat.flat_grad)
+        self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)       # clip 5 + Adam (:345-346)
         return loss.detach()
+
+    def _graph_optimizers(self):
+        return [self.optimizer]
+
+    def train_step(self, tensor_dict, train=True):
+        if not train:
+            x = self.data_processor.checked(self.data_processor.preprocess(tensor_dict['x']))
+            codes = self.encode(tensor_dict['x'])
+            with torch.no_grad():
+                return self.compute_loss(codes, x)[0].detach()
+        out = self._graphed_step(tensor_dict, self._train_step_body)
+        if out is None:
+            out = self._train_step_body(tensor_dict)
+        self.global_step += 1
+        return out
 
     def epoch(self, data_loader, train=True, num_batches=None):
         assert self.optimizer is not None, 'call init_optimizers(lr, schedule_lr) first'

@@ -111,6 +111,10 @@ class Encoder(nn.Module):
         idx = idx.view(z.shape[0], z.shape[1], -1)
         return self.merge_codes(idx) if merged else idx
 
+    def quantizer_needs_init(self):
+        """True while the codebooks still wait for their data-dependent initialisation (first training batch)."""
+        return bool(getattr(self.quantizer, 'initialize', False))
+
     def merge_codes(self, codes):
         """sum_c codes[..., c] * codebook_size**c  (encoder.py:97-110, without its aliasing `+=`)."""
         ret = codes[..., 0].clone()

@@ -1,0 +1,135 @@
+"""Whole-step HIP-graph replay of a training step (no counterpart in the reference: its step is a Python loop over eager
+PyTorch ops).
+
+A training step of this library is ~700 kernel launches issued from Python (ctypes + autograd): 18 ms of host time per step
+at C1, more than the GPU needs at the student step's batch of 8.  `StepGraph` captures ONE step -- zero_grad, forward,
+backward, clip, Adam -- into a HIP graph (torch.cuda.CUDAGraph: every launch of the library goes to torch's current
+stream, so stream capture records them) and replays it per batch:
+
+  * inputs: the batch is copied into static device buffers (the only per-step device work issued from the host, besides
+    a 4-byte learning-rate copy);
+  * dropout: seeds are kernel ARGUMENTS and therefore frozen in the graph; the graph's first node
+    (`vqcpc_rng_salt_advance`) increments a device-side step counter and derives a fresh salt that every RNG call XORs
+    into its seed (csrc/common.h), so masks still change every step;
+  * Adam: `vqcpc_adam_step_dev` reads the learning rate and the step count (bias corrections) from device memory;
+  * outputs (losses, accuracy, code indices) are the graph's static output tensors.
+
+Steps whose batch shapes differ from the captured ones, evaluation steps, label-corruption steps and multi-rank runs
+(the RCCL all-reduce is issued eagerly between kernels) run eagerly, exactly as before.
+
+Pitfall met on ROCm 7.2 / torch 2.10: ending a capture while the PREVIOUS eager step's autograd graph is still alive
+(e.g. a step output that was not detached and is still referenced by the caller) segfaults inside capture_end; every
+output of the trainers' steps is detached for that reason.
+"""
+import torch
+
+from . import hip
+
+
+class StepGraph:
+    def __init__(self, step_fn, optimizers, lr_fn, device, key_fn=None, seed_base=0x5EED5A17):
+        """step_fn(batch_dict) -> outputs (tensor / dict / tuple of tensors): one full training step on device tensors.
+        optimizers: the ops.FlatAdam objects the step uses; lr_fn() -> current learning rate (host float);
+        key_fn(batch) -> extra hashable that selects the graph (the student step's masked event index)."""
+        self.step_fn, self.optimizers, self.lr_fn, self.key_fn = step_fn, list(optimizers), lr_fn, key_fn
+        self.device = torch.device(device)
+        self.seed_base = int(seed_base)
+        self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)       # device step counter (uint64 bits)
+        self.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self.graphs = {}            # key -> (CUDAGraph, static inputs, static outputs)
+        self.pool = None
+        self.replays = 0
+        self._counter_host = None   # host mirror of the device step counter
+        for opt in self.optimizers:
+            opt.use_device_scalars(self.lr_dev, self.counter)
+
+    def _signature(self, batch):
+        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+        return (sig, self.key_fn(batch) if self.key_fn is not None else None)
+
+    def _set_lr(self):
+        self.lr_host[0] = float(self.lr_fn())
+        self.lr_dev.copy_(self.lr_host, non_blocking=True)
+
+    def _body(self, static):
+        hip.call('vqcpc_rng_salt_advance', self.counter, self.seed_base)
+        return self.step_fn(static)
+
+    def capture(self, batch):
+        """Records one step on `batch`'s shapes.  Nothing is executed: the caller replays afterwards."""
+        static = {k: (torch.empty(v.shape, dtype=v.dtype, device=self.device) if torch.is_tensor(v) else v)
+                  for k, v in batch.items()}
+        graph = torch.cuda.CUDAGraph()
+        counts = [opt.step_count for opt in self.optimizers]
+        torch.cuda.synchronize()
+        with torch.cuda.graph(graph, pool=self.pool):
+            out = self._body(static)
+        for opt, c in zip(self.optimizers, counts):      # capture ran the Python side of optimizer.step(): undo its count
+            opt.step_count = c
+        if self.pool is None:
+            self.pool = graph.pool()
+        entry = (graph, static, out)
+        self.graphs[self._signature(batch)] = entry
+        return entry
+
+    def __call__(self, batch):
+        entry = self.graphs.get(self._signature(batch))
+        if entry is None:
+            entry = self.capture(batch)
+        graph, static, out = entry
+        for k, v in batch.items():
+            if torch.is_tensor(v):
+                static[k].copy_(v, non_blocking=True)
+        # the device step counter (Adam's t, the salt sequence) continues where the eager steps left off
+        want = self.optimizers[0].step_count
+        if want != self._counter_host:
+            self.counter.fill_(int(want))
+        self._set_lr()
+        graph.replay()
+        for opt in self.optimizers:
+            opt.step_count += 1
+        self._counter_host = want + 1
+        self.replays += 1
+        return out
+
+    def release(self):
+        for opt in self.optimizers:
+            opt.use_device_scalars(None, None)
+        self.graphs.clear()
+        hip.call('vqcpc_rng_salt_set', 0)
+
+
+class GraphedTraining:
+    """Mixin of the trainers: `enable_step_graph()` makes `train_step(train=True)` replay a captured step after a few
+    eager steps (lazy initialisations -- codebook data init, kernel attributes, allocator -- happen there)."""
+
+    graph_warmup_steps = 2
+    _graph_on = False
+    _graph = None
+    _graph_eager_steps = 0
+
+    def enable_step_graph(self, enabled=True):
+        self._graph_on = bool(enabled)
+        if not enabled and self._graph is not None:
+            self._graph.release()
+            self._graph = None
+        return self
+
+    def _graph_optimizers(self):
+        raise NotImplementedError
+
+    def _graph_key(self, batch):
+        return None
+
+    def _graphed_step(self, batch, body):
+        """Returns body's outputs from a graph replay, or None when this step has to run eagerly."""
+        if not self._graph_on or self.dp.distributed:
+            return None
+        if self._graph_eager_steps < self.graph_warmup_steps:
+            self._graph_eager_steps += 1
+            return None
+        if self._graph is None:
+            self._graph = StepGraph(body, self._graph_optimizers(), self.current_lr, self.flat.flat.device,
+                                    key_fn=self._graph_key)
+        return self._graph(batch)

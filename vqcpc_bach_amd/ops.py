@@ -914,11 +914,20 @@ class FlatAdam:
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=flat_param.device)
         self._ws_bytes = hip.query('vqcpc_sumsq_workspace', flat_param.numel())
         self._ws = hip.workspace(self._ws_bytes, flat_param.device)
+        self._dev = None            # (lr_dev, step_dev) while a StepGraph owns the per-step scalars (graphs.py)
+
+    def use_device_scalars(self, lr_dev, step_dev):
+        self._dev = (lr_dev, step_dev) if lr_dev is not None else None
 
     def step(self, lr=None, grad_scale=1.0):
         self.step_count += 1
         n = self.p.numel()
         hip.call('vqcpc_sumsq', self.g, n, float(grad_scale), self.sumsq, self._ws, self._ws_bytes)
+        if self._dev is not None and torch.cuda.is_current_stream_capturing():
+            # being recorded into a step graph: learning rate and step count are read from device memory at replay time
+            hip.call('vqcpc_adam_step_dev', self.p, self.g, self.m, self.v, n, self._dev[0], float(self.betas[0]),
+                     float(self.betas[1]), float(self.eps), self._dev[1], float(grad_scale), float(self.max_norm), self.sumsq)
+            return
         hip.call('vqcpc_adam_step', self.p, self.g, self.m, self.v, n, float(self.lr if lr is None else lr),
                  float(self.betas[0]), float(self.betas[1]), float(self.eps), self.step_count, float(grad_scale),
                  float(self.max_norm), self.sumsq)

@@ -23,11 +23,12 @@ import torch
 
 from . import ops
 from .encoder import EncoderTrainer
+from .graphs import GraphedTraining
 from .parallel import DataParallelContext, FlatParameters
 from .vqcpc_encoder_trainer import VQCPCEncoderTrainer
 
 
-class StudentEncoderTrainer(EncoderTrainer):
+class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
     def __init__(self, model_dir, dataloader_generator, encoder, num_events_masked, teacher, auxiliary_decoder,
                  quantization_weighting, num_gpus=1):
         super().__init__(dataloader_generator=dataloader_generator)
@@ -146,7 +147,10 @@ class StudentEncoderTrainer(EncoderTrainer):
         m = self.draw_masked_event(E) if masked_event_index is None else int(masked_event_index)
         lo, hi = max(m - num_events_masked, 0), min(m + num_events_masked + 1, E)
         masked_x = x.clone()
-        masked_x[:, lo:hi] = torch.tensor(self.num_tokens_per_channel, dtype=x.dtype, device=x.device).view(1, 1, C)
+        mt = getattr(self, '_mask_tokens', None)            # cached: a host -> device copy is not capturable (graphs.py)
+        if mt is None or mt.device != x.device or mt.dtype != x.dtype:
+            mt = self._mask_tokens = torch.tensor(self.num_tokens_per_channel, dtype=x.dtype, device=x.device).view(1, 1, C)
+        masked_x[:, lo:hi] = mt
         notes = torch.zeros_like(x)
         notes[:, m] = 1
         self._last_masked_event = m
@@ -199,31 +203,69 @@ class StudentEncoderTrainer(EncoderTrainer):
                 enc = self._encode_decode(x, m)
             t = self.forward_teacher(x, m)
             main.wait_stream(side)
-            for tensor in (enc[0], enc[1], *enc[2]):
-                if tensor is not None:
-                    tensor.record_stream(main)
+            if not torch.cuda.is_current_stream_capturing():     # a graph's private pool is not recycled across streams
+                for tensor in (enc[0], enc[1], *enc[2]):
+                    if tensor is not None:
+                        tensor.record_stream(main)
             e = self._encdec_losses(*enc, t['weights_per_category'])
         else:
             t = self.forward_teacher(x, m)
             e = self.forward_encdec(x, t['weights_per_category'], t['notes_to_be_predicted'], m)
         out = dict(t['monitored_quantities'], **e['monitored_quantities'])
         out.update(masked_event_index=t['masked_event_index'], encoding_indices=e['encoding_indices'],
-                   teacher_logits=t['weights_per_category'], student_logits=e['weights_per_category'])
+                   teacher_logits=[lg.detach() for lg in t['weights_per_category']],
+                   student_logits=[lg.detach() for lg in e['weights_per_category']])     # detached: `out` must not keep the step's autograd graph alive
         return t['loss'], e['loss'], out
 
+    def _train_step_body(self, tensor_dict, masked_event_index=None):
+        m = self._graph_m if masked_event_index is None else masked_event_index
+        loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, m)
+        self.flat.zero_grad()
+        with ops.direct_weight_gradients():
+            (loss_teacher + loss_encdec).backward()          # disjoint graphs: the teacher logits are detached
+        self.dp.all_reduce_sum_(self.flat.flat_grad)
+        lr, scale = self.current_lr(), 1.0 / self.dp.world_size
+        self.optimizer_teacher.step(lr=lr, grad_scale=scale)
+        for opt in self.optimizer_enc_dec:
+            opt.step(lr=lr, grad_scale=scale)
+        return out
+
+    _graph_m = None
+
+    def _graph_optimizers(self):
+        return [self.optimizer_teacher] + list(self.optimizer_enc_dec)
+
+    def _graph_key(self, batch):
+        return self._graph_m           # one captured step per masked event index (it selects rows by host-side slicing)
+
+    def precapture_step_graphs(self, tensor_dict):
+        """Captures the step for EVERY masked event index on `tensor_dict`'s shapes (one graph each, one shared memory
+        pool), so that no capture happens later inside a training loop.  Call after the warm-up steps."""
+        assert self._graph_on and not self.dp.distributed and not self.encoder.quantizer_needs_init()
+        if self._graph is None:
+            from .graphs import StepGraph
+            self._graph = StepGraph(self._train_step_body, self._graph_optimizers(), self.current_lr,
+                                    self.flat.flat.device, key_fn=self._graph_key)
+        self._graph_eager_steps = self.graph_warmup_steps
+        for m in range(tensor_dict['x'].shape[1]):
+            self._graph_m = m
+            if self._graph._signature(tensor_dict) not in self._graph.graphs:
+                self._graph.capture(tensor_dict)
+        return len(self._graph.graphs)
+
     def train_step(self, tensor_dict, train=True, masked_event_index=None):
-        with torch.set_grad_enabled(train):
-            loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, masked_event_index)
-        if train:
-            self.flat.zero_grad()
-            with ops.direct_weight_gradients():
-                (loss_teacher + loss_encdec).backward()      # disjoint graphs: the teacher logits are detached
-            self.dp.all_reduce_sum_(self.flat.flat_grad)
-            lr, scale = self.current_lr(), 1.0 / self.dp.world_size
-            self.optimizer_teacher.step(lr=lr, grad_scale=scale)
-            for opt in self.optimizer_enc_dec:
-                opt.step(lr=lr, grad_scale=scale)
-            self.global_step += 1
+        if not train:
+            with torch.no_grad():
+                return self.compute_losses(tensor_dict, masked_event_index)[2]
+        # the masked event is drawn on the host exactly as the reference does (student_encoder_trainer.py:159-160)
+        x = tensor_dict['x']
+        self._graph_m = self.draw_masked_event(x.shape[1]) if masked_event_index is None else int(masked_event_index)
+        out = None
+        if not self.encoder.quantizer_needs_init():
+            out = self._graphed_step(tensor_dict, self._train_step_body)
+        if out is None:
+            out = self._train_step_body(tensor_dict, self._graph_m)
+        self.global_step += 1
         return out
 
     KEYS = ('loss_teacher', 'loss_quantization', 'loss_reconstruction', 'loss_encdec', 'loss_monitor')

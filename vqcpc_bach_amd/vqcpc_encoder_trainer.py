@@ -16,11 +16,12 @@ import torch
 
 from . import ops, vqcpc_helper
 from .encoder import EncoderTrainer
+from .graphs import GraphedTraining
 from .parallel import DataParallelContext, FlatParameters
 from .vqcpc_helper import cpc_scores_and_loss
 
 
-class VQCPCEncoderTrainer(EncoderTrainer):
+class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
     def __init__(self, model_dir, dataloader_generator, encoder, c_net_kwargs, quantization_weighting):
         super().__init__(dataloader_generator=dataloader_generator)
         self.model_dir = model_dir
@@ -204,17 +205,31 @@ class VQCPCEncoderTrainer(EncoderTrainer):
         s = torch.sort(merged)[0]
         return (s[1:] != s[:-1]).sum().float() + 1.0
 
+    def _train_step_body(self, tensor_dict, corrupt_labels=False):
+        """zero_grad / forward / backward / all-reduce / clip / Adam (:310-316): everything a step enqueues on the device."""
+        loss, out = self.compute_losses(tensor_dict, corrupt_labels)
+        self.flat.zero_grad()
+        with ops.direct_weight_gradients():
+            loss.backward()
+        self.dp.all_reduce_sum_(self.flat.flat_grad)
+        self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)
+        return out
+
+    def _graph_optimizers(self):
+        return [self.optimizer]
+
     def train_step(self, tensor_dict, train=True, corrupt_labels=False):
-        """zero_grad / forward / backward / all-reduce / clip / Adam (:310-316).  Returns device-side metrics."""
-        with torch.set_grad_enabled(train):
-            loss, out = self.compute_losses(tensor_dict, corrupt_labels)
-        if train:
-            self.flat.zero_grad()
-            with ops.direct_weight_gradients():
-                loss.backward()
-            self.dp.all_reduce_sum_(self.flat.flat_grad)
-            self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)
-            self.global_step += 1
+        """One iteration.  Returns device-side metrics.  With `enable_step_graph()` a training step is a HIP-graph replay
+        (graphs.py) once the first eager steps have done the lazy initialisations."""
+        if not train:
+            with torch.no_grad():
+                return self.compute_losses(tensor_dict, corrupt_labels)[1]
+        out = None
+        if not corrupt_labels and not self.encoder.quantizer_needs_init():
+            out = self._graphed_step(tensor_dict, self._train_step_body)
+        if out is None:
+            out = self._train_step_body(tensor_dict, corrupt_labels)
+        self.global_step += 1
         return out
 
     def epoch(self, data_loader, train, num_batches, corrupt_labels):

@@ -443,7 +443,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
 // phase that follows its last MFMA phase, so it also runs under the other group's MFMAs.
 //   LDS hazards: tile s+1 is written (by both groups) one full phase pair before anyone reads it; the buffer it
 //   replaces (tile s-1) was last read two barriers earlier by either group.
-template <int EPI>
+template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
                                                                      const float* __restrict__ B, int64_t ldb,
                                                                      float* __restrict__ C, int64_t ldc, int64_t M, int N,
@@ -480,11 +480,20 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     }
     PP_SET_SRC()
     float4 xa0, xa1, xb0, xb1;
-#define PP_LOAD(S_)                                                                       \
+#define PP_OPAQUE(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w));
+#define PP_LOAD(S_, PF0, PF1)                                                                    \
+    if (!(ABL & 2) || s < 1) {                                                            \
     S_##a0 = *reinterpret_cast<const float4*>(a_src + ld_k);                              \
     S_##a1 = *reinterpret_cast<const float4*>(a_src + (int64_t)64 * lda + ld_k);          \
     S_##b0 = *reinterpret_cast<const float4*>(b_src + ld_k);                              \
     S_##b1 = *reinterpret_cast<const float4*>(b_src + (int64_t)64 * ldb + ld_k);          \
+    } else { PP_OPAQUE(S_##a0) PP_OPAQUE(S_##a1) PP_OPAQUE(S_##b0) PP_OPAQUE(S_##b1) }    \
+    if (ABL & 8) {                                                                        \
+        __builtin_amdgcn_sched_barrier(0);                                                \
+        const int pk_ = min(ld_k + 2 * kT2BK, K - kT2BK) - ld_c4;                         \
+        PF0 = a_src[pk_];                                                                 \
+        PF1 = a_src[(int64_t)64 * lda + pk_];                                             \
+    }                                                                                     \
     ld_k += kT2BK;                                                                        \
     if (ld_k == K) {                                                                      \
         ld_k = 0;                                                                         \
@@ -494,7 +503,9 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
 #define PP_ST1(R, PLANE0, ROW, BUFP)                                                 \
     {                                                                                \
         uint2 h_, m_, l_;                                                            \
-        split3x4(R, h_, m_, l_);                                                     \
+        if (ABL & 1) { h_ = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y)); m_ = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w)); l_ = h_; } \
+        else if (ABL & 4) { if (PLANE0 == 0) { split3x4(R, h_, m_, l_); } else { h_ = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y)); m_ = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w)); l_ = h_; } } \
+        else split3x4(R, h_, m_, l_);                                                     \
         /* unpadded 32-byte rows, the two 16-byte chunks of a row XOR-swizzled by bit 3 of the row: fragment reads     \
            (16 consecutive rows, one chunk each) and these stores (4 lanes = one row, rows consecutive) are conflict free */ \
         const int o_ = (ROW) * 32 + ((((ld_c4 >> 3) ^ ((ROW) >> 3)) & 1) << 4) + (ld_c4 & 7) * 2; \
@@ -536,6 +547,14 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     const int ldci = (int)ldc;
     const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;
     const int ldxi = (int)((EPI & E_GATE) ? ep.ldgate : ep.ldadd);
+    float bias_nx0 = 0.0f, bias_nx1 = 0.0f;
+#define PP_BIAS_REQUEST()                                                                                             \
+    if (EPI & E_BIAS) {                                                                                                \
+        const int tb_ = xcd_swizzle(min(ep_tile, tiles - 1), tiles);                                                   \
+        const float* bp_ = ep.bias + (tb_ % tiles_n) * kT2 + wn * 64 + li;                                             \
+        bias_nx0 = bp_[0];                                                                                             \
+        bias_nx1 = bp_[32];                                                                                            \
+    }
 #define PP_EPILOGUE()                                                                                                  \
     {                                                                                                                  \
         const int t_ = xcd_swizzle(ep_tile, tiles);                                                                    \
@@ -554,6 +573,11 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         }                                                                                                              \
         const int64_t row_base = m0 + wm * 128 + 4 * kh;                                                               \
         const int col_base = n0 + wn * 64 + li;                                                                        \
+        /* this tile's two bias values were requested one output tile ago; request the next tile's now (a load per 32x32 \
+           tile inside the store loop cost a full vmcnt(0) drain each: the stores alias C for the compiler) */         \
+        const float bv_cur0 = bias_nx0, bv_cur1 = bias_nx1;                                                            \
+        ep_tile += gridDim.x;                                                                                          \
+        PP_BIAS_REQUEST()                                                                                              \
         _Pragma("unroll") for (int tile = 0; tile < 8; ++tile) {                                                       \
             const int mt = tile >> 1, nt = tile & 1;                                                                   \
             if (HAS_AUX && tile + 1 < 8) {                                                                             \
@@ -563,7 +587,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                                rx, voff_x, ((mt2 * 32 + (r & 3) + 8 * (r >> 2)) * ldxi + nt2 * 32) * 4, 0));           \
             }                                                                                                          \
             const int col = col_base + nt * 32;                                                                        \
-            const float bv = (EPI & E_BIAS) ? ep.bias[col] : 0.0f;                                                     \
+            const float bv = nt ? bv_cur1 : bv_cur0;                                                                   \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
                 const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);                                       \
                 float v = acc[mt][nt][r] + bv;                                                                         \
@@ -576,18 +600,18 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                 acc[mt][nt][r] = 0.0f;                                                                                 \
             }                                                                                                          \
         }                                                                                                              \
-        ep_tile += gridDim.x;                                                                                          \
     }
 
     // one phase pair for stream position s (RB_ = LDS buffer with K tile s, WB_ = buffer for tile s+1).  ONE raw-operand
     // register set: tile s+1 (requested in the previous memory phase) is split and stored, then the same registers are
     // reused for the request of tile s+2 -- a full MFMA phase + two barriers of latency cover.
-#define PP_PHASES(RB_, WB_)                                                       \
+#define PP_PHASES(RB_, WB_, PF0_, PF1_)                                                   \
     {                                                                             \
         if (kt == 0 && s > 0) PP_EPILOGUE()                                       \
         PP_READ_FRAGS(RB_)                                                        \
         PP_STORE(x, WB_)                                                          \
-        PP_LOAD(x)                                                                \
+        if (ABL & 8) asm volatile("" :: "v"(PF0_), "v"(PF1_));                    \
+        PP_LOAD(x, PF0_, PF1_)                                                    \
         PP_BARRIER()                                                              \
         __builtin_amdgcn_s_setprio(1);                                            \
         PP_MFMA()                                                                 \
@@ -598,21 +622,24 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     }
 
     // prologue: K tile 0 split into buffer 0, tile 1 requested
-    PP_LOAD(x)
+    int s = 0, kt = 0;
+    float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f;
+    PP_BIAS_REQUEST()
+    PP_LOAD(x, pf0, pf1)
     PP_STORE(x, buf0)
-    PP_LOAD(x)
+    PP_LOAD(x, pf2, pf3)
     PP_BARRIER()
     if (wm == 1) { PP_BARRIER() }                        // group 1 falls one phase behind
-    int s = 0, kt = 0;
 #pragma unroll 1
     while (s < S) {
-        PP_PHASES(buf0, buf1)
-        PP_PHASES(buf1, buf0)
+        PP_PHASES(buf0, buf1, pf0, pf1)
+        PP_PHASES(buf1, buf0, pf2, pf3)
     }
     if (wm == 0) { PP_BARRIER() }                        // pairs with group 1's last barrier
     PP_EPILOGUE()
 #undef PP_PHASES
 #undef PP_EPILOGUE
+#undef PP_BIAS_REQUEST
 #undef PP_BARRIER
 #undef PP_MFMA
 #undef PP_TERM
@@ -1262,7 +1289,14 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
                                       (int)lds_pp);                                                                        \
             attr_pp = true;                                                                                                \
         }                                                                                                                  \
-        if (use_pp)                                                                                                        \
+        static const int abl = getenv("VQCPC_PP_ABL") ? atoi(getenv("VQCPC_PP_ABL")) : 0;                                  \
+        if (use_pp && abl && EPIV == E_BIAS) {                                                                             \
+            if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 1>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 2>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 3>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 8) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 8>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 4) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 4>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+        } else if (use_pp)                                                                                                 \
             hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
         else                                                                                                               \
             hipLaunchKernelGGL((gemm_nt_x6_256_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \

@@ -172,7 +172,7 @@ def hbm_traffic(kernel, calls_per_step):
     WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
     for gfx950 -- calibrated on the QKV launch: WRITE_SIZE == M*N*4 exactly).  None when the file is absent."""
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r01_gemm_hbm_traffic.json')))
+        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_gemm_hbm_traffic.json')))
         # the PMC passes count kernel launches (a row-split ops.gemm_nt call is two of them): normalise per step, then
         # per call, so that `traffic` has the same unit as `achieved` / `algorithmic_bytes_per_launch`
         return round(d[kernel]['hbm_bytes_per_step'] / calls_per_step)
@@ -313,7 +313,8 @@ def main():
     trainer.train()
     n_params = trainer.flat.numel
     # per-launch HIP events cannot be recorded inside a replayed graph: the kernel-timing samples come from eager steps
-    use_graph = bool(args.graph) and dp.world_size == 1
+    # (a run with fewer than 3 warm-up steps would capture inside the timed region: it stays eager)
+    use_graph = bool(args.graph) and dp.world_size == 1 and args.warmup >= 3
 
     timer = GemmTimer()
     if not args.no_kernel_timing:
@@ -345,7 +346,6 @@ def main():
             return trainer.epoch(batches(n, sample), train=True, num_batches=n, **kw)
 
     if use_graph:                                   # 2 eager steps, then one capture, then replays: all inside the warm-up
-        assert args.warmup >= 3, 'graph replay needs --warmup >= 3 (2 eager steps + the capture); or pass --no-graph'
         trainer.enable_step_graph(True)
     run_epoch(args.warmup, False)                   # includes the data-dependent codebook initialisation (step 0)
     if use_graph and hasattr(trainer, 'precapture_step_graphs'):
@@ -418,7 +418,7 @@ def main():
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
                             frac=round(nt['tflops'] / peak, 4),
                             traffic=(hbm_traffic('gemm_nt', max(1, nt['launches'] // timed_steps)) if args.config == 'C1' and gemm_mode == 1 else None),
-                            traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r01_gemm_hbm_traffic.json)',
+                            traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_gemm_hbm_traffic.json)',
                             algorithmic_bytes_per_launch=round(nt['bytes_per_launch']),
                             launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),
                             flops_per_launch=nt['flops_per_launch'],

@@ -67,6 +67,29 @@ def test_vq_index_bit_exact_vs_oracle(ops, R, ncb, K, dsub):
     assert rel_err(loss.cpu(), loss_ref) < FWD_TOL
 
 
+@pytest.mark.parametrize('K,dsub', [(512, 16), (37, 16), (6, 3), (3, 8), (1, 4)])
+def test_vq_non_finite_rows_and_tiny_codebooks(ops, K, dsub):
+    """Rows that are entirely NaN / +inf select code 0 (every comparison with them is false: torch.argmin on the
+    reference's distance row gives 0 as well), finite rows around them are unaffected, and codebooks with fewer codes
+    than lanes per row (the four lanes of a row split the codes) still pick the first minimum."""
+    gen = torch.Generator().manual_seed(K * 31 + dsub)
+    ncb, R = 2, 300
+    z = torch.randn(R, ncb * dsub, generator=gen)
+    cb = torch.randn(ncb, K, dsub, generator=gen)
+    if K > 2:
+        cb[:, K - 1] = cb[:, 1]                            # tie between a code of lane 1's list and the last code
+    z[7] = float('nan')
+    z[64] = float('inf')
+    z[130, :dsub] = float('-inf')                         # only the first codebook's sub-vector
+    idx = ops.vq_assign(dev(z), dev(cb))
+    finite = torch.ones(R, dtype=torch.bool)
+    finite[[7, 64, 130]] = False
+    ref = O.vq_assign(z[finite], list(cb))
+    assert torch.equal(idx.cpu()[finite], ref)
+    assert idx[7].tolist() == [0, 0] and idx[64].tolist() == [0, 0] and int(idx[130, 0]) == 0
+    assert int(idx[130, 1]) == int(O.vq_assign(z[130:131], list(cb))[0, 1])
+
+
 def test_vq_backward_vs_oracle(ops):
     gen = torch.Generator().manual_seed(3)
     R, ncb, K, dsub = 2000, 2, 128, 16

@@ -53,8 +53,11 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     const int lds_floats = vmax * dlin + pos + nev * pos;
     for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) lds[i] = 0.0f;
     __syncthreads();
-    const int v = blockIdx.y;
-    const int64_t row0 = (int64_t)blockIdx.x * kEmbRowsPerChunk;
+    // voice is the FAST launch index: the nv workgroups of a chunk run together and their interleaved rows (row % nv == v)
+    // make one contiguous stream (with the chunk index fast, concurrent workgroups were 2048 rows apart)
+    const int v = blockIdx.x % nv;
+    const int chunk = blockIdx.x / nv;
+    const int64_t row0 = (int64_t)chunk * kEmbRowsPerChunk;
     const int64_t row1 = min(row0 + kEmbRowsPerChunk, n_rows);
     // rows of this voice: row % tpb % nv == v.  kEmbRowsPerChunk is a multiple of tpb (checked on the host).
     for (int col = threadIdx.x; col < d; col += blockDim.x) {
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
         }
     }
     __syncthreads();
-    float* dst = ws + ((int64_t)blockIdx.x * nv + v) * lds_floats;
+    float* dst = ws + ((int64_t)chunk * nv + v) * lds_floats;
     for (int i = threadIdx.x; i < lds_floats; i += blockDim.x) dst[i] = lds[i];
 }
 
@@ -307,10 +310,14 @@ __global__ __launch_bounds__(256) void block_table_segsum_kernel(const float* __
     extern __shared__ __attribute__((aligned(16))) float acc[];          // [vmax][256]
     for (int i = threadIdx.x; i < vmax * 256; i += 256) acc[i] = 0.0f;
     __syncthreads();
-    const int p = blockIdx.y;
-    const int col = blockIdx.z * 256 + threadIdx.x;
+    // (column tile, position) are the FAST launch indices: the L * ctiles workgroups of a chunk run together and read its
+    // blocks as one contiguous stream (with the chunk index fast, concurrent workgroups each walked their own 1 KB-per-row
+    // strided stream)
+    const int ctiles = (C + 255) >> 8;
+    const int ct = blockIdx.x % ctiles, p = (blockIdx.x / ctiles) % L, chunk = blockIdx.x / (ctiles * L);
+    const int col = ct * 256 + threadIdx.x;
     const bool cok = col < C;
-    const int64_t b0 = (int64_t)blockIdx.x * blocks_per_chunk;
+    const int64_t b0 = (int64_t)chunk * blocks_per_chunk;
     const int64_t b1 = min(b0 + blocks_per_chunk, n_blocks);
     const float* gp = g + (cok ? col : 0);
     float* mine = acc + threadIdx.x;
@@ -328,7 +335,7 @@ __global__ __launch_bounds__(256) void block_table_segsum_kernel(const float* __
     }
     __syncthreads();
     if (cok) {
-        float* dst = ws + (int64_t)blockIdx.x * vmax * L * C;
+        float* dst = ws + (int64_t)chunk * vmax * L * C;
         for (int t = 0; t < vmax; ++t) dst[((int64_t)t * L + p) * C + col] = acc[t * 256 + threadIdx.x];
     }
 }
@@ -412,7 +419,7 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
     hipStream_t s = (hipStream_t)stream;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)embed_pos_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(nchunks, n_voices), dim3(256), lds, s, tokens, n_rows,
+    hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(nchunks * n_voices), dim3(256), lds, s, tokens, n_rows,
                        tokens_per_block, n_voices, vmax, dlin, pos, d_event ? 1 : 0, g_out, (float*)workspace);
     VQ_CHECK_LAUNCH("embed_pos_bwd");
     // stage 2: partials ws[chunk][voice][table | chan | event] -> parallel deterministic column reductions (a single
@@ -468,7 +475,7 @@ int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_tab
     hipStream_t s = (hipStream_t)stream;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)block_table_segsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(block_table_segsum_kernel, dim3(nchunk, L, (unsigned)ceil_div(C, 256)), dim3(256), lds, s, g, tokens,
+    hipLaunchKernelGGL(block_table_segsum_kernel, dim3((unsigned)(nchunk * L * ceil_div(C, 256))), dim3(256), lds, s, g, tokens,
                        (float*)workspace, n_blocks, bpc, L, vmax, C);
     VQ_CHECK_LAUNCH("block_table_segsum");
     const int64_t total = (int64_t)vmax * L * C;

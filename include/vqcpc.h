@@ -342,6 +342,24 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
                        int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * bf16x6 GEMM on pre-split operands (csrc/gemm_planes.hip; no reference counterpart: the same F.linear products as
+ * vqcpc_gemm_nt in mode 1, bit-identical results, with the exact 3-way bf16 split done once by the producer).
+ *   "P3" format of an fp32 matrix X[rows][cols], cols % 16 == 0: three bf16 planes p = 0 (high), 1 (mid), 2 (low) with
+ *   x == high + mid + low exactly, stored K-tile-major: element (p, r, k) at ((p * cols/16 + k/16) * rows + r) * 16 + k % 16
+ *   (bf16 units); vqcpc_planes_bytes(rows, cols) = 6 * rows * cols bytes.
+ *   vqcpc_split3_planes  X (row stride ld floats) -> P3;  vqcpc_join3_planes  P3 -> X (exact; tests)
+ *   vqcpc_gemm_nt_planes C[M,N] = epi(A . B^T) with A = P3 of [M][K], B = P3 of [N][K]; epilogue arguments as vqcpc_gemm_nt.
+ *                        M, N multiples of 256, K of 32, each operand's planes below 4 GB (vqcpc_gemm_nt_planes_supported).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int64_t vqcpc_planes_bytes(int64_t rows, int cols);
+int vqcpc_split3_planes(const float* x, int64_t ld, int64_t rows, int cols, void* planes, void* stream);
+int vqcpc_join3_planes(const void* planes, int64_t rows, int cols, float* x, int64_t ld, void* stream);
+int vqcpc_gemm_nt_planes_supported(int64_t M, int N, int K);
+int vqcpc_gemm_nt_planes(const void* a_planes, const void* b_planes, float* C, int64_t ldc, int64_t M, int N, int K,
+                         const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
+                         float gate_scale, const float* add, int64_t ldadd, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * Whole-step HIP-graph replay (vqcpc_bach_amd/graphs.py).  A captured step freezes its kernel ARGUMENTS, so the values
  * that must change every step live on the device:
  *   - dropout: every seed is XOR-ed with a step salt (0 outside graph replay).  vqcpc_rng_salt_advance is the first node

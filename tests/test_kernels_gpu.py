@@ -1028,3 +1028,46 @@ def test_bad_arguments_raise_with_the_library_message(ops):
         g = torch.randn(9 * 4, 8, device='cuda')
         hip.call('vqcpc_upscale_bwd', g, torch.empty(4, 8, device='cuda'), torch.empty(9, 8, device='cuda'), 4, 9, 8,
                  torch.empty(16, device='cuda'), 16)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# bf16x6 GEMM on pre-split (P3) operands: csrc/gemm_planes.hip
+# ----------------------------------------------------------------------------------------------------------------
+def test_split3_planes_round_trip_is_exact(ops):
+    gen = torch.Generator().manual_seed(11)
+    for rows, cols in [(256, 64), (1000, 256), (37, 1024), (16, 16)]:
+        x = torch.randn(rows, cols, generator=gen) * torch.logspace(-20, 20, rows).reshape(-1, 1)
+        x[0, :4] = torch.tensor([0.0, -0.0, 1e-30, -3.4e38])               # (pieces below 2^-126 would be flushed by the VALU)
+        xd = dev(x)
+        pl = ops.split3_planes(xd)
+        assert bool((ops.join3_planes(pl, rows, cols) == xd).all()), 'high + mid + low must reproduce every fp32 value'
+        wide = dev(torch.randn(rows, cols + 32, generator=gen))              # strided source rows
+        assert torch.equal(ops.join3_planes(ops.split3_planes(wide[:, 16:16 + cols]), rows, cols), wide[:, 16:16 + cols])
+
+
+@pytest.mark.parametrize('M,N,K,epi', [(512, 256, 64, 'bias'), (2048, 768, 256, 'bias'), (1536, 256, 1024, 'none'),
+                                       (4096, 1024, 256, 'relu_drop'), (2560, 1024, 256, 'gate'), (1280, 256, 1024, 'add'),
+                                       (65536 + 256, 512, 160, 'bias')])
+def test_gemm_nt_planes_is_the_x6_gemm(ops, M, N, K, epi):
+    """Same products as the fp32-in bf16x6 GEMM (mode 1); bit-identical where that one runs its 256-tile ping-pong kernel
+    (same MFMA order), within fp32 rounding of the accumulation order otherwise (small shapes take its 128-tile kernel).
+    The large-M case runs many persistent rounds (the run-ahead LDS-DMA crosses output tiles)."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b = dev(torch.randn(M, K, generator=gen)), dev(torch.randn(N, K, generator=gen))
+    bias = dev(torch.randn(N, generator=gen))
+    aux = dev(torch.randn(M, N, generator=gen))
+    kw = dict(none={}, bias=dict(bias=bias), relu_drop=dict(bias=bias, act=1, drop_p=0.1, seed=77),
+              gate=dict(gate=aux, gate_scale=1.25), add=dict(add=aux))[epi]
+    hip.set_gemm_mode(1)
+    try:
+        ref = ops.gemm_nt(a, b, **kw)
+    finally:
+        hip.set_gemm_mode(0)
+    out = ops.gemm_nt_planes(ops.split3_planes(a), ops.split3_planes(b), M, N, K, **kw)
+    if M >= 65536 and epi != 'gate':                      # whole rounds of 256 tiles: rows [0, 65536) at N = 512
+        assert torch.equal(out[:65536], ref[:65536])
+    assert rel_err(out.cpu(), ref.cpu()) < 2e-6
+    exact = a.double() @ b.double().t()
+    if epi in ('none',):
+        assert rel_err(out.cpu(), exact.cpu()) < 2e-6 * max(1, K ** 0.5)

@@ -74,6 +74,34 @@ def gemm_tn(a, b, want_bias=True, into=None):
 # ------------------------------------------------------------------------------------------------------------------
 # bf16 path (BASELINE configs[4]: hip.set_gemm_mode(8)): operands are bf16 IN HBM (vqcpc_gemm_nt_bf16), fp32 accumulate
 # ------------------------------------------------------------------------------------------------------------------
+def split3_planes(x):
+    """fp32 (rows, cols) -> the P3 format of csrc/gemm_planes.hip: three K-tile-major bf16 planes with
+    x == high + mid + low exactly.  Returns a uint8 buffer of 6 * rows * cols bytes tagged with its logical shape."""
+    x = _f32(x)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 16 == 0
+    rows, cols = x.shape
+    out = torch.empty(6 * rows * cols, dtype=torch.uint8, device=x.device)
+    hip.call('vqcpc_split3_planes', x, x.stride(0), rows, cols, out)
+    out.p3_shape = (rows, cols)
+    return out
+
+
+def join3_planes(planes, rows, cols):
+    x = torch.empty(rows, cols, dtype=torch.float32, device=planes.device)
+    hip.call('vqcpc_join3_planes', planes, rows, cols, x, cols)
+    return x
+
+
+def gemm_nt_planes(a_planes, b_planes, M, N, K, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, add=None,
+                   out=None):
+    """C[M, N] = epi(A . B^T) on pre-split (P3) operands: the same products, in the same order, as ops.gemm_nt in mode 1."""
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
+    hip.call('vqcpc_gemm_nt_planes', a_planes, b_planes, out, out.stride(0), M, N, K, bias, int(act), float(drop_p), int(seed),
+             gate, gate.stride(0) if gate is not None else 0, float(gate_scale), add, add.stride(0) if add is not None else 0)
+    return out
+
+
 def cast_bf16(x):
     """fp32 (rows, cols), rows possibly strided -> dense torch.bfloat16 (round to nearest even, like .bfloat16())."""
     if x.dtype == torch.bfloat16:

@@ -443,6 +443,15 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
 // phase that follows its last MFMA phase, so it also runs under the other group's MFMAs.
 //   LDS hazards: tile s+1 is written (by both groups) one full phase pair before anyone reads it; the buffer it
 //   replaces (tile s-1) was last read two barriers earlier by either group.
+// ABL (tools/ablate_pp_gemm.py, env VQCPC_PP_ABL, bias epilogue only) = measurement variants, never used by the library:
+//   1: planes written without the split arithmetic (garbage values)          -> +10-12 % (187 -> 211 TFLOP/s, 557056x768x256)
+//   2: no global loads after the first K tile                                -> +14-19 %
+//   3: both                                                                  -> +25-28 % (234 / 223 / 273 / 241)
+//   4: only the B (weight) operand without the split                          -> +5 %
+//   8: L2 prefetch touches of the next A cache line two K tiles ahead         -> -3 %
+//  16: mid / high A planes read under the MFMAs (56 instead of 72 live fragment registers) and a SECOND raw register
+//      set, i.e. every K tile requested two phase pairs before it is split   -> +-0 % (196 vs 197): the latency of the
+//      global loads is NOT what the memory phase waits for
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
                                                                      const float* __restrict__ B, int64_t ldb,
@@ -480,6 +489,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     }
     PP_SET_SRC()
     float4 xa0, xa1, xb0, xb1;
+    float4 ya0, ya1, yb0, yb1;                          // V2: second raw set (prefetch distance 2)
+    constexpr bool V2 = (ABL & 16) != 0;
 #define PP_OPAQUE(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w));
 #define PP_LOAD(S_, PF0, PF1)                                                                    \
     if (!(ABL & 2) || s < 1) {                                                            \
@@ -523,19 +534,37 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     unsigned char* const buf0 = smem2;
     unsigned char* const buf1 = smem2 + kPPBuf;
     bf16x8 fb[3][2], fa[4][3];                          // all fragments of a K tile: 18 x ds_read_b128 in the memory phase
+#define PP_READ_A(BUFP, PC)                                                                                          \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                 \
+        fa[mt][PC] = *reinterpret_cast<const bf16x8*>((BUFP) + a_off + (PC) * kPPPlane + mt * 32 * 32);
 #define PP_READ_FRAGS(BUFP)                                                                                          \
     _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                               \
         _Pragma("unroll") for (int tl = 0; tl < 2; ++tl)                                                             \
             fb[pc][tl] = *reinterpret_cast<const bf16x8*>((BUFP) + b_off + pc * kPPPlane + tl * 32 * 32);           \
-        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                             \
-            fa[mt][pc] = *reinterpret_cast<const bf16x8*>((BUFP) + a_off + pc * kPPPlane + mt * 32 * 32);           \
+        if (!V2 || pc == 2) {                                                                                        \
+            PP_READ_A(BUFP, pc)                                                                                      \
+        }                                                                                                            \
     }
 #define PP_TERM(PA, PB)                                                                                              \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                               \
         acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][PA], fb[PB][0], acc[mt][0], 0, 0, 0);            \
         acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][PA], fb[PB][1], acc[mt][1], 0, 0, 0);            \
     }
-#define PP_MFMA() PP_TERM(2, 0) PP_TERM(0, 2) PP_TERM(1, 1) PP_TERM(1, 0) PP_TERM(0, 1) PP_TERM(0, 0)
+#define PP_MFMA_V1() PP_TERM(2, 0) PP_TERM(0, 2) PP_TERM(1, 1) PP_TERM(1, 0) PP_TERM(0, 1) PP_TERM(0, 0)
+    // V2: only the B fragments and the LOW A plane are read in the memory phase; the mid / high A planes of this wave's own
+    // rows (group-local staging: nobody writes them meanwhile) are read under the MFMAs that precede their first use, the
+    // high plane into the registers of the low one: 56 instead of 72 live fragment registers
+#define PP_MFMA_V2(BUFP)                                                          \
+    PP_READ_A(BUFP, 1)                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    PP_TERM(2, 0)                                                                 \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    PP_READ_A(BUFP, 0)                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    PP_TERM(1, 1) PP_TERM(1, 0)                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                            \
+    PP_TERM(0, 2) PP_TERM(0, 1) PP_TERM(0, 0)
+#define PP_MFMA(BUFP) if (V2) { PP_MFMA_V2(BUFP) } else { PP_MFMA_V1() }
 #define PP_BARRIER()                          \
     __builtin_amdgcn_sched_barrier(0);        \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
@@ -605,16 +634,16 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     // one phase pair for stream position s (RB_ = LDS buffer with K tile s, WB_ = buffer for tile s+1).  ONE raw-operand
     // register set: tile s+1 (requested in the previous memory phase) is split and stored, then the same registers are
     // reused for the request of tile s+2 -- a full MFMA phase + two barriers of latency cover.
-#define PP_PHASES(RB_, WB_, PF0_, PF1_)                                                   \
+#define PP_PHASES(RB_, WB_, PF0_, PF1_, S_)                                               \
     {                                                                             \
         if (kt == 0 && s > 0) PP_EPILOGUE()                                       \
         PP_READ_FRAGS(RB_)                                                        \
-        PP_STORE(x, WB_)                                                          \
+        PP_STORE(S_, WB_)                                                         \
         if (ABL & 8) asm volatile("" :: "v"(PF0_), "v"(PF1_));                    \
-        PP_LOAD(x, PF0_, PF1_)                                                    \
+        PP_LOAD(S_, PF0_, PF1_)                                                   \
         PP_BARRIER()                                                              \
         __builtin_amdgcn_s_setprio(1);                                            \
-        PP_MFMA()                                                                 \
+        PP_MFMA(RB_)                                                              \
         __builtin_amdgcn_s_setprio(0);                                            \
         PP_BARRIER()                                                              \
         ++s;                                                                      \
@@ -628,12 +657,18 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     PP_LOAD(x, pf0, pf1)
     PP_STORE(x, buf0)
     PP_LOAD(x, pf2, pf3)
+    if (V2) { PP_LOAD(y, pf2, pf3) }                     // V2: tiles 1 (x) and 2 (y) requested
     PP_BARRIER()
     if (wm == 1) { PP_BARRIER() }                        // group 1 falls one phase behind
 #pragma unroll 1
     while (s < S) {
-        PP_PHASES(buf0, buf1, pf0, pf1)
-        PP_PHASES(buf1, buf0, pf2, pf3)
+        if (V2) {
+            PP_PHASES(buf0, buf1, pf0, pf1, x)
+            PP_PHASES(buf1, buf0, pf2, pf3, y)
+        } else {
+            PP_PHASES(buf0, buf1, pf0, pf1, x)
+            PP_PHASES(buf1, buf0, pf2, pf3, x)
+        }
     }
     if (wm == 0) { PP_BARRIER() }                        // pairs with group 1's last barrier
     PP_EPILOGUE()
@@ -642,6 +677,9 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
 #undef PP_BIAS_REQUEST
 #undef PP_BARRIER
 #undef PP_MFMA
+#undef PP_MFMA_V1
+#undef PP_MFMA_V2
+#undef PP_READ_A
 #undef PP_TERM
 #undef PP_READ_FRAGS
 #undef PP_STORE
@@ -1295,6 +1333,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 2>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 3>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 8) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 8>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 16) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 16>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 4) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 4>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
         } else if (use_pp)                                                                                                 \
             hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \

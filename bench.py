@@ -180,6 +180,72 @@ def hbm_traffic(kernel, calls_per_step):
         return None
 
 
+class ClockSampler:
+    """Shader clock / socket power of the busy GPU during the timed region, from sysfs (pp_dpm_sclk, hwmon power1_*), one
+    sample per 25 ms in a thread.  MI355X clocks to its power budget: under this step's GEMMs the shader clock sits near
+    1.8 GHz, not at the 2.4 GHz the nominal MFMA peak is quoted at (MI355X_MICROARCH.md, "DVFS give-back"); the bench
+    line reports the clock next to the roofline fraction so the two can be read together."""
+
+    def __init__(self):
+        import glob
+        self.cards = []
+        for d in glob.glob('/sys/class/drm/card*/device'):
+            if not self._read(d + '/pp_dpm_sclk'):
+                continue
+            pf = None
+            for h in glob.glob(d + '/hwmon/hwmon*'):
+                for n in ('power1_average', 'power1_input'):
+                    if pf is None and self._read(f'{h}/{n}').strip():
+                        pf = f'{h}/{n}'
+            self.cards.append((d, pf))
+        self.samples = {d: [] for d, _ in self.cards}
+        self.stop = False
+        self.thread = None
+
+    @staticmethod
+    def _read(path):
+        try:
+            return open(path).read()
+        except Exception:
+            return ''
+
+    def _loop(self):
+        while not self.stop:
+            for d, pf in self.cards:
+                sclk = None
+                for line in self._read(d + '/pp_dpm_sclk').splitlines():
+                    if '*' in line and not line.startswith('S'):
+                        digits = ''.join(c for c in line.split(':')[1] if c.isdigit())
+                        sclk = int(digits) if digits else None
+                p = self._read(pf).strip() if pf else ''
+                self.samples[d].append((sclk, int(p) / 1e6 if p.isdigit() else None))
+            time.sleep(0.025)
+
+    def start(self):
+        if self.cards:
+            import threading
+            self.thread = threading.Thread(target=self._loop, daemon=True)
+            self.thread.start()
+
+    def finish(self):
+        """{'sclk_mhz_median', 'sclk_mhz_min', 'power_w_median', 'samples'} of the card that drew the most power, samples
+        above 500 W only (the GPU of this process; every GPU of the node is visible in sysfs); None if unavailable."""
+        self.stop = True
+        if self.thread is not None:
+            self.thread.join()
+        try:
+            import statistics
+            best = max(self.samples.values(), key=lambda v: max([x[1] or 0 for x in v] or [0]))
+            busy = [(c, p) for c, p in best if c and p and p > 500]
+            if len(busy) < 3:
+                return None
+            return {'sclk_mhz_median': round(statistics.median(b[0] for b in busy)), 'sclk_mhz_min': min(b[0] for b in busy),
+                    'power_w_median': round(statistics.median(b[1] for b in busy)), 'samples': len(busy),
+                    'source': 'sysfs pp_dpm_sclk / hwmon power1 of the busy GPU, sampled during the timed region'}
+        except Exception:
+            return None
+
+
 def usable_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota (os.cpu_count() reports the
     whole host and oversubscribing OpenMP threads on a quota-limited container is catastrophically slow)."""
@@ -363,14 +429,18 @@ def main():
     torch.cuda.synchronize()
     dt_steps = dp.max_over_ranks(time.perf_counter() - t0)
     # (b) the timed region of `value`: EXACTLY args.steps iterations of epoch(train=True)
+    clock = ClockSampler() if dp.rank == 0 else None
     dp.barrier()
     torch.cuda.synchronize()
+    if clock is not None:
+        clock.start()
     t0 = time.perf_counter()
     means = run_epoch(args.steps, not use_graph)
     torch.cuda.synchronize()
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    clock_info = clock.finish() if clock is not None else None
     timer.enabled = False
     dt = dp.max_over_ranks(dt)
     timed_steps = max(1, len(range(0, args.steps, 4)))
@@ -424,6 +494,8 @@ def main():
                             flops_per_launch=nt['flops_per_launch'],
                             share_of_step=round(nt['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
                             vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3),
+                            frac_at_measured_sclk=(round(nt['tflops'] / (peak * clock_info['sclk_mhz_median'] / 2400.0), 4)
+                                                   if clock_info else None),
                             sampled=(f'HIP events around every GEMM launch of {timed_steps} eager steps run right after the timed '
                                      'region (the timed steps are graph replays)' if use_graph else
                                      'HIP events around every GEMM launch of every 4th step of the timed region'))
@@ -448,6 +520,7 @@ def main():
             'cast_bf16': ({'ms_per_step': round(sum(r[0].elapsed_time(r[1]) for r in timer.records['cast_bf16']) / timed_steps, 3),
                            'note': 'fp32 -> bf16 operand casts of the bf16 path (outside the gemm_nt bracket)'}
                           if timer.records['cast_bf16'] else None),
+            'clock': clock_info,
             'final_loss': round(last_loss, 5),
             'timed': 'trainer.epoch(train=True, num_batches=steps): steps + per-step metric bookkeeping + end-of-epoch host read',
             'step_graph': ({'replays_in_run': graph_replays, 'note': 'each training step is one HIP-graph replay '

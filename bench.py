@@ -379,8 +379,7 @@ def main():
     trainer.train()
     n_params = trainer.flat.numel
     # per-launch HIP events cannot be recorded inside a replayed graph: the kernel-timing samples come from eager steps
-    # (a run with fewer than 3 warm-up steps would capture inside the timed region: it stays eager)
-    use_graph = bool(args.graph) and dp.world_size == 1 and args.warmup >= 3
+    use_graph = bool(args.graph) and dp.world_size == 1
 
     timer = GemmTimer()
     if not args.no_kernel_timing:
@@ -411,11 +410,22 @@ def main():
         with contextlib.redirect_stdout(sys.stderr):
             return trainer.epoch(batches(n, sample), train=True, num_batches=n, **kw)
 
-    if use_graph:                                   # 2 eager steps, then one capture, then replays: all inside the warm-up
-        trainer.enable_step_graph(True)
     run_epoch(args.warmup, False)                   # includes the data-dependent codebook initialisation (step 0)
-    if use_graph and hasattr(trainer, 'precapture_step_graphs'):
-        trainer.precapture_step_graphs(pool[0])     # student step: one graph per masked event index (96 at C3)
+    sampled_eager_steps = 0
+    if use_graph:
+        # individual launches of a replayed graph cannot be bracketed with events from the host: the per-kernel samples
+        # of the roofline object come from eager steps run right BEFORE the graph is captured (same kernels, same shapes,
+        # same launch order; the rocprofv3 kernel trace of this command under profiles/ covers the replayed launches)
+        sampled_eager_steps = 0 if args.no_kernel_timing else min(args.steps, 12)
+        for b in batches(sampled_eager_steps, True, every=1):
+            trainer.train_step(b, train=True)
+        torch.cuda.synchronize()
+        trainer.enable_step_graph(True)             # 2 more eager steps, then one capture, then replays
+        for b in batches(4, False):
+            trainer.train_step(b, train=True)
+        if hasattr(trainer, 'precapture_step_graphs'):
+            trainer.precapture_step_graphs(pool[0])     # student step: one graph per masked event index (96 at C3)
+        torch.cuda.synchronize()
     torch.cuda.synchronize()
     # (a) bare training steps, no metric bookkeeping: reported next to the metric when the two differ
     dp.barrier()
@@ -446,17 +456,10 @@ def main():
     timed_steps = max(1, len(range(0, args.steps, 4)))
     graph_replays = None
     if use_graph:
-        # individual launches of a replayed graph cannot be bracketed with events from the host: the per-kernel samples
-        # of the roofline object come from eager steps run right AFTER the timed region (same kernels, same shapes, same
-        # launch order; the rocprofv3 kernel trace of this command under profiles/ covers the replayed launches)
         g = getattr(trainer, '_graph', None)
         graph_replays = g.replays if g is not None else 0
         trainer.enable_step_graph(False)
-        timed_steps = 0 if args.no_kernel_timing else min(args.steps, 12)
-        for b in batches(timed_steps, True, every=1):
-            trainer.train_step(b, train=True)
-        torch.cuda.synchronize()
-        timed_steps = max(1, timed_steps)
+        timed_steps = max(1, sampled_eager_steps)
     flush_c_stdio()
     dp.barrier()                                    # every rank has emitted whatever its libraries had buffered
     student = config['training_method'].lower() == 'student'
@@ -496,8 +499,8 @@ def main():
                             vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3),
                             frac_at_measured_sclk=(round(nt['tflops'] / (peak * clock_info['sclk_mhz_median'] / 2400.0), 4)
                                                    if clock_info else None),
-                            sampled=(f'HIP events around every GEMM launch of {timed_steps} eager steps run right after the timed '
-                                     'region (the timed steps are graph replays)' if use_graph else
+                            sampled=(f'HIP events around every GEMM launch of {timed_steps} eager steps run right before the graph '
+                                     'capture (the timed steps are graph replays)' if use_graph else
                                      'HIP events around every GEMM launch of every 4th step of the timed region'))
         line = {
             'metric': f'encoder-train windows/sec (Bach 4-voice, seq={seq_len})', 'value': round(value, 2), 'unit': 'windows/s',

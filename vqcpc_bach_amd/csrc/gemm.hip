@@ -577,6 +577,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;
     const int ldxi = (int)((EPI & E_GATE) ? ep.ldgate : ep.ldadd);
     float bias_nx0 = 0.0f, bias_nx1 = 0.0f;
+    const uint64_t drop_se = rng_seed_eff(ep.seed);
+    const uint32_t drop_sh = (uint32_t)(drop_se >> 32), nc1 = (uint32_t)N * kRngMul;
 #define PP_BIAS_REQUEST()                                                                                             \
     if (EPI & E_BIAS) {                                                                                                \
         const int tb_ = xcd_swizzle(min(ep_tile, tiles - 1), tiles);                                                   \
@@ -609,6 +611,9 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         PP_BIAS_REQUEST()                                                                                              \
         _Pragma("unroll") for (int tile = 0; tile < 8; ++tile) {                                                       \
             const int mt = tile >> 1, nt = tile & 1;                                                                   \
+            /* dropout hash input of this lane's first row of the tile; the other 15 rows are multiples of nc1 away */ \
+            const uint32_t x0t = (EPI & E_DROP) ? rng_x0(drop_se, (uint32_t)(row_base + mt * 32 + ep.row0) * (uint32_t)N + \
+                                                                      (uint32_t)(col_base + nt * 32)) : 0u;            \
             if (HAS_AUX && tile + 1 < 8) {                                                                             \
                 const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;                                                 \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) aux[(tile + 1) & 1][r] = __builtin_bit_cast(            \
@@ -621,7 +626,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                 const int64_t row = row_base + mt * 32 + (r & 3) + 8 * (r >> 2);                                       \
                 float v = acc[mt][nt][r] + bv;                                                                         \
                 if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
-                if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * N + col, ep.thr, ep.inv_keep);              \
+                if (EPI & E_DROP)   /* == drop_scale(ep.seed, (row + ep.row0) * N + col, ..): thr > 0 on this path */   \
+                    v *= rng_u24_from_x0(x0t + (uint32_t)((r & 3) + 8 * (r >> 2)) * nc1, drop_sh) >= ep.thr ? ep.inv_keep : 0.0f; \
                 if (EPI & E_GATE) v *= (aux[tile & 1][r] > 0.0f ? ep.gate_scale : 0.0f);                               \
                 if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
@@ -1152,12 +1158,18 @@ static int tn_splits(int64_t M, int N, int K) {
 }
 // 256-tile kernel: one workgroup per CU, so tiles * splits must not exceed the CU count (a 257th workgroup would wait
 // for a whole round)
-static bool tn_can_use_256(int64_t M, int N, int K) { return (N % kT2 == 0) && (K % kT2 == 0) && (M % 32 == 0); }
 static int tn_splits_256(int64_t M, int N, int K) {
     const int64_t tiles = (int64_t)(N / kT2) * (K / kT2);
     int64_t s = std::max<int64_t>(1, kNumCU / tiles);
     s = std::min<int64_t>(s, std::max<int64_t>(1, M / 256));
     return (int)s;
+}
+// ... and when M is too short for the split count to make up for few output tiles (student / decoder steps: 3072 /
+// 12 288 rows, 512 x 512 or 256 x 512 weights: 24-96 workgroups), the 128-tile kernel's 4x more tiles win:
+// 50 -> 30 us, 45 -> 27 us at M = 3072 (tools/bench_tn_small.py)
+static bool tn_can_use_256(int64_t M, int N, int K) {
+    if ((N % kT2) || (K % kT2) || (M % 32)) return false;
+    return (int64_t)(N / kT2) * (K / kT2) * tn_splits_256(M, N, K) >= kNumCU / 2;
 }
 
 // =====================================================================================================================

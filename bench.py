@@ -141,8 +141,27 @@ class GemmTimer:
             timer.records['cast_bf16'].append((e0, e1, 0.0, 6.0 * x.numel(), (x.shape[0], x.shape[1], 0, 'cast')))
             return out
 
+        raw_mask, raw_bits = ops.gemm_nt_relu_mask, ops.gemm_nt_gatebits
+
+        def nt_like(raw, epi, extra_bytes):
+            # the bit-gate forms of the two feed-forward GEMMs are NT GEMM launches like any other: same bracket, same group
+            def f(a, b, *args, **kw):
+                if not timer.enabled:
+                    return raw(a, b, *args, **kw)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = raw(a, b, *args, **kw)
+                e1.record()
+                M, N, K = a.shape[0], b.shape[0], a.shape[1]
+                timer.records['gemm_nt'].append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N) + extra_bytes * M * N,
+                                                 (M, N, K, epi)))
+                return out
+            return f
+
         ops.gemm_nt, ops.gemm_tn, ops.gemm_nt_bf16, ops.cast_bf16 = gemm_nt, gemm_tn, gemm_nt_bf16, cast_bf16
         ops.gemm_tn_bf16 = gemm_tn_bf16
+        ops.gemm_nt_relu_mask = nt_like(raw_mask, 'bias+act+drop_p+mask_out', 1.0 / 8)
+        ops.gemm_nt_gatebits = nt_like(raw_bits, 'gate_bits', 1.0 / 8)
 
     def breakdown(self, name, steps):
         agg = {}

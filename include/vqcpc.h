@@ -342,6 +342,22 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
                        int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * relu / dropout gate of the feed-forward block as a bit mask (transformer_custom.py:285: linear2(dropout(relu(linear1(x))))).
+ *   vqcpc_gemm_nt_relu_mask   C = dropout(relu(A . B^T + bias)) as vqcpc_gemm_nt(act = 1, drop_p, seed), and one bit per
+ *                             element "C > 0" into `mask` (vqcpc_gemm_gatebits_bytes(M, N) bytes; word
+ *                             ((row >> 2) * N/32 + col/32) * 4 + (row & 3), bit col % 32)
+ *   vqcpc_gemm_nt_gatebits    C = (A . B^T) * (bit ? gate_scale : 0): the backward of relu + dropout folded into the dgrad
+ *                             GEMM as with vqcpc_gemm_nt(gate = activation), reading 1/32 of the bytes
+ *   bf16x6 mode, M and N multiples of 256, K of 32 (vqcpc_gemm_gatebits_supported); same numbers as the fp32-gate calls.
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_gemm_gatebits_supported(int64_t M, int N, int K);
+int64_t vqcpc_gemm_gatebits_bytes(int64_t M, int N);
+int vqcpc_gemm_nt_relu_mask(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                            int K, const float* bias, float drop_p, uint64_t seed, void* mask, void* stream);
+int vqcpc_gemm_nt_gatebits(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                           int K, const void* mask, float gate_scale, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------------
  * bf16x6 GEMM on pre-split operands (csrc/gemm_planes.hip; no reference counterpart: the same F.linear products as
  * vqcpc_gemm_nt in mode 1, bit-identical results, with the exact 3-way bf16 split done once by the producer).
  *   "P3" format of an fp32 matrix X[rows][cols], cols % 16 == 0: three bf16 planes p = 0 (high), 1 (mid), 2 (low) with

@@ -1071,3 +1071,69 @@ def test_gemm_nt_planes_is_the_x6_gemm(ops, M, N, K, epi):
     exact = a.double() @ b.double().t()
     if epi in ('none',):
         assert rel_err(out.cpu(), exact.cpu()) < 2e-6 * max(1, K ** 0.5)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# relu / dropout gate as a bit mask (vqcpc_gemm_nt_relu_mask / vqcpc_gemm_nt_gatebits)
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K,p', [(512, 256, 64, 0.0), (4096, 1024, 256, 0.1), (2560, 512, 160, 0.3),
+                                     (65536 + 512, 1024, 256, 0.1)])
+def test_gate_bits_equal_the_fp32_gate(ops, M, N, K, p):
+    """Forward: the same output as gemm_nt(act=1, drop_p) and a mask that is exactly [out > 0] in the documented word
+    layout.  Backward: bit-identical to the dgrad GEMM gated by the fp32 activation, where that one runs the same
+    256-tile kernel order (whole rounds), within fp32 rounding of the accumulation order otherwise."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + N + K)
+    x, w1 = dev(torch.randn(M, K, generator=gen)), dev(torch.randn(N, K, generator=gen))
+    b1 = dev(torch.randn(N, generator=gen))
+    dy, w2t = dev(torch.randn(M, K, generator=gen)), dev(torch.randn(N, K, generator=gen))
+    hip.set_gemm_mode(1)
+    try:
+        assert ops.gatebits_supported(M, N, K)
+        h_ref = ops.gemm_nt(x, w1, bias=b1, act=1, drop_p=p, seed=321)
+        h, mask = ops.gemm_nt_relu_mask(x, w1, b1, drop_p=p, seed=321)
+        da_ref = ops.gemm_nt(dy, w2t, gate=h_ref, gate_scale=1.0 / (1.0 - p))
+        da = ops.gemm_nt_gatebits(dy, w2t, mask, gate_scale=1.0 / (1.0 - p))
+    finally:
+        hip.set_gemm_mode(0)
+    assert rel_err(h.cpu(), h_ref.cpu()) < 2e-6
+    # the mask, unpacked on the host: word ((row >> 2) * N/32 + col/32) * 4 + (row & 3), bit col % 32
+    words = mask.cpu().numpy().astype(np.uint32).reshape(M // 4, N // 32, 4)
+    bits = ((words[..., None] >> np.arange(32, dtype=np.uint32)) & 1).astype(bool)          # (M/4, N/32, 4, 32)
+    unpacked = torch.from_numpy(np.ascontiguousarray(bits.transpose(0, 2, 1, 3)).reshape(M, N))
+    assert torch.equal(unpacked, (h > 0).cpu())
+    assert 0.3 < float(unpacked.float().mean()) / (1.0 - p) < 0.7                           # relu keeps about half
+    gate_ok = ((h > 0) == (h_ref > 0))                     # identical up to elements whose pre-activation is ~0
+    assert float((~gate_ok).float().mean()) < 1e-5
+    err = ((da - da_ref).abs() * gate_ok).max() / da_ref.abs().max()
+    assert float(err) < 2e-6
+    assert not ops.gatebits_supported(M + 128, N, K) and not ops.gatebits_supported(M, N + 32, K)
+
+
+def test_ffn_uses_the_bit_gate_in_bf16x6_mode_and_matches_the_fp32_gate(ops):
+    """FFNFn end to end in mode 1 (bit gate) against the same function with the bit path disabled."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(5)
+    M, d, ff = 1024, 256, 1024
+    x = torch.randn(M, d, generator=gen)
+    w1, b1 = torch.randn(ff, d, generator=gen) * 0.05, torch.randn(ff, generator=gen) * 0.1
+    w2, b2 = torch.randn(d, ff, generator=gen) * 0.05, torch.randn(d, generator=gen) * 0.1
+    gy = torch.randn(M, d, generator=gen)
+    res = {}
+    hip.set_gemm_mode(1)
+    try:
+        for bits in (True, False):
+            saved = ops.gatebits_supported
+            if not bits:
+                ops.gatebits_supported = lambda *a: False
+            try:
+                t = [dev(v).requires_grad_(True) for v in (x, w1, b1, w2, b2)]
+                y = ops.FFNFn.apply(t[0], t[1], t[2], t[3], t[4], 0.1, 99)
+                (y * dev(gy)).sum().backward()
+                res[bits] = [y.detach().cpu()] + [v.grad.cpu() for v in t]
+            finally:
+                ops.gatebits_supported = saved
+    finally:
+        hip.set_gemm_mode(0)
+    for a, b in zip(res[True], res[False]):
+        assert rel_err(a, b) < 5e-6

@@ -609,11 +609,29 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         const float bv_cur0 = bias_nx0, bv_cur1 = bias_nx1;                                                            \
         ep_tile += gridDim.x;                                                                                          \
         PP_BIAS_REQUEST()                                                                                              \
+        /* bit mask of "output > 0" (gemm_common.h): written by the relu / dropout forward (E_MASKOUT), read instead of  \
+           the M x N fp32 activation by the relu / dropout backward (E_GATEBITS): 1/32 of the bytes, 4 loads per tile */  \
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)((EPI & (E_MASKOUT | E_GATEBITS)) ? (void*)ep.mask : (void*)C), 0, 0x7FFFFFFF, 0x00020000);         \
+        const int nw16 = (N >> 5) * 16;                                   /* bytes of one 4-row group of mask words */  \
+        const int mrow4 = (int)((m0 + wm * 128) >> 2), mcb = (n0 >> 5) + wn * 2;                                       \
+        u32x4 gb[2][4];                                                                                                \
+        if (EPI & E_GATEBITS) {                                                                                        \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) gb[0][jj] = __builtin_bit_cast(u32x4,                     \
+                __builtin_amdgcn_raw_buffer_load_b128(rm, kh * nw16, ((mrow4 + 2 * jj) * (N >> 5) + mcb) * 16, 0));    \
+        }                                                                                                              \
         _Pragma("unroll") for (int tile = 0; tile < 8; ++tile) {                                                       \
             const int mt = tile >> 1, nt = tile & 1;                                                                   \
             /* dropout hash input of this lane's first row of the tile; the other 15 rows are multiples of nc1 away */ \
             const uint32_t x0t = (EPI & E_DROP) ? rng_x0(drop_se, (uint32_t)(row_base + mt * 32 + ep.row0) * (uint32_t)N + \
                                                                       (uint32_t)(col_base + nt * 32)) : 0u;            \
+            if ((EPI & E_GATEBITS) && tile + 1 < 8) {                                                                  \
+                const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;                                                 \
+                _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) gb[(tile + 1) & 1][jj] = __builtin_bit_cast(u32x4,    \
+                    __builtin_amdgcn_raw_buffer_load_b128(rm, kh * nw16,                                               \
+                        ((mrow4 + mt2 * 8 + 2 * jj) * (N >> 5) + mcb + nt2) * 16, 0));                                 \
+            }                                                                                                          \
+            uint32_t mword = 0;                                                                                        \
             if (HAS_AUX && tile + 1 < 8) {                                                                             \
                 const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;                                                 \
                 _Pragma("unroll") for (int r = 0; r < 16; ++r) aux[(tile + 1) & 1][r] = __builtin_bit_cast(            \
@@ -630,9 +648,21 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                     v *= rng_u24_from_x0(x0t + (uint32_t)((r & 3) + 8 * (r >> 2)) * nc1, drop_sh) >= ep.thr ? ep.inv_keep : 0.0f; \
                 if (EPI & E_GATE) v *= (aux[tile & 1][r] > 0.0f ? ep.gate_scale : 0.0f);                               \
                 if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
+                if (EPI & E_GATEBITS) v = ((gb[tile & 1][r >> 2][r & 3] >> li) & 1u) ? v * ep.gate_scale : 0.0f;       \
+                if (EPI & E_MASKOUT) {                                                                                 \
+                    const uint64_t bal = __ballot(v > 0.0f);      /* low word: this row for kh = 0, high word: kh = 1 */ \
+                    /* s_nop: the ballot is an SGPR pair written by a VALU compare; nothing pads hazards in front of asm */ \
+                    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"                 \
+                                 : "+v"(mword) : "s"((uint32_t)bal), "n"(r), "s"((uint32_t)(bal >> 32)), "n"(16 + r));   \
+                }                                                                                                      \
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
                                                       ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
                 acc[mt][nt][r] = 0.0f;                                                                                 \
+            }                                                                                                          \
+            if ((EPI & E_MASKOUT) && lane < 32) {    /* lane = r + 16 kh holds the word of row (r & 3) + 8 (r >> 2) + 4 kh */ \
+                const int jj = (lane >> 2) & 3, khh = lane >> 4;                                                       \
+                __builtin_amdgcn_raw_buffer_store_b32(mword, rm, (2 * jj + khh) * nw16 + (lane & 3) * 4,               \
+                                                      ((mrow4 + mt * 8) * (N >> 5) + mcb + nt) * 16, 0);               \
             }                                                                                                          \
         }                                                                                                              \
     }
@@ -1152,7 +1182,9 @@ static int gemm_mode() {
 
 static int tn_splits(int64_t M, int N, int K) {
     const int64_t tiles = ceil_div(N, BM) * ceil_div(K, BN);
-    int64_t s = ceil_div(1024, tiles);
+    // short contractions (student step: 3072 rows) are prologue / epilogue-bound: fewer, longer splits (72 vs 76-81 us
+    // for the 2048 x 512 weights, tools/bench_tn_small.py)
+    int64_t s = ceil_div(M < 8192 ? 512 : 1024, tiles);
     s = std::min<int64_t>(s, ceil_div(M, 8 * TM));   // at least 256 rows per split
     return (int)std::max<int64_t>(s, 1);
 }
@@ -1168,7 +1200,7 @@ static int tn_splits_256(int64_t M, int N, int K) {
 // 12 288 rows, 512 x 512 or 256 x 512 weights: 24-96 workgroups), the 128-tile kernel's 4x more tiles win:
 // 50 -> 30 us, 45 -> 27 us at M = 3072 (tools/bench_tn_small.py)
 static bool tn_can_use_256(int64_t M, int N, int K) {
-    if ((N % kT2) || (K % kT2) || (M % 32)) return false;
+    if ((N % kT2) || (K % kT2) || (M % 32) || M < 8192) return false;
     return (int64_t)(N / kT2) * (K / kT2) * tn_splits_256(M, N, K) >= kNumCU / 2;
 }
 
@@ -1497,6 +1529,78 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                            tiles_k, rows_per_split, ws, ws_bias);
     VQ_CHECK_LAUNCH("gemm_tn");
     return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
+}
+
+
+// ---- relu / dropout gate as a bit mask (gemm_common.h: EpiParams::mask) ---------------------------------------------
+// The forward of F.relu + dropout after linear1 (transformer_custom.py:285) writes, next to its fp32 output, one bit per
+// element "output > 0"; the backward's epilogue d_h = (d_y . W2) * [h > 0] / (1 - p) reads the bits instead of the
+// M x 4d fp32 activation (2.3 GB per layer at C1).  256-tile ping-pong kernel only: M, N multiples of 256, K of 32, bf16x6.
+int vqcpc_gemm_gatebits_supported(int64_t M, int N, int K) {
+    return (gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && g_use_pp.load(std::memory_order_relaxed) &&
+            M >= kT2 && M % kT2 == 0 && N % kT2 == 0 && K % 32 == 0 && K >= 32)
+               ? 1 : 0;
+}
+
+int64_t vqcpc_gemm_gatebits_bytes(int64_t M, int N) { return M * (int64_t)(N / 32) * 4; }
+
+static int gatebits_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                           int K, const EpiParams& ep, int flags, hipStream_t st) {
+    const int tn2 = N / kT2;
+    const int tiles2 = (int)((M / kT2) * tn2);
+    const dim3 grid2((unsigned)std::min(tiles2, kNumCU)), block2(kT2Threads);
+    const size_t lds_pp = 2 * 6 * kT2 * 32;
+#define GB_LAUNCH(EPIV)                                                                                                   \
+    {                                                                                                                      \
+        static bool attr_pp = false;                                                                                       \
+        if (!attr_pp) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      (int)lds_pp);                                                                        \
+            attr_pp = true;                                                                                                \
+        }                                                                                                                  \
+        hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
+        VQ_CHECK_LAUNCH("gemm_nt_x6_pp (mask)");                                                                           \
+        return VQCPC_OK;                                                                                                   \
+    }
+    switch (flags) {
+        case E_BIAS | E_RELU | E_MASKOUT: GB_LAUNCH(E_BIAS | E_RELU | E_MASKOUT)
+        case E_BIAS | E_RELU | E_DROP | E_MASKOUT: GB_LAUNCH(E_BIAS | E_RELU | E_DROP | E_MASKOUT)
+        case E_GATEBITS: GB_LAUNCH(E_GATEBITS)
+        default: break;
+    }
+#undef GB_LAUNCH
+    set_error("gemm gate-bits: epilogue combination %d not instantiated", flags);
+    return VQCPC_EINVAL;
+}
+
+int vqcpc_gemm_nt_relu_mask(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                            int K, const float* bias, float drop_p, uint64_t seed, void* mask, void* stream) {
+    VQ_REQUIRE(A && B && C && bias && mask, "gemm_nt_relu_mask: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_gatebits_supported(M, N, K), "gemm_nt_relu_mask: needs the bf16x6 mode and M, N multiples of 256, K of 32");
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B) && aligned16(mask),
+               "gemm_nt_relu_mask: bad leading dimensions / alignment");
+    VQ_REQUIRE(drop_p >= 0.0f && drop_p < 1.0f, "gemm_nt_relu_mask: drop_p out of range");
+    EpiParams ep{};
+    ep.bias = bias;
+    ep.act = 1;
+    ep.thr = drop_threshold(drop_p);
+    ep.inv_keep = 1.0f / (1.0f - drop_p);
+    ep.seed = seed;
+    ep.mask = (uint32_t*)mask;
+    return gatebits_launch(A, lda, B, ldb, C, ldc, M, N, K, ep, E_BIAS | E_RELU | (ep.thr ? E_DROP : 0) | E_MASKOUT,
+                           (hipStream_t)stream);
+}
+
+int vqcpc_gemm_nt_gatebits(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                           int K, const void* mask, float gate_scale, void* stream) {
+    VQ_REQUIRE(A && B && C && mask, "gemm_nt_gatebits: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_gatebits_supported(M, N, K), "gemm_nt_gatebits: needs the bf16x6 mode and M, N multiples of 256, K of 32");
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B) && aligned16(mask),
+               "gemm_nt_gatebits: bad leading dimensions / alignment");
+    EpiParams ep{};
+    ep.gate_scale = gate_scale;
+    ep.mask = (uint32_t*)const_cast<void*>(mask);
+    return gatebits_launch(A, lda, B, ldb, C, ldc, M, N, K, ep, E_GATEBITS, (hipStream_t)stream);
 }
 
 }  // extern "C"

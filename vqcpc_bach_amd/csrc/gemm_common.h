@@ -6,6 +6,7 @@
 namespace vq {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDS_S = BK + 4;   // padded row stride (floats) of the NT operand tiles
@@ -26,10 +27,13 @@ struct EpiParams {
     int64_t ldadd2;
     int64_t row0;        // global row of the first row of this launch (a GEMM may be cut into two launches by rows): only
                          // the dropout element index needs it
+    uint32_t* mask;      // E_MASKOUT: written, E_GATEBITS: read.  Bit (row, col) of the "output > 0" mask lives in word
+                         // ((row >> 2) * (N / 32) + col / 32) * 4 + (row & 3), bit col % 32: the four rows a lane of the
+                         // 32x32 MFMA layout holds consecutively are one 16-byte load
 };
 
 // epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)
-enum { E_BIAS = 1, E_RELU = 2, E_DROP = 4, E_GATE = 8, E_ADD = 16, E_RUNTIME = 32, E_ADD2 = 64 };
+enum { E_BIAS = 1, E_RELU = 2, E_DROP = 4, E_GATE = 8, E_ADD = 16, E_RUNTIME = 32, E_ADD2 = 64, E_MASKOUT = 128, E_GATEBITS = 256 };
 
 // bijective XCD-aware remap: consecutive tiles (which share an A row panel) land on the same XCD / L2
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {

@@ -44,7 +44,6 @@ constexpr int kDLds = kDStages * kDStage + 8 * 4096;    // 128 KB of stages + a 
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 typedef float fx4 __attribute__((ext_vector_type(4)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));   // a native vector: inline-asm operands cannot be HIP's float4 struct
 
 __device__ __forceinline__ void split8(const fx4& lo, const fx4& hi, bf16x8& h, bf16x8& m, bf16x8& l) {
     uint2 h0, m0, l0, h1, m1, l1;

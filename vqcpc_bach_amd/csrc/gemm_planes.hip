@@ -94,7 +94,6 @@ __global__ __launch_bounds__(256) void join3_planes_kernel(const unsigned short*
 //   before group 0 issues into it.
 // LDS reads are inline asm: for a C++ LDS load hipcc inserts s_waitcnt vmcnt(0) as soon as an LDS-DMA is in flight.
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 constexpr int kPStages = 3;
 constexpr int kPStage = kPBuf;                       // 48 KB
 constexpr int kPLds = kPStages * kPStage;            // 144 KB

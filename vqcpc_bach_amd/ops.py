@@ -52,6 +52,36 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
     return out
 
 
+def gatebits_supported(M, N, K):
+    """True when the relu / dropout gate of an (M, K) -> (M, N) feed-forward projection can travel as a bit mask
+    (bf16x6 mode, full 256-tiles): see include/vqcpc.h."""
+    return hip.get_gemm_mode() == 1 and bool(hip.query('vqcpc_gemm_gatebits_supported', M, N, K))
+
+
+def gemm_nt_relu_mask(a, b, bias, drop_p=0.0, seed=0):
+    """(dropout(relu(a @ b^T + bias)), bit mask of its positive elements): ops.gemm_nt(act=1, ...) plus the mask that
+    gemm_nt_gatebits reads in the backward instead of the activation."""
+    a, lda = _rows(_f32(a))
+    b, ldb = _rows(_f32(b))
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    mask = torch.empty(M * (N // 32), dtype=torch.int32, device=a.device)
+    hip.call('vqcpc_gemm_nt_relu_mask', a, lda, b, ldb, out, N, M, N, K, bias, float(drop_p), int(seed), mask)
+    return out, mask
+
+
+def gemm_nt_gatebits(a, b, mask, gate_scale=1.0):
+    """(a @ b^T) * (bit ? gate_scale : 0) == ops.gemm_nt(a, b, gate=activation, gate_scale=...)."""
+    a, lda = _rows(_f32(a))
+    b, ldb = _rows(_f32(b))
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    hip.call('vqcpc_gemm_nt_gatebits', a, lda, b, ldb, out, N, M, N, K, mask, float(gate_scale))
+    return out
+
+
 def gemm_tn(a, b, want_bias=True, into=None):
     """dW[N,K] = a[M,N]^T @ b[M,K], db[N] = column sums of a.  `into` = (dW, db) accumulates into existing buffers."""
     a, lda = _rows(_f32(a))
@@ -396,7 +426,10 @@ class EncoderLayerFn(torch.autograd.Function):
             ff = gemm_nt_bf16(h2b, w2, bias=b2)
             h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
         else:
-            h2 = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2])
+            if gatebits_supported(Mq, ffd, d):       # relu / dropout gate of the backward as a bit mask (1/32 of the bytes)
+                h2, ctx.gate_mask = gemm_nt_relu_mask(x1, w1, b1, drop_p=p, seed=s[2])
+            else:
+                h2, ctx.gate_mask = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2]), None
             ff = gemm_nt(h2, w2, bias=b2)
         y = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
@@ -451,7 +484,10 @@ class EncoderLayerFn(torch.autograd.Function):
             dx1 = gemm_nt_bf16(da, transpose(w1), add=ds2)
         else:
             # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
-            da = gemm_nt(df, transpose(w2), gate=h2, gate_scale=1.0 / (1.0 - p))
+            if ctx.gate_mask is not None:
+                da = gemm_nt_gatebits(df, transpose(w2), ctx.gate_mask, gate_scale=1.0 / (1.0 - p))
+            else:
+                da = gemm_nt(df, transpose(w2), gate=h2, gate_scale=1.0 / (1.0 - p))
             dw2, db2 = wgrad(df, h2, w2, b2)
             dw1, db1 = wgrad(da, x1, w1, b1)
             dx1 = gemm_nt(da, transpose(w1), add=ds2)
@@ -617,7 +653,10 @@ class FFNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, drop_p, seed):
-        h = gemm_nt(x, w1, bias=b1, act=1, drop_p=float(drop_p), seed=int(seed))
+        if gatebits_supported(x.shape[0], w1.shape[0], w1.shape[1]) and x.dim() == 2:
+            h, ctx.gate_mask = gemm_nt_relu_mask(x, w1, b1, drop_p=float(drop_p), seed=int(seed))
+        else:
+            h, ctx.gate_mask = gemm_nt(x, w1, bias=b1, act=1, drop_p=float(drop_p), seed=int(seed)), None
         y = gemm_nt(h, w2, bias=b2)
         ctx.save_for_backward(x, h, w1, w2)
         ctx.biases = (b1, b2)
@@ -629,7 +668,10 @@ class FFNFn(torch.autograd.Function):
         x, h, w1, w2 = ctx.saved_tensors
         b1, b2 = ctx.biases
         dy = dy.contiguous()
-        da = gemm_nt(dy, transpose(w2), gate=h, gate_scale=1.0 / (1.0 - ctx.p))
+        if ctx.gate_mask is not None:
+            da = gemm_nt_gatebits(dy, transpose(w2), ctx.gate_mask, gate_scale=1.0 / (1.0 - ctx.p))
+        else:
+            da = gemm_nt(dy, transpose(w2), gate=h, gate_scale=1.0 / (1.0 - ctx.p))
         dw2, db2 = wgrad(dy, h, w2, b2)
         dw1, db1 = wgrad(da, x, w1, b1)
         dx = gemm_nt(da, transpose(w1)) if ctx.needs_input_grad[0] else None

@@ -905,8 +905,8 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
     }
 #define X6_ST(R0, R1, PLANE0, RP)                                                              \
     if (MODE == 2) {                                                                           \
-        const uint4 h_ = make_uint4(pack_hi(round_bf16(R0.x), round_bf16(R1.x)), pack_hi(round_bf16(R0.y), round_bf16(R1.y)), \
-                                    pack_hi(round_bf16(R0.z), round_bf16(R1.z)), pack_hi(round_bf16(R0.w), round_bf16(R1.w))); \
+        const uint4 h_ = make_uint4(cvt_pk_bf16(R0.x, R1.x), cvt_pk_bf16(R0.y, R1.y), cvt_pk_bf16(R0.z, R1.z), \
+                                    cvt_pk_bf16(R0.w, R1.w));                                  \
         *reinterpret_cast<uint4*>(smem + (PLANE0) * kTnPlane + (RP) * kTnRS + c4 * 4) = h_;    \
     } else {                                                                                   \
         uint4 h_, m_, l_;                                                                      \

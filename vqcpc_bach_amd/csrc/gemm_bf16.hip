@@ -184,7 +184,9 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
                 float v = V[j][c];                                                                                     \
                 if (EPI & E_BIAS) v += bias4[NT][c];                                                                   \
                 if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
-                if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * N + col + c, ep.thr, ep.inv_keep); \
+                if (EPI & E_DROP)   /* == drop_scale(ep.seed, (row + ep.row0) * N + col + c, ..); thr > 0 on this path */  \
+                    v *= rng_u24_from_x0(x0_lane + (uint32_t)((MT * 32 + 8 * j) * N + NT * 32 + c) * kRngMul, drop_sh) >= ep.thr \
+                             ? ep.inv_keep : 0.0f;                                                                     \
                 if (EPI & E_GATE) {                                                                                    \
                     bool pos;                                                                                          \
                     if (AUX_B16) {                                                                                     \
@@ -203,8 +205,8 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
                              "s"(rc), "s"(((MT * 32 + 8 * j) * ldci + NT * 32) * 4) : "memory");                       \
             if (OUT & B_OUT_BF16) {                                                                                    \
                 u32x2 pk;                                                                                              \
-                pk[0] = pack_hi(round_bf16(ov[0]), round_bf16(ov[1]));                                                 \
-                pk[1] = pack_hi(round_bf16(ov[2]), round_bf16(ov[3]));                                                 \
+                pk[0] = cvt_pk_bf16(ov[0], ov[1]);                                                                     \
+                pk[1] = cvt_pk_bf16(ov[2], ov[3]);                                                                     \
                 asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(pk), "v"(voff_cb), \
                              "s"(rcb), "s"(((MT * 32 + 8 * j) * ldcbi + NT * 32) * 2) : "memory");                     \
             }                                                                                                          \
@@ -247,6 +249,10 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
 #define B_EPILOGUE()                                                                                                   \
     {                                                                                                                  \
         B_EPI_DESC()                                                                                                   \
+        /* dropout hash input of this lane's first element of the output tile; the others are constant offsets away */ \
+        const uint64_t drop_se = rng_seed_eff(ep.seed);                                                                \
+        const uint32_t drop_sh = (uint32_t)(drop_se >> 32);                                                            \
+        const uint32_t x0_lane = rng_x0(drop_se, (uint32_t)(m0 + e_row + ep.row0) * (uint32_t)N + (uint32_t)(n0 + e_col)); \
         const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(                                           \
             (void*)((OUT & B_OUT_F32) ? o.c + m0 * o.ldc + n0 : (float*)smem), 0, 0x7FFFFFFF, 0x00020000);             \
         const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(                                          \

@@ -60,8 +60,16 @@ __device__ __forceinline__ uint32_t round_bf16(float x) {
     const uint32_t u = __float_as_uint(x);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) & 0xFFFF0000u;
 }
+// two fp32 -> one dword of two bf16 (element 0 in the low half), round to nearest even: ONE v_cvt_pk_bf16_f32 on gfx950 (the
+// integer form above is 4 VALU instructions per element + a byte permute per pair)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float e0, float e1) {
+    const f32x2_t v = {e0, e1};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
+}
 __device__ __forceinline__ uint2 round4_bf16(const float4& v) {
-    return make_uint2(pack_hi(round_bf16(v.x), round_bf16(v.y)), pack_hi(round_bf16(v.z), round_bf16(v.w)));
+    return make_uint2(cvt_pk_bf16(v.x, v.y), cvt_pk_bf16(v.z, v.w));
 }
 __device__ __forceinline__ void split3x4(const float4& v, uint2& h, uint2& m, uint2& l) {
     uint32_t h0, h1, h2, h3, m0, m1, m2, m3, l0, l1, l2, l3;

@@ -31,5 +31,6 @@ for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/pmc/$d
     timeout 900 rocprofv3 --kernel-trace --pmc $c -f csv -d /tmp/pmc/$d -- python $REPO/bench.py --steps 2 --warmup 1 --no-graph $COMMON > $OUT/pmc_$d.log 2>&1
 done
-python $REPO/tools/pmc_hbm_traffic.py /tmp/pmc 5   # 1 warm-up + 2 bare train_step + 2 epoch steps > $OUT/gemm_hbm_traffic.json
+# bench.py --steps 2 --warmup 1 --no-graph = 1 warm-up + 2 bare train_step + 2 epoch steps = 5 steps
+python $REPO/tools/pmc_hbm_traffic.py /tmp/pmc 5 > $OUT/gemm_hbm_traffic.json
 cat $OUT/gemm_hbm_traffic.json | head -20

@@ -341,6 +341,11 @@ int64_t vqcpc_gemm_tn_bf16_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
                        int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* dst[i][0 .. counts[i]) += src[i][..] for up to 8 small tensors in one launch (host arrays of device pointers): the
+ * `param.grad += g` of the small per-layer parameters (LayerNorm gamma / beta, relative-position tables) that autograd's
+ * AccumulateGrad would run as one kernel each (transformer_custom.py:282-289, subsampled_relative_attention.py:23-26). */
+int vqcpc_accumulate8(float* const* dst, const float* const* src, const int* counts, int n_tensors, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * relu / dropout gate of the feed-forward block as a bit mask (transformer_custom.py:285: linear2(dropout(relu(linear1(x))))).
  *   vqcpc_gemm_nt_relu_mask   C = dropout(relu(A . B^T + bias)) as vqcpc_gemm_nt(act = 1, drop_p, seed), and one bit per

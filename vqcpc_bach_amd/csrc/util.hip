@@ -293,6 +293,19 @@ __global__ __launch_bounds__(256) void check_tokens_kernel(const int64_t* __rest
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+struct Acc8 {
+    float* dst[8];
+    const float* src[8];
+    int n[8];
+};
+__global__ __launch_bounds__(256) void accumulate8_kernel(Acc8 a) {
+    const int t = blockIdx.y;
+    float* d = a.dst[t];
+    const float* s = a.src[t];
+    const int n = a.n[t];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] += s[i];
+}
+
 }  // namespace vq
 
 using namespace vq;
@@ -413,6 +426,29 @@ int vqcpc_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const
     hipLaunchKernelGGL(adam_dev_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr_dev, beta1, beta2,
                        eps, step_dev, grad_scale, max_norm, sumsq);
     VQ_CHECK_LAUNCH("adam_step_dev");
+    return VQCPC_OK;
+}
+
+
+// dst[i][:] += src[i][:] for up to 8 small tensors in ONE launch: the gradients of the small per-layer parameters
+// (LayerNorm gamma / beta, the relative-position tables) that the layer's backward would otherwise hand to autograd, which
+// adds each into the flat gradient buffer with a kernel of its own (43 launches per C1 step).
+int vqcpc_accumulate8(float* const* dst, const float* const* src, const int* counts, int n_tensors, void* stream) {
+    VQ_REQUIRE(dst && src && counts && n_tensors >= 0 && n_tensors <= 8, "accumulate8: at most 8 tensors");
+    if (n_tensors == 0) return VQCPC_OK;
+    Acc8 a{};
+    int maxn = 0;
+    for (int i = 0; i < n_tensors; ++i) {
+        VQ_REQUIRE(dst[i] && src[i] && counts[i] >= 0, "accumulate8: null pointer");
+        a.dst[i] = dst[i];
+        a.src[i] = src[i];
+        a.n[i] = counts[i];
+        maxn = std::max(maxn, counts[i]);
+    }
+    if (maxn == 0) return VQCPC_OK;
+    const int blocks_x = std::min((maxn + 255) / 256, 64);
+    hipLaunchKernelGGL(accumulate8_kernel, dim3(blocks_x, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
+    VQ_CHECK_LAUNCH("accumulate8");
     return VQCPC_OK;
 }
 

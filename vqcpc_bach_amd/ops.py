@@ -232,6 +232,26 @@ def _live_grad(t):
     return g if (g is not None and g.is_contiguous() and g.dtype == torch.float32) else None
 
 
+def accumulate_small(params, grads):
+    """Small-parameter gradients of a fused layer: where the parameter already owns a gradient buffer (trainers:
+    ops.direct_weight_gradients), all of them are added into those buffers by ONE launch and None is handed to autograd;
+    otherwise the gradients are returned unchanged.  Returns the list to give back to autograd."""
+    import ctypes
+    out, dst, src, cnt = list(grads), [], [], []
+    for i, (prm, g) in enumerate(zip(params, grads)):
+        live = _live_grad(prm) if g is not None else None
+        if live is not None and g.is_contiguous() and g.dtype == torch.float32 and live.numel() == g.numel():
+            dst.append(live.data_ptr())
+            src.append(g.data_ptr())
+            cnt.append(g.numel())
+            out[i] = None
+    for o in range(0, len(dst), 8):
+        n = min(8, len(dst) - o)
+        hip.call('vqcpc_accumulate8', (ctypes.c_void_p * 8)(*dst[o:o + n]), (ctypes.c_void_p * 8)(*src[o:o + n]),
+                 (ctypes.c_int * 8)(*cnt[o:o + n]), n)
+    return out
+
+
 def wgrad(g, x, weight, bias, rows=None):
     """Weight / bias gradient of y = x W^T + b.  When the parameter already owns a gradient buffer the TN GEMM's final
     reduction ACCUMULATES straight into it and (None, None) is returned to autograd -- no temporary, no extra
@@ -442,6 +462,7 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
         ctx.bf16 = (xb, xsb, attb, x1b, h2b) if nat else None
         ctx.biases = (bqkv, bo, b1, b2)
+        ctx.ln_betas = (be1, be2)
         ctx.qkv_tokens = qkv_tokens
         ctx.mark_non_differentiable(probs)
         return y, probs
@@ -452,6 +473,7 @@ class EncoderLayerFn(torch.autograd.Function):
          g2) = ctx.saved_tensors
         L, H, p, s, f, ext_qkv = ctx.meta
         bqkv, bo, b1, b2 = ctx.biases
+        be1, be2 = ctx.ln_betas
         x, ldx = _rows(x)
         M, d = x.shape
         hd, nblk, dev = d // H, M // L, x.device
@@ -520,6 +542,8 @@ class EncoderLayerFn(torch.autograd.Function):
                          ws, nbytes)
                 d_in = dqkv
             if ext_qkv:          # projection lives outside: its gradient leaves through qkv_in, x keeps the residual path
+                de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2),
+                                                                  (de1, de2, dg1, dbe1, dg2, dbe2))
                 return (ds1 if need_dx else None, None, None, None, None, None, d_in, None, None, None, dwo, dbo, de1, de2, dw1,
                         db1, dw2, db2, dg1, dbe1, dg2, dbe2)
             if nat:
@@ -553,6 +577,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 dx = lin(dkv, wt[:, d:])                                   # every row: keys / values path
                 dxs = dx[::f]                                              # kept rows also get the query + residual paths
                 gemm_nt(dq, wt[:, :d], add=ds1, add2=dxs, out=dxs)
+        de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
         return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1,
                 dg2, dbe2)
 

@@ -454,7 +454,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
 //      global loads is NOT what the memory phase waits for
 //  32: the epilogue without its stores                                        -> +15-17 % at K = 256, +5 % at K = 1024
 //      (an LDS-transposed epilogue with 4x fewer, 16-byte stores -- tried on this kernel -- changes nothing, 197 vs 198:
-//      it is the M x N x 4 bytes leaving the CU, not the store instructions)
+//      it is the M x N x 4 bytes leaving the CU, not the store instructions; de-synchronising the workgroups' tile
+//      boundaries with start-up sleeps changes nothing either)
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
                                                                      const float* __restrict__ B, int64_t ldb,

@@ -448,6 +448,11 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
 //   2: no global loads after the first K tile                                -> +14-19 %
 //   3: both                                                                  -> +25-28 % (234 / 223 / 273 / 241)
 //   4: only the B (weight) operand without the split                          -> +5 %
+//      CAUTION: variants 1, 3, 4 feed the MFMAs planes made of raw fp32 bit patterns; part of their gain is the higher
+//      clock of lower-toggle data (MI355X clocks to its power budget), not removed work.  The REAL thing for variant 4 --
+//      weights pre-split once per step into K-tile-major bf16 planes, staged by three 16-byte loads + three ds_write_b128,
+//      bit-identical results -- measured 204 vs 204, 190 vs 191, 220 vs 221 TFLOP/s: no gain (row-major bf16 planes:
+//      3-5 % SLOWER, 768 cache lines of 32 used bytes per K tile thrash the L1); not kept.
 //   8: L2 prefetch touches of the next A cache line two K tiles ahead         -> -3 %
 //  16: mid / high A planes read under the MFMAs (56 instead of 72 live fragment registers) and a SECOND raw register
 //      set, i.e. every K tile requested two phase pairs before it is split   -> +-0 % (196 vs 197): the latency of the

@@ -27,7 +27,8 @@
 // (K = 256 / 1024), so what is left is the cost of moving 48 KB per K tile into the LDS of a CU that is issuing MFMAs,
 // whichever way it is moved.  An activation in P3 costs its producer 6 instead of 4 bytes per element in an HBM-bound
 // kernel -- more than these GEMM gains return at the C1 sizes -- so the training step does NOT use this path; it stays
-// as a tested, opt-in building block (weights could be pre-split for free).
+// as a tested, opt-in building block.  (Pre-splitting ONLY the weight operand of the fp32-in kernel was also measured: no
+// gain -- gemm.hip, ablation notes.)
 #include "gemm_common.h"
 
 namespace vq {

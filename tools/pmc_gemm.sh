@@ -5,7 +5,7 @@ REPO=${GRAFT_REPO_ROOT:-/root/repo}
 N=$1; K=$2; export VQCPC_PP_ABL=${3:-0}
 for grp in "SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_VALU_MFMA_COEXEC_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY" "SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_MISC" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_LDS_DATA_FIFO_FULL" "SQ_LDS_CMD_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INST_CYCLES_VMEM_RD" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_SALU"; do
   rm -rf /tmp/pg
-  timeout 200 rocprofv3 --kernel-trace --pmc $grp -f csv -d /tmp/pg -- python $REPO/tools/_one_gemm.py $N $K > /tmp/pg.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $grp -f csv -d /tmp/pg -- python $REPO/tools/one_gemm.py $N $K > /tmp/pg.log 2>&1
   python - <<PY
 import csv, glob, collections
 tot = collections.defaultdict(float); n = collections.Counter()

@@ -88,3 +88,41 @@ def test_single_rank_rccl_path_runs_here():
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         x = torch.load(os.path.join(d, 'r0.pt'))
         assert x['world'] == 1 and x['init_equal'] and x['codebook_equal'] and x['idx_equal'] and x['grad_worst'] < 5e-4
+
+
+def test_two_ranks_share_this_gpu_over_gloo(tmp_path):
+    """Always runs (1 GPU is enough): TWO ranks, both on device 0, gradients / broadcasts over gloo (device tensors staged
+    through the host).  Everything but the transport is the multi-GPU path: rank-0 weight and codebook broadcasts, shard
+    gradients averaged to the global-batch gradient (vs the oracle on the concatenated batch), bit-identical replicas
+    after 3 steps."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_SHARE_GPU='1', VQCPC_DP_BACKEND='gloo',
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), WORKER, str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [torch.load(tmp_path / f'r{k}.pt') for k in range(2)]
+    for k, x in enumerate(res):
+        assert x['world'] == 2 and x['rank'] == k
+        assert x['init_equal'] and x['codebook_equal'] and x['idx_equal']
+        assert x['grad_worst'] < 5e-4, x['grad_worst']
+    assert res[1]['param_digest'] == res[0]['param_digest'] and res[1]['loss_global'] == res[0]['loss_global']
+
+
+def test_bench_contract_with_two_ranks_sharing_this_gpu():
+    """bench.py under torch.distributed.run with 2 ranks (both on device 0, gloo): ONE JSON line from rank 0, n_gpus = 2,
+    whole-job value = global batch * steps / max-over-ranks time, eager steps (no graph replay across ranks)."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_SHARE_GPU='1', VQCPC_DP_BACKEND='gloo',
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
+           '--batch', '32']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['step_graph'] is None and line['cpu_baseline'] is None
+    assert line['config']['global_batch'] == 64 and line['config']['parallelism'] == 'dp2'
+    assert abs(line['value'] - 64 * 4 / (line['ms_per_step'] * 4e-3)) < 0.01 * line['value']
+    assert line['roofline'] is not None and line['roofline']['achieved'] > 0

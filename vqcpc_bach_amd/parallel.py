@@ -24,6 +24,11 @@ class DataParallelContext:
         self.rank = int(os.environ.get('RANK', 0))
         self.world_size = int(os.environ.get('WORLD_SIZE', 1))
         self.local_rank = int(os.environ.get('LOCAL_RANK', 0))
+        # tests on a 1-GPU box: VQCPC_DP_SHARE_GPU=1 puts every rank on device 0 (with VQCPC_DP_BACKEND=gloo, which moves
+        # device tensors through the host): the whole multi-rank trainer path runs on the GPU kernels, only the transport
+        # differs from RCCL
+        if os.environ.get('VQCPC_DP_SHARE_GPU', '0') == '1':
+            self.local_rank = 0
         if device is None:
             if torch.cuda.is_available():
                 torch.cuda.set_device(self.local_rank)     # mandatory: the reference moves to the DEFAULT device
@@ -35,7 +40,7 @@ class DataParallelContext:
         force = os.environ.get('VQCPC_FORCE_DIST', '0') == '1'      # exercise the RCCL path with a single rank (tests)
         self.force = force
         if (self.world_size > 1 or force) and not dist.is_initialized():
-            backend = backend or ('nccl' if self.device.type == 'cuda' else 'gloo')
+            backend = backend or os.environ.get('VQCPC_DP_BACKEND') or ('nccl' if self.device.type == 'cuda' else 'gloo')
             os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
             os.environ.setdefault('MASTER_PORT', '29500')
             kw = dict(device_id=self.device) if backend == 'nccl' else {}

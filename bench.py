@@ -201,9 +201,11 @@ def hbm_traffic(kernel, calls_per_step):
 
 class ClockSampler:
     """Shader clock / socket power of the busy GPU during the timed region, from sysfs (pp_dpm_sclk, hwmon power1_*), one
-    sample per 25 ms in a thread.  MI355X clocks to its power budget: under this step's GEMMs the shader clock sits near
-    1.8 GHz, not at the 2.4 GHz the nominal MFMA peak is quoted at (MI355X_MICROARCH.md, "DVFS give-back"); the bench
-    line reports the clock next to the roofline fraction so the two can be read together."""
+    sample per 25 ms in a thread.  MI355X clocks to its power budget (MI355X_MICROARCH.md, "DVFS give-back"): sysfs reads
+    1.9-2.0 GHz during the step, and the counter-derived clock INSIDE the bf16x6 GEMM kernels is lower still, 1.26-1.35 GHz
+    (tools/pmc_gemm.sh, profiles/r02_gemm_pmc.txt: their matrix pipes are busy 90 % of those cycles) -- not the 2.4 GHz the
+    nominal MFMA peak is quoted at.  The bench line reports the sysfs clock next to the roofline fraction so that runs on
+    different boxes can be compared; it is an upper bound of the clock the GEMMs see."""
 
     def __init__(self):
         import glob

@@ -1137,3 +1137,23 @@ def test_ffn_uses_the_bit_gate_in_bf16x6_mode_and_matches_the_fp32_gate(ops):
         hip.set_gemm_mode(0)
     for a, b in zip(res[True], res[False]):
         assert rel_err(a, b) < 5e-6
+
+
+@pytest.mark.parametrize('M,N,K,with_bias', [(512, 256, 64, True), (65536, 768, 256, True), (66048, 256, 1024, False),
+                                             (131072, 512, 96, True)])
+def test_gemm_nt_one_wave_per_simd_kernel_is_bitwise_the_ping_pong_kernel(ops, M, N, K, with_bias):
+    """gemm_sw.hip (mode +32): same LDS image, same fragments, same MFMA order as gemm_nt_x6_pp_kernel."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + N + K)
+    a, b = dev(torch.randn(M, K, generator=gen)), dev(torch.randn(N, K, generator=gen))
+    bias = dev(torch.randn(N, generator=gen)) if with_bias else None
+    try:
+        hip.set_gemm_mode(1)
+        ref = ops.gemm_nt(a, b, bias=bias)
+        hip.set_gemm_mode(33)
+        out = ops.gemm_nt(a, b, bias=bias)
+    finally:
+        hip.set_gemm_mode(0)
+    assert torch.equal(out, ref)
+    exact = a.double() @ b.double().t() + (bias.double() if with_bias else 0)
+    assert rel_err(out.cpu(), exact.cpu()) < 2e-6 * max(1, K ** 0.5)

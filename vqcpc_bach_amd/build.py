@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libvqcpc_hip.so')
-SOURCES = ['util.hip', 'vq.hip', 'nce.hip', 'embed_ln.hip', 'relattn.hip', 'relattn_sub.hip', 'relattn16.hip', 'relattn_x.hip', 'gemm.hip', 'gemm_dma.hip', 'gemm_bf16.hip', 'gemm_planes.hip', 'student.hip', 'gru.hip']
+SOURCES = ['util.hip', 'vq.hip', 'nce.hip', 'embed_ln.hip', 'relattn.hip', 'relattn_sub.hip', 'relattn16.hip', 'relattn_x.hip', 'gemm.hip', 'gemm_dma.hip', 'gemm_bf16.hip', 'gemm_planes.hip', 'gemm_sw.hip', 'student.hip', 'gru.hip']
 # the VQ argmin must reproduce separately-rounded sub/mul/add: no FMA contraction in that file
 EXTRA = {'vq.hip': ['-ffp-contract=off']}
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-Wall', '-Wno-unused-function']

@@ -1173,6 +1173,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const flo
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
 static std::atomic<int> g_gemm_mode{-1};
 static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups (A/B switch)
+static std::atomic<int> g_use_sw{0};   // bf16x6 NT 256-tile: software-pipelined one-wave-per-SIMD kernel (gemm_sw.hip), A/B switch
 static std::atomic<int> g_use_dma{0};  // bf16x6 NT 256-tile: LDS-DMA operand delivery (gemm_dma.hip) instead of register staging
 static std::atomic<int> g_use_t2{1};   // bf16x6 NT: use the 256x256 tile kernel where shapes allow (A/B switch)
 static int gemm_mode() {
@@ -1356,6 +1357,8 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         const double eff256 = r256 / ceil(r256), eff128 = r128 / ceil(r128);
         t2_ok = eff256 * 1.08 >= eff128;
     }
+    if (t2_ok && g_use_sw.load(std::memory_order_relaxed) && gemm_nt_sw_ok(M, N, K, flags))
+        return gemm_nt_sw_launch(A, lda, B, ldb, C, ldc, M, N, K, flags, ep, st);
     if (t2_ok && g_use_dma.load(std::memory_order_relaxed) && gemm_nt_dma_ok(M, N, K, flags))
         return gemm_nt_dma_launch(A, lda, B, ldb, C, ldc, M, N, K, flags, ep, st);
     if (t2_ok) {
@@ -1446,10 +1449,14 @@ int vqcpc_gemm_set_mode(int mode) {
     // 8 = plain bf16 operands (one bf16 MFMA per product, fp32 accumulation)
     // +16: 256-tile NT kernel with LDS-DMA operand delivery (gemm_dma.hip) instead of register staging (A/B switch; the
     // register-staged ping-pong kernel is 3-5 % faster: an LDS-DMA instruction costs ~90 issue cycles on its SIMD)
+    // +32: software-pipelined one-wave-per-SIMD 256-tile NT kernel (gemm_sw.hip; A/B switch)
+    const int use_sw = (mode >= 32 && mode < 48) ? 1 : 0;
+    if (use_sw) mode -= 32;
+    g_use_sw.store(use_sw, std::memory_order_relaxed);
     const int use_dma = (mode >= 16 && mode < 32) ? 1 : 0;
     if (use_dma) mode -= 16;
     VQ_REQUIRE((mode >= 0 && mode <= 7) || mode == 8,
-               "gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong, +16: LDS-DMA kernel] or 8 (bf16)");
+               "gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong, +16: LDS-DMA kernel, +32: one-wave-per-SIMD kernel] or 8 (bf16)");
     g_use_dma.store(use_dma, std::memory_order_relaxed);
     if (mode == 8) {
         g_gemm_mode.store(2, std::memory_order_relaxed);

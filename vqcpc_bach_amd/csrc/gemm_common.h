@@ -82,6 +82,10 @@ __device__ __forceinline__ void split3x4(const float4& v, uint2& h, uint2& m, ui
     l = make_uint2(pack_hi(l0, l1), pack_hi(l2, l3));
 }
 
+// software-pipelined one-wave-per-SIMD variant of the 256-tile bf16x6 NT kernel (gemm_sw.hip)
+bool gemm_nt_sw_ok(int64_t M, int N, int K, int flags);
+int gemm_nt_sw_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                      int K, int flags, const EpiParams& ep, hipStream_t st);
 // LDS-DMA variant of the 256-tile bf16x6 NT kernel (gemm_dma.hip)
 bool gemm_nt_dma_ok(int64_t M, int N, int K, int flags);
 int gemm_nt_dma_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,

@@ -185,7 +185,7 @@ def query(name, *args):
 
 def set_gemm_mode(mode):
     """0 = fp32 MFMA (exact), 1 = bf16x6 split MFMA (fp32-class accuracy, faster); +2: 128-tile kernels only,
-    +4: 256-tile NT kernel without the ping-pong wave groups, +16: LDS-DMA 256-tile NT kernel (A/B switches); 8 = plain bf16 operands (one bf16 MFMA per
+    +4: 256-tile NT kernel without the ping-pong wave groups, +16: LDS-DMA 256-tile NT kernel, +32: one-wave-per-SIMD software-pipelined 256-tile NT kernel (A/B switches); 8 = plain bf16 operands (one bf16 MFMA per
     product, fp32 accumulation: reduced precision, for BASELINE configs[4] only).  get_gemm_mode() returns 0 / 1 / 2."""
     global _gemm_mode
     rc = load().vqcpc_gemm_set_mode(int(mode))

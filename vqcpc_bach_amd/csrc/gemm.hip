@@ -460,7 +460,10 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
 //  32: the epilogue without its stores                                        -> +15-17 % at K = 256, +5 % at K = 1024
 //      (an LDS-transposed epilogue with 4x fewer, 16-byte stores -- tried on this kernel -- changes nothing, 197 vs 198:
 //      it is the M x N x 4 bytes leaving the CU, not the store instructions; de-synchronising the workgroups' tile
-//      boundaries with start-up sleeps changes nothing either)
+//      boundaries with start-up sleeps (across or within XCDs) changes nothing either).  In cycles (tools/pmc_gemm.sh,
+//      557056 x 768 x 256): 1.743 M per wave shipped, 1.731 M with the transposed epilogue, 1.524 M without stores -- the
+//      output leaves a CU at ~30 bytes per clock whatever the instruction width (tools/micro/store_rate.hip: 36 / 70 B/clk
+//      for dword / dwordx4 stores alone), and hiding it would take a second accumulator set
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
                                                                      const float* __restrict__ B, int64_t ldb,

@@ -1171,6 +1171,169 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const flo
     }
 }
 
+// Ping-pong variant of gemm_tn_x6_256_kernel (same tile, staging, LDS image and MFMA order => the same partial sums): the
+// 16-row steps of the workgroup are cut into a memory phase (read the 18 fragments of step s, split + store step s+1,
+// request step s+2) and an MFMA phase (48 MFMAs), each closed by a barrier; wave group 1 (the lower 128 output rows) runs one
+// phase behind group 0, so that on every SIMD one wave issues MFMAs while the other one does its memory phase (the lockstep
+// kernel kept the matrix pipes busy 64 % of the cycles: tools/pmc_gemm_tn.sh).
+__global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ B, int64_t ldb, int64_t M,
+                                                                      int N, int K, int tiles_k, int64_t rows_per_split,
+                                                                      float* __restrict__ ws, float* __restrict__ ws_bias) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * kT2, k0 = tk * kT2;
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(m_begin + rows_per_split, M);          // (m_end - m_begin) % 32 == 0 (host)
+    const bool want_bias = (ws_bias != nullptr) && tk == 0;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // staging: thread = (column quad c4 of 64, row pair rp of 8): rows 2rp, 2rp+1 of the 16-row step
+    const int c4 = (tid & 63) * 4, rp = tid >> 6;
+    const float* a_src = A + (m_begin + 2 * rp) * lda + n0 + c4;
+    const float* b_src = B + (m_begin + 2 * rp) * ldb + k0 + c4;
+    float4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;
+#define W2_LOAD(S, MM)                                                                   \
+    S##a0 = *reinterpret_cast<const float4*>(a_src + (int64_t)(MM) * lda);               \
+    S##a1 = *reinterpret_cast<const float4*>(a_src + (int64_t)((MM) + 1) * lda);         \
+    S##b0 = *reinterpret_cast<const float4*>(b_src + (int64_t)(MM) * ldb);               \
+    S##b1 = *reinterpret_cast<const float4*>(b_src + (int64_t)((MM) + 1) * ldb);
+#define W2_STORE(S, BUFP)                                                                \
+    {                                                                                    \
+        uint4 h_, m_, l_;                                                                \
+        const int o_ = rp * kW2RS + c4 * 4;                                              \
+        split3_pair4(S##a0, S##a1, h_, m_, l_);                                          \
+        *reinterpret_cast<uint4*>((BUFP) + 0 * kW2Plane + o_) = h_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 1 * kW2Plane + o_) = m_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 2 * kW2Plane + o_) = l_;                      \
+        split3_pair4(S##b0, S##b1, h_, m_, l_);                                          \
+        *reinterpret_cast<uint4*>((BUFP) + 3 * kW2Plane + o_) = h_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 4 * kW2Plane + o_) = m_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 5 * kW2Plane + o_) = l_;                      \
+        if (want_bias && store_counts) {                                                 \
+            bsum.x += S##a0.x + S##a1.x;                                                 \
+            bsum.y += S##a0.y + S##a1.y;                                                 \
+            bsum.z += S##a0.z + S##a1.z;                                                 \
+            bsum.w += S##a0.w + S##a1.w;                                                 \
+        }                                                                                \
+    }
+#define W2_FRAG(DST, BASE)                                                               \
+    {                                                                                    \
+        uint4 u_;                                                                        \
+        u_.x = *reinterpret_cast<const uint32_t*>(BASE);                                 \
+        u_.y = *reinterpret_cast<const uint32_t*>((BASE) + kW2RS);                       \
+        u_.z = *reinterpret_cast<const uint32_t*>((BASE) + 2 * kW2RS);                   \
+        u_.w = *reinterpret_cast<const uint32_t*>((BASE) + 3 * kW2RS);                   \
+        DST = __builtin_bit_cast(bf16x8, u_);                                            \
+    }
+    // all 18 fragments of a 16-row step: 72 x ds_read_b32 in the memory phase (a[tile 0..3][plane], b[plane][tile 0..1])
+    bf16x8 fa[4][3], fb[3][2];
+#define TP_READ_FRAGS(BUFP)                                                                                               \
+    {                                                                                                                     \
+        const unsigned char* ab_ = (BUFP) + (kh * 4) * kW2RS + (wm * 128 + li) * 4;                                       \
+        const unsigned char* bb_ = (BUFP) + 3 * kW2Plane + (kh * 4) * kW2RS + (wn * 64 + li) * 4;                         \
+        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                                \
+            _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) W2_FRAG(fb[pc][tl], bb_ + pc * kW2Plane + tl * 128)          \
+            _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) W2_FRAG(fa[t4][pc], ab_ + pc * kW2Plane + t4 * 128)          \
+        }                                                                                                                 \
+    }
+#define TP_TERM(PA, PB)                                                                                                   \
+    _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                                                    \
+        acc[t4][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t4][PA], fb[PB][0], acc[t4][0], 0, 0, 0);                 \
+        acc[t4][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t4][PA], fb[PB][1], acc[t4][1], 0, 0, 0);                 \
+    }
+#define TP_MFMA() TP_TERM(2, 0) TP_TERM(0, 2) TP_TERM(1, 1) TP_TERM(1, 0) TP_TERM(0, 1) TP_TERM(0, 0)
+#define TP_BARRIER()                          \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+    // one phase pair for step s: RB_ holds step s, WB_ receives step s+1 (held by the raw set, requested one phase pair
+    // ago), then the raw set is refilled with step s+2 (past the end: the last step again, never used)
+#define TP_PHASES(RB_, WB_)                                                       \
+    {                                                                             \
+        TP_READ_FRAGS(RB_)                                                        \
+        store_counts = st + 1 < nsteps;                                           \
+        W2_STORE(x, WB_)                                                          \
+        {                                                                         \
+            const int64_t nx_ = min((int64_t)(st + 2), nsteps - 1) * kW2TM;       \
+            W2_LOAD(x, nx_)                                                       \
+        }                                                                         \
+        TP_BARRIER()                                                              \
+        __builtin_amdgcn_s_setprio(1);                                            \
+        TP_MFMA()                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                            \
+        TP_BARRIER()                                                              \
+        ++st;                                                                     \
+    }
+
+    unsigned char* const buf0 = smemw;
+    unsigned char* const buf1 = smemw + kW2Buf;
+    const int64_t rows = m_end - m_begin;                     // multiple of 32: an even number of 16-row steps
+    const int64_t nsteps = rows / kW2TM;
+    if (rows > 0) {
+        // the bias sums must count every row exactly once: steps 0 .. nsteps-1 are stored once each (the store of the
+        // clamped "step nsteps" in the last phase is skipped for the sums)
+        int64_t st = 0;
+        bool store_counts = true;
+        W2_LOAD(x, 0)
+        W2_STORE(x, buf0)
+        W2_LOAD(x, min((int64_t)1, nsteps - 1) * kW2TM)
+        TP_BARRIER()
+        if (wm == 1) { TP_BARRIER() }                        // group 1 falls one phase behind
+#pragma unroll 1
+        while (st < nsteps) {
+            TP_PHASES(buf0, buf1)
+            TP_PHASES(buf1, buf0)
+        }
+        if (wm == 0) { TP_BARRIER() }                        // pairs with group 1's last barrier
+    }
+#undef TP_PHASES
+#undef TP_BARRIER
+#undef TP_MFMA
+#undef TP_TERM
+#undef TP_READ_FRAGS
+#undef W2_LOAD
+#undef W2_STORE
+#undef W2_FRAG
+
+    float* out = ws + (int64_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = k0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(int64_t)row * K + col] = acc[mt][nt][r];
+            }
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smemw);          // [8][256]
+        *reinterpret_cast<float4*>(red + rp * kT2 + c4) = bsum;
+        __syncthreads();
+        if (tid < kT2) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g) tot += red[g * kT2 + tid];
+            ws_bias[(int64_t)blockIdx.y * N + n0 + tid] = tot;
+        }
+    }
+}
+
 // GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate),
 // 2 = plain bf16 operands (one MFMA per product, fp32 accumulate; BASELINE configs[4] names bf16): 128-tile kernels only.
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
@@ -1526,6 +1689,16 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
             attr_done = true;
         }
         const int tk2 = K / kT2;
+        if (g_use_pp.load(std::memory_order_relaxed)) {
+            static bool attr_pp = false;
+            if (!attr_pp) {
+                (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          2 * kW2Buf);
+                attr_pp = true;
+            }
+            hipLaunchKernelGGL(gemm_tn_x6_pp_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kW2Buf, s, A, lda,
+                               B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
+        } else
         hipLaunchKernelGGL(gemm_tn_x6_256_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kW2Buf, s, A, lda, B,
                            ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
     } else if (gemm_mode() == 1) {

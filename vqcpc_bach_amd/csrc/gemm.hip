@@ -1028,6 +1028,10 @@ constexpr int kW2TM = 16;                                  // contraction rows p
 constexpr int kW2RS = kT2 * 4 + 16;                        // bytes per row pair (256 dwords + pad)
 constexpr int kW2Plane = (kW2TM / 2) * kW2RS;              // 8 320 B
 constexpr int kW2Buf = 6 * kW2Plane;                       // 49 920 B; two buffers = 99 840 B
+constexpr int kTPRS = (64 + 4) * 4;                        // ping-pong kernel: bytes per row pair of a 64-column block
+constexpr int kTPBlk = (kW2TM / 2) * kTPRS;                // 2 176 B per column block
+constexpr int kTPPlane = 4 * kTPBlk;                       // 8 704 B
+constexpr int kTPBuf = 6 * kTPPlane;                       // 52 224 B; two buffers = 104 448 B
 
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ B, int64_t ldb, int64_t M,
@@ -1212,15 +1216,15 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
 #define W2_STORE(S, BUFP)                                                                \
     {                                                                                    \
         uint4 h_, m_, l_;                                                                \
-        const int o_ = rp * kW2RS + c4 * 4;                                              \
+        const int o_ = (c4 >> 6) * kTPBlk + rp * kTPRS + (c4 & 63) * 4;                  \
         split3_pair4(S##a0, S##a1, h_, m_, l_);                                          \
-        *reinterpret_cast<uint4*>((BUFP) + 0 * kW2Plane + o_) = h_;                      \
-        *reinterpret_cast<uint4*>((BUFP) + 1 * kW2Plane + o_) = m_;                      \
-        *reinterpret_cast<uint4*>((BUFP) + 2 * kW2Plane + o_) = l_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 0 * kTPPlane + o_) = h_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 1 * kTPPlane + o_) = m_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 2 * kTPPlane + o_) = l_;                      \
         split3_pair4(S##b0, S##b1, h_, m_, l_);                                          \
-        *reinterpret_cast<uint4*>((BUFP) + 3 * kW2Plane + o_) = h_;                      \
-        *reinterpret_cast<uint4*>((BUFP) + 4 * kW2Plane + o_) = m_;                      \
-        *reinterpret_cast<uint4*>((BUFP) + 5 * kW2Plane + o_) = l_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 3 * kTPPlane + o_) = h_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 4 * kTPPlane + o_) = m_;                      \
+        *reinterpret_cast<uint4*>((BUFP) + 5 * kTPPlane + o_) = l_;                      \
         if (want_bias && store_counts) {                                                 \
             bsum.x += S##a0.x + S##a1.x;                                                 \
             bsum.y += S##a0.y + S##a1.y;                                                 \
@@ -1239,13 +1243,34 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
     }
     // all 18 fragments of a 16-row step: 72 x ds_read_b32 in the memory phase (a[tile 0..3][plane], b[plane][tile 0..1])
     bf16x8 fa[4][3], fb[3][2];
+    // LDS image of this kernel: plane = 4 column blocks of 64 columns, each [8 row pairs][64 + 4 dwords]: the four dwords of
+    // a fragment (row pairs 4 kh .. 4 kh + 3 of one column) are 68 dwords apart, so TWO ds_read2_b32 fetch a fragment
+    // straight into its four consecutive registers (36 reads per phase).  With the 256-column rows of the lockstep kernel
+    // the dwords are 260 apart, out of ds_read2's reach: hipcc paired other dwords and needed 54 v_mov + 28 v_add per
+    // phase to re-assemble the operands.  Inline asm (one base register per operand and plane, 8-bit dword offsets).
+#define TP_FRAG_ASM(DST, ADDR, OFF)                                                                                       \
+    {                                                                                                                     \
+        unsigned long long p0_, p1_;                                                                                      \
+        asm volatile("ds_read2_b32 %0, %2 offset0:%3 offset1:%4\n\tds_read2_b32 %1, %2 offset0:%5 offset1:%6"            \
+                     : "=&v"(p0_), "=&v"(p1_)                                                                             \
+                     : "v"(ADDR), "n"((OFF) / 4), "n"((OFF) / 4 + kTPRS / 4), "n"((OFF) / 4 + 2 * (kTPRS / 4)),           \
+                       "n"((OFF) / 4 + 3 * (kTPRS / 4)));                                                                 \
+        const u32x4 u_ = {(unsigned)p0_, (unsigned)(p0_ >> 32), (unsigned)p1_, (unsigned)(p1_ >> 32)};                    \
+        DST = __builtin_bit_cast(bf16x8, u_);                                                                             \
+    }
 #define TP_READ_FRAGS(BUFP)                                                                                               \
     {                                                                                                                     \
-        const unsigned char* ab_ = (BUFP) + (kh * 4) * kW2RS + (wm * 128 + li) * 4;                                       \
-        const unsigned char* bb_ = (BUFP) + 3 * kW2Plane + (kh * 4) * kW2RS + (wn * 64 + li) * 4;                         \
+        const unsigned base_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(BUFP);             \
         _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                                \
-            _Pragma("unroll") for (int tl = 0; tl < 2; ++tl) W2_FRAG(fb[pc][tl], bb_ + pc * kW2Plane + tl * 128)          \
-            _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) W2_FRAG(fa[t4][pc], ab_ + pc * kW2Plane + t4 * 128)          \
+            const unsigned bb_ = base_ + (3 + pc) * kTPPlane + wn * kTPBlk + (kh * 4) * kTPRS + li * 4;                   \
+            TP_FRAG_ASM(fb[pc][0], bb_, 0)                                                                                \
+            TP_FRAG_ASM(fb[pc][1], bb_, 128)                                                                              \
+            const unsigned ab0_ = base_ + pc * kTPPlane + (wm * 2) * kTPBlk + (kh * 4) * kTPRS + li * 4;                  \
+            const unsigned ab1_ = ab0_ + kTPBlk;                                                                          \
+            TP_FRAG_ASM(fa[0][pc], ab0_, 0)                                                                               \
+            TP_FRAG_ASM(fa[1][pc], ab0_, 128)                                                                             \
+            TP_FRAG_ASM(fa[2][pc], ab1_, 0)                                                                               \
+            TP_FRAG_ASM(fa[3][pc], ab1_, 128)                                                                             \
         }                                                                                                                 \
     }
 #define TP_TERM(PA, PB)                                                                                                   \
@@ -1278,7 +1303,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
     }
 
     unsigned char* const buf0 = smemw;
-    unsigned char* const buf1 = smemw + kW2Buf;
+    unsigned char* const buf1 = smemw + kTPBuf;
     const int64_t rows = m_end - m_begin;                     // multiple of 32: an even number of 16-row steps
     const int64_t nsteps = rows / kW2TM;
     if (rows > 0) {
@@ -1303,6 +1328,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
 #undef TP_MFMA
 #undef TP_TERM
 #undef TP_READ_FRAGS
+#undef TP_FRAG_ASM
 #undef W2_LOAD
 #undef W2_STORE
 #undef W2_FRAG
@@ -1693,10 +1719,10 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
             static bool attr_pp = false;
             if (!attr_pp) {
                 (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                          2 * kW2Buf);
+                                          2 * kTPBuf);
                 attr_pp = true;
             }
-            hipLaunchKernelGGL(gemm_tn_x6_pp_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kW2Buf, s, A, lda,
+            hipLaunchKernelGGL(gemm_tn_x6_pp_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kTPBuf, s, A, lda,
                                B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
         } else
         hipLaunchKernelGGL(gemm_tn_x6_256_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kW2Buf, s, A, lda, B,

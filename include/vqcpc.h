@@ -362,6 +362,17 @@ int vqcpc_gemm_nt_relu_mask(const float* A, int64_t lda, const float* B, int64_t
 int vqcpc_gemm_nt_gatebits(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
                            int K, const void* mask, float gate_scale, void* stream);
 
+/* Split-K form of vqcpc_gemm_nt for launches that cannot fill the chip (few 128 x 128 tiles, long K: the d_model-wide
+ * projections of the student step, encoder_student_trainer.py:203-262 -> transformer_custom.py:270-295 at 3072 / 768 rows).
+ *   vqcpc_gemm_nt_splitk_workspace   bytes of partial-sum workspace, or 0 when (M, N, K) is not a split-K shape in the
+ *                                    current GEMM mode (then call vqcpc_gemm_nt).
+ *   vqcpc_gemm_nt_splitk             C = A . B^T (+ bias) (+ add); the K range is cut into partial planes in `workspace`,
+ *                                    summed in a fixed order (deterministic).  Epilogues other than bias / add: vqcpc_gemm_nt. */
+int64_t vqcpc_gemm_nt_splitk_workspace(int64_t M, int N, int K);
+int vqcpc_gemm_nt_splitk(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                         int K, const float* bias, const float* add, int64_t ldadd, void* workspace, int64_t workspace_bytes,
+                         void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * bf16x6 GEMM on pre-split operands (csrc/gemm_planes.hip; no reference counterpart: the same F.linear products as
  * vqcpc_gemm_nt in mode 1, bit-identical results, with the exact 3-way bf16 split done once by the producer).

@@ -1123,7 +1123,8 @@ def test_ffn_uses_the_bit_gate_in_bf16x6_mode_and_matches_the_fp32_gate(ops):
     hip.set_gemm_mode(1)
     try:
         for bits in (True, False):
-            saved = ops.gatebits_supported
+            saved = ops.gatebits_supported, ops.GATEBITS_MIN_TILES
+            ops.GATEBITS_MIN_TILES = 0                     # 16 tiles here: below the size at which ops prefers the bit forms
             if not bits:
                 ops.gatebits_supported = lambda *a: False
             try:
@@ -1132,7 +1133,7 @@ def test_ffn_uses_the_bit_gate_in_bf16x6_mode_and_matches_the_fp32_gate(ops):
                 (y * dev(gy)).sum().backward()
                 res[bits] = [y.detach().cpu()] + [v.grad.cpu() for v in t]
             finally:
-                ops.gatebits_supported = saved
+                ops.gatebits_supported, ops.GATEBITS_MIN_TILES = saved
     finally:
         hip.set_gemm_mode(0)
     for a, b in zip(res[True], res[False]):
@@ -1157,3 +1158,47 @@ def test_gemm_nt_one_wave_per_simd_kernel_is_bitwise_the_ping_pong_kernel(ops, M
     assert torch.equal(out, ref)
     exact = a.double() @ b.double().t() + (bias.double() if with_bias else 0)
     assert rel_err(out.cpu(), exact.cpu()) < 2e-6 * max(1, K ** 0.5)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# split-K NT GEMM (vqcpc_gemm_nt_splitk): the under-filled d_model-wide projections of the student / decoder steps
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('M,N,K', [(3072, 512, 2048), (768, 512, 1536), (128, 128, 1024), (4096, 512, 1024)])
+def test_gemm_nt_split_k_matches_the_single_launch(ops, M, N, K):
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + K)
+    a, b = dev(torch.randn(M, K, generator=gen)), dev(torch.randn(N, K, generator=gen) * 0.05)
+    bias, res = dev(torch.randn(N, generator=gen)), dev(torch.randn(M, N, generator=gen))
+    exact = a.double() @ b.double().t()
+    assert hip.query('vqcpc_gemm_nt_splitk_workspace', M, N, K) == 0          # fp32-MFMA mode: never split
+    hip.set_gemm_mode(1)
+    try:
+        ws_bytes = hip.query('vqcpc_gemm_nt_splitk_workspace', M, N, K)
+        planes = ws_bytes // (4 * M * N)
+        assert planes >= 2 and K % (32 * planes) == 0 and K // planes >= 256
+        assert hip.query('vqcpc_gemm_nt_splitk_workspace', M, N, 512) == 0      # short K
+        assert hip.query('vqcpc_gemm_nt_splitk_workspace', 65536, N, K) == 0    # enough tiles already
+        assert hip.query('vqcpc_gemm_nt_splitk_workspace', M + 32, N, K) == 0   # partial tiles
+        for kw in ({}, {'bias': bias}, {'add': res}, {'bias': bias, 'add': res}):
+            ops.SPLIT_K = False
+            single = ops.gemm_nt(a, b, **kw)
+            ops.SPLIT_K = True
+            split = ops.gemm_nt(a, b, **kw)
+            again = ops.gemm_nt(a, b, **kw)
+            ref = exact + (bias.double() if 'bias' in kw else 0) + (res.double() if 'add' in kw else 0)
+            assert torch.equal(split, again)                                    # fixed summation order
+            assert not torch.equal(split, single)                               # ... and really another path
+            assert rel_err(split.cpu(), ref.cpu()) < 2e-6 and rel_err(single.cpu(), ref.cpu()) < 2e-6
+        # strided output / residual (a column block of a wider buffer), workspace too small, wrong shape
+        wide = dev(torch.zeros(M, 2 * N))
+        ops.gemm_nt(a, b, bias=bias, add=res, out=wide[:, N:])
+        assert torch.equal(wide[:, N:], split) and float(wide[:, :N].abs().max()) == 0.0
+        ws = torch.empty(ws_bytes // 4, device='cuda')
+        out = torch.empty(M, N, device='cuda')
+        with pytest.raises(RuntimeError, match='workspace too small'):
+            hip.call('vqcpc_gemm_nt_splitk', a, K, b, K, out, N, M, N, K, None, None, 0, ws, ws_bytes - 4)
+        with pytest.raises(RuntimeError, match='not a split-K shape'):
+            hip.call('vqcpc_gemm_nt_splitk', a, K, b, K, out, N, M, N, 512, None, None, 0, ws, ws_bytes)
+    finally:
+        ops.SPLIT_K = True
+        hip.set_gemm_mode(0)

@@ -17,11 +17,16 @@ T = torch.from_numpy
 
 @pytest.fixture(params=['f32', 'bf16x6'], autouse=True)
 def gemm_mode(request):
-    """Every end-to-end parity test runs with both GEMM arithmetic modes (exact fp32 MFMA, and the bf16x6 split)."""
-    from vqcpc_bach_amd import hip
+    """Every end-to-end parity test runs with both GEMM arithmetic modes (exact fp32 MFMA, and the bf16x6 split).  In the
+    bf16x6 mode the feed-forward gate travels as a bit mask whatever the size (the product prefers the fp32 gate below 160
+    tiles, ops.gatebits_worthwhile: that form is what tests/test_student_gpu.py runs)."""
+    from vqcpc_bach_amd import hip, ops
     hip.load()
     hip.set_gemm_mode(1 if request.param == 'bf16x6' else 0)
+    saved = ops.GATEBITS_MIN_TILES
+    ops.GATEBITS_MIN_TILES = 0
     yield request.param
+    ops.GATEBITS_MIN_TILES = saved
     hip.set_gemm_mode(0)
 
 FWD_TOL, GRAD_TOL = 5e-5, 5e-4

@@ -43,6 +43,12 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
     const int t = xcd_swizzle(blockIdx.x, gridDim.x);
     const int64_t m0 = (int64_t)(t / tiles_n) * BM;
     const int n0 = (t % tiles_n) * BN;
+    if (EPI == 0 && FULL) {
+        // split-K launch (gemm_nt_splitk below): workgroup row y contracts k in [y K, (y + 1) K) into partial plane y
+        A += (int64_t)blockIdx.y * K;
+        B += (int64_t)blockIdx.y * K;
+        C += (int64_t)blockIdx.y * ep.split_plane;
+    }
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -1679,6 +1685,97 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                "gemm_nt: bad gate/add strides (add2 needs add)");
     EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, add2, ldadd2, 0};
     return gemm_nt_launch(A, lda, B, ldb, C, ldc, M, N, K, ep, (hipStream_t)stream, true);
+}
+
+// ---- split-K NT GEMM for launches that cannot fill the chip ----------------------------------------------------------
+// The student step (configs[3]: 8 sequences x 384 tokens = 3072 rows, 768 at the event level) projects back to d_model =
+// 512 columns with K = 1536 / 2048: 96 (24) tiles of 128 x 128 for 256 CUs, each walking 48-64 K tiles alone on its CU.
+// Here the K range is cut over blockIdx.y into `s` partial planes (tiles x s ~ 400-500 workgroups, two per CU) and one
+// float4-per-lane pass sums the planes in a fixed order and applies bias / residual: deterministic, fp32-class (the
+// partial sums are rounded once more than a single accumulation chain would be).
+namespace vq {
+
+static int splitk_choose(int64_t M, int N, int K) {
+    if (gemm_mode() != 1 || M % BM || N % BN || K % BK || K < 1024) return 0;
+    const int64_t tiles = (M / BM) * (N / BN);
+    if (tiles > 160) return 0;
+    const int kt = K / BK;
+    int best = 0;
+    for (int s = 2; s <= 16; ++s)
+        if (kt % s == 0 && K / s >= 256 && tiles * s <= 512) best = s;
+    return best;
+}
+
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __restrict__ ws, int64_t plane, int nsplit,
+                                                              float* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                              const float* __restrict__ bias, const float* __restrict__ add,
+                                                              int64_t ldadd) {
+    const int64_t q = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = N / 4;
+    if (q >= M * n4) return;
+    const int64_t row = q / n4;
+    const int c = (int)(q % n4) * 4;
+    const float4* p = reinterpret_cast<const float4*>(ws + row * N + c);
+    const int64_t st4 = plane / 4;
+#define SK_ADD(X, Y) make_float4(X.x + Y.x, X.y + Y.y, X.z + Y.z, X.w + Y.w)
+    float4 acc = p[0];
+    int s = 1;
+    for (; s + 2 < nsplit; s += 3) {
+        const float4 v0 = p[(s + 0) * st4], v1 = p[(s + 1) * st4], v2 = p[(s + 2) * st4];
+        const float4 a = SK_ADD(v0, v1);
+        const float4 b = SK_ADD(a, v2);
+        acc = SK_ADD(acc, b);
+    }
+    for (; s < nsplit; ++s) {
+        const float4 v = p[s * st4];
+        acc = SK_ADD(acc, v);
+    }
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4*>(bias + c);
+        acc = SK_ADD(acc, b);
+    }
+    if (add) {
+        const float4 r = *reinterpret_cast<const float4*>(add + row * ldadd + c);
+        acc = SK_ADD(acc, r);
+    }
+#undef SK_ADD
+    *reinterpret_cast<float4*>(C + row * ldc + c) = acc;
+}
+
+}  // namespace vq
+
+int64_t vqcpc_gemm_nt_splitk_workspace(int64_t M, int N, int K) {
+    const int s = splitk_choose(M, N, K);
+    return s ? (int64_t)s * M * N * (int64_t)sizeof(float) : 0;
+}
+
+int vqcpc_gemm_nt_splitk(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
+                         int K, const float* bias, const float* add, int64_t ldadd, void* workspace, int64_t workspace_bytes,
+                         void* stream) {
+    VQ_REQUIRE(A && B && C && workspace, "gemm_nt_splitk: null pointer");
+    const int s = splitk_choose(M, N, K);
+    VQ_REQUIRE(s > 0, "gemm_nt_splitk: shape M=%lld N=%d K=%d is not a split-K shape in this GEMM mode (query "
+               "vqcpc_gemm_nt_splitk_workspace first)", (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && ldc % 4 == 0 && (!add || (ldadd >= N && ldadd % 4 == 0)),
+               "gemm_nt_splitk: bad leading dimensions");
+    VQ_REQUIRE(aligned16(A) && aligned16(B) && aligned16(C) && aligned16(workspace) && (!add || aligned16(add)) &&
+               (!bias || aligned16(bias)), "gemm_nt_splitk: operands must be 16-byte aligned");
+    if (workspace_bytes < (int64_t)s * M * N * (int64_t)sizeof(float)) {
+        set_error("gemm_nt_splitk: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    EpiParams ep{};
+    ep.inv_keep = 1.0f;
+    ep.split_plane = M * N;
+    const int tiles_n = N / BN;
+    hipLaunchKernelGGL((gemm_nt_kernel<true, 0, 1>), dim3((unsigned)((M / BM) * tiles_n), (unsigned)s), dim3(kGemmThreads), 0,
+                       st, A, lda, B, ldb, (float*)workspace, (int64_t)N, M, N, K / s, tiles_n, ep);
+    VQ_CHECK_LAUNCH("gemm_nt_splitk");
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((unsigned)ceil_div(M * (N / 4), 256)), dim3(256), 0, st,
+                       (const float*)workspace, M * N, s, C, ldc, M, N, bias, add, ldadd);
+    VQ_CHECK_LAUNCH("splitk_epilogue");
+    return VQCPC_OK;
 }
 
 int64_t vqcpc_gemm_tn_workspace(int64_t M, int N, int K) {

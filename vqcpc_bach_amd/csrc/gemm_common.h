@@ -30,6 +30,7 @@ struct EpiParams {
     uint32_t* mask;      // E_MASKOUT: written, E_GATEBITS: read.  Bit (row, col) of the "output > 0" mask lives in word
                          // ((row >> 2) * (N / 32) + col / 32) * 4 + (row & 3), bit col % 32: the four rows a lane of the
                          // 32x32 MFMA layout holds consecutively are one 16-byte load
+    int64_t split_plane; // split-K launch of the 128-tile kernel (gridDim.y > 1): floats between two partial planes
 };
 
 // epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)

@@ -62,9 +62,69 @@ __global__ __launch_bounds__(kRedCols * kRedGroups) void reduce_splits_kernel(co
     }
 }
 
+// Large segments, few splits (the weight-gradient partial sums of a GEMM: 10^5..10^6 columns x 4..32 splits): one float4
+// column group per lane, all splits walked by that lane in a fixed order with eight 16-byte loads in flight.  The kernel
+// above spends a 1024-lane workgroup on 64 columns, which is right for "many splits of a short vector" only: at the student
+// step's 2048 x 512 gradients (8 splits) it ran at 1 TB/s, this one streams them at the L2 / MALL rate.
+constexpr int kRedVecThreads = 256;
+
+__global__ __launch_bounds__(kRedVecThreads) void reduce_splits_vec_kernel(const float* __restrict__ ws, int64_t stride,
+                                                                          int nsplit, float* __restrict__ out, int64_t count,
+                                                                          const float* __restrict__ ws2, int64_t stride2,
+                                                                          float* __restrict__ out2, int64_t count2,
+                                                                          int accumulate) {
+    int64_t q = (int64_t)blockIdx.x * kRedVecThreads + threadIdx.x;                     // float4 index
+    const int64_t first = (count / 4 + kRedVecThreads - 1) / kRedVecThreads * kRedVecThreads;  // segment 2: workgroup boundary
+    if (q >= first) {
+        q -= first;
+        ws = ws2;
+        stride = stride2;
+        out = out2;
+        count = count2;
+    }
+    if (q * 4 >= count) return;
+    const float4* p = reinterpret_cast<const float4*>(ws) + q;
+    const int64_t st4 = stride / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#define RV_ADD(X, Y) make_float4(X.x + Y.x, X.y + Y.y, X.z + Y.z, X.w + Y.w)
+    int s = 0;
+    for (; s + 7 < nsplit; s += 8) {
+        const float4 v0 = p[(s + 0) * st4], v1 = p[(s + 1) * st4], v2 = p[(s + 2) * st4], v3 = p[(s + 3) * st4];
+        const float4 v4 = p[(s + 4) * st4], v5 = p[(s + 5) * st4], v6 = p[(s + 6) * st4], v7 = p[(s + 7) * st4];
+        const float4 a = RV_ADD(v0, v1), b = RV_ADD(v2, v3), c = RV_ADD(v4, v5), d = RV_ADD(v6, v7);
+        const float4 ab = RV_ADD(a, b), cd = RV_ADD(c, d);
+        const float4 t = RV_ADD(ab, cd);
+        acc = RV_ADD(acc, t);
+    }
+    for (; s < nsplit; ++s) {
+        const float4 v = p[s * st4];
+        acc = RV_ADD(acc, v);
+    }
+    float4* o = reinterpret_cast<float4*>(out) + q;
+    if (accumulate) {
+        const float4 prev = *o;
+        acc = RV_ADD(prev, acc);
+    }
+#undef RV_ADD
+    *o = acc;
+}
+
+static bool reduce_vec_ok(const float* ws, int64_t stride, const float* out, int64_t count) {
+    return count <= 0 || (count % 4 == 0 && stride % 4 == 0 && aligned16(ws) && aligned16(out));
+}
+
 int launch_reduce_splits2(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, const float* ws2,
                           int64_t stride2, float* out2, int64_t count2, int accumulate, hipStream_t stream) {
     if (count <= 0 && count2 <= 0) return VQCPC_OK;
+    if (count >= (1 << 16) && nsplit <= 64 && reduce_vec_ok(ws, stride, out, count) &&
+        reduce_vec_ok(ws2, stride2, out2, count2)) {
+        const int64_t blocks = ceil_div(count / 4, (int64_t)kRedVecThreads) +
+                               ceil_div(std::max<int64_t>(count2, 0) / 4, (int64_t)kRedVecThreads);
+        hipLaunchKernelGGL(reduce_splits_vec_kernel, dim3((unsigned)blocks), dim3(kRedVecThreads), 0, stream, ws, stride,
+                           nsplit, out, count, ws2, stride2, out2, std::max<int64_t>(count2, 0), accumulate);
+        VQ_CHECK_LAUNCH("reduce_splits_vec");
+        return VQCPC_OK;
+    }
     const int64_t blocks = ceil_div(std::max<int64_t>(count, 0), kRedCols) + ceil_div(std::max<int64_t>(count2, 0), kRedCols);
     hipLaunchKernelGGL(reduce_splits_kernel, dim3((unsigned)blocks), dim3(kRedCols * kRedGroups), 0, stream, ws, stride,
                        nsplit, out, std::max<int64_t>(count, 0), ws2, stride2, out2, std::max<int64_t>(count2, 0), accumulate);

@@ -47,15 +47,40 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         add, lda_ = _rows(add)
     if add2 is not None:
         add2, lda2_ = _rows(add2)
+    if (SPLIT_K and M <= _SPLITK_MAX_ROWS and K >= 1024 and not act and not drop_p and gate is None and add2 is None
+            and hip.get_gemm_mode() == 1):
+        # few output tiles, long K (student / decoder steps): K cut over partial planes, see include/vqcpc.h
+        ws_bytes = _splitk_ws.get((M, N, K))
+        if ws_bytes is None:
+            ws_bytes = _splitk_ws[(M, N, K)] = hip.query('vqcpc_gemm_nt_splitk_workspace', M, N, K)
+        if ws_bytes and ldc % 4 == 0 and lda_ % 4 == 0:
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+            hip.call('vqcpc_gemm_nt_splitk', a, lda, b, ldb, out, ldc, M, N, K, bias, add, lda_, ws, ws_bytes)
+            return out
     hip.call('vqcpc_gemm_nt', a, lda, b, ldb, out, ldc, M, N, K, bias, int(act), float(drop_p), int(seed), gate, ldg,
              float(gate_scale), add, lda_, add2, lda2_)
     return out
+
+
+SPLIT_K = True                 # A/B switch (tools/bench_splitk.py)
+_SPLITK_MAX_ROWS = 1 << 14     # 160 tiles of 128 x 128 at most: no shape above this many rows qualifies
+_splitk_ws = {}                # (M, N, K) -> workspace bytes in bf16x6 mode (0: not a split-K shape)
 
 
 def gatebits_supported(M, N, K):
     """True when the relu / dropout gate of an (M, K) -> (M, N) feed-forward projection can travel as a bit mask
     (bf16x6 mode, full 256-tiles): see include/vqcpc.h."""
     return hip.get_gemm_mode() == 1 and bool(hip.query('vqcpc_gemm_gatebits_supported', M, N, K))
+
+
+GATEBITS_MIN_TILES = 160
+
+
+def gatebits_worthwhile(M, N, K):
+    """The bit-mask forms exist in the 256-tile ping-pong kernel only (one workgroup per CU): below ~160 tiles the
+    fp32-gate forms on 128-tiles fill more of the chip and win (3072 x 2048 x 512: 47 vs 63 us, 768 rows: 33 vs 60 us; at
+    192 tiles the bit forms are ahead -- tools/bench_splitk.py)."""
+    return (M // 256) * (N // 256) >= GATEBITS_MIN_TILES and gatebits_supported(M, N, K)
 
 
 def gemm_nt_relu_mask(a, b, bias, drop_p=0.0, seed=0):
@@ -446,7 +471,7 @@ class EncoderLayerFn(torch.autograd.Function):
             ff = gemm_nt_bf16(h2b, w2, bias=b2)
             h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
         else:
-            if gatebits_supported(Mq, ffd, d):       # relu / dropout gate of the backward as a bit mask (1/32 of the bytes)
+            if gatebits_worthwhile(Mq, ffd, d):       # relu / dropout gate of the backward as a bit mask (1/32 of the bytes)
                 h2, ctx.gate_mask = gemm_nt_relu_mask(x1, w1, b1, drop_p=p, seed=s[2])
             else:
                 h2, ctx.gate_mask = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2]), None
@@ -678,7 +703,7 @@ class FFNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w1, b1, w2, b2, drop_p, seed):
-        if gatebits_supported(x.shape[0], w1.shape[0], w1.shape[1]) and x.dim() == 2:
+        if gatebits_worthwhile(x.shape[0], w1.shape[0], w1.shape[1]) and x.dim() == 2:
             h, ctx.gate_mask = gemm_nt_relu_mask(x, w1, b1, drop_p=float(drop_p), seed=int(seed))
         else:
             h, ctx.gate_mask = gemm_nt(x, w1, bias=b1, act=1, drop_p=float(drop_p), seed=int(seed)), None

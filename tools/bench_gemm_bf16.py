@@ -1,0 +1,40 @@
+"""bf16 NT GEMM (configs[4] path) per epilogue / output form at the C4 layer shapes (a quarter of the rows).
+    python tools/bench_gemm_bf16.py [rows]"""
+import os, sys, statistics, torch
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+from vqcpc_bach_amd import hip, ops
+hip.load()
+hip.set_gemm_mode(8)
+M = int(sys.argv[1]) if len(sys.argv) > 1 else 278528
+
+
+def timeit(f, n=5, reps=5):
+    ts = []
+    for r in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record(); torch.cuda.synchronize()
+        if r:
+            ts.append(e0.elapsed_time(e1) / n * 1e3)
+    return statistics.median(ts)
+
+
+for N, K in [(2048, 512), (512, 2048), (512, 512), (1536, 512)]:
+    a = ops.cast_bf16(torch.randn(M, K, device='cuda')); b = ops.cast_bf16(torch.randn(N, K, device='cuda') * 0.05)
+    bias = torch.randn(N, device='cuda')
+    gate_b = torch.randn(M, N, device='cuda').bfloat16()
+    res = torch.randn(M, N, device='cuda')
+    out32 = torch.empty(M, N, device='cuda')
+    forms = [('none -> f32', dict(out=out32)),
+             ('none -> bf16', dict(out_f32=False, out_bf16=True)),
+             ('bias -> f32', dict(bias=bias, out=out32)),
+             ('bias+relu -> bf16', dict(bias=bias, act=1, out_f32=False, out_bf16=True)),
+             ('bias+relu+drop -> bf16', dict(bias=bias, act=1, drop_p=0.1, seed=5, out_f32=False, out_bf16=True)),
+             ('gate_b -> bf16', dict(gate_b=gate_b, gate_scale=1.1, out_f32=False, out_bf16=True)),
+             ('add -> f32', dict(add=res, out=out32))]
+    for name, kw in forms:
+        t = timeit(lambda: ops.gemm_nt_bf16(a, b, **kw))
+        print(f'M={M} N={N} K={K} {name:24s} {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.0f} TFLOP/s', flush=True)
+hip.set_gemm_mode(0)

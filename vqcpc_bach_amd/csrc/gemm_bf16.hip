@@ -57,6 +57,7 @@ struct Bf16Out {
     int64_t ldcb;
     const bf16_t* gate_b;   // bf16 gate operand (B_GATE_BF16): only its sign is used
     int64_t ldgate_b;
+    int stagger;            // start delay of workgroup b: ((b >> 3) & 3) * stagger * 64 clocks (see the kernel)
 };
 
 template <int EPI, int OUT>
@@ -72,6 +73,15 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
     const int T = K / kBBK;                                        // K tiles per output tile (K % 64 == 0: T even)
     const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int S = my_tiles * T;
+
+    // Persistent workgroups with identical tiles run in lockstep: all 256 CUs store their output tiles (64 MB of fp32 per
+    // round) at the same time, and at configs[4]'s row count those bytes go to HBM, not to the 256 MB MALL -- the chip
+    // alternates between a phase that only computes and a phase that only writes.  Starting the four workgroups that share
+    // an XCD slot group a quarter of a tile apart keeps the write stream continuous under the other workgroups' K loops.
+    if (o.stagger > 0) {
+        const int n = (((int)blockIdx.x >> 3) & 3) * o.stagger;
+        for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(1);
+    }
 
     floatx16 acc[4][2];
 #pragma unroll
@@ -522,7 +532,10 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     VQ_REQUIRE(act == 0 || act == 1, "gemm_nt_bf16: act must be 0 or 1");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt_bf16: bad dropout probability");
     EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, nullptr, 0, 0};
-    Bf16Out o{C, ldc, (bf16_t*)Cb, ldcb, (const bf16_t*)gate_bf16, ldgate_bf16};
+    static const int stagger_per_ktile = getenv("VQCPC_BF16_STAGGER") ? atoi(getenv("VQCPC_BF16_STAGGER")) : 0;
+    const int tiles_total = (int)((M / kB) * (N / kB));
+    Bf16Out o{C, ldc, (bf16_t*)Cb, ldcb, (const bf16_t*)gate_bf16, ldgate_bf16,
+              tiles_total >= 4 * kNumCU ? stagger_per_ktile * (K / kBBK) : 0};
     const bool has_gate = gate || gate_bf16;
     const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (has_gate ? E_GATE : 0) |
                       (add ? E_ADD : 0);

@@ -1696,7 +1696,8 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 namespace vq {
 
 static int splitk_choose(int64_t M, int N, int K) {
-    if (gemm_mode() != 1 || M % BM || N % BN || K % BK || K < 1024) return 0;
+    static const int min_k = getenv("VQCPC_SPLITK_MIN_K") ? atoi(getenv("VQCPC_SPLITK_MIN_K")) : 1024;
+    if (gemm_mode() != 1 || M % BM || N % BN || K % BK || K < min_k) return 0;
     const int64_t tiles = (M / BM) * (N / BN);
     if (tiles > 160) return 0;
     const int kt = K / BK;

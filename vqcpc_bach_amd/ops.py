@@ -47,7 +47,7 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         add, lda_ = _rows(add)
     if add2 is not None:
         add2, lda2_ = _rows(add2)
-    if (SPLIT_K and M <= _SPLITK_MAX_ROWS and K >= 1024 and not act and not drop_p and gate is None and add2 is None
+    if (SPLIT_K and M <= _SPLITK_MAX_ROWS and K >= 512 and not act and not drop_p and gate is None and add2 is None
             and hip.get_gemm_mode() == 1):
         # few output tiles, long K (student / decoder steps): K cut over partial planes, see include/vqcpc.h
         ws_bytes = _splitk_ws.get((M, N, K))

@@ -470,6 +470,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
 //      557056 x 768 x 256): 1.743 M per wave shipped, 1.731 M with the transposed epilogue, 1.524 M without stores -- the
 //      output leaves a CU at ~30 bytes per clock whatever the instruction width (tools/micro/store_rate.hip: 36 / 70 B/clk
 //      for dword / dwordx4 stores alone), and hiding it would take a second accumulator set
+//  64 / 128 / 256: output stores with the nt / sc1 / sc0 cache-policy bits     -> +0.7 % / -1 % / +-0 % (202.0 -> 203.5,
+//      190.6 -> 192.0, 205.7 -> 207.3 TFLOP/s with nt): within noise, not adopted (the consumer kernel wants the lines)
 template <int EPI, int ABL = 0>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
                                                                      const float* __restrict__ B, int64_t ldb,
@@ -675,7 +677,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                 }                                                                                                      \
                 if (ABL & 32) { asm volatile("" :: "v"(v)); } else                                                      \
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
-                                                      ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
+                                                      ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4,       \
+                                                      (ABL & 64 ? 2 : 0) | (ABL & 128 ? 16 : 0) | (ABL & 256 ? 1 : 0)); \
                 acc[mt][nt][r] = 0.0f;                                                                                 \
             }                                                                                                          \
             if ((EPI & E_MASKOUT) && lane < 32) {    /* lane = r + 16 kh holds the word of row (r & 3) + 8 (r >> 2) + 4 kh */ \
@@ -1590,6 +1593,10 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             if (abl == 8) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 8>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 32) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 32>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 16) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 16>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 64) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 64>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 128) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 128>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 192) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 192>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 256) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 256>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 4) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 4>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
         } else if (use_pp)                                                                                                 \
             hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \

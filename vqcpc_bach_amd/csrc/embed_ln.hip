@@ -40,12 +40,21 @@ __global__ __launch_bounds__(256) void embed_pos_fwd_kernel(const int64_t* __res
 // atomics and is deterministic.  Partials: ws[chunk][v][vmax + 1][d]  (row vmax = sums of the chan|event columns,
 // event sums are further split per event in a second small array).
 // =====================================================================================================================
-constexpr int kEmbRowsPerChunk = 2048;   // rows of ALL voices per chunk
+constexpr int kEmbRowsPerChunk = 2048;   // rows of ALL voices per chunk (large inputs)
 constexpr int kEmbU = 16;
+// Small inputs (the student step: 8 sequences x 384 tokens) get shorter chunks: with 2048-row chunks two chunks x four
+// voices = 8 workgroups each walked 512 rows one batch of 16 after the other (190 us); ~48 chunks keep the walk to a few
+// batches per workgroup at the price of 48 partial tables for the reduction.
+static int64_t emb_chunk_rows(int64_t n_rows, int tpb) {
+    if (n_rows >= 32 * kEmbRowsPerChunk) return kEmbRowsPerChunk;
+    const int64_t r = std::max<int64_t>(1, ceil_div(ceil_div(n_rows, 48), tpb)) * tpb;
+    return std::min<int64_t>(r, kEmbRowsPerChunk);
+}
 
 __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __restrict__ tokens, int64_t n_rows, int tpb,
                                                             int nv, int vmax, int dlin, int pos, int has_ev,
-                                                            const float* __restrict__ g, float* __restrict__ ws) {
+                                                            const float* __restrict__ g, float* __restrict__ ws,
+                                                            int chunk_rows) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int d = dlin + (has_ev ? 2 : 1) * pos;
     const int nev = has_ev ? tpb / nv : 0;
@@ -57,9 +66,9 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     // make one contiguous stream (with the chunk index fast, concurrent workgroups were 2048 rows apart)
     const int v = blockIdx.x % nv;
     const int chunk = blockIdx.x / nv;
-    const int64_t row0 = (int64_t)chunk * kEmbRowsPerChunk;
-    const int64_t row1 = min(row0 + kEmbRowsPerChunk, n_rows);
-    // rows of this voice: row % tpb % nv == v.  kEmbRowsPerChunk is a multiple of tpb (checked on the host).
+    const int64_t row0 = (int64_t)chunk * chunk_rows;
+    const int64_t row1 = min(row0 + chunk_rows, n_rows);
+    // rows of this voice: row % tpb % nv == v.  chunk_rows is a multiple of tpb (checked on the host).
     for (int col = threadIdx.x; col < d; col += blockDim.x) {
         const int kind = col < dlin ? 0 : (col < dlin + pos ? 1 : 2);                 // table column | channel | event
         const int cbase = kind == 0 ? col : (kind == 1 ? vmax * dlin + (col - dlin) : vmax * dlin + pos + (col - dlin - pos));
@@ -396,7 +405,7 @@ int vqcpc_embed_pos_fwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
 }
 
 int64_t vqcpc_embed_pos_bwd_workspace(int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin, int pos) {
-    const int64_t nchunks = ceil_div(std::max<int64_t>(n_rows, 1), kEmbRowsPerChunk);
+    const int64_t nchunks = ceil_div(std::max<int64_t>(n_rows, 1), emb_chunk_rows(n_rows, tokens_per_block));
     const int64_t per = (int64_t)vmax * dlin + pos + (int64_t)(tokens_per_block / n_voices) * pos;
     return nchunks * n_voices * per * (int64_t)sizeof(float);
 }
@@ -415,12 +424,13 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
         set_error("embed_pos_bwd: workspace too small");
         return VQCPC_EWORKSPACE;
     }
-    const int nchunks = (int)ceil_div(n_rows, kEmbRowsPerChunk);
+    const int chunk_rows = (int)emb_chunk_rows(n_rows, tokens_per_block);
+    const int nchunks = (int)ceil_div(n_rows, chunk_rows);
     hipStream_t s = (hipStream_t)stream;
     if (lds > 64 * 1024)
         (void)hipFuncSetAttribute((const void*)embed_pos_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(nchunks * n_voices), dim3(256), lds, s, tokens, n_rows,
-                       tokens_per_block, n_voices, vmax, dlin, pos, d_event ? 1 : 0, g_out, (float*)workspace);
+                       tokens_per_block, n_voices, vmax, dlin, pos, d_event ? 1 : 0, g_out, (float*)workspace, chunk_rows);
     VQ_CHECK_LAUNCH("embed_pos_bwd");
     // stage 2: partials ws[chunk][voice][table | chan | event] -> parallel deterministic column reductions (a single
     // thread per output walking 272 chunks was latency-bound: 140 us)

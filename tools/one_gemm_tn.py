@@ -1,7 +1,7 @@
 import os, sys, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vqcpc_bach_amd import hip, ops
-hip.load(); hip.set_gemm_mode(1)
+hip.load(); hip.set_gemm_mode(int(os.environ.get('VQCPC_TN_MODE', '1')))
 M, N, K = 557056, int(sys.argv[1]), int(sys.argv[2])
 a = torch.randn(M, N, device='cuda'); b = torch.randn(M, K, device='cuda')
 for _ in range(6):

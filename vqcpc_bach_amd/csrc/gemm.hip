@@ -1197,9 +1197,20 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, kh = lane >> 5;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    // (tile, split) of this workgroup.  The output tiles of ONE split read the same rows of A and B (they differ in the
+    // column tile of one operand only); in dispatch order (x fastest) they would land on different XCDs, i.e. behind
+    // different L2s, and every shared row would be fetched once per tile: 1.6 x the algorithmic HBM bytes.  Remapped so that
+    // the tiles of a split are neighbours on one XCD (workgroup L of the linearised grid runs on XCD L % 8).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.x > 1 && gridDim.y % 8 == 0) {
+        const int L = by * (int)gridDim.x + bx;
+        const int j = L >> 3;
+        bx = j % (int)gridDim.x;
+        by = (j / (int)gridDim.x) * 8 + (L & 7);
+    }
+    const int tn = bx / tiles_k, tk = bx % tiles_k;
     const int n0 = tn * kT2, k0 = tk * kT2;
-    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_begin = (int64_t)by * rows_per_split;
     const int64_t m_end = min(m_begin + rows_per_split, M);          // (m_end - m_begin) % 32 == 0 (host)
     const bool want_bias = (ws_bias != nullptr) && tk == 0;
 
@@ -1342,7 +1353,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
 #undef W2_STORE
 #undef W2_FRAG
 
-    float* out = ws + (int64_t)blockIdx.y * N * K;
+    float* out = ws + (int64_t)by * N * K;
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
 #pragma unroll
@@ -1364,7 +1375,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
             float tot = 0.0f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) tot += red[g * kT2 + tid];
-            ws_bias[(int64_t)blockIdx.y * N + n0 + tid] = tot;
+            ws_bias[(int64_t)by * N + n0 + tid] = tot;
         }
     }
 }

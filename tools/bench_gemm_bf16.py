@@ -38,3 +38,11 @@ for N, K in [(2048, 512), (512, 2048), (512, 512), (1536, 512)]:
         t = timeit(lambda: ops.gemm_nt_bf16(a, b, **kw))
         print(f'M={M} N={N} K={K} {name:24s} {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.0f} TFLOP/s', flush=True)
 hip.set_gemm_mode(0)
+
+# weight-gradient (TN) bf16 kernel
+hip.set_gemm_mode(8)
+for N, K in [(2048, 512), (512, 2048), (1536, 512), (512, 512)]:
+    a = ops.cast_bf16(torch.randn(M, N, device='cuda')); b = ops.cast_bf16(torch.randn(M, K, device='cuda'))
+    t = timeit(lambda: ops.gemm_tn_bf16(a, b))
+    print(f'M={M} N={N} K={K} wgrad (TN, incl. reduction) {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.0f} TFLOP/s', flush=True)
+hip.set_gemm_mode(0)

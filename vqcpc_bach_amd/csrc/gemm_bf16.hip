@@ -359,6 +359,10 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_tn_bf16_kernel(const bf16_t
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, kh = lane >> 5;
+    // (the XCD-aware (tile, split) mapping of gemm_tn_x6_pp_kernel -- tiles of one split on one XCD, HBM fetch 1.6 -> 1.0 x
+    // algorithmic there -- makes THIS kernel slower, 834-879 -> 802-821 TFLOP/s at configs[4]: with 6 x less MFMA time
+    // per operand byte it lives on L2 bandwidth, and sixteen tiles pulling the same rows through one XCD's L2 is worse
+    // than eight L2s each serving two of them out of the MALL; dispatch order kept)
     const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
     const int n0 = tn * kB, k0 = tk * kB;
     const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;

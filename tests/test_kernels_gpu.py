@@ -413,6 +413,32 @@ def test_gemm_nt_two_residuals_in_place(ops):
     assert torch.equal(based[1::4].cpu(), base[1::4])
 
 
+@pytest.mark.parametrize('M,N,K', [(1024, 256, 256), (139264, 256, 256), (2560, 512, 64)])
+def test_gemm_nt_two_residuals_on_the_256_tile_kernel(ops, M, N, K):
+    """bf16x6 mode, full 256-tiles: `add + add2` runs on the ping-pong kernel (second residual fetched per 32 x 32 tile),
+    in place over add2 like the trainer's call."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + N)
+    a, b = dev(torch.randn(M, K, generator=gen)), dev(torch.randn(N, K, generator=gen))
+    add, base = dev(torch.randn(M, N, generator=gen)), dev(torch.randn(M, 2 * N, generator=gen))
+    keep = base.clone()
+    view = base[:, N:]                                                         # row stride 2 N
+    hip.set_gemm_mode(1)
+    try:
+        ops.gemm_nt(a, b, add=add, add2=view, out=view)
+        plain = ops.gemm_nt(a, b, add=add)
+    finally:
+        hip.set_gemm_mode(0)
+    ref = a.double() @ b.double().t() + add.double() + keep[:, N:].double()
+    assert rel_err(base[:, N:].cpu(), ref.cpu()) < 2e-6
+    assert torch.equal(base[:, :N], keep[:, :N])
+    assert rel_err(base[:, N:].cpu(), (plain + keep[:, N:]).cpu()) < 2e-6
+    if M >= 65536:
+        # same accumulation, one more addend: bit-identical to the single-residual launch + the second residual added
+        # afterwards (small shapes run the single-residual form on the skinny fp32-MFMA kernel: other arithmetic)
+        assert torch.equal(base[:, N:], plain + keep[:, N:])
+
+
 def test_gemm_nt_strided_rows_and_epilogue(ops):
     gen = torch.Generator().manual_seed(5)
     M, N, K = 300, 200, 64

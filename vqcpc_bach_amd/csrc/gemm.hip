@@ -617,6 +617,11 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                           \
             (void*)(HAS_AUX ? xsrc + m0 * (int64_t)ldxi + n0 : C), 0, 0x7FFFFFFF, 0x00020000);                         \
         const int voff_x = ((wm * 128 + 4 * kh) * ldxi + wn * 64 + li) * 4;                                            \
+        /* second residual (E_ADD2, two launches per step): fetched per 32x32 tile without a prefetch register set */  \
+        const int ldx2i = (int)ep.ldadd2;                                                                              \
+        const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(                                          \
+            (void*)((EPI & E_ADD2) ? ep.add2 + m0 * (int64_t)ldx2i + n0 : C), 0, 0x7FFFFFFF, 0x00020000);              \
+        const int voff_x2 = ((wm * 128 + 4 * kh) * ldx2i + wn * 64 + li) * 4;                                          \
         float aux[2][16];                                                                                              \
         if (HAS_AUX) {                                                                                                 \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) aux[0][r] = __builtin_bit_cast(                             \
@@ -658,6 +663,12 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                     float, __builtin_amdgcn_raw_buffer_load_b32(                                                       \
                                rx, voff_x, ((mt2 * 32 + (r & 3) + 8 * (r >> 2)) * ldxi + nt2 * 32) * 4, 0));           \
             }                                                                                                          \
+            float a2[16];                                                                                              \
+            if (EPI & E_ADD2) {                                                                                        \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) a2[r] = __builtin_bit_cast(                             \
+                    float, __builtin_amdgcn_raw_buffer_load_b32(                                                       \
+                               rx2, voff_x2, ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldx2i + nt * 32) * 4, 0));          \
+            }                                                                                                          \
             const int col = col_base + nt * 32;                                                                        \
             const float bv = nt ? bv_cur1 : bv_cur0;                                                                   \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
@@ -668,6 +679,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
                     v *= rng_u24_from_x0(x0t + (uint32_t)((r & 3) + 8 * (r >> 2)) * nc1, drop_sh) >= ep.thr ? ep.inv_keep : 0.0f; \
                 if (EPI & E_GATE) v *= (aux[tile & 1][r] > 0.0f ? ep.gate_scale : 0.0f);                               \
                 if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
+                if (EPI & E_ADD2) v += a2[r];                                                                          \
                 if (EPI & E_GATEBITS) v = ((gb[tile & 1][r >> 2][r & 3] >> li) & 1u) ? v * ep.gate_scale : 0.0f;       \
                 if (EPI & E_MASKOUT) {                                                                                 \
                     const uint64_t bal = __ballot(v > 0.0f);      /* low word: this row for kh = 0, high word: kh = 1 */ \
@@ -1538,7 +1550,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
     // the 256-tile kernel runs ONE workgroup per CU: pick it only when its last (partial) round of tiles does not waste
     // more than the ~8 % it gains per tile over the 128-tile kernel (2 workgroups per CU, 4x more tiles)
     bool t2_ok = mode == 1 && g_use_t2.load(std::memory_order_relaxed) && (M % kT2 == 0) && (N % kT2 == 0) &&
-                 (K % (2 * kT2BK) == 0) && !add2;
+                 (K % (2 * kT2BK) == 0) && (!add2 || (flags == (E_ADD | E_ADD2) && g_use_pp.load(std::memory_order_relaxed)));
     if (t2_ok && may_split) {
         // cost model in units of one round of 256-tiles (256 workgroups): a round of the 128-tile kernel (512 workgroups)
         // does half the work ~8 % less efficiently.  A partial last round wastes whole CUs, so a GEMM of 2.1 rounds is cut by
@@ -1623,6 +1635,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             case E_BIAS | E_RELU | E_DROP: T2_LAUNCH(E_BIAS | E_RELU | E_DROP)
             case E_GATE: T2_LAUNCH(E_GATE)
             case E_ADD: T2_LAUNCH(E_ADD)
+            case E_ADD | E_ADD2: T2_LAUNCH(E_ADD | E_ADD2)
             default: break;
         }
 #undef T2_LAUNCH

@@ -22,7 +22,7 @@ def timeit(f, n=20, reps=6):
 
 for M, N, K in [(3072, 512, 2048), (3072, 512, 1536), (3072, 512, 1024), (768, 512, 2048), (768, 512, 1536), (192, 512, 2048),
                 (2048, 512, 2048), (4096, 512, 2048), (1536, 512, 2048), (3072, 512, 512), (768, 512, 512), (768, 1536, 512),
-                (768, 2048, 512), (768, 512, 1024)]:
+                (768, 2048, 512), (768, 512, 1024), (256, 512, 1536), (256, 512, 1024)]:
     a = torch.randn(M, K, device='cuda'); b = torch.randn(N, K, device='cuda') * 0.05
     bias = torch.randn(N, device='cuda'); res = torch.randn(M, N, device='cuda')
     ref = a.double() @ b.double().t()

@@ -1733,8 +1733,11 @@ static int splitk_choose(int64_t M, int N, int K) {
     if (tiles > 160) return 0;
     const int kt = K / BK;
     int best = 0;
+    // at most 16 tiles (the GRU recurrence: 256 x 512 x 1536, one launch per time step on the critical path): planes of
+    // 64 k keep the lone workgroup of a CU to a handful of K tiles (21 -> 15.5 us)
+    static const int min_ks = getenv("VQCPC_SPLITK_MIN_KS") ? atoi(getenv("VQCPC_SPLITK_MIN_KS")) : 64;
     for (int s = 2; s <= 16; ++s)
-        if (kt % s == 0 && K / s >= 256 && tiles * s <= 512) best = s;
+        if (kt % s == 0 && K / s >= (tiles <= 16 ? min_ks : 256) && tiles * s <= 512) best = s;
     return best;
 }
 

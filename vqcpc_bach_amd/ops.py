@@ -53,7 +53,8 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         ws_bytes = _splitk_ws.get((M, N, K))
         if ws_bytes is None:
             ws_bytes = _splitk_ws[(M, N, K)] = hip.query('vqcpc_gemm_nt_splitk_workspace', M, N, K)
-        if ws_bytes and ldc % 4 == 0 and lda_ % 4 == 0:
+        if (ws_bytes and ldc % 4 == 0 and lda_ % 4 == 0 and out.data_ptr() % 16 == 0
+                and (add is None or add.data_ptr() % 16 == 0) and (bias is None or bias.data_ptr() % 16 == 0)):
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
             hip.call('vqcpc_gemm_nt_splitk', a, lda, b, ldb, out, ldc, M, N, K, bias, add, lda_, ws, ws_bytes)
             return out

@@ -346,6 +346,14 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
  * AccumulateGrad would run as one kernel each (transformer_custom.py:282-289, subsampled_relative_attention.py:23-26). */
 int vqcpc_accumulate8(float* const* dst, const float* const* src, const int* counts, int n_tensors, void* stream);
 
+/* Number of distinct merged product codes (sum_c idx[c] K^c) among the rows of up to two (rows, num_codebooks) int64 index
+ * tensors -> out[0] (as float): the `num_codewords` / `num_codewords_negative` metrics of VQCPCEncoderTrainer.epoch
+ * (vqcpc_encoder_trainer.py:320-331, len(torch.unique(.))) without a sort and without a host sync.  One bit per possible
+ * code in LDS: `_supported` is 0 when codebook_size ^ num_codebooks exceeds 2^20 (the caller counts with a sort then). */
+int vqcpc_count_distinct_codes_supported(int num_codebooks, int codebook_size);
+int vqcpc_count_distinct_codes(const int64_t* idx_a, int64_t rows_a, const int64_t* idx_b, int64_t rows_b, int num_codebooks,
+                               int codebook_size, float* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------------------------
  * relu / dropout gate of the feed-forward block as a bit mask (transformer_custom.py:285: linear2(dropout(relu(linear1(x))))).
  *   vqcpc_gemm_nt_relu_mask   C = dropout(relu(A . B^T + bias)) as vqcpc_gemm_nt(act = 1, drop_p, seed), and one bit per

@@ -1228,3 +1228,36 @@ def test_gemm_nt_split_k_matches_the_single_launch(ops, M, N, K):
     finally:
         ops.SPLIT_K = True
         hip.set_gemm_mode(0)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# distinct product codes of a step (vqcpc_count_distinct_codes): epoch()'s num_codewords metrics without a sort
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('ncb,K,rows_a,rows_b', [(1, 64, 1000, 0), (2, 512, 4096, 30720), (2, 512, 7, 0), (4, 32, 5000, 123),
+                                                  (1, 1 << 20, 50000, 50000)])
+def test_count_distinct_codes_equals_torch_unique(ops, ncb, K, rows_a, rows_b):
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(ncb * K + rows_a)
+    hi = min(K, 40) if ncb > 1 else K                          # few distinct values per codebook: plenty of repeats
+    a = dev(torch.randint(0, hi, (rows_a, ncb), generator=gen))
+    b = dev(torch.randint(0, hi, (rows_b, ncb), generator=gen)) if rows_b else None
+    assert hip.query('vqcpc_count_distinct_codes_supported', ncb, K) == 1
+    out = torch.full((1,), -1.0, device='cuda')
+    hip.call('vqcpc_count_distinct_codes', a, rows_a, b, rows_b, ncb, K, out)
+    both = a if b is None else torch.cat([a, b])
+    merged = sum(both[:, c] * K ** c for c in range(ncb))
+    assert float(out[0]) == float(torch.unique(merged).numel())
+    # the largest code is representable and counted
+    top = dev(torch.full((3, ncb), K - 1, dtype=torch.int64))
+    hip.call('vqcpc_count_distinct_codes', top, 3, None, 0, ncb, K, out)
+    assert float(out[0]) == 1.0
+
+
+def test_count_distinct_codes_rejects_spaces_beyond_the_bitmap(ops):
+    from vqcpc_bach_amd import hip
+    assert hip.query('vqcpc_count_distinct_codes_supported', 4, 1024) == 0          # configs[4]: the trainer sorts instead
+    assert hip.query('vqcpc_count_distinct_codes_supported', 3, 128) == 0
+    a = dev(torch.zeros(4, 4, dtype=torch.int64))
+    out = torch.zeros(1, device='cuda')
+    with pytest.raises(RuntimeError, match='exceed'):
+        hip.call('vqcpc_count_distinct_codes', a, 4, None, 0, 4, 1024, out)

@@ -366,6 +366,44 @@ __global__ __launch_bounds__(256) void accumulate8_kernel(Acc8 a) {
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) d[i] += s[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Number of distinct (merged) product codes among the rows of up to two index tensors: the per-step `num_codewords`
+// metrics of VQCPCEncoderTrainer.epoch (vqcpc_encoder_trainer.py:320-331: len(torch.unique(merged codes))).  One
+// workgroup, a bit per possible code in LDS (K^ncb <= 2^20 bits = 128 KB), set with LDS atomics and counted: a set has no
+// order, so the result is deterministic.  Replaces cat + sort + compare + sum (~12 launches per metric per step).
+constexpr int kCountThreads = 1024;
+constexpr int64_t kCountMaxSpace = 1 << 20;
+
+__global__ __launch_bounds__(kCountThreads) void count_distinct_codes_kernel(const int64_t* __restrict__ idx_a, int64_t rows_a,
+                                                                            const int64_t* __restrict__ idx_b, int64_t rows_b,
+                                                                            int ncb, int K, int words, float* __restrict__ out) {
+    extern __shared__ uint32_t code_bits[];
+    __shared__ int wave_tot[kCountThreads / 64];
+    for (int i = threadIdx.x; i < words; i += kCountThreads) code_bits[i] = 0u;
+    __syncthreads();
+    for (int64_t i = threadIdx.x; i < rows_a + rows_b; i += kCountThreads) {
+        const int64_t* row = i < rows_a ? idx_a + i * ncb : idx_b + (i - rows_a) * ncb;
+        int64_t code = 0, mul = 1;
+        for (int c = 0; c < ncb; ++c) {
+            code += row[c] * mul;
+            mul *= K;
+        }
+        if (code >= 0 && code < (int64_t)words * 32) atomicOr(&code_bits[code >> 5], 1u << (code & 31));
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int i = threadIdx.x; i < words; i += kCountThreads) cnt += __popc(code_bits[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if ((threadIdx.x & 63) == 0) wave_tot[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tot = 0;
+        for (int w = 0; w < kCountThreads / 64; ++w) tot += wave_tot[w];
+        out[0] = (float)tot;
+    }
+}
+
 }  // namespace vq
 
 using namespace vq;
@@ -509,6 +547,38 @@ int vqcpc_accumulate8(float* const* dst, const float* const* src, const int* cou
     const int blocks_x = std::min((maxn + 255) / 256, 64);
     hipLaunchKernelGGL(accumulate8_kernel, dim3(blocks_x, n_tensors), dim3(256), 0, (hipStream_t)stream, a);
     VQ_CHECK_LAUNCH("accumulate8");
+    return VQCPC_OK;
+}
+
+int vqcpc_count_distinct_codes_supported(int num_codebooks, int codebook_size) {
+    if (num_codebooks < 1 || codebook_size < 1) return 0;
+    int64_t space = 1;
+    for (int c = 0; c < num_codebooks; ++c) {
+        space *= codebook_size;
+        if (space > kCountMaxSpace) return 0;
+    }
+    return 1;
+}
+
+int vqcpc_count_distinct_codes(const int64_t* idx_a, int64_t rows_a, const int64_t* idx_b, int64_t rows_b, int num_codebooks,
+                               int codebook_size, float* out, void* stream) {
+    VQ_REQUIRE(out && rows_a >= 0 && rows_b >= 0 && (idx_a || rows_a == 0) && (idx_b || rows_b == 0),
+               "count_distinct_codes: bad arguments");
+    VQ_REQUIRE(vqcpc_count_distinct_codes_supported(num_codebooks, codebook_size),
+               "count_distinct_codes: %d codebooks of %d codes exceed the 2^20-code LDS bitmap (count with a sort instead)",
+               num_codebooks, codebook_size);
+    int64_t space = 1;
+    for (int c = 0; c < num_codebooks; ++c) space *= codebook_size;
+    const int words = (int)((space + 31) / 32);
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute((const void*)count_distinct_codes_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)(kCountMaxSpace / 8));
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(count_distinct_codes_kernel, dim3(1), dim3(kCountThreads), (size_t)words * 4, (hipStream_t)stream, idx_a,
+                       rows_a, idx_b, rows_b, num_codebooks, codebook_size, words, out);
+    VQ_CHECK_LAUNCH("count_distinct_codes");
     return VQCPC_OK;
 }
 

@@ -37,6 +37,8 @@ SIGNATURES = {
     'vqcpc_gemm_tn_bf16_supported': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_bf16_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'vqcpc_count_distinct_codes_supported': (c_int, [c_int, c_int]),
+    'vqcpc_count_distinct_codes': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_ptr, c_ptr]),
     'vqcpc_accumulate8': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
     'vqcpc_gemm_gatebits_supported': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_gatebits_bytes': (c_i64, [c_i64, c_int]),

@@ -14,7 +14,7 @@ from itertools import islice
 import numpy as np
 import torch
 
-from . import ops, vqcpc_helper
+from . import hip, ops, vqcpc_helper
 from .encoder import EncoderTrainer
 from .graphs import GraphedTraining
 from .parallel import DataParallelContext, FlatParameters
@@ -201,9 +201,25 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         (NoQuantization returns encoding_indices None) the counters stay 0, as in the reference (:325)."""
         if any(i is None for i in idx_tensors):
             return torch.zeros((), dtype=torch.float32, device=self.flat.flat.device)
-        merged = torch.cat([self.encoder.merge_codes(i.reshape(-1, i.shape[-1])) for i in idx_tensors])
+        flat = [i.reshape(-1, i.shape[-1]).contiguous() for i in idx_tensors]
+        ncb, K = flat[0].shape[1], int(self.encoder.quantizer.codebook_size)
+        if flat[0].is_cuda and len(flat) <= 2 and hip.query('vqcpc_count_distinct_codes_supported', ncb, K):
+            # one launch (a bit per possible product code in LDS) instead of cat + sort + compare + sum
+            out = torch.empty(1, dtype=torch.float32, device=flat[0].device)
+            b = flat[1] if len(flat) == 2 else None
+            hip.call('vqcpc_count_distinct_codes', flat[0], flat[0].shape[0], b, 0 if b is None else b.shape[0], ncb, K, out)
+            return out[0]
+        merged = torch.cat([self.encoder.merge_codes(i) for i in flat])
         s = torch.sort(merged)[0]
         return (s[1:] != s[:-1]).sum().float() + 1.0
+
+    def _step_metrics(self, out):
+        """The per-step summands of epoch()'s means as ONE device vector: loss, quantize, contrastive, num_codewords,
+        num_codewords_negative, accuracy[k] (vqcpc_encoder_trainer.py:320-340).  Computed inside the step so that a
+        captured step (graphs.py) replays it with the rest."""
+        return torch.cat([torch.stack([out['loss'], out['loss_quantize'], out['loss_contrastive'],
+                                       self._count_codewords(out['idx_left'], out['idx_right']),
+                                       self._count_codewords(out['idx_negative'])]), out['accuracy']])
 
     def _train_step_body(self, tensor_dict, corrupt_labels=False):
         """zero_grad / forward / backward / all-reduce / clip / Adam (:310-316): everything a step enqueues on the device."""
@@ -213,6 +229,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
             loss.backward()
         self.dp.all_reduce_sum_(self.flat.flat_grad)
         self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)
+        out['metrics'] = self._step_metrics(out)
         return out
 
     def _graph_optimizers(self):
@@ -223,7 +240,9 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         (graphs.py) once the first eager steps have done the lazy initialisations."""
         if not train:
             with torch.no_grad():
-                return self.compute_losses(tensor_dict, corrupt_labels)[1]
+                out = self.compute_losses(tensor_dict, corrupt_labels)[1]
+                out['metrics'] = self._step_metrics(out)
+                return out
         out = None
         if not corrupt_labels and not self.encoder.quantizer_needs_init():
             out = self._graphed_step(tensor_dict, self._train_step_body)
@@ -244,10 +263,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         n = 0
         for tensor_dict in islice(data_loader, num_batches):
             out = self.train_step(tensor_dict, train=train, corrupt_labels=corrupt_labels)
-            step = torch.cat([torch.stack([out['loss'], out['loss_quantize'], out['loss_contrastive'],
-                                           self._count_codewords(out['idx_left'], out['idx_right']),
-                                           self._count_codewords(out['idx_negative'])]), out['accuracy']])
-            sums += step
+            sums += out['metrics']
             n += 1
         sums /= max(n, 1)
         if self.dp.distributed:                                       # metrics are means over ranks

@@ -57,7 +57,8 @@ struct Bf16Out {
     int64_t ldcb;
     const bf16_t* gate_b;   // bf16 gate operand (B_GATE_BF16): only its sign is used
     int64_t ldgate_b;
-    int stagger;            // start delay of workgroup b: ((b >> 3) & 3) * stagger * 64 clocks (see the kernel)
+    int stagger;            // start delay of workgroup b: ((b >> 3) & 3) * stagger * 64 clocks (see the kernel); -1 = measurement
+                            // variant without the epilogue's global stores (VQCPC_BF16_STAGGER=-1, tools/bench_gemm_bf16.py)
 };
 
 template <int EPI, int OUT>
@@ -210,10 +211,10 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
                 if (EPI & E_ADD) v += AUX.f[j][c];                                                                     \
                 ov[c] = v;                                                                                             \
             }                                                                                                          \
-            if (OUT & B_OUT_F32)                                                                                       \
+            if ((OUT & B_OUT_F32) && o.stagger != -1)                                                                  \
                 asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(ov), "v"(voff_c), \
                              "s"(rc), "s"(((MT * 32 + 8 * j) * ldci + NT * 32) * 4) : "memory");                       \
-            if (OUT & B_OUT_BF16) {                                                                                    \
+            if ((OUT & B_OUT_BF16) && o.stagger != -1) {                                                               \
                 u32x2 pk;                                                                                              \
                 pk[0] = cvt_pk_bf16(ov[0], ov[1]);                                                                     \
                 pk[1] = cvt_pk_bf16(ov[2], ov[3]);                                                                     \
@@ -539,7 +540,7 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     static const int stagger_per_ktile = getenv("VQCPC_BF16_STAGGER") ? atoi(getenv("VQCPC_BF16_STAGGER")) : 0;
     const int tiles_total = (int)((M / kB) * (N / kB));
     Bf16Out o{C, ldc, (bf16_t*)Cb, ldcb, (const bf16_t*)gate_bf16, ldgate_bf16,
-              tiles_total >= 4 * kNumCU ? stagger_per_ktile * (K / kBBK) : 0};
+              stagger_per_ktile < 0 ? stagger_per_ktile : (tiles_total >= 4 * kNumCU ? stagger_per_ktile * (K / kBBK) : 0)};
     const bool has_gate = gate || gate_bf16;
     const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (has_gate ? E_GATE : 0) |
                       (add ? E_ADD : 0);

@@ -377,6 +377,9 @@ int vqcpc_gemm_nt_gatebits(const float* A, int64_t lda, const float* B, int64_t 
  *   vqcpc_gemm_nt_splitk             C = A . B^T (+ bias) (+ add); the K range is cut into partial planes in `workspace`,
  *                                    summed in a fixed order (deterministic).  Epilogues other than bias / add: vqcpc_gemm_nt. */
 int64_t vqcpc_gemm_nt_splitk_workspace(int64_t M, int N, int K);
+/* rows of an (M, N, K) product that vqcpc_gemm_nt hands to whole rounds of its 256-tile kernel when it cuts the launch by rows
+ * (M when it does not): the caller may run rows [main, M) through vqcpc_gemm_nt_splitk and rows [0, main) through vqcpc_gemm_nt */
+int64_t vqcpc_gemm_nt_main_rows(int64_t M, int N, int K);
 int vqcpc_gemm_nt_splitk(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
                          int K, const float* bias, const float* add, int64_t ldadd, void* workspace, int64_t workspace_bytes,
                          void* stream);

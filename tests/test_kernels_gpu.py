@@ -1261,3 +1261,32 @@ def test_count_distinct_codes_rejects_spaces_beyond_the_bitmap(ops):
     out = torch.zeros(1, device='cuda')
     with pytest.raises(RuntimeError, match='exceed'):
         hip.call('vqcpc_count_distinct_codes', a, 4, None, 0, 4, 1024, out)
+
+
+def test_gemm_nt_remainder_rows_go_through_split_k(ops):
+    """139 264 x 256 x 1024 is 2.125 rounds of 256-tiles: vqcpc_gemm_nt cuts it by rows (whole rounds + a 128-tile
+    remainder launch); ops.gemm_nt sends the remainder rows through the split-K entry point instead."""
+    from vqcpc_bach_amd import hip
+    M, N, K = 139264, 256, 1024
+    gen = torch.Generator().manual_seed(3)
+    a, b = dev(torch.randn(M, K, generator=gen)), dev(torch.randn(N, K, generator=gen) * 0.05)
+    bias, res = dev(torch.randn(N, generator=gen)), dev(torch.randn(M, N, generator=gen))
+    hip.set_gemm_mode(1)
+    try:
+        main = hip.query('vqcpc_gemm_nt_main_rows', M, N, K)
+        assert main == 131072 and hip.query('vqcpc_gemm_nt_main_rows', 131072, N, K) == 131072
+        assert hip.query('vqcpc_gemm_nt_splitk_workspace', M - main, N, K) > 0
+        for kw in ({'bias': bias}, {'add': res}, {}):
+            ops.SPLIT_K = False
+            single = ops.gemm_nt(a, b, **kw)
+            ops.SPLIT_K = True
+            cut = ops.gemm_nt(a, b, **kw)
+            assert torch.equal(cut[:main], single[:main])                     # the same whole rounds of the same kernel
+            assert not torch.equal(cut[main:], single[main:])                 # ... and another path for the rest
+            ref = (a[main:].double() @ b.double().t() + (bias.double() if 'bias' in kw else 0)
+                   + (res[main:].double() if 'add' in kw else 0))
+            assert rel_err(cut[main:].cpu(), ref.cpu()) < 2e-6
+    finally:
+        ops.SPLIT_K = True
+        hip.set_gemm_mode(0)
+    assert hip.query('vqcpc_gemm_nt_main_rows', M, N, K) == M                 # fp32-MFMA mode: no 256-tile kernel, no cut

@@ -1727,7 +1727,7 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 namespace vq {
 
 static int splitk_choose(int64_t M, int N, int K) {
-    static const int min_k = getenv("VQCPC_SPLITK_MIN_K") ? atoi(getenv("VQCPC_SPLITK_MIN_K")) : 1024;
+    static const int min_k = getenv("VQCPC_SPLITK_MIN_K") ? atoi(getenv("VQCPC_SPLITK_MIN_K")) : 768;
     if (gemm_mode() != 1 || M % BM || N % BN || K % BK || K < min_k) return 0;
     const int64_t tiles = (M / BM) * (N / BN);
     if (tiles > 160) return 0;
@@ -1778,6 +1778,22 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 }
 
 }  // namespace vq
+
+// Rows of an (M, N, K) product that vqcpc_gemm_nt gives to whole rounds of the 256-tile kernel when it cuts the launch by
+// rows (M when it does not cut): a caller with a workspace can run the remaining rows through vqcpc_gemm_nt_splitk instead
+// of the single under-filled 128-tile launch (bias / residual epilogues, K >= 1024).
+int64_t vqcpc_gemm_nt_main_rows(int64_t M, int N, int K) {
+    if (gemm_mode() != 1 || !g_use_t2.load(std::memory_order_relaxed) || M % kT2 || N % kT2 || K % (2 * kT2BK)) return M;
+    const int64_t mt = M / kT2, tn = N / kT2, t256 = mt * tn;
+    const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
+    const double c256 = ceil((double)t256 / kNumCU);
+    const double c128 = ceil((double)tiles / (2 * kNumCU)) * 0.54;
+    const int64_t main_mt = (t256 / kNumCU) * kNumCU / tn;
+    if (main_mt <= 0 || main_mt >= mt) return M;
+    const int64_t rem_tiles128 = (mt - main_mt) * 2 * ceil_div(N, BN);
+    const double csplit = ceil((double)(main_mt * tn) / kNumCU) + ceil((double)rem_tiles128 / (2 * kNumCU)) * 0.54 + 0.03;
+    return (csplit < c256 && csplit < c128) ? main_mt * kT2 : M;
+}
 
 int64_t vqcpc_gemm_nt_splitk_workspace(int64_t M, int N, int K) {
     const int s = splitk_choose(M, N, K);

@@ -45,6 +45,7 @@ SIGNATURES = {
     'vqcpc_gemm_nt_relu_mask': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_f32, c_u64, c_ptr,
                                         c_ptr]),
     'vqcpc_gemm_nt_splitk_workspace': (c_i64, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_nt_main_rows': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_nt_splitk': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr,
                                      c_i64, c_ptr]),
     'vqcpc_gemm_nt_gatebits': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_f32, c_ptr]),

@@ -58,11 +58,29 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
             ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
             hip.call('vqcpc_gemm_nt_splitk', a, lda, b, ldb, out, ldc, M, N, K, bias, add, lda_, ws, ws_bytes)
             return out
+    if (SPLIT_K and M > _SPLITK_MAX_ROWS and K >= 768 and not act and not drop_p and gate is None and add2 is None
+            and hip.get_gemm_mode() == 1):
+        # a launch that vqcpc_gemm_nt would cut by rows (whole rounds of 256-tiles + an under-filled 128-tile remainder:
+        # 139 264 x 256 x 1024 = 2.125 rounds): the remainder rows go through the split-K path
+        cut = _rowcut.get((M, N, K))
+        if cut is None:
+            m_main = hip.query('vqcpc_gemm_nt_main_rows', M, N, K)
+            ws_bytes = hip.query('vqcpc_gemm_nt_splitk_workspace', M - m_main, N, K) if 0 < m_main < M else 0
+            cut = _rowcut[(M, N, K)] = (m_main, ws_bytes)
+        m_main, ws_bytes = cut
+        if (ws_bytes and ldc % 4 == 0 and lda_ % 4 == 0 and out.data_ptr() % 16 == 0
+                and (add is None or add.data_ptr() % 16 == 0) and (bias is None or bias.data_ptr() % 16 == 0)):
+            hip.call('vqcpc_gemm_nt', a, lda, b, ldb, out, ldc, m_main, N, K, bias, 0, 0.0, 0, None, 0, 1.0, add, lda_, None, 0)
+            ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device=a.device)
+            hip.call('vqcpc_gemm_nt_splitk', a[m_main:], lda, b, ldb, out[m_main:], ldc, M - m_main, N, K, bias,
+                     None if add is None else add[m_main:], lda_, ws, ws_bytes)
+            return out
     hip.call('vqcpc_gemm_nt', a, lda, b, ldb, out, ldc, M, N, K, bias, int(act), float(drop_p), int(seed), gate, ldg,
              float(gate_scale), add, lda_, add2, lda2_)
     return out
 
 
+_rowcut = {}                   # (M, N, K) -> (rows of the whole 256-tile rounds, split-K workspace bytes of the rest)
 SPLIT_K = True                 # A/B switch (tools/bench_splitk.py)
 _SPLITK_MAX_ROWS = 1 << 14     # 160 tiles of 128 x 128 at most: no shape above this many rows qualifies
 _splitk_ws = {}                # (M, N, K) -> workspace bytes in bf16x6 mode (0: not a split-K shape)

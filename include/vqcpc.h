@@ -119,6 +119,11 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* out[C][R] = in[R][C]^T (weight transposes for the dgrad form of vqcpc_gemm_nt) */
 int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream);
+/* The transposes of n row-major matrices that live in one buffer, in one launch: matrix i = base_in + desc[4 i] with
+ * desc[4 i + 1] rows and desc[4 i + 2] columns, its transpose is written at the same offset of base_out; desc[4 i + 3] = number
+ * of 32 x 32 tiles of the matrices before it (ascending), total_tiles = their sum over all n.  `desc` is device memory.
+ * (dgrad operands W^T of every nn.Linear of a backward pass: the trainers' flat parameter buffer -> a flat arena.) */
+int vqcpc_transpose_many(const float* base_in, float* base_out, const int64_t* desc, int n, int64_t total_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused self-attention with learned relative bias.

@@ -1290,3 +1290,57 @@ def test_gemm_nt_remainder_rows_go_through_split_k(ops):
         ops.SPLIT_K = True
         hip.set_gemm_mode(0)
     assert hip.query('vqcpc_gemm_nt_main_rows', M, N, K) == M                 # fp32-MFMA mode: no 256-tile kernel, no cut
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# batched weight transposes (vqcpc_transpose_many, ops.WEIGHT_T)
+# ----------------------------------------------------------------------------------------------------------------
+def test_transpose_many_equals_single_transposes(ops):
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(1)
+    shapes = [(256, 64), (33, 7), (1, 100), (512, 2048), (96, 96), (5, 1)]
+    flat = dev(torch.randn(sum(r * c for r, c in shapes) + 64, generator=gen))
+    arena = torch.full_like(flat, -7.0)
+    rows, off, tiles = [], 16, 0                                  # first matrix at a non-zero offset
+    for r, c in shapes:
+        rows.append((off, r, c, tiles))
+        tiles += ((r + 31) // 32) * ((c + 31) // 32)
+        off += r * c
+    desc = torch.tensor(rows, dtype=torch.int64).cuda()
+    hip.call('vqcpc_transpose_many', flat, arena, desc, len(shapes), tiles)
+    for (o, r, c, _) in rows:
+        assert torch.equal(arena[o:o + r * c].view(c, r), flat[o:o + r * c].view(r, c).t())
+    assert float(arena[:16].max()) == -7.0 and float(arena[off:].max()) == -7.0        # nothing outside the matrices
+
+
+def test_weight_transposes_are_served_from_the_arena_inside_a_backward_pass(ops):
+    """ops.transpose inside `direct_weight_gradients(flat)`: first pass learns the weights, later passes serve them from
+    the arena (one launch), always equal to the plain transpose -- also after the weights changed; tensors outside the
+    flat buffer and overlapping sub-blocks are never cached."""
+    from vqcpc_bach_amd import hip
+    flat = dev(torch.randn(4 * 64 * 48 + 8))
+    w1, w2 = flat[:64 * 48].view(64, 48), flat[64 * 48:2 * 64 * 48].view(48, 64)
+    sub = flat[:32 * 48].view(32, 48)                              # overlaps w1
+    outside = dev(torch.randn(16, 24))
+    calls = []
+    raw = hip.call
+    hip.call = lambda name, *a: (calls.append(name), raw(name, *a))[1]
+    try:
+        for step in range(3):
+            calls.clear()
+            with ops.direct_weight_gradients(flat):
+                got = [ops.transpose(t) for t in (w1, w2, sub, outside)]
+            for g, t in zip(got, (w1, w2, sub, outside)):
+                assert torch.equal(g, t.t())
+            if step == 0:
+                assert calls.count('vqcpc_transpose') == 4 and 'vqcpc_transpose_many' not in calls
+            else:
+                assert calls.count('vqcpc_transpose_many') == 1 and calls.count('vqcpc_transpose') == 2   # sub, outside
+            flat.mul_(1.5)                                          # the "optimiser step"
+        with ops.direct_weight_gradients():                         # no flat buffer: plain transposes
+            calls.clear()
+            assert torch.equal(ops.transpose(w1), w1.t()) and calls == ['vqcpc_transpose']
+        calls.clear()
+        assert torch.equal(ops.transpose(w1), w1.t()) and calls == ['vqcpc_transpose']       # outside a backward pass
+    finally:
+        hip.call = raw

@@ -163,6 +163,39 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
     }
 }
 
+// All the W^T operands of a backward pass in ONE launch: matrix i lives at base_in + desc[4 i] (rows desc[4 i + 1], cols
+// desc[4 i + 2]) and its transpose goes to the same offset of base_out; desc[4 i + 3] = index of its first 32 x 32 tile
+// in the launch (ascending), so a workgroup finds its matrix by bisection.  (A training step transposed 25-80 weights
+// with one 5 us launch each.)
+__global__ __launch_bounds__(256) void transpose_many_kernel(const float* __restrict__ base_in, float* __restrict__ base_out,
+                                                             const int64_t* __restrict__ desc, int n) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;
+    const int64_t t = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[4 * mid + 3] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int64_t off = desc[4 * lo];
+    const int R = (int)desc[4 * lo + 1], C = (int)desc[4 * lo + 2];
+    const int local = (int)(t - desc[4 * lo + 3]), tiles_c = (C + 31) / 32;
+    const float* in = base_in + off;
+    float* out = base_out + off;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c0 = (local % tiles_c) * 32, r0 = (local / tiles_c) * 32;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + k * 8, c = c0 + tx;
+        if (r < R && c < C) tile[ty + k * 8][tx] = in[(int64_t)r * C + c];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int c = c0 + ty + k * 8, r = r0 + tx;
+        if (r < R && c < C) out[(int64_t)c * R + r] = tile[tx][ty + k * 8];
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float selu_f(float x) {
     const float alpha = 1.6732632423543772848170429916717f, scale = 1.0507009873554804934193349852946f;
@@ -428,6 +461,17 @@ int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream) {
     hipLaunchKernelGGL(transpose_kernel, dim3(ceil_div(C, 32), ceil_div(R, 32)), dim3(256), 0, (hipStream_t)stream, in,
                        out, R, C);
     VQ_CHECK_LAUNCH("transpose");
+    return VQCPC_OK;
+}
+
+int vqcpc_transpose_many(const float* base_in, float* base_out, const int64_t* desc, int n, int64_t total_tiles,
+                         void* stream) {
+    if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(base_in && base_out && desc && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31) && base_in != base_out,
+               "transpose_many: bad arguments");
+    hipLaunchKernelGGL(transpose_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, (hipStream_t)stream, base_in, base_out,
+                       desc, n);
+    VQ_CHECK_LAUNCH("transpose_many");
     return VQCPC_OK;
 }
 

@@ -266,7 +266,7 @@ class Decoder(GraphedTraining, nn.Module):
         codes = self.encode(tensor_dict['x'])
         loss, _, _, _ = self.compute_loss(codes, x)
         self.flat.zero_grad()
-        with ops.direct_weight_gradients():
+        with ops.direct_weight_gradients(self.flat.flat):
             loss.backward()
         self.dp.all_reduce_sum_(self.flat.flat_grad)
         self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)       # clip 5 + Adam (:345-346)

@@ -4,6 +4,8 @@ stream and the autograd tape here; every numerical operation below is a libvqcpc
 Layout convention: activations are 2-D `(rows, features)` fp32 tensors whose rows may be strided (`stride(1) == 1`);
 row = block * L + token (block-major), i.e. the reference's time-first `(L, N, E)` transposed.
 """
+import os
+
 import torch
 
 from . import hip
@@ -249,6 +251,7 @@ def gemm_tn_bf16(a, b, want_bias=True, into=None):
 
 
 _DIRECT_WGRAD = False
+BATCHED_TRANSPOSES = os.environ.get('VQCPC_BATCHED_TRANSPOSES', '1') != '0'      # A/B switch
 
 
 class direct_weight_gradients:
@@ -256,14 +259,22 @@ class direct_weight_gradients:
     straight into the parameters' existing `.grad` buffers (the flat all-reduce bucket) and hand `None` to autograd.
     Outside it (plain `backward()`, `torch.autograd.grad`) gradients are returned to autograd as usual."""
 
+    def __init__(self, flat_parameters=None):
+        """flat_parameters: the trainer's flat fp32 parameter buffer -- the transposed dgrad operands of its weights are
+        then prepared by one launch (ops.WEIGHT_T) instead of one per weight."""
+        self.flat = flat_parameters
+
     def __enter__(self):
         global _DIRECT_WGRAD
         self.prev, _DIRECT_WGRAD = _DIRECT_WGRAD, True
+        if self.flat is not None and BATCHED_TRANSPOSES:
+            WEIGHT_T.begin(self.flat)
         return self
 
     def __exit__(self, *exc):
         global _DIRECT_WGRAD
         _DIRECT_WGRAD = self.prev
+        WEIGHT_T.end()
         return False
 
 
@@ -316,9 +327,70 @@ def wgrad(g, x, weight, bias, rows=None):
 
 def transpose(w):
     w = _f32(w).contiguous()
+    hit = WEIGHT_T.lookup(w)
+    if hit is not None:
+        return hit
     out = torch.empty(w.shape[1], w.shape[0], dtype=torch.float32, device=w.device)
     hip.call('vqcpc_transpose', w, out, w.shape[0], w.shape[1])
     return out
+
+
+class _WeightTransposes:
+    """W^T of every 2-D weight a backward pass asks for, refreshed by ONE launch when the pass begins
+    (`direct_weight_gradients(flat_parameters)`), instead of one 5 us launch per weight in the middle of it (25 per CPC
+    step, 80 per student step).  Only tensors inside the trainer's flat parameter buffer are cached (their addresses are
+    stable and nothing else can live there); a weight is learned the first time `transpose` is asked for it and served
+    from the arena from the next step on.  The arena is valid between `begin` and `end` only: weights change in the
+    optimiser step that follows."""
+
+    def __init__(self):
+        self.flat = None
+        self.arena = None
+        self.entries = {}          # data_ptr -> (offset, rows, cols)
+        self.uploaded = {}         # the entries the device table covers
+        self.desc = None
+        self.total_tiles = 0
+        self.active = False
+
+    def _reset(self, flat):
+        self.flat, self.arena = flat, torch.empty_like(flat)
+        self.entries, self.uploaded, self.desc, self.total_tiles = {}, {}, None, 0
+
+    def begin(self, flat):
+        if self.flat is None or self.flat.data_ptr() != flat.data_ptr() or self.flat.numel() != flat.numel():
+            self._reset(flat)
+        if len(self.entries) != len(self.uploaded) and not torch.cuda.is_current_stream_capturing():
+            rows, tiles = [], 0
+            for key, (off, r, c) in sorted(self.entries.items(), key=lambda kv: kv[1][0]):
+                rows.append((off, r, c, tiles))
+                tiles += ((r + 31) // 32) * ((c + 31) // 32)
+            self.desc = torch.tensor(rows, dtype=torch.int64).to(flat.device)
+            self.total_tiles, self.uploaded = tiles, dict(self.entries)
+        if self.uploaded:
+            hip.call('vqcpc_transpose_many', self.flat, self.arena, self.desc, len(self.uploaded), self.total_tiles)
+        self.active = True
+
+    def end(self):
+        self.active = False
+
+    def lookup(self, w):
+        if not self.active or w.dim() != 2:
+            return None
+        ptr = w.data_ptr()
+        ent = self.uploaded.get(ptr)
+        if ent is not None and ent[1] == w.shape[0] and ent[2] == w.shape[1]:
+            return self.arena[ent[0]:ent[0] + ent[1] * ent[2]].view(ent[2], ent[1])
+        base = self.flat.data_ptr()
+        off = (ptr - base) // 4
+        n = w.shape[0] * w.shape[1]
+        if base <= ptr and off + n <= self.flat.numel() and ptr not in self.entries:
+            # no overlap with another registered matrix (a sub-block of a weight next to the whole weight would share arena space)
+            if all(off + n <= o or o + r * c <= off for (o, r, c) in self.entries.values()):
+                self.entries[ptr] = (off, w.shape[0], w.shape[1])
+        return None
+
+
+WEIGHT_T = _WeightTransposes()
 
 
 # ------------------------------------------------------------------------------------------------------------------

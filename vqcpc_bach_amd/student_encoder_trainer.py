@@ -221,7 +221,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         m = self._graph_m if masked_event_index is None else masked_event_index
         loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, m)
         self.flat.zero_grad()
-        with ops.direct_weight_gradients():
+        with ops.direct_weight_gradients(self.flat.flat):
             (loss_teacher + loss_encdec).backward()          # disjoint graphs: the teacher logits are detached
         self.dp.all_reduce_sum_(self.flat.flat_grad)
         lr, scale = self.current_lr(), 1.0 / self.dp.world_size

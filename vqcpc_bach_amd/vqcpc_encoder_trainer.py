@@ -225,7 +225,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         """zero_grad / forward / backward / all-reduce / clip / Adam (:310-316): everything a step enqueues on the device."""
         loss, out = self.compute_losses(tensor_dict, corrupt_labels)
         self.flat.zero_grad()
-        with ops.direct_weight_gradients():
+        with ops.direct_weight_gradients(self.flat.flat):
             loss.backward()
         self.dp.all_reduce_sum_(self.flat.flat_grad)
         self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)

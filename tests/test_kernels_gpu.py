@@ -1344,3 +1344,42 @@ def test_weight_transposes_are_served_from_the_arena_inside_a_backward_pass(ops)
         assert torch.equal(ops.transpose(w1), w1.t()) and calls == ['vqcpc_transpose']       # outside a backward pass
     finally:
         hip.call = raw
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# glue nodes: stacked embedding tables, row split of the encoder output
+# ----------------------------------------------------------------------------------------------------------------
+def test_stack_tables_fn_equals_pad_and_stack(ops):
+    gen = torch.Generator().manual_seed(2)
+    sizes = [57, 49, 56, 33]
+    for direct in (False, True):
+        ws = [dev(torch.randn(n, 32, generator=gen)).requires_grad_(True) for n in sizes]
+        ref_ws = [w.detach().clone().requires_grad_(True) for w in ws]
+        gout = dev(torch.randn(4, 57, 32, generator=gen))
+        ref = torch.stack([torch.nn.functional.pad(w, (0, 0, 0, 57 - w.shape[0])) for w in ref_ws], dim=0)
+        (ref * gout).sum().backward()
+        if direct:                                   # the trainers' situation: .grad buffers exist, gradients are added in place
+            for w in ws:
+                w.grad = torch.full_like(w, 0.5)
+        out = ops.StackTablesFn.apply(*ws)
+        assert torch.equal(out, ref.detach())
+        if direct:
+            with ops.direct_weight_gradients():
+                (out * gout).sum().backward()
+        else:
+            (out * gout).sum().backward()
+        for w, r in zip(ws, ref_ws):
+            assert torch.equal(w.grad, r.grad + (0.5 if direct else 0.0))
+
+
+def test_split_rows_fn_equals_slicing(ops):
+    gen = torch.Generator().manual_seed(4)
+    x = dev(torch.randn(100, 8, generator=gen)).requires_grad_(True)
+    xr = x.detach().clone().requires_grad_(True)
+    a, b, c = ops.SplitRowsFn.apply(x, 30, 50, 20)
+    ar, br, cr = xr[:30], xr[30:80], xr[80:]
+    assert torch.equal(a, ar) and torch.equal(b, br) and torch.equal(c, cr)
+    ga, gc = dev(torch.randn(30, 8, generator=gen)), dev(torch.randn(20, 8, generator=gen))
+    ((a * ga).sum() + (c * gc).sum()).backward()                  # the middle block receives no gradient
+    ((ar * ga).sum() + (cr * gc).sum()).backward()
+    assert torch.equal(x.grad, xr.grad)

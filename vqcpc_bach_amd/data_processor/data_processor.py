@@ -61,6 +61,5 @@ class DataProcessor(nn.Module):
 
     def stacked_tables(self):
         """(num_channels, vmax, embedding_size) zero-padded stack of the per-voice tables (autograd-visible)."""
-        vmax = max(e.weight.shape[0] for e in self.embeddings)
-        return torch.stack([torch.nn.functional.pad(e.weight, (0, 0, 0, vmax - e.weight.shape[0]))
-                            for e in self.embeddings], dim=0)
+        from .. import ops
+        return ops.StackTablesFn.apply(*[e.weight for e in self.embeddings])

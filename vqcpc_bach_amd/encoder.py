@@ -4,6 +4,7 @@ import os
 import torch
 from torch import nn
 
+from . import ops
 from .utils import dict_pretty_print, flatten
 
 
@@ -48,7 +49,7 @@ class Encoder(nn.Module):
             self.quantizer.initialize = False
 
     # ---- forward ---------------------------------------------------------------------------------------------
-    def encode_many(self, xs, corrupt_flags=None):
+    def encode_many(self, xs, corrupt_flags=None, with_loss_rows=False):
         """Encode several token tensors (batch_i, ticks_i, voices) in ONE pass: all 16-token blocks are independent
         (relative_transformer_downscaler.py:98-115), so the calls of vqcpc_encoder_trainer.py:201-231 merge into one
         launch sequence.  The FIRST tensor plays the role of the reference's first call for the data-dependent
@@ -74,11 +75,14 @@ class Encoder(nn.Module):
         if self.upscaler is not None:
             zq = self.upscaler(zq)
         out = []
-        for t, s, n in zip(toks, starts, sizes):
+        zq_parts = ops.SplitRowsFn.apply(zq, *sizes) if (len(sizes) > 1 and zq.requires_grad) else None
+        for i, (t, s, n) in enumerate(zip(toks, starts, sizes)):
             b, nb = t.shape[0], t.shape[1]
             idx_i = idx[s:s + n].view(b, nb, -1) if idx is not None else None
-            out.append((zq[s:s + n].view(b, nb, -1), idx_i, ql[s:s + n].view(b, nb)))
-        return out
+            zq_i = zq_parts[i] if zq_parts is not None else zq[s:s + n]
+            out.append((zq_i.view(b, nb, -1), idx_i, ql[s:s + n].view(b, nb)))
+        # with_loss_rows: also the quantisation loss of ALL rows of the pass (the trainer's q-loss sums every segment)
+        return (out, ql) if with_loss_rows else out
 
     def forward(self, x, corrupt_labels=False):
         """x (batch, num_ticks, num_voices) ints from the dataloader ->

@@ -307,6 +307,62 @@ def accumulate_small(params, grads):
     return out
 
 
+def _accumulate_into(dst_tensors, src_tensors):
+    """dst[i] += src[i] for up to 8 contiguous fp32 tensors per launch."""
+    import ctypes
+    for o in range(0, len(dst_tensors), 8):
+        d, sr = dst_tensors[o:o + 8], src_tensors[o:o + 8]
+        hip.call('vqcpc_accumulate8', (ctypes.c_void_p * 8)(*[t.data_ptr() for t in d]),
+                 (ctypes.c_void_p * 8)(*[t.data_ptr() for t in sr]), (ctypes.c_int * 8)(*[t.numel() for t in sr]), len(d))
+
+
+class SplitRowsFn(torch.autograd.Function):
+    """x (R, ...) -> consecutive row blocks of the given sizes (copies).  Backward is ONE concatenation of the incoming
+    gradients; autograd's own slice backward would fill a zero tensor of the full size per block, copy the block in and add
+    the results up (3 blocks of the encoder output: 8 kernels instead of 1)."""
+
+    @staticmethod
+    def forward(ctx, x, *sizes):
+        ctx.sizes, ctx.tail = sizes, x.shape[1:]
+        out, s = [], 0
+        for n in sizes:
+            out.append(x[s:s + n].clone())
+            s += n
+        assert s == x.shape[0]
+        return tuple(out)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        ref = next(g for g in grads if g is not None)
+        parts = [g if g is not None else torch.zeros((n,) + tuple(ctx.tail), dtype=ref.dtype, device=ref.device)
+                 for g, n in zip(grads, ctx.sizes)]
+        return (torch.cat(parts, dim=0),) + (None,) * len(ctx.sizes)
+
+
+class StackTablesFn(torch.autograd.Function):
+    """(nv, vmax, emb) zero-padded stack of per-voice embedding tables (data_processor.stacked_tables): a fill + ONE launch
+    forward and ONE launch backward (the slices of the incoming gradient are added straight into the tables' gradient
+    buffers), instead of pad x nv + stack and their autograd mirror images (about 25 small kernels per step)."""
+
+    @staticmethod
+    def forward(ctx, *tables):
+        vmax, emb = max(t.shape[0] for t in tables), tables[0].shape[1]
+        out = torch.zeros(len(tables), vmax, emb, dtype=torch.float32, device=tables[0].device)
+        if tables[0].is_cuda and all(t.is_contiguous() and t.dtype == torch.float32 for t in tables):
+            _accumulate_into([out[c, :t.shape[0]] for c, t in enumerate(tables)], [t.detach() for t in tables])
+        else:
+            for c, t in enumerate(tables):
+                out[c, :t.shape[0]] = t
+        ctx.tables = tables
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        g = g.contiguous()
+        grads = [g[c, :t.shape[0]] for c, t in enumerate(ctx.tables)]       # rows of one voice: a contiguous block
+        return tuple(accumulate_small(ctx.tables, grads)) if g.is_cuda else tuple(grads)
+
+
 def wgrad(g, x, weight, bias, rows=None):
     """Weight / bias gradient of y = x W^T + b.  When the parameter already owns a gradient buffer the TN GEMM's final
     reduction ACCUMULATES straight into it and (None, None) is returned to autograd -- no temporary, no extra

@@ -164,7 +164,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
             corrupt.append(corrupt_labels)
         xs += [tensor_dict['x_left'], tensor_dict['x_right']]
         corrupt += [False, False]
-        enc = self.encoder.encode_many(xs, corrupt)
+        enc, ql_rows = self.encoder.encode_many(xs, corrupt, with_loss_rows=True)
         (z_neg, idx_neg, ql_neg) = enc[0]
         (z_left, idx_left, ql_left), (z_right, idx_right, ql_right) = enc[-2], enc[-1]
         zdim = z_neg.shape[-1]
@@ -172,11 +172,13 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
 
         c = self.c_module(z_left, h=None)
         contrastive, hits = cpc_scores_and_loss(self.fks_module, c, z_right, z_neg)
-        ql_total = ql_left.sum() + ql_right.sum() + ql_neg.sum()
+        # quantization_loss (vqcpc_helper.py:32-51) sums the per-block losses of EVERY encoder call of the step: one sum over
+        # the rows of the merged pass instead of one per segment (and their slice / add backward nodes)
+        ql_total = ql_rows.sum()
         n_terms = 3 * B
         hits_back = None
         if bidir:                                                                 # :277-296
-            z_nb, _, ql_nb = enc[1]
+            z_nb = enc[1][0]
             # reference quirk kept for parity: the backward negatives are NOT permuted to negative-major before
             # FksModule's raw .view (:286-292), so window b is scored against rows n*B + b of the (B*N, K, z) tensor
             z_nb = z_nb.reshape(B, N, Kr, -1, zdim)[:, :, :, 0, :].reshape(B * N, Kr, zdim)
@@ -184,8 +186,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
             c_back = self.c_module_back(z_right.flip(dims=[1]), h=None)
             contrastive_back, hits_back = cpc_scores_and_loss(self.fks_module_back, c_back, z_left, z_nb)
             contrastive = contrastive + contrastive_back
-            ql_total = ql_total + ql_nb.sum()
-            n_terms = 4 * B
+            n_terms = 4 * B                                                       # ql_total already holds the fourth segment
         q_loss = ql_total / n_terms                                               # quantization_loss, helper :32-51
         loss = contrastive + self.quantization_weighting * q_loss
         accuracy = hits.mean(0)

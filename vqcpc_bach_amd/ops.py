@@ -637,12 +637,15 @@ class EncoderLayerFn(torch.autograd.Function):
         ctx.ln_betas = (be1, be2)
         ctx.qkv_tokens = qkv_tokens
         ctx.mark_non_differentiable(probs)
+        ctx.set_materialize_grads(False)        # no zero tensor of the size of the attention maps for the unused output
         return y, probs
 
     @staticmethod
     def backward(ctx, dy, _dprobs):
         (x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
          g2) = ctx.saved_tensors
+        if dy is None:
+            dy = torch.zeros_like(x1)
         L, H, p, s, f, ext_qkv = ctx.meta
         bqkv, bo, b1, b2 = ctx.biases
         be1, be2 = ctx.ln_betas
@@ -784,6 +787,7 @@ class AttnXFn(torch.autograd.Function):
         ctx.save_for_backward(qsrc, kvsrc, probs, e1, e2)
         ctx.meta = (n, Lq, Lk, H, hd, int(mask), float(drop_p), int(seed))
         ctx.mark_non_differentiable(probs)
+        ctx.set_materialize_grads(False)        # the attention maps are an unused output: no 150 MB zero gradient for them
         return att, probs
 
     @staticmethod
@@ -792,7 +796,7 @@ class AttnXFn(torch.autograd.Function):
         n, Lq, Lk, H, hd, mask, p, seed = ctx.meta
         d = H * hd
         dev = qsrc.device
-        datt = datt.contiguous()
+        datt = datt.contiguous() if datt is not None else torch.zeros(n * Lq, d, dtype=torch.float32, device=dev)
         de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
         if kvsrc is None:
             dqsrc, dkvsrc = torch.empty(n * Lq, 3 * d, dtype=torch.float32, device=dev), None
@@ -824,6 +828,7 @@ class AddLayerNormFn(torch.autograd.Function):
         hip.call('vqcpc_add_layernorm_fwd', x, ldx, r, gamma, beta, y, mean, rstd, M, d, 1e-5, float(drop_p), int(seed))
         ctx.save_for_backward(x, r, gamma, mean, rstd)
         ctx.meta = (float(drop_p), int(seed))
+        ctx.beta = beta
         return y
 
     @staticmethod
@@ -841,6 +846,7 @@ class AddLayerNormFn(torch.autograd.Function):
         ws = hip.workspace(nbytes, dev)
         hip.call('vqcpc_add_layernorm_bwd', dy.contiguous(), x, ldx, r, gamma, mean, rstd, ds, dr, dg, db, M, d, p, seed, ws,
                  nbytes)
+        dg, db = accumulate_small([gamma, ctx.beta], [dg, db])       # one launch into the live gradient buffers (trainers)
         return ds, (dr if dr is not None else ds), dg, db, None, None
 
 
@@ -955,6 +961,7 @@ class VQFn(torch.autograd.Function):
         ctx.save_for_backward(z, codebooks, idx)
         ctx.meta = (float(beta), int(bool(squared)))
         ctx.mark_non_differentiable(idx)
+        ctx.set_materialize_grads(False)
         return zq, idx, loss
 
     @staticmethod
@@ -1079,11 +1086,14 @@ class NCEFn(torch.autograd.Function):
         hip.call('vqcpc_nce_fwd', c, W, z_pos, z_neg, B, K, N, zdim, cdim, f_pos, f_neg, loss_b, hits)
         ctx.save_for_backward(c, W, z_pos, z_neg, f_pos, f_neg)
         ctx.mark_non_differentiable(hits, f_pos, f_neg)
+        ctx.set_materialize_grads(False)
         return loss_b, hits, f_pos, f_neg
 
     @staticmethod
     def backward(ctx, g_loss_b, _gh, _gp, _gn):
         c, W, z_pos, z_neg, f_pos, f_neg = ctx.saved_tensors
+        if g_loss_b is None:
+            g_loss_b = torch.zeros(c.shape[0], dtype=torch.float32, device=c.device)
         B, cdim = c.shape
         zdim, _, K = W.shape
         N = z_neg.shape[1]

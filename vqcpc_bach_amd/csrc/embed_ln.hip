@@ -282,6 +282,28 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
     }
 }
 
+// embedding backward, stage 3: the reduced partials tmp[voice][table | chan | event] go to the three gradient tensors; the
+// event sums also run over the voices (ascending).  One launch instead of a reduction per voice and per output.
+__global__ __launch_bounds__(256) void embed_pos_scatter_kernel(const float* __restrict__ tmp, int nv, int64_t tab, int pos,
+                                                                int nev, float* __restrict__ d_table,
+                                                                float* __restrict__ d_chan, float* __restrict__ d_event) {
+    const int64_t per = tab + pos + (int64_t)nev * pos;
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t n1 = (int64_t)nv * (tab + pos);
+    if (i < n1) {
+        const int v = (int)(i / (tab + pos));
+        const int64_t j = i - (int64_t)v * (tab + pos);
+        const float x = tmp[(int64_t)v * per + j];
+        if (j < tab) d_table[(int64_t)v * tab + j] = x;
+        else d_chan[(int64_t)v * pos + (j - tab)] = x;
+    } else if (i < n1 + (int64_t)nev * pos) {
+        const int64_t e = i - n1;
+        float acc = 0.0f;
+        for (int v = 0; v < nv; ++v) acc += tmp[(int64_t)v * per + tab + pos + e];
+        d_event[e] = acc;
+    }
+}
+
 static int ln_blocks(int64_t M) { return (int)std::min<int64_t>(ceil_div(M, 4), 2048); }
 
 // =====================================================================================================================
@@ -407,7 +429,7 @@ int vqcpc_embed_pos_fwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
 int64_t vqcpc_embed_pos_bwd_workspace(int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin, int pos) {
     const int64_t nchunks = ceil_div(std::max<int64_t>(n_rows, 1), emb_chunk_rows(n_rows, tokens_per_block));
     const int64_t per = (int64_t)vmax * dlin + pos + (int64_t)(tokens_per_block / n_voices) * pos;
-    return nchunks * n_voices * per * (int64_t)sizeof(float);
+    return (nchunks + 1) * n_voices * per * (int64_t)sizeof(float);          // partials + one reduced [voice][per] block
 }
 
 int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_block, int n_voices, int vmax, int dlin,
@@ -434,20 +456,16 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
     VQ_CHECK_LAUNCH("embed_pos_bwd");
     // stage 2: partials ws[chunk][voice][table | chan | event] -> parallel deterministic column reductions (a single
     // thread per output walking 272 chunks was latency-bound: 140 us)
-    const float* wsf = (const float*)workspace;
+    // (one reduction over the chunks for all voices and outputs at once + one scatter: 2 launches instead of 2 nv + 1)
+    float* wsf = (float*)workspace;
     const int64_t per = (int64_t)vmax * dlin + pos + (int64_t)nev * pos;
-    for (int v = 0; v < n_voices; ++v) {
-        int rc = launch_reduce_splits(wsf + v * per, (int64_t)n_voices * per, nchunks, d_table + (int64_t)v * vmax * dlin,
-                                      (int64_t)vmax * dlin, 0, s);
-        if (rc) return rc;
-        rc = launch_reduce_splits(wsf + v * per + (int64_t)vmax * dlin, (int64_t)n_voices * per, nchunks, d_chan + v * pos, pos,
-                                  0, s);
-        if (rc) return rc;
-    }
-    if (nev) {      // event sums also run over the voices: (chunk, voice) pairs are consecutive blocks of `per` floats
-        int rc = launch_reduce_splits(wsf + (int64_t)vmax * dlin + pos, per, nchunks * n_voices, d_event, (int64_t)nev * pos, 0, s);
-        if (rc) return rc;
-    }
+    float* tmp = wsf + (int64_t)nchunks * n_voices * per;
+    int rc = launch_reduce_splits(wsf, (int64_t)n_voices * per, nchunks, tmp, (int64_t)n_voices * per, 0, s);
+    if (rc) return rc;
+    const int64_t total = (int64_t)n_voices * ((int64_t)vmax * dlin + pos) + (int64_t)nev * pos;
+    hipLaunchKernelGGL(embed_pos_scatter_kernel, dim3((unsigned)ceil_div(total, 256)), dim3(256), 0, s, tmp, n_voices,
+                       (int64_t)vmax * dlin, pos, nev, d_table, d_chan, d_event);
+    VQ_CHECK_LAUNCH("embed_pos_scatter");
     return VQCPC_OK;
 }
 

@@ -1,4 +1,6 @@
 // Wavefront-primitive kernels: fused embedding-table gather + positional concat, fused residual + dropout + LayerNorm.
+#include <stdlib.h>
+
 #include "common.h"
 #include "gemm_common.h"   // round4_bf16 (bf16 copies of LayerNorm outputs for the bf16 GEMM path)
 
@@ -305,6 +307,12 @@ __global__ __launch_bounds__(256) void embed_pos_scatter_kernel(const float* __r
 }
 
 static int ln_blocks(int64_t M) { return (int)std::min<int64_t>(ceil_div(M, 4), 2048); }
+// backward: 512 workgroups (2 per CU) stream faster than 2048 and leave a quarter of the column partials to reduce:
+// 573 -> 488 us at 557 056 x 256, 522 -> 516 us at 278 528 x 512 (tools/bench_ln.py; 384 and fewer fall off again)
+static int ln_bwd_blocks(int64_t M) {
+    static const int cap = getenv("VQCPC_LN_BWD_BLOCKS") ? atoi(getenv("VQCPC_LN_BWD_BLOCKS")) : 512;
+    return (int)std::min<int64_t>(ceil_div(M, 4), cap);
+}
 
 // =====================================================================================================================
 // Block-table gather / segment sum.  The input of the FIRST encoder layer takes only vmax * L distinct values (token id x
@@ -552,7 +560,7 @@ int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, con
 }
 
 int64_t vqcpc_add_layernorm_bwd_workspace(int64_t M, int d) {
-    return (int64_t)ln_blocks(std::max<int64_t>(M, 1)) * 2 * d * (int64_t)sizeof(float);
+    return (int64_t)ln_bwd_blocks(std::max<int64_t>(M, 1)) * 2 * d * (int64_t)sizeof(float);
 }
 
 int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
@@ -576,7 +584,7 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
     hipStream_t s = (hipStream_t)stream;
     const uint32_t thr = drop_threshold(drop_p);
     const float ik = 1.0f / (1.0f - drop_p);
-    const int blocks = ln_blocks(M);
+    const int blocks = ln_bwd_blocks(M);
     if (r)
         hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
                            d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);

@@ -47,15 +47,20 @@ def parse():
     ap.add_argument('--batch', type=int, default=None, help='windows per GPU (default: the config\'s)')
     ap.add_argument('--dropout', type=float, default=None, help='default: 0.1 (0.2 for --config DEC, as its reference config)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-steps', type=int, default=12)
+    ap.add_argument('--cpu-batch', type=int, default=16, help='SURVEY.md section 8(d): the C1 model at B = 16 on the host cores')
+    ap.add_argument('--cpu-steps', type=int, default=8)
+    ap.add_argument('--live-pmc', dest='live_pmc', action='store_true', default=None,
+                    help='after the timed region, run three short rocprofv3 --pmc passes of this command (FETCH_SIZE, WRITE_SIZE, '
+                         'GRBM_GUI_ACTIVE) for roofline.traffic and the effective clock (default: on for N = 1, config C1)')
+    ap.add_argument('--no-live-pmc', dest='live_pmc', action='store_false')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--host-inputs', action='store_true',
                     help='batches start in (pinned) host memory: the PCIe-inclusive rate quoted in DESIGN.md, never `value`')
     ap.add_argument('--gemm-mode', default=os.environ.get('VQCPC_GEMM_MODE', 'bf16x6'), choices=['f32', 'bf16x6', 'bf16', '0', '1', '8'],
                     help='f32: v_mfma_f32_32x32x2_f32 on fp32 operands; bf16x6: exact 3-way bf16 split, 6 bf16 MFMAs/product')
     ap.add_argument('--graph', dest='graph', action='store_true', default=True,
-                    help='replay the training step from a HIP graph (vqcpc_bach_amd/graphs.py); single-rank runs only')
+                    help='replay the training step from HIP graphs (vqcpc_bach_amd/graphs.py): one graph per step on one rank, '
+                         'two around the eager RCCL all-reduce on several (VQCPC_DP_GRAPH=capture|off changes that)')
     ap.add_argument('--no-graph', dest='graph', action='store_false')
     ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM times of the sampled steps, to stderr')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
@@ -186,17 +191,87 @@ class GemmTimer:
                     flops_per_launch=flops / len(recs), bytes_per_launch=sum(r[3] for r in recs) / len(recs))
 
 
-def hbm_traffic(kernel, calls_per_step):
-    """HBM bytes per launch of the dominant kernel from the rocprofv3 PMC passes committed under profiles/ (FETCH_SIZE and
-    WRITE_SIZE collected in separate --pmc runs of this same command; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes
-    for gfx950 -- calibrated on the QKV launch: WRITE_SIZE == M*N*4 exactly).  None when the file is absent."""
+def hbm_traffic_from_file(kernel, calls_per_step):
+    """Fallback when the live PMC passes are off / unavailable: HBM bytes per launch of the dominant kernel from the
+    rocprofv3 PMC passes committed under profiles/ (same collection as live_pmc below, run by hand).  None if absent."""
+    for name in ('r03_gemm_hbm_traffic.json', 'r02_gemm_hbm_traffic.json'):
+        try:
+            d = json.load(open(os.path.join(ROOT, 'profiles', name)))
+            return round(d[kernel]['hbm_bytes_per_step'] / calls_per_step), f'from_file: profiles/{name}'
+        except Exception:
+            continue
+    return None, None
+
+
+def live_pmc(args, B, timeout_s=100):
+    """HBM traffic and effective clock of the dominant kernel, measured IN THIS RUN (after the timed region, rank 0, N = 1):
+    three rocprofv3 passes over a short eager run of this very command -- `--pmc FETCH_SIZE`, `--pmc WRITE_SIZE` (they do
+    not fit one pass: MI355X_MICROARCH.md, rocprofv3 PMC slots) and `--pmc GRBM_GUI_ACTIVE SQ_VALU_MFMA_BUSY_CYCLES` --
+    each with --kernel-trace only (no other trace domain).  FETCH_SIZE is doubled as the guide prescribes for gfx950 wide
+    streaming reads (calibrated here on the QKV launch: WRITE_SIZE == M*N*4 exactly); effective clock =
+    GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time; MFMA pipe busy = SQ_VALU_MFMA_BUSY_CYCLES / (GUI_ACTIVE / 8 x 1024 SIMDs).
+    Returns {'gemm_nt': {...}, 'gemm_tn': {...}, 'steps': n} or {'error': ...}; never raises."""
+    import csv, glob, shutil, signal, subprocess, tempfile
+    if shutil.which('rocprofv3') is None:
+        return {'error': 'rocprofv3 not on PATH'}
+    steps, warm = 2, 2
+    n_steps = warm + 2 * steps                   # warm-up epoch + the bare-step loop + the timed epoch of the inner run
+    inner = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(steps), '--warmup', str(warm),
+             '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--no-graph',
+             '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc']
+    out = {'steps': n_steps}
+    tmp = tempfile.mkdtemp(prefix='vqcpc_pmc_', dir='/tmp')
+    env = dict(os.environ, TMPDIR='/tmp')
     try:
-        d = json.load(open(os.path.join(ROOT, 'profiles', 'r02_gemm_hbm_traffic.json')))
-        # the PMC passes count kernel launches (a row-split ops.gemm_nt call is two of them): normalise per step, then
-        # per call, so that `traffic` has the same unit as `achieved` / `algorithmic_bytes_per_launch`
-        return round(d[kernel]['hbm_bytes_per_step'] / calls_per_step)
-    except Exception:
-        return None
+        acc = {}
+        for tag, counters in (('fetch', ['FETCH_SIZE']), ('write', ['WRITE_SIZE']),
+                              ('clock', ['GRBM_GUI_ACTIVE', 'SQ_VALU_MFMA_BUSY_CYCLES'])):
+            d = os.path.join(tmp, tag)
+            cmd = ['rocprofv3', '--kernel-trace', '--pmc'] + counters + ['-f', 'csv', '-d', d, '--'] + inner
+            proc = subprocess.Popen(cmd, cwd='/tmp', env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                    start_new_session=True)
+            try:
+                proc.wait(timeout=timeout_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(proc.pid, signal.SIGKILL)       # the whole group: rocprofv3 and the profiled python
+                proc.wait()
+                return {'error': f'rocprofv3 pass "{tag}" exceeded {timeout_s} s'}
+            dur = {}
+            for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
+                for r in csv.DictReader(open(f)):
+                    dur[r['Dispatch_Id']] = float(r['End_Timestamp']) - float(r['Start_Timestamp'])
+            for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
+                for r in csv.DictReader(open(f)):
+                    k = r['Kernel_Name']
+                    grp = 'gemm_nt' if 'gemm_nt' in k else 'gemm_tn' if 'gemm_tn' in k else None
+                    if grp is None:
+                        continue
+                    a_ = acc.setdefault(grp, {})
+                    c = r['Counter_Name']
+                    big = dur.get(r['Dispatch_Id'], 0.0) >= 2e5        # clock: launches of >= 0.2 ms (no ramp-up share)
+                    if tag == 'clock' and not big:
+                        continue
+                    a_[c] = a_.get(c, 0.0) + float(r['Counter_Value'])
+                    a_['n_' + c] = a_.get('n_' + c, 0) + 1
+                    if tag == 'clock' and c == 'GRBM_GUI_ACTIVE':
+                        a_['ns'] = a_.get('ns', 0.0) + dur[r['Dispatch_Id']]
+        for grp, a_ in acc.items():
+            o = out.setdefault(grp, {})
+            if a_.get('n_FETCH_SIZE') and a_.get('n_FETCH_SIZE') == a_.get('n_WRITE_SIZE'):
+                o['kernel_launches_per_step'] = a_['n_FETCH_SIZE'] / n_steps
+                o['hbm_bytes_per_step'] = (2.0 * a_['FETCH_SIZE'] + a_['WRITE_SIZE']) * 1024.0 / n_steps
+            if a_.get('ns'):
+                cyc = a_['GRBM_GUI_ACTIVE'] / 8.0
+                o['effective_clock_mhz'] = round(cyc / a_['ns'] * 1e3)
+                if a_.get('SQ_VALU_MFMA_BUSY_CYCLES'):
+                    o['mfma_pipe_busy'] = round(a_['SQ_VALU_MFMA_BUSY_CYCLES'] / (cyc * 1024.0), 3)
+        if 'gemm_nt' not in out:
+            return {'error': 'no gemm_nt rows in the rocprofv3 output'}
+        return out
+    except Exception as e:
+        return {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
 
 
 class ClockSampler:
@@ -289,6 +364,7 @@ def usable_cores():
 def cpu_baseline_worker(cfg_name, dropout, batch, steps):
     """Runs in a child process (so that a slow host cannot stall the GPU measurement): prints one JSON object."""
     usable = usable_cores()
+    second_batch = 8 if cfg_name in ('C0', 'C1') else 0
     if cfg_name == 'C3':                                  # student step: oracle/student_oracle.py
         from oracle import student_oracle as O
         cfg = O.make_cfg('C3', dropout=dropout, B=batch)
@@ -329,10 +405,20 @@ def cpu_baseline_worker(cfg_name, dropout, batch, steps):
     except Exception:
         pass
     unit = 'sequences/s' if cfg_name in ('C3', 'DEC') else 'windows/s'
-    print(json.dumps(dict(value=round(batch * steps / dt, 3), unit=unit, cores=cores, kind='port',
-                          sample=f'{cfg_name} model, B={batch} {unit[:-2]}/step, {steps} timed steps after 1 warm-up, fp32, '
-                                 f'dropout {dropout}, torch {torch.__version__} CPU on {model} ({usable} usable cores, fastest of '
-                                 f'{cands} threads used), {dt:.1f} s')), flush=True)
+    res = dict(value=round(batch * steps / dt, 3), unit=unit, cores=cores, threads=cores, host_cores_usable=usable, kind='port',
+               sample=f'{cfg_name} model, B={batch} {unit[:-2]}/step, {steps} timed steps after 1 warm-up, fp32, '
+                      f'dropout {dropout}, torch {torch.__version__} CPU on {model}; {cores} threads used (the fastest of '
+                      f'{cands} on the {usable} cores this process may use), {dt:.1f} s')
+    if second_batch and second_batch != batch:          # a second batch size: windows/s on the CPU is NOT flat in B
+        cfg2 = O.make_cfg(cfg_name, dropout=dropout, B=second_batch)
+        otr2 = O.OracleTrainer(cfg2, O.init_state(cfg2, seed=0), lr=1e-4)
+        b2 = [O.synthetic_batch(cfg2, seed=1234 + i) for i in range(5)]
+        otr2.step(b2[0], train=True, gen=gen)
+        t0 = time.perf_counter()
+        for b in b2[1:]:
+            otr2.step(b, train=True, gen=gen)
+        res['other_batch'] = dict(batch=second_batch, value=round(second_batch * 4 / (time.perf_counter() - t0), 3), threads=cores)
+    print(json.dumps(res), flush=True)
 
 
 def cpu_baseline(cfg_name, dropout, batch, steps, timeout_s=240):
@@ -344,7 +430,7 @@ def cpu_baseline(cfg_name, dropout, batch, steps, timeout_s=240):
                              env=dict(os.environ, HIP_VISIBLE_DEVICES='', CUDA_VISIBLE_DEVICES=''))
         return json.loads(out.stdout.strip().splitlines()[-1])
     except Exception as e:       # never lose the GPU measurement to a slow / odd host
-        return dict(value=None, unit='windows/s', cores=usable_cores(), kind='port',
+        return dict(value=None, unit='windows/s', cores=usable_cores(), threads=None, kind='port',
                     sample=f'cpu baseline failed: {type(e).__name__}: {str(e)[:200]}')
 
 
@@ -399,8 +485,10 @@ def main():
     trainer.init_optimizers(lr=config['lr'], schedule_lr=config.get('schedule_lr', False), dp=dp)
     trainer.train()
     n_params = trainer.flat.numel
-    # per-launch HIP events cannot be recorded inside a replayed graph: the kernel-timing samples come from eager steps
-    use_graph = bool(args.graph) and dp.world_size == 1
+    # per-launch HIP events cannot be recorded inside a replayed graph: the kernel-timing samples come from eager steps.
+    # Multi-rank runs replay the step too: two graphs around the eagerly issued RCCL all-reduce (graphs.py)
+    from vqcpc_bach_amd.graphs import dp_graph_mode
+    use_graph = bool(args.graph) and (not dp.distributed or dp_graph_mode() != 'off')
 
     timer = GemmTimer()
     if not args.no_kernel_timing:
@@ -478,12 +566,17 @@ def main():
     timer.enabled = False
     dt = dp.max_over_ranks(dt)
     timed_steps = max(1, len(range(0, args.steps, 4)))
-    graph_replays = None
+    graph_replays, graphs_per_step = None, None
     if use_graph:
         g = getattr(trainer, '_graph', None)
         graph_replays = g.replays if g is not None else 0
+        graphs_per_step = 2 if (g is not None and g.finish_fn is not None) else 1
         trainer.enable_step_graph(False)
         timed_steps = max(1, sampled_eager_steps)
+    pmc = None
+    want_pmc = args.live_pmc if args.live_pmc is not None else (dp.world_size == 1 and args.config == 'C1' and not args.host_inputs)
+    if want_pmc and dp.rank == 0 and dp.world_size == 1:
+        pmc = live_pmc(args, B)
     flush_c_stdio()
     dp.barrier()                                    # every rank has emitted whatever its libraries had buffered
     student = config['training_method'].lower() == 'student'
@@ -512,17 +605,34 @@ def main():
                                'gemm_nt_skinny_kernel in fp32); one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate')
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=0>, gemm_nt_skinny_kernel; fp32 v_mfma_f32_32x32x2_f32)'
+            calls_per_step = max(1, nt['launches'] // timed_steps)
+            traffic = traffic_src = eff_mhz = pipe_busy = None
+            if pmc and 'gemm_nt' in pmc:
+                g_ = pmc['gemm_nt']
+                if 'hbm_bytes_per_step' in g_:
+                    traffic = round(g_['hbm_bytes_per_step'] / calls_per_step)
+                    traffic_src = ('live: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE passes over '
+                                   f'`bench.py --steps 2 --warmup 2 --no-graph` ({pmc["steps"]} steps, '
+                                   f'{g_["kernel_launches_per_step"]:.0f} gemm_nt kernel launches per step) run by this process '
+                                   'after the timed region; FETCH_SIZE x2 (gfx950) + WRITE_SIZE')
+                eff_mhz, pipe_busy = g_.get('effective_clock_mhz'), g_.get('mfma_pipe_busy')
+            if traffic is None and args.config == 'C1' and gemm_mode == 1:
+                traffic, traffic_src = hbm_traffic_from_file('gemm_nt', calls_per_step)
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
                             frac=round(nt['tflops'] / peak, 4),
-                            traffic=(hbm_traffic('gemm_nt', max(1, nt['launches'] // timed_steps)) if args.config == 'C1' and gemm_mode == 1 else None),
-                            traffic_unit='HBM bytes per launch (PMC FETCH_SIZE x2 + WRITE_SIZE, profiles/r02_gemm_hbm_traffic.json)',
+                            traffic=traffic, traffic_unit='HBM bytes per ops.gemm_nt call', traffic_source=traffic_src,
                             algorithmic_bytes_per_launch=round(nt['bytes_per_launch']),
                             launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),
                             flops_per_launch=nt['flops_per_launch'],
                             share_of_step=round(nt['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
                             vs_fp32_mfma_peak=round(nt['tflops'] / PEAK_F32_MFMA_TFLOPS, 3),
-                            frac_at_measured_sclk=(round(nt['tflops'] / (peak * clock_info['sclk_mhz_median'] / 2400.0), 4)
-                                                   if clock_info else None),
+                            # the clock the kernels actually run at: GRBM_GUI_ACTIVE / kernel wall time (live PMC pass); the
+                            # sysfs value in `clock` is NOT it (profiles/r03_gemm_clock.txt: 1.4-1.5 GHz vs 1.9 in sysfs)
+                            effective_clock_mhz=eff_mhz, mfma_pipe_busy_at_effective_clock=pipe_busy,
+                            frac_at_measured_sclk=(round(nt['tflops'] / (peak * eff_mhz / 2400.0), 4) if eff_mhz else None),
+                            frac_at_sysfs_sclk=(round(nt['tflops'] / (peak * clock_info['sclk_mhz_median'] / 2400.0), 4)
+                                                if clock_info else None),
+                            pmc_error=(pmc or {}).get('error'),
                             sampled=(f'HIP events around every GEMM launch of {timed_steps} eager steps run right before the graph '
                                      'capture (the timed steps are graph replays)' if use_graph else
                                      'HIP events around every GEMM launch of every 4th step of the timed region'))
@@ -539,19 +649,26 @@ def main():
                                     f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}'),
                        'global_batch': B * dp.world_size, 'seq_len': seq_len,
                        'parallelism': f'dp{dp.world_size}', 'params': n_params,
+                       'path': ('what train_model() selects by default: bf16x6 GEMM arithmetic + step-graph replay'
+                                if (gemm_mode == 1 and use_graph) else 'non-default switches (see gemm / step_graph)'),
                        'gemm': ('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else
                                 'bf16 operands, fp32 accumulate (reduced precision)' if gemm_mode == 2 else 'fp32 MFMA')},
             'roofline': roofline,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
-                         'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3)} if tn else None),
+                         'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
+                         'effective_clock_mhz': (pmc or {}).get('gemm_tn', {}).get('effective_clock_mhz'),
+                         'mfma_pipe_busy_at_effective_clock': (pmc or {}).get('gemm_tn', {}).get('mfma_pipe_busy')} if tn else None),
             'cast_bf16': ({'ms_per_step': round(sum(r[0].elapsed_time(r[1]) for r in timer.records['cast_bf16']) / timed_steps, 3),
                            'note': 'fp32 -> bf16 operand casts of the bf16 path (outside the gemm_nt bracket)'}
                           if timer.records['cast_bf16'] else None),
             'clock': clock_info,
             'final_loss': round(last_loss, 5),
             'timed': 'trainer.epoch(train=True, num_batches=steps): steps + per-step metric bookkeeping + end-of-epoch host read',
-            'step_graph': ({'replays_in_run': graph_replays, 'note': 'each training step is one HIP-graph replay '
-                            '(vqcpc_bach_amd/graphs.py); --no-graph runs the same launches eagerly'} if use_graph else None),
+            'step_graph': ({'replays_in_run': graph_replays, 'graphs_per_step': graphs_per_step,
+                            'note': ('each training step is one HIP-graph replay' if graphs_per_step == 1 else
+                                     'each training step is two HIP-graph replays around the eagerly issued all-reduce of the '
+                                     'gradient bucket') + ' (vqcpc_bach_amd/graphs.py); --no-graph runs the same launches eagerly'}
+                           if use_graph else None),
             'train_step_only': {'value': round(B * dp.world_size * args.steps / dt_steps, 2),
                                 'ms_per_step': round(1e3 * dt_steps / args.steps, 3),
                                 'host_enqueue_ms_per_step': round(1e3 * t_enqueued / n_host, 3),

@@ -82,9 +82,33 @@ def main():
     for b in batches:
         tr.train_step({k: v[lo:hi] for k, v in b.items()}, train=True)
     m = tr.epoch(iter([{k: v[lo:hi] for k, v in full.items()}]), train=False, num_batches=1, corrupt_labels=False)
+    eager_digest = digest(tr.flat.flat)
+
+    # the data-parallel step as GRAPH REPLAYS (graphs.py: two graphs around the eagerly issued all-reduce; one graph with the
+    # collective captured under VQCPC_DP_GRAPH=capture) against an eager twin that starts from the same parameters and
+    # Adam state: 2 eager warm-up steps + 4 replays
+    del loss, out                 # graphs.py pitfall: no autograd graph of an earlier step may be alive when a capture ends
+    sd_now = {n: p.detach().cpu().clone() for n, p in tr.named_parameters()}
+    twin = build_trainer(cfg, sd_now, lr=1e-3)
+    twin.optimizer.m.copy_(tr.optimizer.m)
+    twin.optimizer.v.copy_(tr.optimizer.v)
+    twin.optimizer.step_count = tr.optimizer.step_count
+    twin.train()
+    tr.train()
+    tr.enable_step_graph(True)
+    more = [O.synthetic_batch(cfg, seed=40 + i) for i in range(6)]
+    for b in more:
+        tr.train_step({k: v[lo:hi].cuda() for k, v in b.items()}, train=True)
+        twin.train_step({k: v[lo:hi].cuda() for k, v in b.items()}, train=True)
+    g = tr._graph
+    graph_replays = g.replays if g is not None else 0
+    graph_two = bool(g is not None and g.finish_fn is not None)
+    graph_vs_eager = float((tr.flat.flat - twin.flat.flat).abs().max() / twin.flat.flat.abs().max())
     torch.cuda.synchronize()
     torch.save(dict(rank=rank, world=world, init_equal=init_equal, codebook_equal=codebook_equal, grad_worst=grad_worst,
-                    idx_equal=idx_equal, param_digest=digest(tr.flat.flat), loss_global=m['loss'], names=len(names)),
+                    idx_equal=idx_equal, param_digest=eager_digest, loss_global=m['loss'], names=len(names),
+                    graph_replays=graph_replays, graph_two=graph_two, graph_vs_eager=graph_vs_eager,
+                    graph_digest=digest(tr.flat.flat)),
                os.path.join(out_dir, f'r{rank}.pt'))
     dp.barrier()
     dp.shutdown()

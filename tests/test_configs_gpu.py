@@ -113,6 +113,80 @@ def test_c1_model_dimensions_vs_oracle(first_layer_path):
     _step_vs_oracle(cfg, seed=31)
 
 
+def test_c1_model_dimensions_with_the_products_own_gate_selection(gemm_mode):
+    """The module fixture forces the bit-mask feed-forward gate at every size; the PRODUCT takes it only where the 256-tile
+    kernel fills the chip (>= ops.GATEBITS_MIN_TILES = 160 tiles) and the fp32 gate on 128-tiles below.  Here the product's
+    own threshold is restored: at B = 8 the full layers of stack 1 (17 408 rows x 1024: 272 tiles) take the bit mask and
+    every other layer (4 352 / 1 088 rows: 68 / 16 tiles) the fp32 gate, so BOTH branches are oracle-checked in one step."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('the bit-mask gate exists in the bf16x6 mode only')
+    from vqcpc_bach_amd import ops
+    assert ops.GATEBITS_MIN_TILES == 0          # the fixture's override ...
+    ops.GATEBITS_MIN_TILES = 160                # ... replaced by the library's value (the fixture restores it afterwards)
+    cfg = O.make_cfg('C1', B=8)
+    rows = 8 * (8 + 8 + 15 * 8) * 16
+    assert ops.gatebits_worthwhile(rows, 1024, 256) and not ops.gatebits_worthwhile(rows // 4, 1024, 256)
+    _step_vs_oracle(cfg, seed=31)
+
+
+def _full_size_c4_properties(bf16):
+    """BASELINE configs[4] at FULL size (B = 256, 16 + 16 blocks, 69 632 blocks of 16 tokens per step, d_model 512, 4 + 4
+    layers, 4 x 1024 codes): the launch geometry that only the benchmark used to run (row-cut rounds, split-K remainders, the
+    bit-mask gate, 4 codebooks of 1024 codes in LDS), checked through size-independent properties:
+      * the product's code assignment on ITS OWN 61 440 x 64 encoder outputs == the oracle's canonical argmin, bit for bit;
+      * a window's loss involves its own blocks only: loss(batch) == mean(loss(first half), loss(second half));
+      * one training step leaves a finite gradient bucket, finite parameters and a sane gradient norm."""
+    from vqcpc_bach_amd import configs, getters, hip, ops
+    from vqcpc_bach_amd.utils import SEEDS
+    config = configs.make_config('C4', dropout=0.0)
+    dlg = getters.get_dataloader_generator('bach', 'vqcpc', dict(config['dataloader_generator_kwargs'], device='cuda', seed=7))
+    enc = getters.get_encoder('/tmp/vqcpc_test_c4_full', dlg, config)
+    tr = getters.get_encoder_trainer('/tmp/vqcpc_test_c4_full', dlg, 'vqcpc', enc, config['auxiliary_networks_kwargs'])
+    tr.to('cuda')
+    tr.init_optimizers(lr=1e-4, schedule_lr=False)
+    B = config['batch_size']
+    assert B == 256
+    batch = next(dlg.dataloaders(batch_size=B)[0])
+    if bf16:
+        hip.set_gemm_mode(8)
+    try:
+        tr.eval()
+        with torch.no_grad():
+            tr.compute_losses(batch)                               # data-dependent codebook initialisation happens here
+            loss, out = tr.compute_losses(batch)
+            halves = [tr.compute_losses({k: v[s] for k, v in batch.items()})[0] for s in (slice(0, B // 2), slice(B // 2, B))]
+            tol = 2e-4 if bf16 else 2e-5            # bf16: a half batch takes other tiles -> other (bf16-level) summation orders
+            assert abs(float(loss) - 0.5 * (float(halves[0]) + float(halves[1]))) < tol * abs(float(loss))
+            tokens = enc.data_processor.preprocess(batch['negative_samples'].reshape(-1, 4, 4))
+            z = enc.downscaler.forward_tokens(tokens.reshape(1, -1, 16), enc.data_processor)[0]
+            assert z.shape == (B * 15 * 16, 64)
+            cb = torch.stack(list(enc.quantizer.embeddings))
+            assert cb.shape == (4, 1024, 16)
+            idx = ops.vq_assign(z, cb)
+            ref = O.vq_assign(z.cpu(), [e.detach().cpu() for e in enc.quantizer.embeddings])
+            assert torch.equal(idx.cpu(), ref)
+            assert torch.equal(idx, out['idx_negative'].reshape(-1, 4))
+            assert idx.unique().numel() > 256                      # the check is not vacuous: many codes in use
+        tr.train()
+        SEEDS.manual_seed(5)
+        tr.train_step(batch, train=True)
+        assert bool(torch.isfinite(tr.flat.flat_grad).all()) and bool(torch.isfinite(tr.flat.flat).all())
+        assert 0.0 < tr.optimizer.grad_norm() < 1e4
+    finally:
+        if bf16:
+            hip.set_gemm_mode(0)
+
+
+def test_full_size_c4_step_properties():
+    _full_size_c4_properties(bf16=False)
+
+
+def test_full_size_c4_step_properties_bf16_mode(gemm_mode):
+    if gemm_mode != 'f32':
+        pytest.skip('sets its own GEMM mode')
+    _full_size_c4_properties(bf16=True)
+
+
 def test_c4_model_dimensions_vs_oracle():
     """configs[4] at B = 4: 1088 blocks of 16 tokens through 4 + 4 layers at d_model 512, 4 x 1024 codes."""
     cfg = O.make_cfg('C4', B=4)

@@ -154,3 +154,45 @@ def test_student_config_through_the_alias(tmp_path):
     trainer, model_dir, history = run_main_encoder(config, train=True, load=False, model_root=str(tmp_path))
     assert len(history) == 1 and np.isfinite(history[0][0]['loss_encdec'])
     assert os.path.exists(f'{model_dir}/overfitted/quantizer')
+
+
+def test_train_model_defaults_are_the_benchmarked_path():
+    """A caller who follows main_encoder.py and chooses nothing gets what bench.py measures: bf16x6 GEMM arithmetic and
+    HIP-graph replay of the training step ("the benched path is not the drop-in default").  Fresh process, so
+    that no earlier test has made a process-wide choice; explicit choices still win."""
+    import subprocess
+    from conftest import ROOT
+    code = r'''
+import os, sys, torch
+sys.path.insert(0, os.path.join(%r, 'tests'))
+sys.path.insert(0, %r)
+import vqcpc_bach_amd
+from vqcpc_bach_amd import hip
+from test_dropin_gpu import make_reference_style_config, run_main_encoder
+vqcpc_bach_amd.install_as_vqcpcb()
+hip.load()
+assert hip.get_gemm_mode() == 0                       # bare library default: exact fp32 MFMA
+cfg = make_reference_style_config()
+cfg.update(num_batches=6, num_epochs=1)
+tr, _, hist = run_main_encoder(cfg, train=True, load=False, model_root=sys.argv[1])
+assert hip.get_gemm_mode() == 1, hip.get_gemm_mode()  # train_model chose bf16x6
+assert tr._graph is not None and tr._graph.replays >= 3, 'training steps are graph replays by default'
+print('REPLAYS', tr._graph.replays)
+# explicit choices win
+hip.set_gemm_mode(0)
+cfg2 = make_reference_style_config(); cfg2.update(num_batches=4, num_epochs=1, timestamp='t2')
+from VQCPCB.getters import get_dataloader_generator, get_encoder, get_encoder_trainer
+dlg = get_dataloader_generator(cfg2['dataset'], cfg2['training_method'], cfg2['dataloader_generator_kwargs'])
+cfg2['quantizer_kwargs']['initialize'] = True
+enc = get_encoder(sys.argv[1] + '/m2', dlg, cfg2)
+tr2 = get_encoder_trainer(sys.argv[1] + '/m2', dlg, 'vqcpc', enc, cfg2['auxiliary_networks_kwargs'])
+tr2.to('cuda'); tr2.enable_step_graph(False)
+tr2.train_model(batch_size=16, num_batches=4, num_epochs=1, lr=1e-4, schedule_lr=False, corrupt_labels=False)
+assert hip.get_gemm_mode() == 0 and tr2._graph is None
+print('OK')
+''' % (ROOT, ROOT)
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = {k: v for k, v in os.environ.items() if k not in ('VQCPC_GEMM_MODE', 'VQCPC_STEP_GRAPH')}
+        r = subprocess.run([sys.executable, '-c', code, d], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

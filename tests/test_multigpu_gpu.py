@@ -43,6 +43,16 @@ def _launch(world, script, *args, timeout=900):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
 
 
+def _check_graphed_dp(res, two_graphs=True):
+    """The data-parallel step as graph replays: replays happened on every rank, the replicas are still bit-identical, and
+    the result equals the eager twin's (same tolerance as the single-rank graph tests)."""
+    for x in res:
+        assert x['graph_replays'] >= 4, x['graph_replays']
+        assert x['graph_two'] == two_graphs
+        assert x['graph_vs_eager'] < 2e-6, x['graph_vs_eager']
+        assert x['graph_digest'] == res[0]['graph_digest'], 'replicas must stay bit-identical through graph replays'
+
+
 needs_multi = pytest.mark.skipif(_world() < 2, reason='needs >= 2 visible GPUs (self-activates on a multi-GPU node)')
 
 
@@ -61,6 +71,7 @@ def test_rccl_data_parallel_training_contract(tmp_path):
     for x in res[1:]:
         assert x['param_digest'] == res[0]['param_digest'], 'replicas must stay bit-identical after 3 steps'
         assert x['loss_global'] == res[0]['loss_global']
+    _check_graphed_dp(res)
 
 
 @needs_multi
@@ -88,6 +99,22 @@ def test_single_rank_rccl_path_runs_here():
         assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
         x = torch.load(os.path.join(d, 'r0.pt'))
         assert x['world'] == 1 and x['init_equal'] and x['codebook_equal'] and x['idx_equal'] and x['grad_worst'] < 5e-4
+        _check_graphed_dp([x])                       # graph 1, RCCL all-reduce (eager, world 1), graph 2
+
+
+def test_single_rank_rccl_all_reduce_captured_inside_the_step_graph():
+    """VQCPC_DP_GRAPH=capture: ONE graph per step with the RCCL all-reduce recorded in it (torch's NCCL ops are
+    capturable); single rank here, the multi-GPU test above takes the same switch on a multi-GPU node."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_FORCE_DIST='1', VQCPC_DP_GRAPH='capture', RANK='0',
+                   WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()),
+                   PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+        r = subprocess.run([sys.executable, WORKER, d], capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+        assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+        x = torch.load(os.path.join(d, 'r0.pt'))
+        assert x['world'] == 1 and x['grad_worst'] < 5e-4
+        _check_graphed_dp([x], two_graphs=False)
 
 
 def test_two_ranks_share_this_gpu_over_gloo(tmp_path):
@@ -107,11 +134,13 @@ def test_two_ranks_share_this_gpu_over_gloo(tmp_path):
         assert x['init_equal'] and x['codebook_equal'] and x['idx_equal']
         assert x['grad_worst'] < 5e-4, x['grad_worst']
     assert res[1]['param_digest'] == res[0]['param_digest'] and res[1]['loss_global'] == res[0]['loss_global']
+    _check_graphed_dp(res)                           # two graph replays per step around the (gloo) all-reduce
 
 
 def test_bench_contract_with_two_ranks_sharing_this_gpu():
     """bench.py under torch.distributed.run with 2 ranks (both on device 0, gloo): ONE JSON line from rank 0, n_gpus = 2,
-    whole-job value = global batch * steps / max-over-ranks time, eager steps (no graph replay across ranks)."""
+    whole-job value = global batch * steps / max-over-ranks time; the timed steps are graph replays (two per step around the
+    all-reduce), as on one rank."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_SHARE_GPU='1', VQCPC_DP_BACKEND='gloo',
                PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
@@ -122,7 +151,8 @@ def test_bench_contract_with_two_ranks_sharing_this_gpu():
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
-    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['step_graph'] is None and line['cpu_baseline'] is None
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['cpu_baseline'] is None
+    assert line['step_graph'] is not None and line['step_graph']['replays_in_run'] >= 8 and line['step_graph']['graphs_per_step'] == 2
     assert line['config']['global_batch'] == 64 and line['config']['parallelism'] == 'dp2'
     assert abs(line['value'] - 64 * 4 / (line['ms_per_step'] * 4e-3)) < 0.01 * line['value']
     assert line['roofline'] is not None and line['roofline']['achieved'] > 0

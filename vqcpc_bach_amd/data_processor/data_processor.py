@@ -44,12 +44,17 @@ class DataProcessor(nn.Module):
         """Device int32[1] (or None if nothing was checked yet): non-zero once any token id was out of range."""
         return getattr(self, '_token_flag', None)
 
-    def raise_if_bad_tokens(self, flag_value=None):
+    def raise_if_bad_tokens(self, flag_value=None, dp=None):
+        """dp: the trainer's DataParallelContext -- in a multi-rank run the flag is summed over the ranks first, so that
+        every rank raises together (one rank raising alone leaves the others blocked in their next collective)."""
         flag = self.bad_token_flag()
         if flag is None:
             return
         if flag_value is None:
-            flag_value = int(flag.item())
+            if dp is not None and dp.distributed:
+                flag_value = int(dp.all_reduce_sum_(flag.clone()).item())
+            else:
+                flag_value = int(flag.item())
         if flag_value:
             flag.zero_()
             raise IndexError(f'token id out of range: voice c takes ids in [0, {[e.weight.shape[0] for e in self.embeddings]}[c]) '

@@ -31,7 +31,7 @@ from ..graphs import GraphedTraining
 from ..parallel import DataParallelContext, FlatParameters
 from ..transformer.transformer_custom import (TransformerCustom, TransformerDecoderCustom, TransformerDecoderLayerCustom,
                                               TransformerEncoderCustom, TransformerEncoderLayerCustom, mask_code)
-from ..utils import dict_pretty_print, flatten
+from ..utils import dict_pretty_print, flatten, SEEDS
 
 
 class HeadsFn(torch.autograd.Function):
@@ -173,6 +173,7 @@ class Decoder(GraphedTraining, nn.Module):
         assert dev.type == 'cuda', 'call .to(device) first: the training step has no CPU path'
         self.dp = dp if dp is not None else (self.dp or DataParallelContext(device=dev))
         self.is_main = self.dp.rank == 0
+        SEEDS.set_rank(self.dp.rank)            # per-rank dropout masks, whatever the launcher seeded
         self.flat = FlatParameters(self._trainable())
         self.dp.broadcast_(self.flat.flat, src=0)
         self.lr, self.schedule_lr = lr, schedule_lr
@@ -261,16 +262,24 @@ class Decoder(GraphedTraining, nn.Module):
         """:327-336 + the merge the reference forgot: frozen encoder, inference only -> merged codes (B, S)."""
         return self.encoder.encode_indices(x, merged=True)
 
-    def _train_step_body(self, tensor_dict):
+    def _step_compute(self, tensor_dict):
         x = self.data_processor.checked(self.data_processor.preprocess(tensor_dict['x']))
         codes = self.encode(tensor_dict['x'])
-        loss, _, _, _ = self.compute_loss(codes, x)
+        with torch.enable_grad():              # whatever the caller's ambient grad mode: this IS the training step
+            loss, _, _, _ = self.compute_loss(codes, x)
         self.flat.zero_grad()
-        with ops.direct_weight_gradients(self.flat.flat):
+        with ops.direct_weight_gradients(self.flat):
             loss.backward()
-        self.dp.all_reduce_sum_(self.flat.flat_grad)
-        self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)       # clip 5 + Adam (:345-346)
         return loss.detach()
+
+    def _step_apply(self, loss):
+        self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)       # clip 5 + Adam (:345-346)
+        return loss
+
+    def _train_step_body(self, tensor_dict):
+        loss = self._step_compute(tensor_dict)
+        self._all_reduce_gradients()
+        return self._step_apply(loss)
 
     def _graph_optimizers(self):
         return [self.optimizer]
@@ -281,7 +290,7 @@ class Decoder(GraphedTraining, nn.Module):
             codes = self.encode(tensor_dict['x'])
             with torch.no_grad():
                 return self.compute_loss(codes, x)[0].detach()
-        out = self._graphed_step(tensor_dict, self._train_step_body)
+        out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
         if out is None:
             out = self._train_step_body(tensor_dict)
         self.global_step += 1
@@ -300,12 +309,13 @@ class Decoder(GraphedTraining, nn.Module):
             self.dp.all_reduce_sum_(total)
             total /= self.dp.world_size
         means = {'loss': float(total.item())}                    # the host sync of the epoch
-        self.data_processor.raise_if_bad_tokens()
-        self.encoder.data_processor.raise_if_bad_tokens()
+        self.data_processor.raise_if_bad_tokens(dp=self.dp)
+        self.encoder.data_processor.raise_if_bad_tokens(dp=self.dp)
         return means
 
     def train_model(self, batch_size, num_batches, num_epochs, lr, schedule_lr, plot=False, num_workers=0, **kwargs):
         best_val = 1e8
+        self.use_training_defaults()               # bf16x6 GEMMs + step-graph replay unless the caller chose otherwise
         self.init_optimizers(lr=lr, schedule_lr=schedule_lr)
         history = []
         for epoch_id in range(num_epochs):

@@ -57,7 +57,6 @@ class RelativeTransformerDownscaler(Downscaler):
         """x (blocks * L0, d) -> (blocks, d): run the stacks, subsampling by stride between them."""
         L = self.sequence_length
         d = x.shape[1]
-        ops._BF16_OF[0] = None           # no bf16 copy exists for the embedding output (bf16 path only)
         for si, (transfo, factor) in enumerate(zip(self.transformers, self.downscale_factors)):
             fq = first_qkv if si == 0 else None
             if _sub_supported(L, factor, self.d_model // transfo.layers[0].nhead):

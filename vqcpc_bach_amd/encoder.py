@@ -149,6 +149,8 @@ class EncoderTrainer(nn.Module):
             except Exception:                  # tensorboard is optional (not installed in the ROCm image)
                 self.writer = None
         best_val = 1e8
+        if hasattr(self, 'use_training_defaults'):
+            self.use_training_defaults()           # bf16x6 GEMMs + step-graph replay unless the caller chose otherwise
         self.init_optimizers(lr=lr, schedule_lr=schedule_lr)
         history = []
         for epoch_id in range(num_epochs):

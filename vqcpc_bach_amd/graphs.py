@@ -14,29 +14,51 @@ stream, so stream capture records them) and replays it per batch:
   * Adam: `vqcpc_adam_step_dev` reads the learning rate and the step count (bias corrections) from device memory;
   * outputs (losses, accuracy, code indices) are the graph's static output tensors.
 
-Steps whose batch shapes differ from the captured ones, evaluation steps, label-corruption steps and multi-rank runs
-(the RCCL all-reduce is issued eagerly between kernels) run eagerly, exactly as before.
+Multi-rank runs replay TWO graphs per step around ONE eagerly issued RCCL all-reduce of the flat gradient bucket:
+graph 1 = zero_grad, forward, backward (and the step's metric vector), then `dist.all_reduce` on the same stream, then
+graph 2 = clip + Adam.  The collective itself is not captured (`VQCPC_DP_GRAPH=capture` records it inside a single graph
+instead -- RCCL supports stream capture -- and `VQCPC_DP_GRAPH=off` keeps multi-rank steps eager): what a graph buys is the
+~18 ms of host launch work per step, and that is all in the two halves; a stream-ordered collective between two replays
+costs the host one call.  So the data-parallel step is the same captured step that the single-GPU benchmark replays.
+
+Steps whose batch shapes differ from the captured ones, evaluation steps and label-corruption steps run eagerly, exactly
+as before.
 
 Pitfall met on ROCm 7.2 / torch 2.10: ending a capture while the PREVIOUS eager step's autograd graph is still alive
 (e.g. a step output that was not detached and is still referenced by the caller) segfaults inside capture_end; every
 output of the trainers' steps is detached for that reason.
 """
+import os
+
 import torch
 
 from . import hip
 
 
+def dp_graph_mode():
+    """How a multi-rank step is replayed: 'split' (two graphs around an eager all-reduce, default), 'capture' (one graph,
+    the RCCL all-reduce recorded in it) or 'off' (eager multi-rank steps)."""
+    mode = os.environ.get('VQCPC_DP_GRAPH', 'split')
+    assert mode in ('split', 'capture', 'off'), mode
+    return mode
+
+
 class StepGraph:
-    def __init__(self, step_fn, optimizers, lr_fn, device, key_fn=None, seed_base=0x5EED5A17):
+    def __init__(self, step_fn, optimizers, lr_fn, device, key_fn=None, seed_base=0x5EED5A17, between_fn=None,
+                 finish_fn=None):
         """step_fn(batch_dict) -> outputs (tensor / dict / tuple of tensors): one full training step on device tensors.
         optimizers: the ops.FlatAdam objects the step uses; lr_fn() -> current learning rate (host float);
-        key_fn(batch) -> extra hashable that selects the graph (the student step's masked event index)."""
+        key_fn(batch) -> extra hashable that selects the graph (the student step's masked event index).
+        Two-graph form (multi-rank): step_fn records everything up to the gradients, `between_fn()` runs EAGERLY between the
+        two replays (the all-reduce of the gradient bucket), finish_fn(outputs of step_fn) -> outputs records the rest."""
         self.step_fn, self.optimizers, self.lr_fn, self.key_fn = step_fn, list(optimizers), lr_fn, key_fn
+        self.between_fn, self.finish_fn = between_fn, finish_fn
+        assert (between_fn is None) == (finish_fn is None)
         self.device = torch.device(device)
         self.seed_base = int(seed_base)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)       # device step counter (uint64 bits)
         self.lr_dev = torch.zeros(1, dtype=torch.float32, device=self.device)
-        self.lr_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+        self._lr_set = None         # the value lr_dev holds (as far as the stream order is concerned)
         self.graphs = {}            # key -> (CUDAGraph, static inputs, static outputs)
         self.pool = None
         self.replays = 0
@@ -45,12 +67,17 @@ class StepGraph:
             opt.use_device_scalars(self.lr_dev, self.counter)
 
     def _signature(self, batch):
-        sig = tuple((k, tuple(v.shape), v.dtype) for k, v in sorted(batch.items()) if torch.is_tensor(v))
+        # tensors by shape / dtype; everything else (flags, python scalars) BY VALUE: it is baked into the captured launches
+        sig = tuple((k, tuple(v.shape), v.dtype) if torch.is_tensor(v) else (k, repr(v)) for k, v in sorted(batch.items()))
         return (sig, self.key_fn(batch) if self.key_fn is not None else None)
 
     def _set_lr(self):
-        self.lr_host[0] = float(self.lr_fn())
-        self.lr_dev.copy_(self.lr_host, non_blocking=True)
+        """The learning rate travels as a kernel ARGUMENT of a fill launch (stream-ordered, no host buffer the next step
+        could overwrite while this step's copy is still queued), and only when it changed."""
+        lr = float(self.lr_fn())
+        if lr != self._lr_set:
+            self.lr_dev.fill_(lr)
+            self._lr_set = lr
 
     def _body(self, static):
         hip.call('vqcpc_rng_salt_advance', self.counter, self.seed_base)
@@ -65,11 +92,16 @@ class StepGraph:
         torch.cuda.synchronize()
         with torch.cuda.graph(graph, pool=self.pool):
             out = self._body(static)
-        for opt, c in zip(self.optimizers, counts):      # capture ran the Python side of optimizer.step(): undo its count
-            opt.step_count = c
         if self.pool is None:
             self.pool = graph.pool()
-        entry = (graph, static, out)
+        graph2 = None
+        if self.finish_fn is not None:                   # second half: same memory pool, replayed right after the first
+            graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph2, pool=self.pool):
+                out = self.finish_fn(out)
+        for opt, c in zip(self.optimizers, counts):      # capture ran the Python side of optimizer.step(): undo its count
+            opt.step_count = c
+        entry = ((graph, graph2), static, out)
         self.graphs[self._signature(batch)] = entry
         return entry
 
@@ -77,7 +109,7 @@ class StepGraph:
         entry = self.graphs.get(self._signature(batch))
         if entry is None:
             entry = self.capture(batch)
-        graph, static, out = entry
+        (graph, graph2), static, out = entry
         for k, v in batch.items():
             if torch.is_tensor(v):
                 static[k].copy_(v, non_blocking=True)
@@ -87,6 +119,9 @@ class StepGraph:
             self.counter.fill_(int(want))
         self._set_lr()
         graph.replay()
+        if graph2 is not None:
+            self.between_fn()
+            graph2.replay()
         for opt in self.optimizers:
             opt.step_count += 1
         self._counter_host = want + 1
@@ -109,8 +144,20 @@ class GraphedTraining:
     _graph = None
     _graph_eager_steps = 0
 
+    _graph_explicit = False
+
+    def use_training_defaults(self):
+        """Called by `train_model()` (the reference's entry point, encoder.py:244): a caller who chose nothing gets the
+        configuration bench.py measures -- bf16x6 GEMM arithmetic and step-graph replay (`VQCPC_STEP_GRAPH=0`,
+        `VQCPC_GEMM_MODE=...`, `enable_step_graph(False)` or `hip.set_gemm_mode()` beforehand override it)."""
+        hip.use_training_default_gemm_mode()
+        if not self._graph_explicit and os.environ.get('VQCPC_STEP_GRAPH', '1') != '0':
+            self.enable_step_graph(True)
+            self._graph_explicit = False
+
     def enable_step_graph(self, enabled=True):
         self._graph_on = bool(enabled)
+        self._graph_explicit = True
         if not enabled and self._graph is not None:
             self._graph.release()
             self._graph = None
@@ -122,14 +169,26 @@ class GraphedTraining:
     def _graph_key(self, batch):
         return None
 
-    def _graphed_step(self, batch, body):
+    def _all_reduce_gradients(self):
+        self.dp.all_reduce_sum_(self.flat.flat_grad)
+
+    def _new_step_graph(self, body, parts):
+        """parts = (compute, apply): the halves of `body` before / after the gradient all-reduce."""
+        dev = self.flat.flat.device
+        if self.dp.distributed and not (dp_graph_mode() == 'capture' and self.dp.backend == 'nccl'):
+            return StepGraph(parts[0], self._graph_optimizers(), self.current_lr, dev, key_fn=self._graph_key,
+                             between_fn=self._all_reduce_gradients, finish_fn=parts[1])
+        return StepGraph(body, self._graph_optimizers(), self.current_lr, dev, key_fn=self._graph_key)
+
+    def _graphed_step(self, batch, body, parts=None):
         """Returns body's outputs from a graph replay, or None when this step has to run eagerly."""
-        if not self._graph_on or self.dp.distributed:
+        if not self._graph_on:
+            return None
+        if self.dp.distributed and (parts is None or dp_graph_mode() == 'off'):
             return None
         if self._graph_eager_steps < self.graph_warmup_steps:
             self._graph_eager_steps += 1
             return None
         if self._graph is None:
-            self._graph = StepGraph(body, self._graph_optimizers(), self.current_lr, self.flat.flat.device,
-                                    key_fn=self._graph_key)
+            self._graph = self._new_step_graph(body, parts)
         return self._graph(batch)

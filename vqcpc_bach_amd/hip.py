@@ -194,10 +194,21 @@ def set_gemm_mode(mode):
     """0 = fp32 MFMA (exact), 1 = bf16x6 split MFMA (fp32-class accuracy, faster); +2: 128-tile kernels only,
     +4: 256-tile NT kernel without the ping-pong wave groups, +16: LDS-DMA 256-tile NT kernel, +32: one-wave-per-SIMD software-pipelined 256-tile NT kernel (A/B switches); 8 = plain bf16 operands (one bf16 MFMA per
     product, fp32 accumulation: reduced precision, for BASELINE configs[4] only).  get_gemm_mode() returns 0 / 1 / 2."""
-    global _gemm_mode
+    global _gemm_mode, _gemm_mode_explicit
     rc = load().vqcpc_gemm_set_mode(int(mode))
     _check(rc, 'vqcpc_gemm_set_mode')
     _gemm_mode = None
+    _gemm_mode_explicit = True
+
+
+def use_training_default_gemm_mode():
+    """What `train_model()` selects when the caller chose nothing (neither set_gemm_mode() nor VQCPC_GEMM_MODE): the
+    bf16x6 split-MFMA arithmetic, i.e. the configuration bench.py measures (fp32-class accuracy: every parity suite runs in
+    this mode too).  The bare library default stays the exact fp32 MFMA."""
+    global _gemm_mode_explicit
+    if not _gemm_mode_explicit and 'VQCPC_GEMM_MODE' not in os.environ:
+        set_gemm_mode(1)
+        _gemm_mode_explicit = False          # still "nobody chose": a later explicit choice wins as usual
 
 
 def force_general_attention(on):
@@ -206,6 +217,7 @@ def force_general_attention(on):
 
 
 _gemm_mode = None
+_gemm_mode_explicit = False
 
 
 def get_gemm_mode():

@@ -188,13 +188,19 @@ def cast_bf16(x):
     return out
 
 
-_BF16_OF = [None]      # (data_ptr, shape, bf16 copy) of the most recent layer output: the next layer's GEMM operand
+def _attach_bf16_copy(y, yb):
+    """The producing layer hands the bf16 copy its LayerNorm kernel wrote to the consumer ON the fp32 tensor object: no
+    global slot keyed by address (a freed-and-reused address would match a stale copy), and the copy lives exactly as
+    long as the tensor it mirrors."""
+    y._vqcpc_bf16 = (y.data_ptr(), y._version, yb)
 
 
 def _bf16_copy_of(x):
-    """The bf16 copy that the producing kernel wrote next to the fp32 tensor `x` (same values, rounded), if any."""
-    ent, _BF16_OF[0] = _BF16_OF[0], None                 # consumed at most once, by the very next layer
-    if ent is not None and ent[0] == x.data_ptr() and ent[1] == tuple(x.shape) and x.is_contiguous():
+    """The bf16 copy that the producing kernel wrote next to the fp32 tensor `x` (same values, rounded), if any: `x` must
+    be the very tensor object the producer returned (same storage offset, not modified in place since)."""
+    ent = getattr(x, '_vqcpc_bf16', None)
+    if (ent is not None and ent[0] == x.data_ptr() and ent[1] == x._version and x.is_contiguous()
+            and tuple(ent[2].shape) == tuple(x.shape)):
         return ent[2]
     return None
 
@@ -260,8 +266,9 @@ class direct_weight_gradients:
     Outside it (plain `backward()`, `torch.autograd.grad`) gradients are returned to autograd as usual."""
 
     def __init__(self, flat_parameters=None):
-        """flat_parameters: the trainer's flat fp32 parameter buffer -- the transposed dgrad operands of its weights are
-        then prepared by one launch (ops.WEIGHT_T) instead of one per weight."""
+        """flat_parameters: the trainer's parallel.FlatParameters (or its flat fp32 buffer) -- the transposed dgrad operands
+        of its weights are then prepared by one launch (ops.WEIGHT_T, a cache owned by that object) instead of one per
+        weight."""
         self.flat = flat_parameters
 
     def __enter__(self):
@@ -394,44 +401,37 @@ def transpose(w):
 class _WeightTransposes:
     """W^T of every 2-D weight a backward pass asks for, refreshed by ONE launch when the pass begins
     (`direct_weight_gradients(flat_parameters)`), instead of one 5 us launch per weight in the middle of it (25 per CPC
-    step, 80 per student step).  Only tensors inside the trainer's flat parameter buffer are cached (their addresses are
-    stable and nothing else can live there); a weight is learned the first time `transpose` is asked for it and served
-    from the arena from the next step on.  The arena is valid between `begin` and `end` only: weights change in the
-    optimiser step that follows."""
+    step, 80 per student step).  ONE instance per flat parameter buffer (a trainer), created on first use and kept for the
+    life of the process: captured step graphs (graphs.py) bake in the arena and descriptor-table device pointers and the
+    frozen (n, total_tiles) arguments of the transpose_many node, so neither is ever freed or overwritten -- a new
+    descriptor table (weights learned after a capture) is a NEW tensor and the old ones stay alive and valid.
+    Only tensors inside the flat buffer are cached (their addresses are stable and nothing else can live there); a weight
+    is learned the first time `transpose` is asked for it and served from the arena from the next pass on.  The arena is
+    valid between `begin` and `end` only: weights change in the optimiser step that follows."""
 
-    def __init__(self):
-        self.flat = None
-        self.arena = None
+    def __init__(self, flat):
+        self.flat = flat                 # keeps the buffer (and hence its address) alive
+        self.arena = torch.empty_like(flat)
         self.entries = {}          # data_ptr -> (offset, rows, cols)
-        self.uploaded = {}         # the entries the device table covers
+        self.uploaded = {}         # the entries the current device table covers
         self.desc = None
+        self.retired = []          # earlier descriptor tables: captured graphs may still read them
         self.total_tiles = 0
-        self.active = False
 
-    def _reset(self, flat):
-        self.flat, self.arena = flat, torch.empty_like(flat)
-        self.entries, self.uploaded, self.desc, self.total_tiles = {}, {}, None, 0
-
-    def begin(self, flat):
-        if self.flat is None or self.flat.data_ptr() != flat.data_ptr() or self.flat.numel() != flat.numel():
-            self._reset(flat)
+    def refresh(self):
         if len(self.entries) != len(self.uploaded) and not torch.cuda.is_current_stream_capturing():
             rows, tiles = [], 0
             for key, (off, r, c) in sorted(self.entries.items(), key=lambda kv: kv[1][0]):
                 rows.append((off, r, c, tiles))
                 tiles += ((r + 31) // 32) * ((c + 31) // 32)
-            self.desc = torch.tensor(rows, dtype=torch.int64).to(flat.device)
+            if self.desc is not None:
+                self.retired.append(self.desc)
+            self.desc = torch.tensor(rows, dtype=torch.int64).to(self.flat.device)
             self.total_tiles, self.uploaded = tiles, dict(self.entries)
         if self.uploaded:
             hip.call('vqcpc_transpose_many', self.flat, self.arena, self.desc, len(self.uploaded), self.total_tiles)
-        self.active = True
-
-    def end(self):
-        self.active = False
 
     def lookup(self, w):
-        if not self.active or w.dim() != 2:
-            return None
         ptr = w.data_ptr()
         ent = self.uploaded.get(ptr)
         if ent is not None and ent[1] == w.shape[0] and ent[2] == w.shape[1]:
@@ -446,7 +446,33 @@ class _WeightTransposes:
         return None
 
 
-WEIGHT_T = _WeightTransposes()
+class _WeightTransposeRegistry:
+    """`ops.WEIGHT_T`: hands out the per-trainer caches and tracks the one that is active (between begin and end of a
+    backward pass).  The cache lives ON its owner (a parallel.FlatParameters, or the flat tensor itself), so it dies with
+    the trainer -- and with the trainer's step graphs, the only other holders of its device pointers."""
+
+    def __init__(self):
+        self.current = None
+
+    def begin(self, owner):
+        flat = owner if torch.is_tensor(owner) else owner.flat
+        inst = getattr(owner, '_vqcpc_weight_t', None)
+        if inst is None or inst.flat.data_ptr() != flat.data_ptr() or inst.flat.numel() != flat.numel():
+            inst = _WeightTransposes(flat)
+            owner._vqcpc_weight_t = inst
+        inst.refresh()
+        self.current = inst
+
+    def end(self):
+        self.current = None
+
+    def lookup(self, w):
+        if self.current is None or w.dim() != 2:
+            return None
+        return self.current.lookup(w)
+
+
+WEIGHT_T = _WeightTransposeRegistry()
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -576,7 +602,7 @@ class EncoderLayerFn(torch.autograd.Function):
         Mq_ = M // f
         # bf16 mode (configs[4]): the layer's GEMMs take bf16 operands from HBM; activations that only feed GEMMs get a bf16
         # copy from the producing epilogue (FFN hidden) or from a cast pass (x, attention output, LayerNorm output)
-        nat = bf16_native((M, 2 * d, d), (Mq_, d, d), (Mq_, ffd, d), (Mq_, d, ffd)) and \
+        nat = bf16_native((M, 3 * d if (f == 1 and qkv_in is None) else 2 * d, d), (Mq_, d, d), (Mq_, ffd, d), (Mq_, d, ffd)) and \
             hip.query('vqcpc_gemm_tn_bf16_supported', Mq_, d, d)
         lin = gemm_nt_bf16 if nat else gemm_nt
         xb = None                                       # bf16 copies: GEMM operands now, weight-gradient operands later
@@ -628,7 +654,8 @@ class EncoderLayerFn(torch.autograd.Function):
         rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         yb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
         hip.call('vqcpc_add_layernorm_fwd_b16', x1, d, ff, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, p, s[3])
-        _BF16_OF[0] = (y.data_ptr(), (Mq, d), yb) if nat else None
+        if nat:
+            _attach_bf16_copy(y, yb)
         ctx.save_for_backward(x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)

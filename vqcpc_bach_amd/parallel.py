@@ -37,6 +37,7 @@ class DataParallelContext:
                 device = torch.device('cpu')
         self.device = torch.device(device)
         self.owns_group = False
+        self.backend = None
         force = os.environ.get('VQCPC_FORCE_DIST', '0') == '1'      # exercise the RCCL path with a single rank (tests)
         self.force = force
         if (self.world_size > 1 or force) and not dist.is_initialized():
@@ -46,6 +47,8 @@ class DataParallelContext:
             kw = dict(device_id=self.device) if backend == 'nccl' else {}
             dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world_size, **kw)
             self.owns_group = True
+        if dist.is_available() and dist.is_initialized():
+            self.backend = dist.get_backend()
 
     @property
     def distributed(self):

@@ -24,6 +24,7 @@ import torch
 from . import ops
 from .encoder import EncoderTrainer
 from .graphs import GraphedTraining
+from .utils import SEEDS
 from .parallel import DataParallelContext, FlatParameters
 from .vqcpc_encoder_trainer import VQCPCEncoderTrainer
 
@@ -65,6 +66,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         assert dev.type == 'cuda', 'call .to(device) first: the training step has no CPU path'
         self.dp = dp if dp is not None else (self.dp or DataParallelContext(device=dev))
         self.is_main = self.dp.rank == 0
+        SEEDS.set_rank(self.dp.rank)            # per-rank dropout masks, whatever the launcher seeded
         self.flat = FlatParameters(self._modules_with_params())
         self.dp.broadcast_(self.flat.flat, src=0)
         if self.dp.distributed:
@@ -217,18 +219,26 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
                    student_logits=[lg.detach() for lg in e['weights_per_category']])     # detached: `out` must not keep the step's autograd graph alive
         return t['loss'], e['loss'], out
 
-    def _train_step_body(self, tensor_dict, masked_event_index=None):
+    def _step_compute(self, tensor_dict, masked_event_index=None):
         m = self._graph_m if masked_event_index is None else masked_event_index
-        loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, m)
+        with torch.enable_grad():              # whatever the caller's ambient grad mode: this IS the training step
+            loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, m)
         self.flat.zero_grad()
-        with ops.direct_weight_gradients(self.flat.flat):
+        with ops.direct_weight_gradients(self.flat):
             (loss_teacher + loss_encdec).backward()          # disjoint graphs: the teacher logits are detached
-        self.dp.all_reduce_sum_(self.flat.flat_grad)
+        return out
+
+    def _step_apply(self, out):
         lr, scale = self.current_lr(), 1.0 / self.dp.world_size
         self.optimizer_teacher.step(lr=lr, grad_scale=scale)
         for opt in self.optimizer_enc_dec:
             opt.step(lr=lr, grad_scale=scale)
         return out
+
+    def _train_step_body(self, tensor_dict, masked_event_index=None):
+        out = self._step_compute(tensor_dict, masked_event_index)
+        self._all_reduce_gradients()
+        return self._step_apply(out)
 
     _graph_m = None
 
@@ -241,11 +251,9 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
     def precapture_step_graphs(self, tensor_dict):
         """Captures the step for EVERY masked event index on `tensor_dict`'s shapes (one graph each, one shared memory
         pool), so that no capture happens later inside a training loop.  Call after the warm-up steps."""
-        assert self._graph_on and not self.dp.distributed and not self.encoder.quantizer_needs_init()
+        assert self._graph_on and not self.encoder.quantizer_needs_init()
         if self._graph is None:
-            from .graphs import StepGraph
-            self._graph = StepGraph(self._train_step_body, self._graph_optimizers(), self.current_lr,
-                                    self.flat.flat.device, key_fn=self._graph_key)
+            self._graph = self._new_step_graph(self._train_step_body, (self._step_compute, self._step_apply))
         self._graph_eager_steps = self.graph_warmup_steps
         for m in range(tensor_dict['x'].shape[1]):
             self._graph_m = m
@@ -262,7 +270,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         self._graph_m = self.draw_masked_event(x.shape[1]) if masked_event_index is None else int(masked_event_index)
         out = None
         if not self.encoder.quantizer_needs_init():
-            out = self._graphed_step(tensor_dict, self._train_step_body)
+            out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
         if out is None:
             out = self._train_step_body(tensor_dict, self._graph_m)
         self.global_step += 1
@@ -284,6 +292,6 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
             self.dp.all_reduce_sum_(sums)
             sums /= self.dp.world_size
         means = dict(zip(self.KEYS, sums.cpu().tolist()))     # the host sync of the epoch
-        self.teacher.data_processor.raise_if_bad_tokens()
-        self.encoder.data_processor.raise_if_bad_tokens()
+        self.teacher.data_processor.raise_if_bad_tokens(dp=self.dp)
+        self.encoder.data_processor.raise_if_bad_tokens(dp=self.dp)
         return means

@@ -9,6 +9,12 @@ class DropoutSeeds:
     def __init__(self, base=0x5EED):
         self.base = int(base) & 0xFFFFFFFF
         self.counter = 0
+        self.rank_salt = 0          # set once per process by the trainers' init_optimizers (data-parallel rank)
+
+    def set_rank(self, rank):
+        """Data-parallel replicas must draw DIFFERENT dropout masks (they see different windows of one global batch); the
+        salt survives manual_seed(), so seeding every rank alike -- as a launcher script naturally does -- is safe."""
+        self.rank_salt = (int(rank) * 0x9E3779B1) & 0xFFFFFFFF
 
     def manual_seed(self, base):
         self.base = int(base) & 0xFFFFFFFF
@@ -16,7 +22,7 @@ class DropoutSeeds:
 
     def next(self):
         self.counter += 1
-        return (self.base << 32) + self.counter * 0x10000
+        return (((self.base + self.rank_salt) & 0xFFFFFFFF) << 32) + self.counter * 0x10000
 
 
 SEEDS = DropoutSeeds()

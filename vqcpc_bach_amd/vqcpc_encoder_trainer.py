@@ -17,6 +17,7 @@ import torch
 from . import hip, ops, vqcpc_helper
 from .encoder import EncoderTrainer
 from .graphs import GraphedTraining
+from .utils import SEEDS
 from .parallel import DataParallelContext, FlatParameters
 from .vqcpc_helper import cpc_scores_and_loss
 
@@ -78,6 +79,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         assert dev.type == 'cuda', 'call .to(device) first: the training step has no CPU path'
         self.dp = dp if dp is not None else (self.dp or DataParallelContext(device=dev))
         self.is_main = self.dp.rank == 0
+        SEEDS.set_rank(self.dp.rank)            # per-rank dropout masks, whatever the launcher seeded
         self.flat = FlatParameters(self._modules_with_params())
         self.dp.broadcast_(self.flat.flat, src=0)                       # identical replicas
         if self.dp.distributed:
@@ -222,16 +224,26 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
                                        self._count_codewords(out['idx_left'], out['idx_right']),
                                        self._count_codewords(out['idx_negative'])]), out['accuracy']])
 
-    def _train_step_body(self, tensor_dict, corrupt_labels=False):
-        """zero_grad / forward / backward / all-reduce / clip / Adam (:310-316): everything a step enqueues on the device."""
-        loss, out = self.compute_losses(tensor_dict, corrupt_labels)
+    def _step_compute(self, tensor_dict, corrupt_labels=False):
+        """zero_grad / forward / backward (:310-312) + the step's metric vector: everything before the gradient all-reduce."""
+        with torch.enable_grad():              # whatever the caller's ambient grad mode: this IS the training step
+            loss, out = self.compute_losses(tensor_dict, corrupt_labels)
         self.flat.zero_grad()
-        with ops.direct_weight_gradients(self.flat.flat):
+        with ops.direct_weight_gradients(self.flat):
             loss.backward()
-        self.dp.all_reduce_sum_(self.flat.flat_grad)
-        self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)
         out['metrics'] = self._step_metrics(out)
         return out
+
+    def _step_apply(self, out):
+        """clip + Adam (:313-316) on the (all-reduced) flat gradient; the rank sum becomes a mean inside the kernels."""
+        self.optimizer.step(lr=self.current_lr(), grad_scale=1.0 / self.dp.world_size)
+        return out
+
+    def _train_step_body(self, tensor_dict, corrupt_labels=False):
+        """Everything a step enqueues on the device: compute, ONE all-reduce of the gradient bucket, apply."""
+        out = self._step_compute(tensor_dict, corrupt_labels)
+        self._all_reduce_gradients()
+        return self._step_apply(out)
 
     def _graph_optimizers(self):
         return [self.optimizer]
@@ -246,7 +258,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
                 return out
         out = None
         if not corrupt_labels and not self.encoder.quantizer_needs_init():
-            out = self._graphed_step(tensor_dict, self._train_step_body)
+            out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
         if out is None:
             out = self._train_step_body(tensor_dict, corrupt_labels)
         self.global_step += 1
@@ -266,13 +278,13 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
             out = self.train_step(tensor_dict, train=train, corrupt_labels=corrupt_labels)
             sums += out['metrics']
             n += 1
-        sums /= max(n, 1)
-        if self.dp.distributed:                                       # metrics are means over ranks
-            self.dp.all_reduce_sum_(sums)
-            sums /= self.dp.world_size
+        sums /= max(n, 1) * self.dp.world_size
         flag = dproc.bad_token_flag()
         if flag is not None:
             sums = torch.cat([sums, flag.float()])
+        # metrics are means over ranks; the out-of-range-token flag rides in the same all-reduce, so EVERY rank raises
+        # together (a rank raising alone would leave the others blocked in their next collective)
+        self.dp.all_reduce_sum_(sums)
         host = sums.cpu().tolist()                                    # the only host sync of the epoch
         if flag is not None:
             dproc.raise_if_bad_tokens(host.pop())                     # nn.Embedding's IndexError, one epoch late at most

@@ -62,6 +62,10 @@ def parse():
                     help='replay the training step from HIP graphs (vqcpc_bach_amd/graphs.py): one graph per step on one rank, '
                          'two around the eager RCCL all-reduce on several (VQCPC_DP_GRAPH=capture|off changes that)')
     ap.add_argument('--no-graph', dest='graph', action='store_false')
+    ap.add_argument('--grad-products', type=int, default=6, choices=[3, 6],
+                    help='opt-in gradient arithmetic of the bf16x6 mode (include/vqcpc.h): 3 = two rounded bf16 planes and three '
+                         'MFMAs per product in the input- / weight-gradient GEMMs (~2^-17 per product); the forward, the losses '
+                         'and the code assignment are unaffected.  Default 6 = the exact split everywhere (the headline)')
     ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM times of the sampled steps, to stderr')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -217,7 +221,8 @@ def live_pmc(args, B, timeout_s=100):
     steps, warm = 2, 2
     n_steps = warm + 2 * steps                   # warm-up epoch + the bare-step loop + the timed epoch of the inner run
     inner = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(steps), '--warmup', str(warm),
-             '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--no-graph',
+             '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-products',
+             str(args.grad_products), '--no-graph',
              '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc']
     out = {'steps': n_steps}
     tmp = tempfile.mkdtemp(prefix='vqcpc_pmc_', dir='/tmp')
@@ -458,6 +463,7 @@ def main():
     hip.load()
     gemm_mode = 2 if args.gemm_mode in ('bf16', '8') else (1 if args.gemm_mode in ('bf16x6', '1') else 0)
     hip.set_gemm_mode(8 if gemm_mode == 2 else gemm_mode)
+    hip.set_gradient_products(args.grad_products)
     dp = DataParallelContext()
     assert dp.world_size == args.gpus or dp.world_size == 1, f'--gpus {args.gpus} but WORLD_SIZE={dp.world_size}'
     dev = dp.device
@@ -650,7 +656,9 @@ def main():
                        'global_batch': B * dp.world_size, 'seq_len': seq_len,
                        'parallelism': f'dp{dp.world_size}', 'params': n_params,
                        'path': ('what train_model() selects by default: bf16x6 GEMM arithmetic + step-graph replay'
-                                if (gemm_mode == 1 and use_graph) else 'non-default switches (see gemm / step_graph)'),
+                                if (gemm_mode == 1 and use_graph and args.grad_products == 6) else
+                                'non-default switches (see gemm / gradient_products / step_graph)'),
+                       'gradient_products': args.grad_products,
                        'gemm': ('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else
                                 'bf16 operands, fp32 accumulate (reduced precision)' if gemm_mode == 2 else 'fp32 MFMA')},
             'roofline': roofline,

@@ -111,6 +111,15 @@ int vqcpc_embedding_bwd(const float* g, int64_t ldg, const int64_t* sorted_idx, 
  * Process-wide; the initial value comes from the environment variable VQCPC_GEMM_MODE (0, 1, or 8; default 0). */
 int vqcpc_gemm_set_mode(int mode);
 int vqcpc_gemm_get_mode(void);
+/* Gradient arithmetic of the bf16x6 mode -- OPT-IN, default 6 (= the forward's exact split everywhere).  With 3, the
+ * 256 x 256-tile GEMMs launched while a gradient scope is open (the trainers open one around loss.backward(), i.e. the
+ * input-gradient NT GEMMs and the weight-gradient TN GEMMs of torch.autograd's backward of F.linear) split each operand into
+ * TWO bf16 planes by rounding (h = rn(x), m = rn(x - h): |x - h - m| <= 2^-18 |x|) and evaluate hh + hm + mh: three MFMAs
+ * per product, ~2^-17 relative per product, fp32 accumulation.  Forward GEMMs (and hence losses and the code assignment)
+ * are never affected.  vqcpc_gemm_gradient_scope(1) opens a scope, (0) closes it (nesting counted); process-wide. */
+int vqcpc_gemm_set_gradient_products(int products);
+int vqcpc_gemm_get_gradient_products(void);
+int vqcpc_gemm_gradient_scope(int open);
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                   float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream);

@@ -86,13 +86,18 @@ def _oracle_step(cfg, seed):
     return _ORACLE_CACHE[key]
 
 
-def _step_vs_oracle(cfg, seed):
+def _step_vs_oracle(cfg, seed, trainer_backward=False):
     sd, batch, otr, ref = _oracle_step(cfg, seed)
     tr = build_trainer(cfg, sd, lr=1e-4)
     tr.train()
     loss, out = tr.compute_losses(batch)
     tr.flat.zero_grad()
-    loss.backward()
+    if trainer_backward:                       # as the trainers' step does it: weight gradients straight into the bucket,
+        from vqcpc_bach_amd import ops         # batched transposes, and the gradient scope of the GEMM library open
+        with ops.direct_weight_gradients(tr.flat):
+            loss.backward()
+    else:
+        loss.backward()
     for k in ('idx_left', 'idx_right', 'idx_negative'):
         assert torch.equal(out[k].cpu().reshape(ref[k].shape), ref[k]), f'{k}: index assignment differs from the oracle'
     used = torch.cat([ref[k].reshape(-1, cfg['ncb']) for k in ('idx_left', 'idx_right', 'idx_negative')]).unique().numel()
@@ -185,6 +190,20 @@ def test_full_size_c4_step_properties_bf16_mode(gemm_mode):
     if gemm_mode != 'f32':
         pytest.skip('sets its own GEMM mode')
     _full_size_c4_properties(bf16=True)
+
+
+def test_c1_model_dimensions_with_three_product_gradient_arithmetic(gemm_mode):
+    """Opt-in gradient arithmetic (hip.set_gradient_products(3), include/vqcpc.h): the forward is untouched -- indices
+    bit-exact, losses within 5e-5 -- and every gradient stays within the SAME 5e-4 of the oracle's (measured: the worst
+    tensor moves from ~1e-5 to ~2e-5)."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('a switch of the bf16x6 mode')
+    from vqcpc_bach_amd import hip
+    hip.set_gradient_products(3)
+    try:
+        _step_vs_oracle(O.make_cfg('C1', B=8), seed=31, trainer_backward=True)
+    finally:
+        hip.set_gradient_products(6)
 
 
 def test_c4_model_dimensions_vs_oracle():

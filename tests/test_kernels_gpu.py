@@ -1383,3 +1383,53 @@ def test_split_rows_fn_equals_slicing(ops):
     ((a * ga).sum() + (c * gc).sum()).backward()                  # the middle block receives no gradient
     ((ar * ga).sum() + (cr * gc).sum()).backward()
     assert torch.equal(x.grad, xr.grad)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# opt-in gradient arithmetic of the bf16x6 mode (hip.set_gradient_products(3): two rounded planes, three products)
+# ----------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind,M,N,K,epi', [('nt', 65536, 256, 1024, 'add'), ('nt', 32768, 1024, 256, 'none'),
+                                            ('nt', 65536, 256, 256, 'add2'), ('tn', 131072, 256, 256, ''),
+                                            ('tn', 65536, 1024, 256, '')])
+def test_three_product_gradient_arithmetic(ops, bf16x6, kind, M, N, K, epi):
+    """Inside a gradient scope with hip.set_gradient_products(3) the 256-tile NT / TN kernels evaluate hh + hm + mh on two
+    ROUNDED planes per operand: ~2^-17 per product, i.e. rms error ~5e-6 of an N(0,1) product's rms -- an order above the
+    six-product split (5e-7) and 500 x below a one-product bf16 GEMM (2.3e-3).  Outside a scope, and with the default of 6,
+    nothing changes (bit-identical to the six-product result)."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M + N + K)
+    if kind == 'nt':
+        a, b = torch.randn(M, K, device='cuda', generator=gen), torch.randn(N, K, device='cuda', generator=gen)
+        add = torch.randn(M, N, device='cuda', generator=gen) if epi in ('add', 'add2') else None
+        add2 = torch.randn(M, N, device='cuda', generator=gen) if epi == 'add2' else None
+        ref = a.double() @ b.double().t()
+        for t in (add, add2):
+            if t is not None:
+                ref = ref + t.double()
+        fn = lambda: ops.gemm_nt(a, b, add=add, add2=add2)
+    else:
+        a, b = torch.randn(M, N, device='cuda', generator=gen), torch.randn(M, K, device='cuda', generator=gen)
+        ref = a.double().t() @ b.double()
+        fn = lambda: ops.gemm_tn(a, b, want_bias=False)[0]
+
+    def rms_err(x):
+        return float((x.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+
+    six = fn()
+    assert hip.get_gradient_products() == 6
+    try:
+        hip.set_gradient_products(3)
+        assert torch.equal(fn(), six), 'outside a gradient scope the setting must not change anything'
+        hip.gradient_scope(True)
+        try:
+            three = fn()
+            assert torch.equal(fn(), three), 'deterministic'
+        finally:
+            hip.gradient_scope(False)
+        assert torch.equal(fn(), six)
+    finally:
+        hip.set_gradient_products(6)
+    e6, e3 = rms_err(six), rms_err(three)
+    assert e6 < 2.5e-6, e6                       # fp32-class (the TN contraction over 10^5 rows adds accumulation noise)
+    assert 1e-6 < e3 < 1.2e-5, e3                # ~2^-17 per product: visibly not the six-product result, 500 x below bf16
+    assert float((three.double() - ref).abs().max() / ref.abs().max()) < 2e-5

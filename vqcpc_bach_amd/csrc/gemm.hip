@@ -472,7 +472,11 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_256_kernel(const flo
 //      for dword / dwordx4 stores alone), and hiding it would take a second accumulator set
 //  64 / 128 / 256: output stores with the nt / sc1 / sc0 cache-policy bits     -> +0.7 % / -1 % / +-0 % (202.0 -> 203.5,
 //      190.6 -> 192.0, 205.7 -> 207.3 TFLOP/s with nt): within noise, not adopted (the consumer kernel wants the lines)
-template <int EPI, int ABL = 0>
+// NP = bf16 planes per operand.  3: the exact 3-way truncation split, six products (hh, hm + mh, hl + lh + mm): fp32-class.
+//      2: GRADIENT arithmetic (vqcpc_gemm_set_gradient_products(3), opt-in, never the default): each operand is
+//         h = rn_bf16(x), m = rn_bf16(x - h) (|x - h - m| <= 2^-18 |x|), products hh + (hm + mh), the mm term (2^-18) dropped:
+//         ~2^-17 per product, unbiased -- 4 LDS planes per K tile, 12 fragment reads and 24 MFMAs per phase.
+template <int EPI, int ABL = 0, int NP = 3>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
                                                                      const float* __restrict__ B, int64_t ldb,
                                                                      float* __restrict__ C, int64_t ldc, int64_t M, int N,
@@ -510,7 +514,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     PP_SET_SRC()
     float4 xa0, xa1, xb0, xb1;
     float4 ya0, ya1, yb0, yb1;                          // V2: second raw set (prefetch distance 2)
-    constexpr bool V2 = (ABL & 16) != 0;
+    constexpr bool V3 = (ABL & 1024) != 0 && NP == 3;    // paired loads (below); uses V2's fragment schedule for its registers
+    constexpr bool V2 = ((ABL & 16) != 0 || V3) && NP == 3;
 #define PP_OPAQUE(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w));
 #define PP_LOAD(S_, PF0, PF1)                                                                    \
     if (!(ABL & 2) || s < 1) {                                                            \
@@ -534,7 +539,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
 #define PP_ST1(R, PLANE0, ROW, BUFP)                                                 \
     {                                                                                \
         uint2 h_, m_, l_;                                                            \
-        if (ABL & 1) { h_ = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y)); m_ = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w)); l_ = h_; } \
+        if (NP == 2) { split2x4(R, h_, m_); l_ = h_; }                               \
+        else if (ABL & 1) { h_ = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y)); m_ = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w)); l_ = h_; } \
         else if (ABL & 4) { if (PLANE0 == 0) { split3x4(R, h_, m_, l_); } else { h_ = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y)); m_ = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w)); l_ = h_; } } \
         else split3x4(R, h_, m_, l_);                                                     \
         /* unpadded 32-byte rows, the two 16-byte chunks of a row XOR-swizzled by bit 3 of the row: fragment reads     \
@@ -542,23 +548,23 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         const int o_ = (ROW) * 32 + ((((ld_c4 >> 3) ^ ((ROW) >> 3)) & 1) << 4) + (ld_c4 & 7) * 2; \
         *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 0) * kPPPlane + o_) = h_;     \
         *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 1) * kPPPlane + o_) = m_;     \
-        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 2) * kPPPlane + o_) = l_;     \
+        if (NP == 3) *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 2) * kPPPlane + o_) = l_; \
     }
 #define PP_STORE(S_, BUFP) \
-    PP_ST1(S_##a0, 0, ld_row, BUFP) PP_ST1(S_##a1, 0, ld_row + 64, BUFP) PP_ST1(S_##b0, 3, ld_row, BUFP) PP_ST1(S_##b1, 3, ld_row + 64, BUFP)
+    PP_ST1(S_##a0, 0, ld_row, BUFP) PP_ST1(S_##a1, 0, ld_row + 64, BUFP) PP_ST1(S_##b0, NP, ld_row, BUFP) PP_ST1(S_##b1, NP, ld_row + 64, BUFP)
 
-    constexpr int kPPPlane = kT2 * 32, kPPBuf = 6 * kPPPlane;      // 8 KB planes, 48 KB per buffer
+    constexpr int kPPPlane = kT2 * 32, kPPBuf = 2 * NP * kPPPlane;  // 8 KB planes, 48 KB (NP = 2: 32 KB) per buffer
     const int swz = ((kh ^ (li >> 3)) & 1) << 4;                   // every fragment row is base + li with base % 16 == 0
     const int a_off = (wm * 128 + li) * 32 + swz;
-    const int b_off = 3 * kPPPlane + (wn * 64 + li) * 32 + swz;
+    const int b_off = NP * kPPPlane + (wn * 64 + li) * 32 + swz;
     unsigned char* const buf0 = smem2;
     unsigned char* const buf1 = smem2 + kPPBuf;
-    bf16x8 fb[3][2], fa[4][3];                          // all fragments of a K tile: 18 x ds_read_b128 in the memory phase
+    bf16x8 fb[NP][2], fa[4][NP];                        // all fragments of a K tile: 18 (12) x ds_read_b128 in the memory phase
 #define PP_READ_A(BUFP, PC)                                                                                          \
     _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                                 \
         fa[mt][PC] = *reinterpret_cast<const bf16x8*>((BUFP) + a_off + (PC) * kPPPlane + mt * 32 * 32);
 #define PP_READ_FRAGS(BUFP)                                                                                          \
-    _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                               \
+    _Pragma("unroll") for (int pc = 0; pc < NP; ++pc) {                                                              \
         _Pragma("unroll") for (int tl = 0; tl < 2; ++tl)                                                             \
             fb[pc][tl] = *reinterpret_cast<const bf16x8*>((BUFP) + b_off + pc * kPPPlane + tl * 32 * 32);           \
         if (!V2 || pc == 2) {                                                                                        \
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][PA], fb[PB][0], acc[mt][0], 0, 0, 0);            \
         acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mt][PA], fb[PB][1], acc[mt][1], 0, 0, 0);            \
     }
-#define PP_MFMA_V1() PP_TERM(2, 0) PP_TERM(0, 2) PP_TERM(1, 1) PP_TERM(1, 0) PP_TERM(0, 1) PP_TERM(0, 0)
+#define PP_MFMA_V1() PP_TERM(NP - 1, 0) PP_TERM(0, NP - 1) PP_TERM(1, 1) PP_TERM(1, 0) PP_TERM(0, 1) PP_TERM(0, 0)
     // V2: only the B fragments and the LOW A plane are read in the memory phase; the mid / high A planes of this wave's own
     // rows (group-local staging: nobody writes them meanwhile) are read under the MFMAs that precede their first use, the
     // high plane into the registers of the low one: 56 instead of 72 live fragment registers
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     PP_TERM(1, 1) PP_TERM(1, 0)                                                   \
     __builtin_amdgcn_sched_barrier(0);                                            \
     PP_TERM(0, 2) PP_TERM(0, 1) PP_TERM(0, 0)
-#define PP_MFMA(BUFP) if (V2) { PP_MFMA_V2(BUFP) } else { PP_MFMA_V1() }
+#define PP_MFMA(BUFP) if constexpr (NP == 2 || (ABL & 512) != 0) { PP_TERM(1, 0) PP_TERM(0, 1) PP_TERM(0, 0) } else if constexpr (V2) { PP_MFMA_V2(BUFP) } else { PP_MFMA_V1() }
 #define PP_BARRIER()                          \
     __builtin_amdgcn_sched_barrier(0);        \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
@@ -712,9 +718,28 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         if (ABL & 8) asm volatile("" :: "v"(PF0_), "v"(PF1_));                    \
         PP_LOAD(S_, PF0_, PF1_)                                                   \
         PP_BARRIER()                                                              \
-        __builtin_amdgcn_s_setprio(1);                                            \
+        if (!(ABL & 6144)) __builtin_amdgcn_s_setprio(1);                         \
         PP_MFMA(RB_)                                                              \
-        __builtin_amdgcn_s_setprio(0);                                            \
+        if (!(ABL & 6144)) __builtin_amdgcn_s_setprio(0);                         \
+        PP_BARRIER()                                                              \
+        ++s;                                                                      \
+        kt = (kt + 1 == T) ? 0 : kt + 1;                                          \
+    }
+
+    // V3 (ABL 1024): K tiles 2j and 2j+1 are the two 64-byte halves of the SAME 128-byte lines of both operands.  Requested
+    // one K step apart (as above) the second half has left the L1 by the time it is asked for and every line crosses the
+    // L2 -> L1 path twice; here both halves are requested back to back (sets x and y) in the even phases, none in the odd
+    // ones: x (tile 2j) is split in the next phase, y (tile 2j+1) in the one after.
+#define PP_PHASES3(RB_, WB_, S_, LOADPAIR_)                                       \
+    {                                                                             \
+        if (kt == 0 && s > 0) PP_EPILOGUE()                                       \
+        PP_READ_FRAGS(RB_)                                                        \
+        PP_STORE(S_, WB_)                                                         \
+        if (LOADPAIR_) { PP_LOAD(x, pf0, pf1) PP_LOAD(y, pf2, pf3) }              \
+        PP_BARRIER()                                                              \
+        if (!(ABL & 6144)) __builtin_amdgcn_s_setprio(1);                         \
+        PP_MFMA(RB_)                                                              \
+        if (!(ABL & 6144)) __builtin_amdgcn_s_setprio(0);                         \
         PP_BARRIER()                                                              \
         ++s;                                                                      \
         kt = (kt + 1 == T) ? 0 : kt + 1;                                          \
@@ -725,14 +750,21 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     float pf0 = 0.f, pf1 = 0.f, pf2 = 0.f, pf3 = 0.f;
     PP_BIAS_REQUEST()
     PP_LOAD(x, pf0, pf1)
+    if (V3) { PP_LOAD(y, pf2, pf3) }                     // V3: tiles 0 (x) and 1 (y) requested together
     PP_STORE(x, buf0)
-    PP_LOAD(x, pf2, pf3)
-    if (V2) { PP_LOAD(y, pf2, pf3) }                     // V2: tiles 1 (x) and 2 (y) requested
+    if (!V3) { PP_LOAD(x, pf2, pf3) }
+    if (V2 && !V3) { PP_LOAD(y, pf2, pf3) }              // V2: tiles 1 (x) and 2 (y) requested
     PP_BARRIER()
     if (wm == 1) { PP_BARRIER() }                        // group 1 falls one phase behind
+    // ABL 2048: no priority flips at all; ABL 4096: static priority 1 for the younger wave group only (MI355X_MICROARCH.md,
+    // "Two waves per SIMD", items 2 and 4)
+    if ((ABL & 4096) && __builtin_amdgcn_readfirstlane(wm) == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll 1
     while (s < S) {
-        if (V2) {
+        if (V3) {
+            PP_PHASES3(buf0, buf1, y, true)              // even phase: tile s+1 (y) stored, tiles s+2 (x), s+3 (y) requested
+            PP_PHASES3(buf1, buf0, x, false)             // odd phase:  tile s+1 (x) stored
+        } else if (V2) {
             PP_PHASES(buf0, buf1, pf0, pf1, x)
             PP_PHASES(buf1, buf0, pf2, pf3, y)
         } else {
@@ -743,6 +775,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
     if (wm == 0) { PP_BARRIER() }                        // pairs with group 1's last barrier
     PP_EPILOGUE()
 #undef PP_PHASES
+#undef PP_PHASES3
 #undef PP_EPILOGUE
 #undef PP_BIAS_REQUEST
 #undef PP_BARRIER
@@ -1201,6 +1234,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_256_kernel(const flo
 // request step s+2) and an MFMA phase (48 MFMAs), each closed by a barrier; wave group 1 (the lower 128 output rows) runs one
 // phase behind group 0, so that on every SIMD one wave issues MFMAs while the other one does its memory phase (the lockstep
 // kernel kept the matrix pipes busy 64 % of the cycles: tools/pmc_gemm_tn.sh).
+template <int NP>
 __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const float* __restrict__ A, int64_t lda,
                                                                       const float* __restrict__ B, int64_t ldb, int64_t M,
                                                                       int N, int K, int tiles_k, int64_t rows_per_split,
@@ -1249,14 +1283,14 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
     {                                                                                    \
         uint4 h_, m_, l_;                                                                \
         const int o_ = (c4 >> 6) * kTPBlk + rp * kTPRS + (c4 & 63) * 4;                  \
-        split3_pair4(S##a0, S##a1, h_, m_, l_);                                          \
+        if constexpr (NP == 2) { split2_pair4(S##a0, S##a1, h_, m_); } else { split3_pair4(S##a0, S##a1, h_, m_, l_); } \
         *reinterpret_cast<uint4*>((BUFP) + 0 * kTPPlane + o_) = h_;                      \
         *reinterpret_cast<uint4*>((BUFP) + 1 * kTPPlane + o_) = m_;                      \
-        *reinterpret_cast<uint4*>((BUFP) + 2 * kTPPlane + o_) = l_;                      \
-        split3_pair4(S##b0, S##b1, h_, m_, l_);                                          \
-        *reinterpret_cast<uint4*>((BUFP) + 3 * kTPPlane + o_) = h_;                      \
-        *reinterpret_cast<uint4*>((BUFP) + 4 * kTPPlane + o_) = m_;                      \
-        *reinterpret_cast<uint4*>((BUFP) + 5 * kTPPlane + o_) = l_;                      \
+        if constexpr (NP == 3) *reinterpret_cast<uint4*>((BUFP) + 2 * kTPPlane + o_) = l_; \
+        if constexpr (NP == 2) { split2_pair4(S##b0, S##b1, h_, m_); } else { split3_pair4(S##b0, S##b1, h_, m_, l_); } \
+        *reinterpret_cast<uint4*>((BUFP) + (NP + 0) * kTPPlane + o_) = h_;               \
+        *reinterpret_cast<uint4*>((BUFP) + (NP + 1) * kTPPlane + o_) = m_;               \
+        if constexpr (NP == 3) *reinterpret_cast<uint4*>((BUFP) + (NP + 2) * kTPPlane + o_) = l_; \
         if (want_bias && store_counts) {                                                 \
             bsum.x += S##a0.x + S##a1.x;                                                 \
             bsum.y += S##a0.y + S##a1.y;                                                 \
@@ -1274,7 +1308,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
         DST = __builtin_bit_cast(bf16x8, u_);                                            \
     }
     // all 18 fragments of a 16-row step: 72 x ds_read_b32 in the memory phase (a[tile 0..3][plane], b[plane][tile 0..1])
-    bf16x8 fa[4][3], fb[3][2];
+    bf16x8 fa[4][NP], fb[NP][2];
     // LDS image of this kernel: plane = 4 column blocks of 64 columns, each [8 row pairs][64 + 4 dwords]: the four dwords of
     // a fragment (row pairs 4 kh .. 4 kh + 3 of one column) are 68 dwords apart, so TWO ds_read2_b32 fetch a fragment
     // straight into its four consecutive registers (36 reads per phase).  With the 256-column rows of the lockstep kernel
@@ -1293,8 +1327,8 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
 #define TP_READ_FRAGS(BUFP)                                                                                               \
     {                                                                                                                     \
         const unsigned base_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(BUFP);             \
-        _Pragma("unroll") for (int pc = 0; pc < 3; ++pc) {                                                                \
-            const unsigned bb_ = base_ + (3 + pc) * kTPPlane + wn * kTPBlk + (kh * 4) * kTPRS + li * 4;                   \
+        _Pragma("unroll") for (int pc = 0; pc < NP; ++pc) {                                                               \
+            const unsigned bb_ = base_ + (NP + pc) * kTPPlane + wn * kTPBlk + (kh * 4) * kTPRS + li * 4;                   \
             TP_FRAG_ASM(fb[pc][0], bb_, 0)                                                                                \
             TP_FRAG_ASM(fb[pc][1], bb_, 128)                                                                              \
             const unsigned ab0_ = base_ + pc * kTPPlane + (wm * 2) * kTPBlk + (kh * 4) * kTPRS + li * 4;                  \
@@ -1310,7 +1344,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
         acc[t4][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t4][PA], fb[PB][0], acc[t4][0], 0, 0, 0);                 \
         acc[t4][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t4][PA], fb[PB][1], acc[t4][1], 0, 0, 0);                 \
     }
-#define TP_MFMA() TP_TERM(2, 0) TP_TERM(0, 2) TP_TERM(1, 1) TP_TERM(1, 0) TP_TERM(0, 1) TP_TERM(0, 0)
+#define TP_MFMA() if constexpr (NP == 2) { TP_TERM(1, 0) TP_TERM(0, 1) TP_TERM(0, 0) } else { TP_TERM(NP - 1, 0) TP_TERM(0, NP - 1) TP_TERM(1, 1) TP_TERM(1, 0) TP_TERM(0, 1) TP_TERM(0, 0) }
 #define TP_BARRIER()                          \
     __builtin_amdgcn_sched_barrier(0);        \
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
@@ -1335,7 +1369,7 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
     }
 
     unsigned char* const buf0 = smemw;
-    unsigned char* const buf1 = smemw + kTPBuf;
+    unsigned char* const buf1 = smemw + 2 * NP * kTPPlane;
     const int64_t rows = m_end - m_begin;                     // multiple of 32: an even number of 16-row steps
     const int64_t nsteps = rows / kW2TM;
     if (rows > 0) {
@@ -1396,6 +1430,14 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
 // 2 = plain bf16 operands (one MFMA per product, fp32 accumulate; BASELINE configs[4] names bf16): 128-tile kernels only.
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
 static std::atomic<int> g_gemm_mode{-1};
+// Gradient arithmetic (opt-in): products per fp32 product of the 256-tile bf16x6 kernels while a gradient scope is open
+// (vqcpc_gemm_gradient_scope: the trainers open it around loss.backward()).  6 = the forward's exact split (default);
+// 3 = two rounded planes per operand, hh + hm + mh (gemm_nt_x6_pp_kernel<.., NP = 2>): ~2^-17 per product.
+static std::atomic<int> g_grad_products{6};
+static std::atomic<int> g_grad_scope{0};
+static int gradient_products_now() {
+    return g_grad_scope.load(std::memory_order_relaxed) > 0 ? g_grad_products.load(std::memory_order_relaxed) : 6;
+}
 static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups (A/B switch)
 static std::atomic<int> g_use_sw{0};   // bf16x6 NT 256-tile: software-pipelined one-wave-per-SIMD kernel (gemm_sw.hip), A/B switch
 static std::atomic<int> g_use_dma{0};  // bf16x6 NT 256-tile: LDS-DMA operand delivery (gemm_dma.hip) instead of register staging
@@ -1594,6 +1636,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         const bool use_pp = g_use_pp.load(std::memory_order_relaxed) != 0 && flags != E_GATE;
         const size_t lds2 = 2 * kT2Buf;
         const size_t lds_pp = 2 * 6 * kT2 * 32;          // ping-pong kernel: unpadded swizzled planes (96 KB)
+        const size_t lds_pp2 = 2 * 4 * kT2 * 32;         // its two-plane gradient variant (64 KB)
 #define T2_LAUNCH(EPIV)                                                                                                    \
     {                                                                                                                      \
         static bool attr_done = false;                                                                                     \
@@ -1609,7 +1652,20 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             attr_pp = true;                                                                                                \
         }                                                                                                                  \
         static const int abl = getenv("VQCPC_PP_ABL") ? atoi(getenv("VQCPC_PP_ABL")) : 0;                                  \
-        if (use_pp && abl && EPIV == E_BIAS) {                                                                             \
+        if (use_pp && ((EPIV) == 0 || (EPIV) == E_ADD || (EPIV) == (E_ADD | E_ADD2)) && gradient_products_now() == 3) {    \
+            /* opt-in gradient arithmetic (input-gradient GEMMs inside a gradient scope): two planes, three products */    \
+            constexpr int EG = ((EPIV) == 0 || (EPIV) == E_ADD || (EPIV) == (E_ADD | E_ADD2)) ? (EPIV) : 0;                \
+            static bool attr_g = false;                                                                                    \
+            if (!attr_g) {                                                                                                 \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EG, 0, 2>,                                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp2);                       \
+                attr_g = true;                                                                                             \
+            }                                                                                                              \
+            hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EG, 0, 2>), grid2, block2, lds_pp2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
+            VQ_CHECK_LAUNCH("gemm_nt_x6_pp (gradient arithmetic)");                                                        \
+            return VQCPC_OK;                                                                                               \
+        }                                                                                                                  \
+        if (use_pp && abl && (EPIV) == E_BIAS) {                                                                             \
             if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 1>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 2>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 3>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
@@ -1620,6 +1676,10 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             if (abl == 128) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 128>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 192) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 192>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 256) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 256>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 1024) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 1024>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 1024>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 2048) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 2048>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 2048>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 4096) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 4096>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 4096>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
+            if (abl == 512) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 512>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 4) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 4>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
         } else if (use_pp)                                                                                                 \
             hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
@@ -1672,6 +1732,20 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
 }
 
 extern "C" {
+
+int vqcpc_gemm_set_gradient_products(int products) {
+    VQ_REQUIRE(products == 3 || products == 6, "gemm_set_gradient_products: 3 or 6, got %d", products);
+    g_grad_products.store(products, std::memory_order_relaxed);
+    return VQCPC_OK;
+}
+
+int vqcpc_gemm_get_gradient_products(void) { return g_grad_products.load(std::memory_order_relaxed); }
+
+int vqcpc_gemm_gradient_scope(int open) {
+    if (open) g_grad_scope.fetch_add(1, std::memory_order_relaxed);
+    else if (g_grad_scope.load(std::memory_order_relaxed) > 0) g_grad_scope.fetch_sub(1, std::memory_order_relaxed);
+    return VQCPC_OK;
+}
 
 int vqcpc_gemm_set_mode(int mode) {
     // bit 0: arithmetic (0 fp32 MFMA, 1 bf16x6); bit 1 set: bf16x6 WITHOUT the 256x256-tile kernels (A/B testing);
@@ -1866,11 +1940,17 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         if (g_use_pp.load(std::memory_order_relaxed)) {
             static bool attr_pp = false;
             if (!attr_pp) {
-                (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           2 * kTPBuf);
+                (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          2 * 4 * kTPPlane);
                 attr_pp = true;
             }
-            hipLaunchKernelGGL(gemm_tn_x6_pp_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kTPBuf, s, A, lda,
+            if (gradient_products_now() == 3)          // opt-in gradient arithmetic, inside a gradient scope only
+                hipLaunchKernelGGL(gemm_tn_x6_pp_kernel<2>, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * 4 * kTPPlane, s,
+                                   A, lda, B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
+            else
+            hipLaunchKernelGGL(gemm_tn_x6_pp_kernel<3>, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kTPBuf, s, A, lda,
                                B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
         } else
         hipLaunchKernelGGL(gemm_tn_x6_256_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kW2Buf, s, A, lda, B,
@@ -1918,6 +1998,18 @@ static int gatebits_launch(const float* A, int64_t lda, const float* B, int64_t 
     const int tiles2 = (int)((M / kT2) * tn2);
     const dim3 grid2((unsigned)std::min(tiles2, kNumCU)), block2(kT2Threads);
     const size_t lds_pp = 2 * 6 * kT2 * 32;
+    if (flags == E_GATEBITS && gradient_products_now() == 3) {      // opt-in gradient arithmetic (see gemm_nt_launch)
+        static bool attr_g = false;
+        if (!attr_g) {
+            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_GATEBITS, 0, 2>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 2 * 4 * kT2 * 32);
+            attr_g = true;
+        }
+        hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_GATEBITS, 0, 2>), grid2, block2, 2 * 4 * kT2 * 32, st, A, lda, B, ldb, C, ldc, M,
+                           N, K, tn2, tiles2, ep);
+        VQ_CHECK_LAUNCH("gemm_nt_x6_pp (mask, gradient arithmetic)");
+        return VQCPC_OK;
+    }
 #define GB_LAUNCH(EPIV)                                                                                                   \
     {                                                                                                                      \
         static bool attr_pp = false;                                                                                       \

@@ -83,6 +83,25 @@ __device__ __forceinline__ void split3x4(const float4& v, uint2& h, uint2& m, ui
     l = make_uint2(pack_hi(l0, l1), pack_hi(l2, l3));
 }
 
+// Two-plane split of the gradient arithmetic (NP = 2 kernels): h = rn_bf16(x) (cvt_pk_bf16 above: round to nearest even),
+// m = rn_bf16(x - h) -- the subtraction is exact in fp32 -- so |x - h - m| <= 2^-18 |x|.  Packed pairs, low half first.
+__device__ __forceinline__ void split2_pair(float a, float b, uint32_t& h, uint32_t& m) {
+    h = cvt_pk_bf16(a, b);
+    const float ra = a - __uint_as_float(h << 16), rb = b - __uint_as_float(h & 0xFFFF0000u);
+    m = cvt_pk_bf16(ra, rb);
+}
+__device__ __forceinline__ void split2x4(const float4& v, uint2& h, uint2& m) {
+    split2_pair(v.x, v.y, h.x, m.x);
+    split2_pair(v.z, v.w, h.y, m.y);
+}
+// row-pair interleaved form of the weight-gradient (TN) kernel: dword c = (row0[c], row1[c])
+__device__ __forceinline__ void split2_pair4(const float4& r0, const float4& r1, uint4& h, uint4& m) {
+    split2_pair(r0.x, r1.x, h.x, m.x);
+    split2_pair(r0.y, r1.y, h.y, m.y);
+    split2_pair(r0.z, r1.z, h.z, m.z);
+    split2_pair(r0.w, r1.w, h.w, m.w);
+}
+
 // software-pipelined one-wave-per-SIMD variant of the 256-tile bf16x6 NT kernel (gemm_sw.hip)
 bool gemm_nt_sw_ok(int64_t M, int N, int K, int flags);
 int gemm_nt_sw_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,

@@ -57,6 +57,9 @@ SIGNATURES = {
                                      c_f32, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_set_mode': (c_int, [c_int]),
     'vqcpc_gemm_get_mode': (c_int, []),
+    'vqcpc_gemm_set_gradient_products': (c_int, [c_int]),
+    'vqcpc_gemm_get_gradient_products': (c_int, []),
+    'vqcpc_gemm_gradient_scope': (c_int, [c_int]),
     'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_transpose': (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
@@ -209,6 +212,20 @@ def use_training_default_gemm_mode():
     if not _gemm_mode_explicit and 'VQCPC_GEMM_MODE' not in os.environ:
         set_gemm_mode(1)
         _gemm_mode_explicit = False          # still "nobody chose": a later explicit choice wins as usual
+
+
+def set_gradient_products(products):
+    """Opt-in gradient arithmetic of the bf16x6 mode (include/vqcpc.h): 6 (default) or 3 MFMAs per product for the
+    256-tile GEMMs launched inside a gradient scope (ops.direct_weight_gradients, i.e. the trainers' loss.backward())."""
+    _check(load().vqcpc_gemm_set_gradient_products(int(products)), 'vqcpc_gemm_set_gradient_products')
+
+
+def get_gradient_products():
+    return int(load().vqcpc_gemm_get_gradient_products())
+
+
+def gradient_scope(open_):
+    _check(load().vqcpc_gemm_gradient_scope(1 if open_ else 0), 'vqcpc_gemm_gradient_scope')
 
 
 def force_general_attention(on):

@@ -274,6 +274,7 @@ class direct_weight_gradients:
     def __enter__(self):
         global _DIRECT_WGRAD
         self.prev, _DIRECT_WGRAD = _DIRECT_WGRAD, True
+        hip.gradient_scope(True)           # the GEMMs launched from here on are gradient GEMMs (hip.set_gradient_products)
         if self.flat is not None and BATCHED_TRANSPOSES:
             WEIGHT_T.begin(self.flat)
         return self
@@ -281,6 +282,7 @@ class direct_weight_gradients:
     def __exit__(self, *exc):
         global _DIRECT_WGRAD
         _DIRECT_WGRAD = self.prev
+        hip.gradient_scope(False)
         WEIGHT_T.end()
         return False
 

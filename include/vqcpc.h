@@ -210,6 +210,9 @@ int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64
  * dropout element index = m*d + c.   mean/rstd [M] are saved for the backward.
  * bwd: d_s [M][d] = gradient w.r.t. (x + dropout(r)) = gradient of the x path; d_r = d_s * mask / (1-p) (may alias d_s
  * when p == 0; pass NULL then); d_gamma / d_beta overwritten.
+ * r == NULL: `x` is the residual sum s = x0 + dropout(r) itself (formed by the producing GEMM's epilogue: vqcpc_gemm_nt with
+ * bias, drop_p, seed and add = x0 uses the same mask, element index m*N + c with N == d) -- forward: y = LN(s); backward
+ * with drop_p > 0 and d_r != NULL: d_r = d_s * mask / (1-p) with the mask regenerated from (seed, index), no r stream.
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
                             float* mean, float* rstd, int64_t M, int d, float eps, float drop_p, uint64_t seed,

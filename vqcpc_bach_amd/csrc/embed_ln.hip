@@ -185,7 +185,10 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 }
 
 // backward: d_s, d_r and per-workgroup partial d_gamma / d_beta (ws[block][2][d])
-template <bool HAS_R>
+// HAS_R: x and r are separate inputs (s = x + dropout(r) is rebuilt here).  MASKED (and !HAS_R): `x` IS the residual sum s (the
+// producing GEMM's epilogue formed it); the dropout mask of the sub-layer output is still regenerated from (seed, index)
+// for d_r = d_s . mask -- one input stream fewer.
+template <bool HAS_R, bool MASKED = HAS_R>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          int64_t ldx, const float* __restrict__ r,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -215,13 +218,15 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
             if (it < nit && col < d) {
                 float4 xv = nt_load4(x + row * ldx + col);
                 msk[it] = make_float4(1.f, 1.f, 1.f, 1.f);
-                if (HAS_R) {
-                    const float4 rv = nt_load4(r + row * d + col);
+                if (MASKED) {
                     const uint64_t e = (uint64_t)row * d + col;
                     msk[it].x = drop_scale(seed, e + 0, thr, inv_keep);
                     msk[it].y = drop_scale(seed, e + 1, thr, inv_keep);
                     msk[it].z = drop_scale(seed, e + 2, thr, inv_keep);
                     msk[it].w = drop_scale(seed, e + 3, thr, inv_keep);
+                }
+                if (HAS_R) {
+                    const float4 rv = nt_load4(r + row * d + col);
                     xv.x += rv.x * msk[it].x;
                     xv.y += rv.y * msk[it].y;
                     xv.z += rv.z * msk[it].z;
@@ -253,7 +258,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                 o.z = rs * (gy[it].z - m1 - xh[it].z * m2);
                 o.w = rs * (gy[it].w - m1 - xh[it].w * m2);
                 nt_store4(d_s + row * d + col, o);
-                if (HAS_R && d_r != nullptr) {
+                if (MASKED && d_r != nullptr) {
                     o.x *= msk[it].x;
                     o.y *= msk[it].y;
                     o.z *= msk[it].z;
@@ -588,6 +593,9 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
     if (r)
         hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
                            d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
+    else if (thr && d_r)     // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
+        hipLaunchKernelGGL((add_ln_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd,
+                           d_s, d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
     else
         hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
                            d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);

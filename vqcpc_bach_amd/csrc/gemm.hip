@@ -1696,6 +1696,10 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             case E_GATE: T2_LAUNCH(E_GATE)
             case E_ADD: T2_LAUNCH(E_ADD)
             case E_ADD | E_ADD2: T2_LAUNCH(E_ADD | E_ADD2)
+            // s = x + dropout(a W^T + b): the residual sum that LayerNorm normalises (transformer_custom.py:282-283,288-289),
+            // produced by the out-proj / FFN2 epilogue so that the LayerNorm kernels read ONE input stream
+            case E_BIAS | E_ADD: T2_LAUNCH(E_BIAS | E_ADD)
+            case E_BIAS | E_DROP | E_ADD: T2_LAUNCH(E_BIAS | E_DROP | E_ADD)
             default: break;
         }
 #undef T2_LAUNCH
@@ -1720,6 +1724,8 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         NT_CASE(E_GATE)
         NT_CASE(E_ADD)
         NT_CASE(E_ADD | E_ADD2)
+        NT_CASE(E_BIAS | E_ADD)
+        NT_CASE(E_BIAS | E_DROP | E_ADD)
         default:
             if (full) { NT_LAUNCH(true, E_RUNTIME); }
             else { NT_LAUNCH(false, E_RUNTIME); }

@@ -634,31 +634,33 @@ class EncoderLayerFn(torch.autograd.Function):
             probs = torch.empty(nblk, H, L // f, L, dtype=torch.float32, device=dev)
             hip.call('vqcpc_relattn_sub_fwd', qproj, d, qkv, 2 * d, e1, e2, att, d, probs, nblk, L, f, H, hd, p, s[0])
         attb = cast_bf16(att) if nat else None
-        a = lin(attb if nat else att, wo, bias=bo)
+        # s1 = x + dropout(att Wo^T + bo): the residual sum is formed by the out-proj epilogue (bias -> dropout -> + x), so the
+        # LayerNorm kernels read ONE input stream and the backward needs neither x nor the projection output again
+        s1 = lin(attb if nat else att, wo, bias=bo, drop_p=p, seed=s[1], add=xs)
         x1 = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         x1b = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
-        hip.call('vqcpc_add_layernorm_fwd_b16', xs, ldxs, a, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5, p, s[1])
+        hip.call('vqcpc_add_layernorm_fwd_b16', s1, d, None, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5, 0.0, 0)
         h2b = None
         if nat:     # the FFN hidden activation exists in bf16 only: FFN2, the backward gate and the weight gradient read it
             h2b = gemm_nt_bf16(x1b, w1, bias=b1, act=1, drop_p=p, seed=s[2], out_f32=False, out_bf16=True)
-            ff = gemm_nt_bf16(h2b, w2, bias=b2)
+            s2 = gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add=x1)
             h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
         else:
             if gatebits_worthwhile(Mq, ffd, d):       # relu / dropout gate of the backward as a bit mask (1/32 of the bytes)
                 h2, ctx.gate_mask = gemm_nt_relu_mask(x1, w1, b1, drop_p=p, seed=s[2])
             else:
                 h2, ctx.gate_mask = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2]), None
-            ff = gemm_nt(h2, w2, bias=b2)
+            s2 = gemm_nt(h2, w2, bias=b2, drop_p=p, seed=s[3], add=x1)          # x1 + dropout(FFN(x1))
         y = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         yb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
-        hip.call('vqcpc_add_layernorm_fwd_b16', x1, d, ff, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, p, s[3])
+        hip.call('vqcpc_add_layernorm_fwd_b16', s2, d, None, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, 0.0, 0)
         if nat:
             _attach_bf16_copy(y, yb)
-        ctx.save_for_backward(x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1,
+        ctx.save_for_backward(x, qkv, qproj, probs, att, s1, x1, mean1, rstd1, h2, s2, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
         ctx.bf16 = (xb, xsb, attb, x1b, h2b) if nat else None
@@ -671,7 +673,7 @@ class EncoderLayerFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy, _dprobs):
-        (x, qkv, qproj, probs, att, a, x1, mean1, rstd1, h2, ff, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
+        (x, qkv, qproj, probs, att, s1, x1, mean1, rstd1, h2, s2, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
          g2) = ctx.saved_tensors
         if dy is None:
             dy = torch.zeros_like(x1)
@@ -688,6 +690,7 @@ class EncoderLayerFn(torch.autograd.Function):
         nat = ctx.bf16 is not None
 
         def ln_bwd(dyv, xin, ldxin, r, gamma, mean, rstd, seed):
+            # r None: xin is the residual sum itself (s-form, include/vqcpc.h); the mask of d_r is regenerated from `seed`
             ds = torch.empty(Mq, d, dtype=torch.float32, device=dev)
             dr = torch.empty(Mq, d, dtype=torch.float32, device=dev) if p > 0 else None
             drb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None    # GEMM-operand copy of dr
@@ -699,7 +702,7 @@ class EncoderLayerFn(torch.autograd.Function):
                      ws, nbytes)
             return ds, (dr if dr is not None else ds), dg, db, drb
 
-        ds2, df, dg2, dbe2, dfb = ln_bwd(dy, x1, d, ff, g2, mean2, rstd2, s[3])
+        ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, mean2, rstd2, s[3])
         lin = gemm_nt_bf16 if nat else gemm_nt
         if nat:
             xb, xsb, attb, x1b, h2b = ctx.bf16
@@ -718,7 +721,7 @@ class EncoderLayerFn(torch.autograd.Function):
             dw1, db1 = wgrad(da, x1, w1, b1)
             dx1 = gemm_nt(da, transpose(w1), add=ds2)
         del da, df, ds2
-        ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, xs, ldxs, a, g1, mean1, rstd1, s[1])
+        ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, mean1, rstd1, s[1])
         if nat:
             dwo, dbo = wgrad(dAb, attb, wo, bo)
             datt = gemm_nt_bf16(dAb, transpose(wo))

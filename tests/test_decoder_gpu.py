@@ -523,3 +523,40 @@ def test_decoder_full_config_through_getters_vs_oracle(gemm_mode):
     a = dec.epoch(iter([{'x': x}]), train=False, num_batches=1)['loss']
     b = dec.epoch(iter([{'x': x}]), train=False, num_batches=1)['loss']
     assert a == b
+
+
+@pytest.mark.parametrize('name', ['mha_self_causal_T24', 'mha_self_full_T16', 'mha_cross_anticausal_S6_T12'])
+def test_multihead_attention_forward_api_against_the_reference(name, gemm_mode):
+    """`MultiheadAttentionCustom.forward(query, key, value, attn_mask=...)` -- the reference's own signature
+    (multihead_attention_custom.py:122), time-first tensors and the ADDITIVE mask matrices of decoders/decoder.py:294-308 --
+    against fixtures produced by the reference's module: output, per-head attention weights, gradients w.r.t. the inputs and
+    every parameter."""
+    from vqcpc_bach_amd.transformer.multihead_attention_custom import MultiheadAttentionCustom
+    g = load_golden(name)
+    H, S, Tq = int(g['H']), int(g['S']), int(g['T'])
+    q0 = T(g['q'])
+    n, d = q0.shape[1], q0.shape[2]
+    cross = S != Tq
+    m = MultiheadAttentionCustom(embed_dim=d, num_heads=H,
+                                 attention_bias_type='relative_attention_target_source' if cross else 'relative_attention',
+                                 num_channels_k=1, num_events_k=S, num_channels_q=1, num_events_q=Tq, dropout=0.0)
+    m.load_state_dict({k[3:]: T(np.array(v)) for k, v in g.items() if k.startswith('sd/')})
+    m.cuda().eval()
+    q = q0.cuda().requires_grad_(True)
+    mem = T(g['mem']).cuda().requires_grad_(True) if cross else q
+    am = T(g['attn_mask']).cuda() if 'attn_mask' in g else None
+    out, w = m(q, mem, mem, attn_mask=am)
+    assert out.shape == (Tq, n, d) and w.shape == (n, H, Tq, S)
+    assert rel_err(out.detach().cpu(), g['out']) < FWD_TOL
+    assert rel_err(w.detach().cpu(), g['weights']) < FWD_TOL
+    if am is not None:
+        assert float(w.detach().cpu()[:, :, torch.isinf(T(g['attn_mask']))].abs().max()) == 0.0     # masked weights exactly 0
+    (out * T(g['g']).cuda()).sum().backward()
+    assert rel_err(q.grad.cpu(), g['d_q']) < GRAD_TOL
+    if cross:
+        assert rel_err(mem.grad.cpu(), g['d_mem']) < GRAD_TOL
+    for k, p in m.named_parameters():
+        assert rel_err(p.grad.cpu(), g[f'grad/{k}']) < GRAD_TOL, k
+    assert m(q.detach(), mem.detach(), mem.detach(), attn_mask=am, need_weights=False)[1] is None
+    with pytest.raises(NotImplementedError):
+        m(q.detach(), mem.detach(), mem.detach(), attn_mask=torch.randn(Tq, S, device='cuda'))

@@ -86,3 +86,29 @@ def test_c3_config_through_getters_has_reference_sizes():
     import pytest
     with pytest.raises(AssertionError, match='no CPU path'):
         tr.init_optimizers(lr=1e-5, schedule_lr=False)
+
+
+def test_additive_attention_masks_are_recognised_as_index_rules():
+    """decoders/decoder.py:294-308 builds additive (T, S) masks; the product's kernels evaluate index rules.  The classifier
+    that bridges the two (MultiheadAttentionCustom.forward / layer src_mask tensors) on the reference's own constructions."""
+    import pytest
+    import torch
+    from vqcpc_bach_amd import ops
+    from vqcpc_bach_amd.transformer.multihead_attention_custom import classify_additive_mask
+    from vqcpc_bach_amd.transformer.transformer_custom import mask_code
+
+    def square_subsequent(sz):                                     # Decoder._generate_square_subsequent_mask
+        mask = (torch.triu(torch.ones(sz, sz)) == 1).transpose(0, 1)
+        return mask.float().masked_fill(mask == 0, float('-inf')).masked_fill(mask == 1, float(0.0))
+
+    for S, r in ((6, 1), (24, 1), (6, 2), (3, 16)):
+        causal = torch.repeat_interleave(square_subsequent(S), r, dim=0)
+        anti = torch.repeat_interleave(square_subsequent(S).t(), r, dim=0)      # _generate_anticausal_mask(S, S * r)
+        assert classify_additive_mask(causal) == ops.MASK_CAUSAL and mask_code(causal) == ops.MASK_CAUSAL
+        assert classify_additive_mask(anti) == ops.MASK_ANTICAUSAL
+        assert classify_additive_mask(torch.zeros(S * r, S)) == ops.MASK_NONE
+    with pytest.raises(NotImplementedError):
+        classify_additive_mask(torch.zeros(4, 4).masked_fill(torch.eye(4) == 1, float('-inf')))
+    with pytest.raises(NotImplementedError):
+        classify_additive_mask(torch.full((4, 4), -1.0))
+    assert mask_code('causal') == ops.MASK_CAUSAL and mask_code(None) == ops.MASK_NONE

@@ -76,6 +76,46 @@ def gen_decoder_layer(name, n, H, S, T, d, ff, seed):
          H=np.array(H), **arrays)
 
 
+def gen_mha_forward(name, n, H, S, T, d, mask, seed):
+    """MultiheadAttentionCustom.forward itself (multihead_attention_custom.py:122-353) with the additive masks of
+    decoders/decoder.py:294-308: self-attention (S == T; query = key = value) or encoder-decoder attention (key = value = memory
+    of S rows, T = r S queries), outputs + gradients w.r.t. the inputs and every parameter."""
+    from VQCPCB.transformer.multihead_attention_custom import MultiheadAttentionCustom
+    torch.manual_seed(seed)
+    cross = S != T
+    m = MultiheadAttentionCustom(embed_dim=d, num_heads=H,
+                                 attention_bias_type='relative_attention_target_source' if cross else 'relative_attention',
+                                 num_channels_k=1, num_events_k=S, num_channels_q=1, num_events_q=T, dropout=0.0)
+    perturb_1d(m)
+    m.eval()
+    q = torch.randn(T, n, d, requires_grad=True)
+    mem = torch.randn(S, n, d, requires_grad=True) if cross else q
+    sq = torch.triu(torch.ones(S, S)).t()                                   # _generate_square_subsequent_mask(S)
+    causal = torch.zeros(S, S).masked_fill(sq == 0, float('-inf'))
+    if mask == 'causal':
+        am = torch.repeat_interleave(causal, T // S, dim=0)
+    elif mask == 'anticausal':
+        am = torch.repeat_interleave(causal.t(), T // S, dim=0)
+    else:
+        am = None
+    out, w = m(q, mem, mem, attn_mask=am)
+    g = torch.randn_like(out)
+    (out * g).sum().backward()
+    arrays = sd_arrays('sd', m)
+    arrays.update({f'grad/{k}': npy(p.grad) for k, p in m.named_parameters()})
+    extra = dict(mem=npy(mem), d_mem=npy(mem.grad)) if cross else {}
+    if am is not None:
+        extra['attn_mask'] = npy(am)
+    save(name, q=npy(q), out=npy(out), weights=npy(w), g=npy(g), d_q=npy(q.grad), H=np.array(H), S=np.array(S),
+         T=np.array(T), **extra, **arrays)
+
+
+def gen_mha_all():
+    gen_mha_forward('mha_self_causal_T24', n=3, H=2, S=24, T=24, d=32, mask='causal', seed=90)
+    gen_mha_forward('mha_self_full_T16', n=2, H=2, S=16, T=16, d=32, mask=None, seed=91)
+    gen_mha_forward('mha_cross_anticausal_S6_T12', n=3, H=2, S=6, T=12, d=32, mask='anticausal', seed=92)
+
+
 def build_decoder(cfg, enc):
     dp = BachDataProcessor(embedding_size=cfg['dec_emb'], num_events=cfg['events'], num_tokens_per_channel=cfg['vocab'])
     nc = len(cfg['vocab'])
@@ -179,10 +219,14 @@ def gen_decoder_step(name, cfg, seed, lr=1e-3, logit_gain=1.0):
 
 
 if __name__ == '__main__':
+    if '--mha-only' in sys.argv:       # only the MultiheadAttentionCustom.forward fixtures
+        gen_mha_all()
+        sys.exit(0)
     gen_relbias_cross('relbias_cross_S3_T48', n=2, H=2, S=3, T=48, hd=8, seed=70)
     gen_relbias_cross('relbias_cross_S6_T12', n=3, H=3, S=6, T=12, hd=4, seed=71)
     gen_relbias_cross('relbias_cross_S40_T80', n=1, H=2, S=40, T=80, hd=8, seed=72)
     gen_decoder_layer('decoder_layer_S3_T48', n=3, H=2, S=3, T=48, d=32, ff=64, seed=73)
+    gen_mha_all()
     tiny = dict(emb=8, vocab=[11, 12, 13, 14], d=32, H=2, layers=[1, 1], ff=64, D=8, K=16, ncb=2, zdim=8, up_hidden=16,
                 events=12, B=3, Kl=2, Kr=2, dec_emb=8, dec_d=32, dec_H=2, dec_enc_layers=2, dec_dec_layers=2, dec_ff=64, dec_pos=4,
                 enc_attn='anticausal', cross_attn='anticausal')

@@ -1,11 +1,36 @@
-"""Parameter container of the reference's MultiheadAttentionCustom
-(VQCPCB/transformer/multihead_attention_custom.py:8-120): in_proj_weight/bias, out_proj, attn_bias.{e1,e2}, same
-names, shapes and initialisation.  The arithmetic of its forward (:122-353) lives in ops.EncoderLayerFn (encoder
-path) and, for the decoder's masked / cross attentions, in `forward_rows` below (ops.AttnXFn)."""
+"""The reference's MultiheadAttentionCustom (VQCPCB/transformer/multihead_attention_custom.py:8-353): in_proj_weight/bias,
+out_proj, attn_bias.{e1,e2} with the same names, shapes and initialisation, and `forward(query, key, value, ...,
+attn_mask=...)` with the same signature and return contract.  On the training paths the arithmetic lives in
+ops.EncoderLayerFn (encoder layers, fused) and in `forward_rows` below (decoder's masked / cross attentions, ops.AttnXFn);
+`forward` is the API-compatible entry for callers that reach below the trainers and runs the same kernels."""
 import torch
 from torch import nn
 
 from .subsampled_relative_attention import SubsampledRelativeAttention
+
+
+def classify_additive_mask(attn_mask):
+    """The additive (T, S) masks the reference builds (decoders/decoder.py:294-308: 0 = keep, -inf = masked; T = r S, every
+    source position repeated r times along the target axis) -> the index rule the attention kernels evaluate:
+    ops.MASK_CAUSAL keeps j <= i // r, ops.MASK_ANTICAUSAL keeps j >= i // r, an all-zero mask is ops.MASK_NONE.
+    Any other pattern raises NotImplementedError (the reference never builds one on the path).  One small host read."""
+    from .. import ops
+    assert attn_mask.dim() == 2, 'attn_mask: (target length, source length)'
+    T, S = attn_mask.shape
+    m = attn_mask.detach().to('cpu', torch.float32)
+    keep = m == 0
+    if not bool((keep | torch.isinf(m) & (m < 0)).all()):
+        raise NotImplementedError('attn_mask: only 0 / -inf additive masks are supported')
+    if bool(keep.all()):
+        return ops.MASK_NONE
+    if T % S == 0:
+        p = (torch.arange(T) // (T // S)).unsqueeze(1)
+        j = torch.arange(S).unsqueeze(0)
+        if torch.equal(keep, j <= p):
+            return ops.MASK_CAUSAL
+        if torch.equal(keep, j >= p):
+            return ops.MASK_ANTICAUSAL
+    raise NotImplementedError('attn_mask: not the causal / anticausal pattern of decoders/decoder.py:294-308')
 
 
 class MultiheadAttentionCustom(nn.Module):
@@ -47,3 +72,30 @@ class MultiheadAttentionCustom(nn.Module):
             q, kv = ops.CrossProjFn.apply(x, memory, self.in_proj_weight, self.in_proj_bias)
             att, probs = ops.AttnXFn.apply(q, kv, e1, e2, n, T, S, self.num_heads, mask, drop_p, seed)
         return ops.LinearFn.apply(att, self.out_proj.weight, self.out_proj.bias), probs
+
+    def forward(self, query, key, value, key_padding_mask=None, need_weights=True, attn_mask=None, static_k=None,
+                static_v=None):
+        """multihead_attention_custom.py:122-353.  query (L, N, E), key / value (S, N, E) time-first; self-attention when
+        the three are the same tensor, encoder-decoder attention when key is value (:154-196); attn_mask: additive (L, S)
+        matrix (0 / -inf) as built by decoders/decoder.py:294-308, or None.  -> (attn_output (L, N, E), attention weights
+        (N, H, L, S) -- per head, as the reference returns them -- or None)."""
+        from .. import ops
+        from ..utils import SEEDS
+        if key_padding_mask is not None or static_k is not None or static_v is not None:
+            raise NotImplementedError('key_padding_mask / static_k / static_v are not used on the path')
+        L, N, E = query.shape
+        assert E == self.embed_dim and key.shape == value.shape and key.shape[1:] == (N, E)
+        S = key.shape[0]
+        assert L == self.seq_len and S == self.seq_len_src, 'the relative-attention tables are tied to (seq_len_tgt, seq_len_src)'
+        qkv_same = query is key and key is value
+        if not qkv_same:
+            kv_same = key is value or torch.equal(key, value)
+            qkv_same = kv_same and query.shape == key.shape and torch.equal(query, key)      # :154-155, host syncs
+            if not kv_same:
+                raise NotImplementedError('key and value must be the same tensor (self- or encoder-decoder attention)')
+        mask = ops.MASK_NONE if attn_mask is None else classify_additive_mask(attn_mask)
+        p = self.dropout if self.training else 0.0
+        rows = query.transpose(0, 1).reshape(N * L, E)
+        memory = None if qkv_same else key.transpose(0, 1).reshape(N * S, E)
+        out, probs = self.forward_rows(rows, N, mask, memory=memory, drop_p=p, seed=SEEDS.next() if p > 0 else 0)
+        return out.view(N, L, E).transpose(0, 1), (probs if need_weights else None)

@@ -61,8 +61,8 @@ class TransformerEncoderLayerCustom(nn.Module):
 
     def forward(self, src, src_mask=None, src_key_padding_mask=None):
         """API-compatible entry: src (L, N, E) time-first -> (out (L, N, E), {'a_self_encoder': (N, H, L, L)}).
-        `src_mask`: None, or one of 'causal' / 'anticausal' (the reference passes the additive matrices of
-        decoders/decoder.py:292-308; here they are index rules evaluated inside the attention kernel)."""
+        `src_mask`: None, 'causal' / 'anticausal', or the additive (L, L) matrix the reference passes
+        (decoders/decoder.py:292-308) -- recognised as one of the two index rules the attention kernels evaluate."""
         assert src_key_padding_mask is None, 'key padding masks are not used on the path'
         L, N, E = src.shape
         rows = src.transpose(0, 1).reshape(N * L, E)
@@ -74,9 +74,13 @@ class TransformerEncoderLayerCustom(nn.Module):
 
 
 def mask_code(mask):
-    """'causal' / 'anticausal' / 'full' / None / ops.MASK_* -> ops.MASK_*."""
+    """'causal' / 'anticausal' / 'full' / None / ops.MASK_* / an additive (T, S) mask tensor as the reference builds them
+    (decoders/decoder.py:294-308: 0 where attention is allowed, -inf elsewhere) -> ops.MASK_*."""
     if isinstance(mask, int):
         return mask
+    if torch.is_tensor(mask):
+        from .multihead_attention_custom import classify_additive_mask
+        return classify_additive_mask(mask)
     table = {None: ops.MASK_NONE, 'full': ops.MASK_NONE, 'causal': ops.MASK_CAUSAL, 'anticausal': ops.MASK_ANTICAUSAL}
     if mask not in table:
         raise NotImplementedError(f'attention mask {mask!r}: pass "causal", "anticausal", "full" or None (additive mask '

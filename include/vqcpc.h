@@ -306,6 +306,17 @@ int vqcpc_gru_cell_fwd(const float* gi, const float* gh, const float* h_prev, fl
 int vqcpc_gru_cell_bwd(const float* gi, const float* gh, const float* h_prev, const float* d_y, const float* d_h, float* d_gi,
                        float* d_gh, float* d_hprev, int64_t B, int H, float drop_p, uint64_t seed, uint64_t idx_base,
                        void* stream);
+/* One launch per time step (recurrent product + gate arithmetic fused; H % 64 == 0 -- vqcpc_gru_step_supported):
+ * fwd: gh[B][3H] = h_prev W_hh^T + b_hh (h_prev NULL = zeros: gh = b_hh), then the cell of vqcpc_gru_cell_fwd on gi, gh;
+ * bwd (step t -> t-1): dh = dgh_next[B][3H] . whh_t[H][3H]^T + dhp[B][H] (+ d_y * mask), then the cell backward of step t-1
+ *      (gi, gh, h_prev of THAT step): d_gi, d_gh [B][3H]; dhp is overwritten with dh * u (the next launch's direct term).
+ * Replaces one vqcpc_gemm_nt + one gate launch (+ a split-K reduction) per step of nn.GRU (vqcpc_helper.py:54-76). */
+int vqcpc_gru_step_supported(int64_t B, int H);
+int vqcpc_gru_step_fwd(const float* gi, const float* w_hh, const float* b_hh, const float* h_prev, float* gh, float* h_out,
+                       float* y_out, int64_t B, int H, float drop_p, uint64_t seed, uint64_t idx_base, void* stream);
+int vqcpc_gru_step_bwd(const float* dgh_next, const float* whh_t, float* dhp, const float* gi, const float* gh,
+                       const float* h_prev, const float* d_y, float* d_gi, float* d_gh, int64_t B, int H, float drop_p,
+                       uint64_t seed, uint64_t idx_base, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Student (distilled VQ-VAE) step, SURVEY.md section 8 row A23.

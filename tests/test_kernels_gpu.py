@@ -865,10 +865,11 @@ def test_nce_golden(ops):
 
 
 @pytest.mark.parametrize('B,T,inp,hid,layers,p', [(5, 3, 8, 12, 2, 0.0), (256, 8, 32, 512, 2, 0.0), (7, 1, 16, 32, 1, 0.0),
-                                                  (33, 4, 32, 64, 3, 0.3)])
+                                                  (33, 4, 32, 64, 3, 0.3), (40, 5, 32, 128, 2, 0.2), (64, 2, 16, 192, 2, 0.0)])
 def test_gru_context_network(ops, B, T, inp, hid, layers, p):
-    """CModule on the library's own GRU (GEMMs + gate kernels) against the oracle's explicit recurrence, forward and
-    every gradient; with p > 0 the inter-layer dropout masks are reproduced through vqcpc_dropout_mask."""
+    """CModule on the library's own GRU (GEMMs + gate kernels; hid % 64 == 0: one fused launch per step, csrc/gru.hip)
+    against the oracle's explicit recurrence, forward and every gradient; with p > 0 the inter-layer dropout masks are
+    reproduced through vqcpc_dropout_mask."""
     from vqcpc_bach_amd.utils import SEEDS
     from vqcpc_bach_amd.vqcpc_helper import CModule
     gen = torch.Generator().manual_seed(B + T + hid)
@@ -1433,3 +1434,39 @@ def test_three_product_gradient_arithmetic(ops, bf16x6, kind, M, N, K, epi):
     assert e6 < 2.5e-6, e6                       # fp32-class (the TN contraction over 10^5 rows adds accumulation noise)
     assert 1e-6 < e3 < 1.2e-5, e3                # ~2^-17 per product: visibly not the six-product result, 500 x below bf16
     assert float((three.double() - ref).abs().max() / ref.abs().max()) < 2e-5
+
+
+def test_gru_fused_steps_equal_the_gemm_plus_gate_launches(ops):
+    """vqcpc_gru_step_fwd / _bwd (one launch per time step) against the same layer run as GEMM + gate launches: same values
+    up to the summation order of the fp32 recurrent product (both are exact-fp32 MFMA chains, split differently)."""
+    from vqcpc_bach_amd import hip
+    assert hip.query('vqcpc_gru_step_supported', 256, 512) == 1 and hip.query('vqcpc_gru_step_supported', 8, 96) == 0
+    gen = torch.Generator().manual_seed(5)
+    B, T, inp, hid = 200, 6, 32, 256
+    x0 = torch.randn(T * B, inp, generator=gen)
+    ws = [torch.randn(3 * hid, inp, generator=gen) * 0.2, torch.randn(3 * hid, hid, generator=gen) * 0.06,
+          torch.randn(3 * hid, generator=gen) * 0.1, torch.randn(3 * hid, generator=gen) * 0.1]
+    gout = torch.randn(T * B, hid, generator=gen)
+    res = {}
+    calls = []
+    raw = hip.call
+    hip.call = lambda name, *a: (calls.append(name), raw(name, *a))[1]
+    try:
+        for fused in (True, False):
+            ops.GRU_FUSED_STEPS = fused
+            calls.clear()
+            x = dev(x0).requires_grad_(True)
+            prm = [dev(w).requires_grad_(True) for w in ws]
+            y = ops.GRULayerFn.apply(x, prm[0], prm[1], prm[2], prm[3], T, 0.25, 77, False)
+            (y * dev(gout)).sum().backward()
+            res[fused] = [y.detach(), x.grad] + [w.grad for w in prm]
+            if fused:
+                assert calls.count('vqcpc_gru_step_fwd') == T and calls.count('vqcpc_gru_step_bwd') == T - 1
+                assert calls.count('vqcpc_gru_cell_fwd') == 0 and calls.count('vqcpc_gru_cell_bwd') == 1
+            else:
+                assert calls.count('vqcpc_gru_step_fwd') == 0 and calls.count('vqcpc_gru_cell_fwd') == T
+    finally:
+        hip.call = raw
+        ops.GRU_FUSED_STEPS = True
+    for a, b in zip(res[True], res[False]):
+        assert rel_err(a.cpu(), b.cpu()) < 2e-6

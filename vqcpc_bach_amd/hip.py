@@ -118,6 +118,10 @@ SIGNATURES = {
     'vqcpc_gru_cell_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64, c_ptr]),
     'vqcpc_gru_cell_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64,
                                    c_ptr]),
+    'vqcpc_gru_step_supported': (c_int, [c_i64, c_int]),
+    'vqcpc_gru_step_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64, c_ptr]),
+    'vqcpc_gru_step_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64,
+                                   c_u64, c_ptr]),
     'vqcpc_same_sequence_negatives': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr]),
     'vqcpc_softmax_ce': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_ptr]),
     'vqcpc_scale_rows': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_ptr]),

@@ -1046,6 +1046,9 @@ class DropoutSeluFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------------
 # A15: GRU layer of the context network (time-major rows: row = t * B + b)
 # ------------------------------------------------------------------------------------------------------------------
+GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)
+
+
 class GRULayerFn(torch.autograd.Function):
     """One nn.GRU layer with h0 = 0.  x (T*B, in) time-major -> y: all steps (T*B, H) with dropout(p) applied
     (last_only = False, feeds the next layer) or the last step only (B, H) (last_only = True, top layer).
@@ -1065,8 +1068,13 @@ class GRULayerFn(torch.autograd.Function):
         h = torch.empty(TB + B, H, dtype=torch.float32, device=dev)          # rows [t*B, (t+1)*B) = h_{t-1}; h_{-1} = 0
         h[:B].zero_()
         y = None if last_only else torch.empty(TB, H, dtype=torch.float32, device=dev)
+        fused = GRU_FUSED_STEPS and bool(hip.query('vqcpc_gru_step_supported', B, H)) and w_hh.is_contiguous()
         for t in range(T):
             sl = slice(t * B, (t + 1) * B)
+            if fused:      # ONE launch per step: recurrent product + gates (h_{-1} = 0: no product at t = 0)
+                hip.call('vqcpc_gru_step_fwd', gi[sl], w_hh, b_hh, h[sl] if t > 0 else None, gh[sl],
+                         h[(t + 1) * B:(t + 2) * B], None if y is None else y[sl], B, H, p, int(seed), t * B * H)
+                continue
             gemm_nt(h[sl], w_hh, bias=b_hh, out=gh[sl])
             hip.call('vqcpc_gru_cell_fwd', gi[sl], gh[sl], h[sl], h[(t + 1) * B:(t + 2) * B],
                      None if y is None else y[sl], B, H, p, int(seed), t * B * H)
@@ -1086,11 +1094,18 @@ class GRULayerFn(torch.autograd.Function):
         whh_t = transpose(w_hh)                                              # (H, 3H): dgrad operand
         dh = None
         dhp = torch.empty(B, H, dtype=torch.float32, device=dev)
+        fused = GRU_FUSED_STEPS and bool(hip.query('vqcpc_gru_step_supported', B, H))
         for t in range(T - 1, -1, -1):
             sl = slice(t * B, (t + 1) * B)
             d_y = (g if t == T - 1 else None) if last_only else g[sl]
+            if fused and t < T - 1:
+                # ONE launch per step: d h_t = dgh_{t+1} W_hh + dh_{t+1} * u_{t+1} (in dhp), then the cell backward of step t
+                nx = slice((t + 1) * B, (t + 2) * B)
+                hip.call('vqcpc_gru_step_bwd', dgh[nx], whh_t, dhp, gi[sl], gh[sl], h[sl] if t > 0 else None, d_y, dgi[sl],
+                         dgh[sl], B, H, p, seed, t * B * H)
+                continue
             hip.call('vqcpc_gru_cell_bwd', gi[sl], gh[sl], h[sl], d_y, dh, dgi[sl], dgh[sl], dhp, B, H, p, seed, t * B * H)
-            if t > 0:
+            if t > 0 and not fused:
                 dh = gemm_nt(dgh[sl], whh_t, add=dhp)                        # d h_{t-1} = dgh W_hh + dh * u
         b_ih, b_hh = ctx.biases
         dw_hh, db_hh = wgrad(dgh, h[:T * B], w_hh, b_hh)                     # step 0 multiplies the zero rows h_{-1}

@@ -1470,3 +1470,40 @@ def test_gru_fused_steps_equal_the_gemm_plus_gate_launches(ops):
         ops.GRU_FUSED_STEPS = True
     for a, b in zip(res[True], res[False]):
         assert rel_err(a.cpu(), b.cpu()) < 2e-6
+
+
+@pytest.mark.parametrize('M,N,K', [(65536, 256, 256), (131072, 1024, 256), (557056, 256, 512)])
+def test_gemm_tn_quad_row_lds_image_is_bit_identical_to_the_row_pair_image(ops, bf16x6, M, N, K):
+    """gemm_tn_x6_pq_kernel (four consecutive rows per staging thread, fragments by two ds_read_b64) against
+    gemm_tn_x6_pp_kernel (row pairs, two ds_read2_b32): the same products in the same order, so the weight gradient is
+    bit-identical (the bias sums are accumulated four rows at a time instead of two: fp32-rounding apart); also in the
+    opt-in three-product gradient arithmetic."""
+    import os
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M // 1000 + N + K)
+    a, b = torch.randn(M, N, device='cuda', generator=gen), torch.randn(M, K, device='cuda', generator=gen)
+    saved = os.environ.get('VQCPC_TN_PQ')
+    res = {}
+    try:
+        for pq in ('0', '1'):
+            os.environ['VQCPC_TN_PQ'] = pq
+            dw, db = ops.gemm_tn(a, b)
+            hip.set_gradient_products(3)
+            hip.gradient_scope(True)
+            try:
+                dw3, _ = ops.gemm_tn(a, b)
+            finally:
+                hip.gradient_scope(False)
+                hip.set_gradient_products(6)
+            res[pq] = (dw, db, dw3)
+    finally:
+        if saved is None:
+            os.environ.pop('VQCPC_TN_PQ', None)
+        else:
+            os.environ['VQCPC_TN_PQ'] = saved
+    assert torch.equal(res['0'][0], res['1'][0]), 'weight gradient: same products, same order'
+    assert torch.equal(res['0'][2], res['1'][2])
+    assert rel_err(res['1'][1].cpu(), res['0'][1].cpu()) < 1e-6
+    ref = a.double().t() @ b.double()
+    assert rel_err(res['1'][0].cpu(), ref.cpu()) < 3e-6
+    assert rel_err(res['1'][1].cpu(), a.double().sum(0).cpu()) < 3e-6

@@ -1,15 +1,15 @@
 #!/bin/bash
 # Round profiles on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03
 # kernel-trace summaries of the bench command for every measured configuration + the two PMC passes (FETCH_SIZE, WRITE_SIZE;
 # counters in their own runs, kernel trace only) for the HBM traffic of the GEMM launches.  Raw output: gpurun_out/<tag>/.
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-kernel-timing"
+COMMON="--no-cpu-baseline --no-kernel-timing --no-live-pmc"
 run_trace() {   # name, bench args
     local name=$1; shift
     rm -rf /tmp/prof_$name

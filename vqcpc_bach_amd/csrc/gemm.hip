@@ -1426,6 +1426,221 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pp_kernel(const floa
     }
 }
 
+// gemm_tn_x6_pp_kernel with a different LDS image (same products in the same order => bit-identical partial sums).
+// Counters (tools/pmc_compare.py, profiles/r03_gemm_tn_lds.txt): per wave and 16-row step the kernel above spends 192 LDS-array
+// cycles (36 ds_read2_b32 at 4 cycles + 6 ds_write_b128) against 113 in the NT kernel (18 ds_read_b128 + 12 ds_write_b64), and
+// 400 instead of 250 cycles stalled on LDS issue -- the row-pair image makes every fragment four separate dwords.  Here a
+// thread stages FOUR consecutive rows of four columns of ONE operand (waves 0-3: A, waves 4-7: B; 16-byte row loads as
+// before), so the four m-values of a column are 8 contiguous bytes, and the image is [plane][col & 3][m >> 3][(m >> 2) & 1]
+// [col >> 2] x 8 bytes (+64 B per col & 3 block): a fragment is two ds_read_b64 (2 LDS cycles each, conflict-free: the 32
+// lanes of a group read 4 x 64 contiguous bytes in 4 distinct bank windows), the 12 ds_write_b64 of a thread are 512
+// contiguous bytes per wave instruction.
+template <int NP>
+__global__ __launch_bounds__(kT2Threads, 2) void gemm_tn_x6_pq_kernel(const float* __restrict__ A, int64_t lda,
+                                                                      const float* __restrict__ B, int64_t ldb, int64_t M,
+                                                                      int N, int K, int tiles_k, int64_t rows_per_split,
+                                                                      float* __restrict__ ws, float* __restrict__ ws_bias) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    // (tile, split) of this workgroup.  The output tiles of ONE split read the same rows of A and B (they differ in the
+    // column tile of one operand only); in dispatch order (x fastest) they would land on different XCDs, i.e. behind
+    // different L2s, and every shared row would be fetched once per tile: 1.6 x the algorithmic HBM bytes.  Remapped so that
+    // the tiles of a split are neighbours on one XCD (workgroup L of the linearised grid runs on XCD L % 8).
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.x > 1 && gridDim.y % 8 == 0) {
+        const int L = by * (int)gridDim.x + bx;
+        const int j = L >> 3;
+        bx = j % (int)gridDim.x;
+        by = (j / (int)gridDim.x) * 8 + (L & 7);
+    }
+    const int tn = bx / tiles_k, tk = bx % tiles_k;
+    const int n0 = tn * kT2, k0 = tk * kT2;
+    const int64_t m_begin = (int64_t)by * rows_per_split;
+    const int64_t m_end = min(m_begin + rows_per_split, M);          // (m_end - m_begin) % 32 == 0 (host)
+    const bool want_bias = (ws_bias != nullptr) && tk == 0;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // staging: thread = (operand, row quad rq of 4, column quad c4 of 64): rows 4rq .. 4rq+3 of the 16-row step
+    const int c4 = (tid & 63) * 4, rq = (tid >> 6) & 3, opnd = tid >> 8;          // opnd is uniform per wave group
+    const int64_t ld_s = opnd ? ldb : lda;
+    const float* s_src = (opnd ? B + k0 : A + n0) + (m_begin + 4 * rq) * ld_s + c4;
+    float4 x0, x1, x2, x3;
+    constexpr int kPQES = 2048 + 64;                  // bytes per (col & 3) block: [m >> 3][(m >> 2) & 1][64 slots] x 8 B, + 64 B
+    constexpr int kPQPlane = 4 * kPQES;               // 8448 B
+    const int st_off = opnd * NP * kPQPlane + (rq >> 1) * 1024 + (rq & 1) * 512 + (c4 >> 2) * 8;
+#define W2_LOAD(S, MM)                                                                   \
+    S##0 = *reinterpret_cast<const float4*>(s_src + (int64_t)(MM) * ld_s);               \
+    S##1 = *reinterpret_cast<const float4*>(s_src + (int64_t)((MM) + 1) * ld_s);         \
+    S##2 = *reinterpret_cast<const float4*>(s_src + (int64_t)((MM) + 2) * ld_s);         \
+    S##3 = *reinterpret_cast<const float4*>(s_src + (int64_t)((MM) + 3) * ld_s);
+#define PQ_COL(S, E, EI, BUFP)                                                           \
+    {                                                                                    \
+        uint2 h_, m_, l_;                                                                \
+        if constexpr (NP == 2) {                                                         \
+            split2_pair((S##0).E, (S##1).E, h_.x, m_.x);                                     \
+            split2_pair((S##2).E, (S##3).E, h_.y, m_.y);                                     \
+        } else {                                                                         \
+            uint32_t h0_, m0_, l0_, h1_, m1_, l1_;                                       \
+            split3((S##0).E, h0_, m0_, l0_);                                               \
+            split3((S##1).E, h1_, m1_, l1_);                                               \
+            h_.x = pack_hi(h0_, h1_); m_.x = pack_hi(m0_, m1_); l_.x = pack_hi(l0_, l1_); \
+            split3((S##2).E, h0_, m0_, l0_);                                               \
+            split3((S##3).E, h1_, m1_, l1_);                                               \
+            h_.y = pack_hi(h0_, h1_); m_.y = pack_hi(m0_, m1_); l_.y = pack_hi(l0_, l1_); \
+        }                                                                                \
+        unsigned char* d_ = (BUFP) + st_off + (EI) * kPQES;                              \
+        *reinterpret_cast<uint2*>(d_ + 0 * kPQPlane) = h_;                               \
+        *reinterpret_cast<uint2*>(d_ + 1 * kPQPlane) = m_;                               \
+        if constexpr (NP == 3) *reinterpret_cast<uint2*>(d_ + 2 * kPQPlane) = l_;        \
+    }
+#define W2_STORE(S, BUFP)                                                                \
+    {                                                                                    \
+        PQ_COL(S, x, 0, BUFP) PQ_COL(S, y, 1, BUFP) PQ_COL(S, z, 2, BUFP) PQ_COL(S, w, 3, BUFP) \
+        if (want_bias && store_counts && opnd == 0) {                                    \
+            bsum.x += ((S##0).x + (S##1).x) + ((S##2).x + (S##3).x);                             \
+            bsum.y += ((S##0).y + (S##1).y) + ((S##2).y + (S##3).y);                             \
+            bsum.z += ((S##0).z + (S##1).z) + ((S##2).z + (S##3).z);                             \
+            bsum.w += ((S##0).w + (S##1).w) + ((S##2).w + (S##3).w);                             \
+        }                                                                                \
+    }
+#define W2_FRAG(DST, BASE)                                                               \
+    {                                                                                    \
+        uint4 u_;                                                                        \
+        u_.x = *reinterpret_cast<const uint32_t*>(BASE);                                 \
+        u_.y = *reinterpret_cast<const uint32_t*>((BASE) + kW2RS);                       \
+        u_.z = *reinterpret_cast<const uint32_t*>((BASE) + 2 * kW2RS);                   \
+        u_.w = *reinterpret_cast<const uint32_t*>((BASE) + 3 * kW2RS);                   \
+        DST = __builtin_bit_cast(bf16x8, u_);                                            \
+    }
+    // all 18 fragments of a 16-row step: 72 x ds_read_b32 in the memory phase (a[tile 0..3][plane], b[plane][tile 0..1])
+    bf16x8 fa[4][NP], fb[NP][2];
+    // LDS image of this kernel: plane = 4 column blocks of 64 columns, each [8 row pairs][64 + 4 dwords]: the four dwords of
+    // a fragment (row pairs 4 kh .. 4 kh + 3 of one column) are 68 dwords apart, so TWO ds_read2_b32 fetch a fragment
+    // straight into its four consecutive registers (36 reads per phase).  With the 256-column rows of the lockstep kernel
+    // the dwords are 260 apart, out of ds_read2's reach: hipcc paired other dwords and needed 54 v_mov + 28 v_add per
+    // phase to re-assemble the operands.  Inline asm (one base register per operand and plane, 8-bit dword offsets).
+#define TP_FRAG_ASM(DST, ADDR, OFF)                                                                                       \
+    {                                                                                                                     \
+        unsigned long long p0_, p1_;                                                                                      \
+        asm volatile("ds_read_b64 %0, %2 offset:%3\n\tds_read_b64 %1, %2 offset:%4"                                      \
+                     : "=&v"(p0_), "=&v"(p1_) : "v"(ADDR), "n"(OFF), "n"((OFF) + 512));                                   \
+        const u32x4 u_ = {(unsigned)p0_, (unsigned)(p0_ >> 32), (unsigned)p1_, (unsigned)(p1_ >> 32)};                    \
+        DST = __builtin_bit_cast(bf16x8, u_);                                                                             \
+    }
+    // fragment of output row / column n (lane li within a 32-tile): block (n & 3) = li & 3, slot n >> 2, half by the offset
+#define TP_READ_FRAGS(BUFP)                                                                                               \
+    {                                                                                                                     \
+        const unsigned base_ = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)(BUFP) +            \
+                               (li & 3) * kPQES + kh * 1024 + (li >> 2) * 8;                                              \
+        _Pragma("unroll") for (int pc = 0; pc < NP; ++pc) {                                                               \
+            const unsigned bb_ = base_ + (NP + pc) * kPQPlane + wn * 128;                                                 \
+            TP_FRAG_ASM(fb[pc][0], bb_, 0)                                                                                \
+            TP_FRAG_ASM(fb[pc][1], bb_, 64)                                                                               \
+            const unsigned ab_ = base_ + pc * kPQPlane + wm * 256;                                                        \
+            TP_FRAG_ASM(fa[0][pc], ab_, 0)                                                                                \
+            TP_FRAG_ASM(fa[1][pc], ab_, 64)                                                                               \
+            TP_FRAG_ASM(fa[2][pc], ab_, 128)                                                                              \
+            TP_FRAG_ASM(fa[3][pc], ab_, 192)                                                                              \
+        }                                                                                                                 \
+    }
+#define TP_TERM(PA, PB)                                                                                                   \
+    _Pragma("unroll") for (int t4 = 0; t4 < 4; ++t4) {                                                                    \
+        acc[t4][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t4][PA], fb[PB][0], acc[t4][0], 0, 0, 0);                 \
+        acc[t4][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[t4][PA], fb[PB][1], acc[t4][1], 0, 0, 0);                 \
+    }
+#define TP_MFMA() if constexpr (NP == 2) { TP_TERM(1, 0) TP_TERM(0, 1) TP_TERM(0, 0) } else { TP_TERM(NP - 1, 0) TP_TERM(0, NP - 1) TP_TERM(1, 1) TP_TERM(1, 0) TP_TERM(0, 1) TP_TERM(0, 0) }
+#define TP_BARRIER()                          \
+    __builtin_amdgcn_sched_barrier(0);        \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); \
+    __builtin_amdgcn_sched_barrier(0);
+    // one phase pair for step s: RB_ holds step s, WB_ receives step s+1 (held by the raw set, requested one phase pair
+    // ago), then the raw set is refilled with step s+2 (past the end: the last step again, never used)
+#define TP_PHASES(RB_, WB_)                                                       \
+    {                                                                             \
+        TP_READ_FRAGS(RB_)                                                        \
+        store_counts = st + 1 < nsteps;                                           \
+        W2_STORE(x, WB_)                                                          \
+        {                                                                         \
+            const int64_t nx_ = min((int64_t)(st + 2), nsteps - 1) * kW2TM;       \
+            W2_LOAD(x, nx_)                                                       \
+        }                                                                         \
+        TP_BARRIER()                                                              \
+        __builtin_amdgcn_s_setprio(1);                                            \
+        TP_MFMA()                                                                 \
+        __builtin_amdgcn_s_setprio(0);                                            \
+        TP_BARRIER()                                                              \
+        ++st;                                                                     \
+    }
+
+    unsigned char* const buf0 = smemw;
+    unsigned char* const buf1 = smemw + 2 * NP * kPQPlane;
+    const int64_t rows = m_end - m_begin;                     // multiple of 32: an even number of 16-row steps
+    const int64_t nsteps = rows / kW2TM;
+    if (rows > 0) {
+        // the bias sums must count every row exactly once: steps 0 .. nsteps-1 are stored once each (the store of the
+        // clamped "step nsteps" in the last phase is skipped for the sums)
+        int64_t st = 0;
+        bool store_counts = true;
+        W2_LOAD(x, 0)
+        W2_STORE(x, buf0)
+        W2_LOAD(x, min((int64_t)1, nsteps - 1) * kW2TM)
+        TP_BARRIER()
+        if (wm == 1) { TP_BARRIER() }                        // group 1 falls one phase behind
+#pragma unroll 1
+        while (st < nsteps) {
+            TP_PHASES(buf0, buf1)
+            TP_PHASES(buf1, buf0)
+        }
+        if (wm == 0) { TP_BARRIER() }                        // pairs with group 1's last barrier
+    }
+#undef TP_PHASES
+#undef TP_BARRIER
+#undef TP_MFMA
+#undef TP_TERM
+#undef TP_READ_FRAGS
+#undef TP_FRAG_ASM
+#undef W2_LOAD
+#undef W2_STORE
+#undef PQ_COL
+#undef W2_FRAG
+
+    float* out = ws + (int64_t)by * N * K;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = k0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(int64_t)row * K + col] = acc[mt][nt][r];
+            }
+        }
+    }
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smemw);          // [4 row quads][256]
+        if (opnd == 0) *reinterpret_cast<float4*>(red + rq * kT2 + c4) = bsum;
+        __syncthreads();
+        if (tid < kT2) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) tot += red[g * kT2 + tid];
+            ws_bias[(int64_t)by * N + n0 + tid] = tot;
+        }
+    }
+}
+
 // GEMM arithmetic mode: 0 = fp32 MFMA (exact fp32), 1 = bf16x6 split on the bf16 MFMA (fp32-class accuracy, 2.67x rate),
 // 2 = plain bf16 operands (one MFMA per product, fp32 accumulate; BASELINE configs[4] names bf16): 128-tile kernels only.
 // Initialised from VQCPC_GEMM_MODE, changeable through vqcpc_gemm_set_mode().
@@ -1945,19 +2160,35 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         const int tk2 = K / kT2;
         if (g_use_pp.load(std::memory_order_relaxed)) {
             static bool attr_pp = false;
+            constexpr int kPQBuf3 = 2 * 6 * 4 * (2048 + 64), kPQBuf2 = 2 * 4 * 4 * (2048 + 64);       // gemm_tn_x6_pq_kernel images
             if (!attr_pp) {
                 (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pp_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           2 * kTPBuf);
                 (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pp_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                           2 * 4 * kTPPlane);
+                (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pq_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kPQBuf3);
+                (void)hipFuncSetAttribute((const void*)gemm_tn_x6_pq_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          kPQBuf2);
                 attr_pp = true;
             }
-            if (gradient_products_now() == 3)          // opt-in gradient arithmetic, inside a gradient scope only
-                hipLaunchKernelGGL(gemm_tn_x6_pp_kernel<2>, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * 4 * kTPPlane, s,
-                                   A, lda, B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
+            // A/B switch: VQCPC_TN_PQ=0 keeps the row-pair LDS image of gemm_tn_x6_pp_kernel
+            const char* pq_env = getenv("VQCPC_TN_PQ");          // read per launch: tests flip it inside one process
+            const bool use_pq = !(pq_env && pq_env[0] == '0');
+            const dim3 g_((N / kT2) * tk2, splits), b_(kT2Threads);
+            if (gradient_products_now() == 3) {        // opt-in gradient arithmetic, inside a gradient scope only
+                if (use_pq)
+                    hipLaunchKernelGGL(gemm_tn_x6_pq_kernel<2>, g_, b_, kPQBuf2, s, A, lda, B, ldb, M, N, K, tk2, rows_per_split,
+                                       ws, ws_bias);
+                else
+                    hipLaunchKernelGGL(gemm_tn_x6_pp_kernel<2>, g_, b_, 2 * 4 * kTPPlane, s, A, lda, B, ldb, M, N, K, tk2,
+                                       rows_per_split, ws, ws_bias);
+            } else if (use_pq)
+                hipLaunchKernelGGL(gemm_tn_x6_pq_kernel<3>, g_, b_, kPQBuf3, s, A, lda, B, ldb, M, N, K, tk2, rows_per_split, ws,
+                                   ws_bias);
             else
-            hipLaunchKernelGGL(gemm_tn_x6_pp_kernel<3>, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kTPBuf, s, A, lda,
-                               B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
+                hipLaunchKernelGGL(gemm_tn_x6_pp_kernel<3>, g_, b_, 2 * kTPBuf, s, A, lda, B, ldb, M, N, K, tk2, rows_per_split,
+                                   ws, ws_bias);
         } else
         hipLaunchKernelGGL(gemm_tn_x6_256_kernel, dim3((N / kT2) * tk2, splits), dim3(kT2Threads), 2 * kW2Buf, s, A, lda, B,
                            ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);

@@ -28,6 +28,10 @@ def main():
     cases = [('NT 557056 x 256 x 1024', 'one_gemm.py', [256, 1024], {'VQCPC_ONE_GEMM_MODE': '1'}, ['gemm_nt_x6_'], 1024 // 16 * (M // 256) * 1 / 256.0),
              ('TN row-pair image (pp)', 'one_gemm_tn.py', [1024, 256], {'VQCPC_TN_MODE': '1', 'VQCPC_TN_PQ': '0'}, ['gemm_tn_x6_p'], M / 16.0 * 4 / 256.0),
              ('TN quad-row image (pq)', 'one_gemm_tn.py', [1024, 256], {'VQCPC_TN_MODE': '1', 'VQCPC_TN_PQ': '1'}, ['gemm_tn_x6_p'], M / 16.0 * 4 / 256.0)]
+    if os.environ.get('PMC_COMPARE') == 'nt':       # the output-tile epilogue: K = 256 (16 steps per tile) against K = 1024 (64)
+        cases = [('NT 557056 x 256 x 1024', 'one_gemm.py', [256, 1024], {'VQCPC_ONE_GEMM_MODE': '1'}, ['gemm_nt_x6_'], 544.0),
+                 ('NT 557056 x 1024 x 256', 'one_gemm.py', [1024, 256], {'VQCPC_ONE_GEMM_MODE': '1'}, ['gemm_nt_x6_'], 544.0),
+                 ('NT 1024 x 256, no stores (ABL 32)', 'one_gemm.py', [1024, 256], {'VQCPC_ONE_GEMM_MODE': '1', 'VQCPC_PP_ABL': '32'}, ['gemm_nt_x6_'], 544.0)]
     res = {}
     for label, script, args, env, match, steps_per_wg in cases:
         r = {}

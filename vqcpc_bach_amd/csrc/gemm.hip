@@ -1845,7 +1845,9 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
     if (t2_ok) {
         const int tn2 = N / kT2;
         const int tiles2 = (int)((M / kT2) * tn2);
-        const dim3 grid2((unsigned)std::min(tiles2, kNumCU)), block2(kT2Threads);
+        // VQCPC_PP_GRID (measurement only): fewer persistent workgroups than CUs, to tell a per-CU store limit from a chip-wide burst
+        static const int grid_cap = getenv("VQCPC_PP_GRID") ? atoi(getenv("VQCPC_PP_GRID")) : kNumCU;
+        const dim3 grid2((unsigned)std::min(tiles2, grid_cap)), block2(kT2Threads);
         // the gate epilogue (relu / dropout backward: reads an M x N operand, N = 4 K) is HBM-bound; all eight waves storing
         // together (lockstep kernel) keep more bytes in flight than one wave group at a time: 0.92 vs 1.21 ms at C1
         const bool use_pp = g_use_pp.load(std::memory_order_relaxed) != 0 && flags != E_GATE;

@@ -66,6 +66,8 @@ def parse():
                     help='opt-in gradient arithmetic of the bf16x6 mode (include/vqcpc.h): 3 = two rounded bf16 planes and three '
                          'MFMAs per product in the input- / weight-gradient GEMMs (~2^-17 per product); the forward, the losses '
                          'and the code assignment are unaffected.  Default 6 = the exact split everywhere (the headline)')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the extra (non-headline) measurement of the opt-in three-product gradient arithmetic')
     ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM times of the sampled steps, to stderr')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -223,7 +225,7 @@ def live_pmc(args, B, timeout_s=100):
     inner = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(steps), '--warmup', str(warm),
              '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-products',
              str(args.grad_products), '--no-graph',
-             '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc']
+             '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc', '--no-extras']
     out = {'steps': n_steps}
     tmp = tempfile.mkdtemp(prefix='vqcpc_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
@@ -579,6 +581,37 @@ def main():
         graphs_per_step = 2 if (g is not None and g.finish_fn is not None) else 1
         trainer.enable_step_graph(False)
         timed_steps = max(1, sampled_eager_steps)
+    # Extra, NOT the headline: the same steps with the opt-in three-product gradient arithmetic (include/vqcpc.h), measured
+    # after the timed region so that it cannot touch `value`.  Forward (losses, code assignment) identical; gradients carry
+    # ~2^-17 per product instead of ~2^-24.  Under the socket's power cap the MFMA count is what the GEMM rate follows
+    # (profiles/r03_gemm_power_limit.txt), so this is the measured price of the exact split in the backward pass.
+    extra_g3 = None
+    if (gemm_mode == 1 and args.grad_products == 6 and not args.no_extras and args.config == 'C1' and dp.world_size == 1
+            and not args.host_inputs):
+        try:
+            hip.set_gradient_products(3)
+            if use_graph:
+                trainer.enable_step_graph(True)
+                trainer._graph_eager_steps = 0
+            n3 = min(args.steps, 20)
+            for b in batches(6, False):
+                trainer.train_step(b, train=True)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            m3 = run_epoch(n3, False)
+            torch.cuda.synchronize()
+            dt3 = time.perf_counter() - t0
+            extra_g3 = {'value': round(B * n3 / dt3, 2), 'unit': 'windows/s', 'ms_per_step': round(1e3 * dt3 / n3, 3), 'steps': n3,
+                        'final_loss': round(float(m3['loss']), 5),
+                        'note': 'NOT the headline: input- and weight-gradient GEMMs with two rounded bf16 planes and three MFMAs '
+                                'per product (hip.set_gradient_products(3) / bench.py --grad-products 3); forward, losses and code '
+                                'assignment unchanged, gradient rms error 4.4e-6 instead of 5e-7 (tools/bench_grad3.py)'}
+        except Exception as e:                        # never lose the headline line to the extra
+            extra_g3 = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+        finally:
+            hip.set_gradient_products(args.grad_products)
+            if use_graph:
+                trainer.enable_step_graph(False)
     pmc = None
     want_pmc = args.live_pmc if args.live_pmc is not None else (dp.world_size == 1 and args.config == 'C1' and not args.host_inputs)
     if want_pmc and dp.rank == 0 and dp.world_size == 1:
@@ -635,6 +668,12 @@ def main():
                             # the clock the kernels actually run at: GRBM_GUI_ACTIVE / kernel wall time (live PMC pass); the
                             # sysfs value in `clock` is NOT it (profiles/r03_gemm_clock.txt: 1.4-1.5 GHz vs 1.9 in sysfs)
                             effective_clock_mhz=eff_mhz, mfma_pipe_busy_at_effective_clock=pipe_busy,
+                            effective_clock_note=('GRBM_GUI_ACTIVE / 8 XCDs / kernel wall time over the gemm_nt launches >= 0.2 ms of '
+                                                  'the live PMC pass; counter collection serialises the kernels (idle gaps, lower '
+                                                  'average power), so this is an UPPER bound of the clock inside the graph-replayed '
+                                                  'step: the same kernels launched back to back sustain 1.39-1.45 GHz '
+                                                  '(profiles/r03_gemm_clock.txt), and 1.44 TFLOP/s per CU on 32-64 CUs against 0.845 on '
+                                                  '256: the chip is power-limited (profiles/r03_gemm_power_limit.txt)') if eff_mhz else None,
                             frac_at_measured_sclk=(round(nt['tflops'] / (peak * eff_mhz / 2400.0), 4) if eff_mhz else None),
                             frac_at_sysfs_sclk=(round(nt['tflops'] / (peak * clock_info['sclk_mhz_median'] / 2400.0), 4)
                                                 if clock_info else None),
@@ -682,6 +721,8 @@ def main():
                                 'host_enqueue_ms_per_step': round(1e3 * t_enqueued / n_host, 3),
                                 'note': 'same steps without epoch()\'s metric bookkeeping; not the metric'},
         }
+        if extra_g3 is not None:
+            line['extra_gradient_products_3'] = extra_g3
         if student:     # BASELINE configs[3]: an extra measurement, not the headline metric
             line['metric'], line['unit'] = 'student-train sequences/sec (Bach 4-voice, 24 beats = 384 tokens)', 'sequences/s'
             tk, dk = config['auxiliary_networks_kwargs']['teacher_kwargs'], config['downscaler_kwargs']

@@ -1766,7 +1766,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_nt_skinny_kernel(const float* __
 
 static bool skinny_ok(int64_t M, int N, int K, int flags, int* nw) {
     if (flags & ~(E_BIAS | E_ADD)) return false;
-    if (M > 1024 || ceil_div(M, BM) * ceil_div(N, BN) >= 128) return false;     // enough big tiles: use them
+    // narrow outputs (N <= 64: output_linear to the codebook dimension, the upscaler's second layer, d x of the first GRU layer):
+    // a 128-wide tile computes 2-4x the columns that exist and leaves one workgroup per 128 rows to walk K alone
+    // (34 816 x 32 x 512: 69 us, 2048 x 32 x 1536: 115 us); 32 x 32 tiles with the K range over the waves: 3-6x faster
+    const bool narrow = N <= 64 && K >= 128 && M <= (1 << 21);          // gridDim.y = M / 32
+    if (!narrow && (M > 1024 || ceil_div(M, BM) * ceil_div(N, BN) >= 128)) return false;     // enough big tiles: use them
     *nw = K >= 1024 ? 8 : 4;
     return K % (8 * *nw) == 0;
 }

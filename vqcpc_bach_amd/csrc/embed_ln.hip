@@ -258,12 +258,12 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                 o.z = rs * (gy[it].z - m1 - xh[it].z * m2);
                 o.w = rs * (gy[it].w - m1 - xh[it].w * m2);
                 nt_store4(d_s + row * d + col, o);
-                if (MASKED && d_r != nullptr) {
+                if (MASKED && (d_r != nullptr || dr_b16 != nullptr)) {
                     o.x *= msk[it].x;
                     o.y *= msk[it].y;
                     o.z *= msk[it].z;
                     o.w *= msk[it].w;
-                    nt_store4(d_r + row * d + col, o);
+                    if (d_r != nullptr) nt_store4(d_r + row * d + col, o);      // bf16 path: only the bf16 copy is consumed
                 }
                 // bf16 copy of the gradient of the sub-layer output r (= d_s when there is no dropout): GEMM operand
                 if (dr_b16) *reinterpret_cast<uint2*>(dr_b16 + row * d + col) = round4_bf16(o);
@@ -593,7 +593,7 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
     if (r)
         hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
                            d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
-    else if (thr && d_r)     // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
+    else if (thr && (d_r || d_r_bf16))     // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
         hipLaunchKernelGGL((add_ln_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd,
                            d_s, d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
     else

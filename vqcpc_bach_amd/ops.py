@@ -692,7 +692,8 @@ class EncoderLayerFn(torch.autograd.Function):
         def ln_bwd(dyv, xin, ldxin, r, gamma, mean, rstd, seed):
             # r None: xin is the residual sum itself (s-form, include/vqcpc.h); the mask of d_r is regenerated from `seed`
             ds = torch.empty(Mq, d, dtype=torch.float32, device=dev)
-            dr = torch.empty(Mq, d, dtype=torch.float32, device=dev) if p > 0 else None
+            # bf16 path: the gradient of the sub-layer output only feeds GEMMs, which read its bf16 copy -> no fp32 d_r stream
+            dr = torch.empty(Mq, d, dtype=torch.float32, device=dev) if (p > 0 and not nat) else None
             drb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None    # GEMM-operand copy of dr
             dg = torch.empty(d, dtype=torch.float32, device=dev)
             db = torch.empty(d, dtype=torch.float32, device=dev)
@@ -700,7 +701,7 @@ class EncoderLayerFn(torch.autograd.Function):
             ws = hip.workspace(nbytes, dev)
             hip.call('vqcpc_add_layernorm_bwd_b16', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed,
                      ws, nbytes)
-            return ds, (dr if dr is not None else ds), dg, db, drb
+            return ds, (dr if dr is not None else (None if (nat and p > 0) else ds)), dg, db, drb
 
         ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, mean2, rstd2, s[3])
         lin = gemm_nt_bf16 if nat else gemm_nt

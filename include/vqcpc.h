@@ -159,6 +159,17 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
  * token r of a block = tokens[r] * L + r); the kernels read them through the token indirection from the L2-resident
  * table instead of a gathered (n_blocks * L, 3d) copy.  d_qkv is still per token (its segment sum is the table gradient:
  * vqcpc_block_table_segsum).  L in {16, 4} only; workspace = vqcpc_relattn_bwd_workspace. */
+/* bf16-output forms of the L = 16 attention for the bf16 training path (configs[4]): the attention context (forward) and the
+ * gradient of the in_proj output (backward) only feed GEMMs there, which read bf16 from HBM; the kernels round to nearest even
+ * on the way out instead of writing fp32 for a cast pass.  ctx_b16 [n_blocks*16][ldo], d_qkv_b16 [n_blocks*16][ldg] bf16
+ * (leading dimensions in elements); tokens non-NULL: qkv is the first layer's block table.  Workspace of vqcpc_relattn_bwd. */
+int vqcpc_relattn16_b16_supported(int L, int H, int hd);
+int vqcpc_relattn16_fwd_b16(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, void* ctx_b16,
+                            int64_t ldo, float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* stream);
+int vqcpc_relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens,
+                            const float* probs, const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* d_e1,
+                            float* d_e2, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                            int64_t workspace_bytes, void* stream);
 int vqcpc_relattn_tab_fwd(const float* table, int64_t ldt, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
                           int64_t ldo, float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed,
                           void* stream);

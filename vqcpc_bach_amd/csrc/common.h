@@ -114,5 +114,10 @@ int relattn16_fwd(const float* qkv, int64_t ldq, const int64_t* tokens, const fl
 int relattn16_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens, const float* probs,
                   const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* ws, int64_t n_blocks, int H, int hd,
                   float drop_p, uint64_t seed, hipStream_t s, int* nsplit);
+int relattn16_fwd_b16(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, void* ctx_b16,
+                      int64_t ldo, float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, hipStream_t s);
+int relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens, const float* probs,
+                      const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* ws, int64_t n_blocks, int H, int hd,
+                      float drop_p, uint64_t seed, hipStream_t s, int* nsplit);
 
 }  // namespace vq

@@ -581,6 +581,42 @@ int vqcpc_relattn_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
     return VQCPC_EINVAL;
 }
 
+/* bf16-output forms of the L = 16 matrix-core attention (the bf16 training path, BASELINE configs[4]): ctx / d_qkv are bf16
+ * buffers (leading dimensions in elements); `tokens` non-NULL = qkv is the first layer's block table (vqcpc_relattn_tab_*). */
+int vqcpc_relattn16_b16_supported(int L, int H, int hd) { return (!g_force_general && use_mfma16(L, H, hd)) ? 1 : 0; }
+
+int vqcpc_relattn16_fwd_b16(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, void* ctx_b16,
+                            int64_t ldo, float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* stream) {
+    if (n_blocks == 0) return VQCPC_OK;
+    VQ_REQUIRE(qkv && e1 && e2 && ctx_b16 && probs, "relattn16_fwd_b16: null pointer");
+    VQ_REQUIRE(vqcpc_relattn16_b16_supported(16, H, hd), "relattn16_fwd_b16: unsupported H=%d hd=%d", H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= 3 * H * hd && ldo >= H * hd && n_blocks >= 0 && aligned16(qkv) &&
+                   aligned16(e1) && aligned16(e2) && aligned16(ctx_b16),
+               "relattn16_fwd_b16: bad strides / alignment");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn16_fwd_b16: bad dropout probability");
+    return relattn16_fwd_b16(qkv, ldq, tokens, e1, e2, ctx_b16, ldo, probs, n_blocks, H, hd, drop_p, seed, (hipStream_t)stream);
+}
+
+int vqcpc_relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens,
+                            const float* probs, const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* d_e1,
+                            float* d_e2, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                            int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(d_ctx && qkv && probs && e1 && e2 && d_qkv_b16 && d_e1 && d_e2 && workspace, "relattn16_bwd_b16: null pointer");
+    VQ_REQUIRE(vqcpc_relattn16_b16_supported(16, H, hd), "relattn16_bwd_b16: unsupported H=%d hd=%d", H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldq >= 3 * H * hd && ldg >= 3 * H * hd && ldo >= H * hd &&
+                   n_blocks >= 1 && aligned16(qkv) && aligned16(d_ctx) && aligned16(e1) && aligned16(e2) && aligned16(d_qkv_b16),
+               "relattn16_bwd_b16: bad strides / alignment");
+    if (workspace_bytes < vqcpc_relattn_bwd_workspace(n_blocks, 16, H, hd)) {
+        set_error("relattn16_bwd_b16: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int nsplit = 0;
+    int rc = relattn16_bwd_b16(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, d_qkv_b16, ldg, (float*)workspace, n_blocks, H, hd,
+                               drop_p, seed, s, &nsplit);
+    return rc ? rc : finish_de16((float*)workspace, nsplit, H, hd, d_e1, d_e2, s);
+}
+
 int vqcpc_relattn_tab_fwd(const float* table, int64_t ldt, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
                           int64_t ldo, float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed,
                           void* stream) {

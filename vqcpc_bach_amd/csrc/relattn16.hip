@@ -63,6 +63,29 @@ __device__ __forceinline__ void store_ct(float* __restrict__ p, const float (&v)
     else p[0] = v[0];
 }
 
+// bf16 outputs of the bf16 training path (BASELINE configs[4]): the attention context / its input gradients only feed GEMMs
+// there, which read bf16 from HBM -- the kernels round on the way out instead of writing fp32 for a cast pass to re-read.
+__device__ __forceinline__ unsigned short bf16_rn(float x) {
+    const uint32_t u = __float_as_uint(x);
+    return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
+}
+template <int CT>
+__device__ __forceinline__ void store_ct_b16(unsigned short* __restrict__ p, const float (&v)[CT]) {
+    if (CT == 4) {
+        *reinterpret_cast<uint2*>(p) = make_uint2((uint32_t)bf16_rn(v[0]) | ((uint32_t)bf16_rn(v[1 % CT]) << 16),
+                                                  (uint32_t)bf16_rn(v[2 % CT]) | ((uint32_t)bf16_rn(v[3 % CT]) << 16));
+    } else if (CT == 2) {
+        *reinterpret_cast<uint32_t*>(p) = (uint32_t)bf16_rn(v[0]) | ((uint32_t)bf16_rn(v[1 % CT]) << 16);
+    } else {
+        p[0] = bf16_rn(v[0]);
+    }
+}
+template <int CT, bool B16>
+__device__ __forceinline__ void store_out(float* __restrict__ base, int64_t off, const float (&v)[CT]) {
+    if (B16) store_ct_b16<CT>(reinterpret_cast<unsigned short*>(base) + off, v);
+    else store_ct<CT>(base + off, v);
+}
+
 __device__ __forceinline__ float grp16_sum(float v) {
     v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
     return v;
@@ -74,7 +97,7 @@ __device__ __forceinline__ float grp16_max(float v) {
 }
 
 // =====================================================================================================================
-template <int HD>
+template <int HD, bool B16 = false>      // B16: `ctx` points to bf16 elements (ldo in elements)
 __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const float* __restrict__ qkv, int64_t ldq,
                                                                        const int64_t* __restrict__ tokens,
                                                                        const float* __restrict__ e1,
@@ -150,7 +173,7 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
             float v[CT];
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) v[ct] = o[ct][r];
-            store_ct<CT>(ctx + (n * 16 + 4 * g + r) * ldo + h * HD + CT * c, v);
+            store_out<CT, B16>(ctx, (n * 16 + 4 * g + r) * ldo + h * HD + CT * c, v);
         }
     }
 }
@@ -158,7 +181,7 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
 // =====================================================================================================================
 // grid = (chunks, H).  Wave w of a workgroup walks the blocks chunk*bpc + w, + 4, ... of head blockIdx.y and keeps the
 // relative-embedding gradient of its head in registers; partials ws[(chunk*4 + w)][H][31][HD] (deterministic reduce).
-template <int HD>
+template <int HD, bool B16 = false>      // B16: `d_qkv` points to bf16 elements (ldg in elements)
 __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ qkv, int64_t ldq,
     const int64_t* __restrict__ tokens, const float* __restrict__ probs, const float* __restrict__ e1,
@@ -295,10 +318,10 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
                     vk[ct] = dk[ct][r];
                     vv[ct] = dv[ct][r];
                 }
-                float* gp = d_qkv + (n * 16 + 4 * g + r) * ldg + h * HD + CT * c;
-                store_ct<CT>(gp, vq);
-                store_ct<CT>(gp + d, vk);
-                store_ct<CT>(gp + 2 * d, vv);
+                const int64_t go = (n * 16 + 4 * g + r) * ldg + h * HD + CT * c;
+                store_out<CT, B16>(d_qkv, go, vq);
+                store_out<CT, B16>(d_qkv, go + d, vk);
+                store_out<CT, B16>(d_qkv, go + 2 * d, vv);
             }
         }
         if (kPipe) cur = nxt;
@@ -330,24 +353,24 @@ int64_t relattn16_bwd_workspace(int64_t n_blocks, int H, int hd) {
     return (chunks * kA16Waves + 1) * H * 31 * hd * (int64_t)sizeof(float);
 }
 
-template <int HD>
+template <int HD, bool B16 = false>
 static int a16_fwd_t(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
                      int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
     const int64_t total = n_blocks * H;
-    hipLaunchKernelGGL(relattn16_fwd_kernel<HD>, dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64), 0, s, qkv,
+    hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64), 0, s, qkv,
                        ldq, tokens, e1, e2, ctx, ldo, probs, total, H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed);
     VQ_CHECK_LAUNCH("relattn16_fwd");
     return VQCPC_OK;
 }
 
-template <int HD>
+template <int HD, bool B16 = false>
 static int a16_bwd_t(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens,
                      const float* probs, const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* ws,
                      int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s, int* nsplit) {
     const int bpc = a16_blocks_per_chunk(n_blocks, H);
     const int chunks = (int)ceil_div(n_blocks, bpc);
-    hipLaunchKernelGGL(relattn16_bwd_kernel<HD>, dim3(chunks, H), dim3(kA16Waves * 64), 0, s, d_ctx, ldo, qkv, ldq, tokens,
+    hipLaunchKernelGGL((relattn16_bwd_kernel<HD, B16>), dim3(chunks, H), dim3(kA16Waves * 64), 0, s, d_ctx, ldo, qkv, ldq, tokens,
                        probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, bpc, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed);
     VQ_CHECK_LAUNCH("relattn16_bwd");
@@ -371,6 +394,26 @@ int relattn16_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq
     if (hd == 32)
         return a16_bwd_t<32>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
     return a16_bwd_t<64>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+}
+
+// bf16-output forms (ctx / d_qkv are bf16 buffers; leading dimensions in elements)
+int relattn16_fwd_b16(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, void* ctx_b16,
+                      int64_t ldo, float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, hipStream_t s) {
+    float* c = reinterpret_cast<float*>(ctx_b16);
+    if (hd == 16) return a16_fwd_t<16, true>(qkv, ldq, tokens, e1, e2, c, ldo, probs, n_blocks, H, drop_p, seed, s);
+    if (hd == 32) return a16_fwd_t<32, true>(qkv, ldq, tokens, e1, e2, c, ldo, probs, n_blocks, H, drop_p, seed, s);
+    return a16_fwd_t<64, true>(qkv, ldq, tokens, e1, e2, c, ldo, probs, n_blocks, H, drop_p, seed, s);
+}
+
+int relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens, const float* probs,
+                      const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* ws, int64_t n_blocks, int H, int hd,
+                      float drop_p, uint64_t seed, hipStream_t s, int* nsplit) {
+    float* g = reinterpret_cast<float*>(d_qkv_b16);
+    if (hd == 16)
+        return a16_bwd_t<16, true>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+    if (hd == 32)
+        return a16_bwd_t<32, true>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+    return a16_bwd_t<64, true>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
 }
 
 }  // namespace vq

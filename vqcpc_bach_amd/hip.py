@@ -118,6 +118,11 @@ SIGNATURES = {
     'vqcpc_gru_cell_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64, c_ptr]),
     'vqcpc_gru_cell_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64,
                                    c_ptr]),
+    'vqcpc_relattn16_b16_supported': (c_int, [c_int, c_int, c_int]),
+    'vqcpc_relattn16_fwd_b16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_f32, c_u64,
+                                        c_ptr]),
+    'vqcpc_relattn16_bwd_b16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
+                                        c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
     'vqcpc_gru_step_supported': (c_int, [c_i64, c_int]),
     'vqcpc_gru_step_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64, c_ptr]),
     'vqcpc_gru_step_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64,

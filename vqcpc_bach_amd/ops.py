@@ -616,15 +616,25 @@ class EncoderLayerFn(torch.autograd.Function):
         if f == 1:
             Mq, xs, ldxs = M, x, ldx
             qkv = lin(xb if nat else x, wqkv, bias=bqkv) if qkv_in is None else _f32(qkv_in).contiguous()
-            att = torch.empty(M, d, dtype=torch.float32, device=dev)
             probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
-            if qkv_tokens is not None:
-                hip.call('vqcpc_relattn_tab_fwd', qkv, 3 * d, qkv_tokens, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+            # bf16 path at L = 16: the attention context only feeds the out-proj GEMM, which reads bf16 -> the kernel writes
+            # bf16 directly (no fp32 tensor, no cast pass)
+            b16_att = nat and ATT_B16_OUT and bool(hip.query('vqcpc_relattn16_b16_supported', L, H, hd))
+            attb_direct = None
+            if b16_att:
+                attb_direct = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
+                att = None
+                hip.call('vqcpc_relattn16_fwd_b16', qkv, 3 * d, qkv_tokens, e1, e2, attb_direct, d, probs, nblk, H, hd, p, s[0])
             else:
-                hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+                att = torch.empty(M, d, dtype=torch.float32, device=dev)
+                if qkv_tokens is not None:
+                    hip.call('vqcpc_relattn_tab_fwd', qkv, 3 * d, qkv_tokens, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
+                else:
+                    hip.call('vqcpc_relattn_fwd', qkv, 3 * d, e1, e2, att, d, probs, nblk, L, H, hd, p, s[0])
             qproj = qkv
         else:
             assert L % f == 0 and qkv_in is None
+            attb_direct = None
             Mq = M // f
             xs, ldxs = _rows(x[::f])                                       # query / residual rows: a stride, not a copy
             xsb = xb[::f].contiguous() if nat else None
@@ -633,7 +643,7 @@ class EncoderLayerFn(torch.autograd.Function):
             att = torch.empty(Mq, d, dtype=torch.float32, device=dev)
             probs = torch.empty(nblk, H, L // f, L, dtype=torch.float32, device=dev)
             hip.call('vqcpc_relattn_sub_fwd', qproj, d, qkv, 2 * d, e1, e2, att, d, probs, nblk, L, f, H, hd, p, s[0])
-        attb = cast_bf16(att) if nat else None
+        attb = (attb_direct if (f == 1 and attb_direct is not None) else cast_bf16(att)) if nat else None
         # s1 = x + dropout(att Wo^T + bo): the residual sum is formed by the out-proj epilogue (bias -> dropout -> + x), so the
         # LayerNorm kernels read ONE input stream and the backward needs neither x nor the projection output again
         s1 = lin(attb if nat else att, wo, bias=bo, drop_p=p, seed=s[1], add=xs)
@@ -733,10 +743,21 @@ class EncoderLayerFn(torch.autograd.Function):
         de2 = torch.empty_like(e2)
         need_dx = ctx.needs_input_grad[0]
         if f == 1:
-            dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
             nbytes = hip.query('vqcpc_relattn_bwd_workspace', nblk, L, H, hd)
             ws = hip.workspace(nbytes, dev)
             tok = ctx.qkv_tokens
+            if (nat and not ext_qkv and tok is None and ATT_B16_OUT
+                    and hip.query('vqcpc_relattn16_b16_supported', L, H, hd)):
+                # bf16 path: d qkv only feeds the two GEMMs below -> written as bf16 by the attention backward itself
+                dqkvb = torch.empty(M, 3 * d, dtype=torch.bfloat16, device=dev)
+                hip.call('vqcpc_relattn16_bwd_b16', datt, d, qkv, 3 * d, None, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk, H, hd,
+                         p, s[0], ws, nbytes)
+                dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
+                dx = gemm_nt_bf16(dqkvb, transpose(wqkv), add=ds1) if need_dx else None
+                de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
+                return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
+                        dbe1, dg2, dbe2)
+            dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
             if tok is not None:
                 hip.call('vqcpc_relattn_tab_bwd', datt, d, qkv, 3 * d, tok, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd,
                          p, s[0], ws, nbytes)
@@ -1047,6 +1068,7 @@ class DropoutSeluFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------------
 # A15: GRU layer of the context network (time-major rows: row = t * B + b)
 # ------------------------------------------------------------------------------------------------------------------
+ATT_B16_OUT = os.environ.get('VQCPC_ATT_B16_OUT', '1') != '0'        # A/B switch: bf16 outputs straight from the L = 16 attention
 GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)
 
 

@@ -31,6 +31,7 @@ output of the trainers' steps is detached for that reason.
 import os
 
 import torch
+import torch.distributed
 
 from . import hip
 
@@ -90,17 +91,22 @@ class StepGraph:
         graph = torch.cuda.CUDAGraph()
         counts = [opt.step_count for opt in self.optimizers]
         torch.cuda.synchronize()
-        with torch.cuda.graph(graph, pool=self.pool):
-            out = self._body(static)
-        if self.pool is None:
-            self.pool = graph.pool()
-        graph2 = None
-        if self.finish_fn is not None:                   # second half: same memory pool, replayed right after the first
-            graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph2, pool=self.pool):
-                out = self.finish_fn(out)
-        for opt, c in zip(self.optimizers, counts):      # capture ran the Python side of optimizer.step(): undo its count
-            opt.step_count = c
+        # with a process group alive its watchdog thread polls events while we capture: only calls of THIS thread may
+        # invalidate the capture
+        mode = 'thread_local' if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 'global'
+        try:
+            with torch.cuda.graph(graph, pool=self.pool, capture_error_mode=mode):
+                out = self._body(static)
+            if self.pool is None:
+                self.pool = graph.pool()
+            graph2 = None
+            if self.finish_fn is not None:               # second half: same memory pool, replayed right after the first
+                graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph2, pool=self.pool, capture_error_mode=mode):
+                    out = self.finish_fn(out)
+        finally:
+            for opt, c in zip(self.optimizers, counts):  # capture ran the Python side of optimizer.step(): undo its count
+                opt.step_count = c
         entry = ((graph, graph2), static, out)
         self.graphs[self._signature(batch)] = entry
         return entry
@@ -191,4 +197,17 @@ class GraphedTraining:
             return None
         if self._graph is None:
             self._graph = self._new_step_graph(body, parts)
-        return self._graph(batch)
+        try:
+            return self._graph(batch)
+        except RuntimeError as e:
+            # a failed CAPTURE (e.g. a runtime that cannot record one of the step's calls) must not take the training run
+            # down: fall back to eager steps for good and say so once.  Errors of a replayed step are real errors.
+            if self._graph.replays > 0:
+                raise
+            import warnings
+            warnings.warn(f'step-graph capture failed ({str(e)[:200]}); continuing with eager steps')
+            torch.cuda.synchronize()
+            self._graph_on = False
+            self._graph.release()
+            self._graph = None
+            return None

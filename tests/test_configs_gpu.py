@@ -126,8 +126,9 @@ def test_c1_model_dimensions_with_the_products_own_gate_selection(gemm_mode):
     if gemm_mode != 'bf16x6':
         pytest.skip('the bit-mask gate exists in the bf16x6 mode only')
     from vqcpc_bach_amd import ops
-    assert ops.GATEBITS_MIN_TILES == 0          # the fixture's override ...
-    ops.GATEBITS_MIN_TILES = 160                # ... replaced by the library's value (the fixture restores it afterwards)
+    assert ops.GATEBITS_MIN_TILES == 0 and ops.SFORM_MIN_TILES == 0      # the fixture's overrides ...
+    ops.GATEBITS_MIN_TILES = 160                # ... replaced by the library's values (the fixture restores them afterwards)
+    ops.SFORM_MIN_TILES = 128                   # two-input LayerNorm below 128 tiles (68 / 17 / 4 at this batch)
     cfg = O.make_cfg('C1', B=8)
     rows = 8 * (8 + 8 + 15 * 8) * 16
     assert ops.gatebits_worthwhile(rows, 1024, 256) and not ops.gatebits_worthwhile(rows // 4, 1024, 256)

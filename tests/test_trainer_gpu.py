@@ -19,14 +19,17 @@ T = torch.from_numpy
 def gemm_mode(request):
     """Every end-to-end parity test runs with both GEMM arithmetic modes (exact fp32 MFMA, and the bf16x6 split).  In the
     bf16x6 mode the feed-forward gate travels as a bit mask whatever the size (the product prefers the fp32 gate below 160
-    tiles, ops.gatebits_worthwhile: that form is what tests/test_student_gpu.py runs)."""
+    tiles, ops.gatebits_worthwhile: that form is what tests/test_student_gpu.py runs), and the residual sums that LayerNorm
+    normalises are formed in the GEMM epilogues whatever the size (the product: from 128 tiles, ops.SFORM_MIN_TILES; the
+    two-input LayerNorm form is what tests/test_student_gpu.py and the product-selection test of test_configs_gpu.py run)."""
     from vqcpc_bach_amd import hip, ops
     hip.load()
     hip.set_gemm_mode(1 if request.param == 'bf16x6' else 0)
-    saved = ops.GATEBITS_MIN_TILES
+    saved = ops.GATEBITS_MIN_TILES, ops.SFORM_MIN_TILES
     ops.GATEBITS_MIN_TILES = 0
+    ops.SFORM_MIN_TILES = 0           # residual sums formed in the GEMM epilogues whatever the size (product: >= 128 tiles)
     yield request.param
-    ops.GATEBITS_MIN_TILES = saved
+    ops.GATEBITS_MIN_TILES, ops.SFORM_MIN_TILES = saved
     hip.set_gemm_mode(0)
 
 FWD_TOL, GRAD_TOL = 5e-5, 5e-4

@@ -576,6 +576,23 @@ def linear(x, weight, bias=None):
 # ------------------------------------------------------------------------------------------------------------------
 # one post-LN relative-attention encoder layer (A6/A7/A8), forward + hand-scheduled backward
 # ------------------------------------------------------------------------------------------------------------------
+SFORM_MIN_TILES = 128      # 256 x 256 tiles from which the residual sum is formed in the GEMM epilogue (tests set 0)
+
+
+def _residual_sum_in_epilogue(M, N, K, nat):
+    """Where the residual sum s = x + dropout(a W^T + b) is formed.  True: in the producing GEMM's epilogue (LayerNorm then
+    reads one stream) -- pays where the 256-tile ping-pong kernel runs the GEMM (C1 / C4: >= 128 tiles).  False: the
+    projection output and the residual stay two LayerNorm inputs -- the under-filled projections of the student / decoder-sized
+    steps run on the 128-tile kernel (3072 x 512 x 512 with the dropout + residual epilogue: 87 us against 38 us with the
+    bias alone) or through the split-K entry point (3072 x 512 x 2048: 59 us against 112 us; its plane-sum epilogue has no
+    dropout); measured on C3: 13.5 -> 16.4 ms/step with the epilogue form everywhere."""
+    if nat:
+        return True
+    if hip.get_gemm_mode() != 1:
+        return SFORM_MIN_TILES == 0
+    return (M // 256) * (N // 256) >= SFORM_MIN_TILES and M % 256 == 0 and N % 256 == 0 or SFORM_MIN_TILES == 0
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """y = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)),  x1 = LN1(x + drop(Wo attn(x) + bo)).
     Parameter order: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, e1, e2, linear1.weight,
@@ -646,33 +663,47 @@ class EncoderLayerFn(torch.autograd.Function):
         attb = (attb_direct if (f == 1 and attb_direct is not None) else cast_bf16(att)) if nat else None
         # s1 = x + dropout(att Wo^T + bo): the residual sum is formed by the out-proj epilogue (bias -> dropout -> + x), so the
         # LayerNorm kernels read ONE input stream and the backward needs neither x nor the projection output again
-        s1 = lin(attb if nat else att, wo, bias=bo, drop_p=p, seed=s[1], add=xs)
+        sform1 = _residual_sum_in_epilogue(Mq, d, d, nat)
         x1 = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         x1b = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
-        hip.call('vqcpc_add_layernorm_fwd_b16', s1, d, None, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5, 0.0, 0)
+        if sform1:
+            s1 = lin(attb if nat else att, wo, bias=bo, drop_p=p, seed=s[1], add=xs)
+            hip.call('vqcpc_add_layernorm_fwd_b16', s1, d, None, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5, 0.0, 0)
+        else:           # s1 holds the projection output a; LayerNorm adds x and the dropout itself
+            s1 = lin(att, wo, bias=bo)
+            hip.call('vqcpc_add_layernorm_fwd_b16', xs, ldxs, s1, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5, p, s[1])
         h2b = None
         if nat:     # the FFN hidden activation exists in bf16 only: FFN2, the backward gate and the weight gradient read it
             h2b = gemm_nt_bf16(x1b, w1, bias=b1, act=1, drop_p=p, seed=s[2], out_f32=False, out_bf16=True)
             s2 = gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add=x1)
+            sform2 = True
             h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
         else:
             if gatebits_worthwhile(Mq, ffd, d):       # relu / dropout gate of the backward as a bit mask (1/32 of the bytes)
                 h2, ctx.gate_mask = gemm_nt_relu_mask(x1, w1, b1, drop_p=p, seed=s[2])
             else:
                 h2, ctx.gate_mask = gemm_nt(x1, w1, bias=b1, act=1, drop_p=p, seed=s[2]), None
-            s2 = gemm_nt(h2, w2, bias=b2, drop_p=p, seed=s[3], add=x1)          # x1 + dropout(FFN(x1))
+            sform2 = _residual_sum_in_epilogue(Mq, d, ffd, nat)
+            if sform2:
+                s2 = gemm_nt(h2, w2, bias=b2, drop_p=p, seed=s[3], add=x1)      # x1 + dropout(FFN(x1))
+            else:
+                s2 = gemm_nt(h2, w2, bias=b2)                                   # FFN(x1): LayerNorm adds x1 and the dropout
         y = torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         yb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
-        hip.call('vqcpc_add_layernorm_fwd_b16', s2, d, None, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, 0.0, 0)
+        if sform2:
+            hip.call('vqcpc_add_layernorm_fwd_b16', s2, d, None, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, 0.0, 0)
+        else:
+            hip.call('vqcpc_add_layernorm_fwd_b16', x1, d, s2, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, p, s[3])
         if nat:
             _attach_bf16_copy(y, yb)
         ctx.save_for_backward(x, qkv, qproj, probs, att, s1, x1, mean1, rstd1, h2, s2, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
+        ctx.sform = (sform1, sform2)
         ctx.bf16 = (xb, xsb, attb, x1b, h2b) if nat else None
         ctx.biases = (bqkv, bo, b1, b2)
         ctx.ln_betas = (be1, be2)
@@ -713,7 +744,11 @@ class EncoderLayerFn(torch.autograd.Function):
                      ws, nbytes)
             return ds, (dr if dr is not None else (None if (nat and p > 0) else ds)), dg, db, drb
 
-        ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, mean2, rstd2, s[3])
+        sform1, sform2 = ctx.sform
+        if sform2:
+            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, mean2, rstd2, s[3])
+        else:
+            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, x1, d, s2, g2, mean2, rstd2, s[3])
         lin = gemm_nt_bf16 if nat else gemm_nt
         if nat:
             xb, xsb, attb, x1b, h2b = ctx.bf16
@@ -732,7 +767,10 @@ class EncoderLayerFn(torch.autograd.Function):
             dw1, db1 = wgrad(da, x1, w1, b1)
             dx1 = gemm_nt(da, transpose(w1), add=ds2)
         del da, df, ds2
-        ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, mean1, rstd1, s[1])
+        if sform1:
+            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, mean1, rstd1, s[1])
+        else:
+            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, xs, ldxs, s1, g1, mean1, rstd1, s[1])
         if nat:
             dwo, dbo = wgrad(dAb, attb, wo, bo)
             datt = gemm_nt_bf16(dAb, transpose(wo))

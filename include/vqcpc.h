@@ -170,6 +170,21 @@ int vqcpc_relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, i
                             const float* probs, const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* d_e1,
                             float* d_e2, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* workspace,
                             int64_t workspace_bytes, void* stream);
+/* the same for any block length the LDS-tiled kernels serve (L in {16, 4}; L = 16 is forwarded to the matrix-core kernels). */
+int vqcpc_relattn_b16_supported(int L, int H, int hd);
+int vqcpc_relattn_fwd_b16(const float* qkv, int64_t ldq, const float* e1, const float* e2, void* ctx_b16, int64_t ldo,
+                          float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* stream);
+int vqcpc_relattn_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
+                          const float* e2, void* d_qkv_b16, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L,
+                          int H, int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
+/* all-bf16 forms (no token indirection): qkv_b16 [n_blocks*16][ldq] is the bf16 output of the in_proj GEMM, d_ctx_b16 the bf16
+ * output of the out-proj input-gradient GEMM -- the two kernels' dominant streams at half the bytes. */
+int vqcpc_relattn16_fwd_b16io(const void* qkv_b16, int64_t ldq, const float* e1, const float* e2, void* ctx_b16, int64_t ldo,
+                              float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* stream);
+int vqcpc_relattn16_bwd_b16io(const void* d_ctx_b16, int64_t ldo, const void* qkv_b16, int64_t ldq, const float* probs,
+                              const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* d_e1, float* d_e2,
+                              int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                              int64_t workspace_bytes, void* stream);
 int vqcpc_relattn_tab_fwd(const float* table, int64_t ldt, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
                           int64_t ldo, float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed,
                           void* stream);
@@ -213,6 +228,16 @@ int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64
                           const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
                           int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd,
                           float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
+/* bf16-output forms of the query-subsampled kernels (the bf16 training path): ctx_b16 / d_kv_b16 hold bf16 elements; d_q (1/8 of
+ * the gradient bytes, operand of an fp32 GEMM with two residual inputs) stays fp32. */
+int vqcpc_relattn_sub_b16_supported(int L, int F, int H, int hd);
+int vqcpc_relattn_sub_fwd_b16(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                              void* ctx_b16, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd,
+                              float drop_p, uint64_t seed, void* stream);
+int vqcpc_relattn_sub_bwd_b16(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                              const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, void* d_kv_b16,
+                              int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd,
+                              float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Fused residual + dropout + LayerNorm:  y = LN(x + dropout(r)) * gamma + beta   (eps inside the sqrt, biased var).

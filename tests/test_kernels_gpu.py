@@ -772,6 +772,103 @@ def test_relattn_query_subsampled(ops, n, L, H, hd, p):
     assert float(g[:, :, :d].reshape(n, L // F, F, d)[:, :, 1:].abs().max()) == 0.0   # dropped queries: zero gradient
 
 
+@pytest.mark.parametrize('n,L,H,hd,p', [(300, 16, 8, 64, 0.1), (77, 4, 8, 64, 0.1), (129, 4, 2, 16, 0.0), (50, 16, 4, 32, 0.0),
+                                        (64, 16, 2, 16, 0.1)])
+def test_relattn_bf16_output_forms_are_the_rounded_fp32_results(ops, n, L, H, hd, p):
+    """bf16 training path (configs[4]): ctx / d qkv written as bf16 by the attention kernels == the fp32 kernels' results rounded
+    to nearest even (what the removed cast pass produced), bit for bit; everything else (probs, d e1 / d e2) unchanged."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(n + L + hd)
+    d, seed = H * hd, 31
+    qkv = torch.randn(n * L, 3 * d, generator=gen).cuda()
+    e1, e2 = torch.randn(H * L, hd, generator=gen).cuda(), torch.randn(H * L, hd, generator=gen).cuda()
+    dctx = torch.randn(n * L, d, generator=gen).cuda()
+    assert hip.query('vqcpc_relattn_b16_supported', L, H, hd)
+    nbytes = hip.query('vqcpc_relattn_bwd_workspace', n, L, H, hd)
+    ws = hip.workspace(nbytes, 'cuda')
+    outs = []
+    for b16 in (False, True):
+        dt = torch.bfloat16 if b16 else torch.float32
+        ctx = torch.empty(n * L, d, device='cuda', dtype=dt)
+        probs = torch.empty(n, H, L, L, device='cuda')
+        dqkv = torch.empty(n * L, 3 * d, device='cuda', dtype=dt)
+        de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
+        sfx = '_b16' if b16 else ''
+        hip.call('vqcpc_relattn_fwd' + sfx, qkv, 3 * d, e1, e2, ctx, d, probs, n, L, H, hd, p, seed)
+        hip.call('vqcpc_relattn_bwd' + sfx, dctx, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, n, L, H, hd, p, seed, ws,
+                 nbytes)
+        outs.append((ctx, probs, dqkv, de1, de2))
+    (c0, p0, g0, a0, b0), (c1, p1, g1, a1, b1) = outs
+    assert torch.equal(c0.bfloat16(), c1) and torch.equal(g0.bfloat16(), g1)
+    assert torch.equal(p0, p1) and torch.equal(a0, a1) and torch.equal(b0, b1)
+
+
+@pytest.mark.parametrize('n,H,hd,p', [(300, 8, 64, 0.1), (65, 4, 32, 0.0), (33, 2, 16, 0.1)])
+def test_relattn16_all_bf16_form_equals_fp32_inputs_holding_the_same_values(ops, n, H, hd, p):
+    """q | k | v and d ctx handed over as bf16 (vqcpc_relattn16_*_b16io) == the bf16-output kernels on fp32 tensors that hold
+    the same (bf16-representable) values: the conversion on load is exact, so every output is bit-identical."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(n + hd)
+    L, d, seed = 16, H * hd, 77
+    qkv_b = torch.randn(n * L, 3 * d, generator=gen).cuda().bfloat16()
+    dctx_b = torch.randn(n * L, d, generator=gen).cuda().bfloat16()
+    e1, e2 = torch.randn(H * L, hd, generator=gen).cuda(), torch.randn(H * L, hd, generator=gen).cuda()
+    nbytes = hip.query('vqcpc_relattn_bwd_workspace', n, L, H, hd)
+    ws = hip.workspace(nbytes, 'cuda')
+    outs = []
+    for io in (False, True):
+        ctx = torch.empty(n * L, d, device='cuda', dtype=torch.bfloat16)
+        probs = torch.empty(n, H, L, L, device='cuda')
+        dqkv = torch.empty(n * L, 3 * d, device='cuda', dtype=torch.bfloat16)
+        de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
+        if io:
+            hip.call('vqcpc_relattn16_fwd_b16io', qkv_b, 3 * d, e1, e2, ctx, d, probs, n, H, hd, p, seed)
+            hip.call('vqcpc_relattn16_bwd_b16io', dctx_b, d, qkv_b, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, n, H, hd, p, seed,
+                     ws, nbytes)
+        else:
+            qkv, dctx = qkv_b.float(), dctx_b.float()
+            hip.call('vqcpc_relattn16_fwd_b16', qkv, 3 * d, None, e1, e2, ctx, d, probs, n, H, hd, p, seed)
+            hip.call('vqcpc_relattn16_bwd_b16', dctx, d, qkv, 3 * d, None, probs, e1, e2, dqkv, 3 * d, de1, de2, n, H, hd, p, seed,
+                     ws, nbytes)
+        outs.append((ctx, probs, dqkv, de1, de2))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize('n,L,H,hd,p', [(300, 16, 8, 64, 0.1), (129, 4, 8, 64, 0.1), (40, 16, 2, 16, 0.0), (33, 4, 4, 32, 0.0),
+                                        (50, 16, 4, 32, 0.1)])
+def test_relattn_query_subsampled_bf16_output_forms(ops, n, L, H, hd, p):
+    """Query-subsampled kernels: ctx and d k | v as bf16 == the rounded fp32 results; d q stays fp32 and is unchanged."""
+    from vqcpc_bach_amd import hip
+    F = 4
+    LQ = L // F
+    gen = torch.Generator().manual_seed(n + L + H + 5)
+    d, seed = H * hd, 123
+    q_in = torch.randn(n * LQ, d, generator=gen).cuda()
+    kv_in = torch.randn(n * L, 2 * d, generator=gen).cuda()
+    e1, e2 = torch.randn(H * L, hd, generator=gen).cuda(), torch.randn(H * L, hd, generator=gen).cuda()
+    dctx = torch.randn(n * LQ, d, generator=gen).cuda()
+    assert hip.query('vqcpc_relattn_sub_b16_supported', L, F, H, hd)
+    nbytes = hip.query('vqcpc_relattn_sub_bwd_workspace', n, L, F, H, hd)
+    ws = hip.workspace(nbytes, 'cuda')
+    outs = []
+    for b16 in (False, True):
+        dt = torch.bfloat16 if b16 else torch.float32
+        sfx = '_b16' if b16 else ''
+        ctx = torch.empty(n * LQ, d, device='cuda', dtype=dt)
+        probs = torch.empty(n, H, LQ, L, device='cuda')
+        dq = torch.empty(n * LQ, d, device='cuda')
+        dkv = torch.empty(n * L, 2 * d, device='cuda', dtype=dt)
+        de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
+        hip.call('vqcpc_relattn_sub_fwd' + sfx, q_in, d, kv_in, 2 * d, e1, e2, ctx, d, probs, n, L, F, H, hd, p, seed)
+        hip.call('vqcpc_relattn_sub_bwd' + sfx, dctx, d, q_in, d, kv_in, 2 * d, probs, e1, e2, dq, d, dkv, 2 * d, de1, de2, n, L, F,
+                 H, hd, p, seed, ws, nbytes)
+        outs.append((ctx, probs, dq, dkv, de1, de2))
+    (c0, p0, q0, k0, a0, b0), (c1, p1, q1, k1, a1, b1) = outs
+    assert torch.equal(c0.bfloat16(), c1) and torch.equal(k0.bfloat16(), k1)
+    assert torch.equal(p0, p1) and torch.equal(q0, q1) and torch.equal(a0, a1) and torch.equal(b0, b1)
+
+
 @pytest.mark.parametrize('L,H,d,ff', [(16, 2, 32, 64), (4, 2, 32, 48), (16, 8, 256, 512)])
 def test_encoder_layer_query_stride_equals_full_then_select(ops, L, H, d, ff):
     """EncoderLayerFn(qstride=4) == oracle layer followed by [::4]: outputs, input gradient, parameter gradients."""

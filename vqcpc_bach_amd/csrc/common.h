@@ -106,6 +106,27 @@ int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out
 int launch_reduce_splits2(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, const float* ws2,
                           int64_t stride2, float* out2, int64_t count2, int accumulate, hipStream_t stream);
 
+// Outputs of the attention kernels on the bf16 training path (BASELINE configs[4]): context / input gradients that only feed
+// GEMMs are written as bf16 by the producing kernel (`out16` != 0: `base` holds bf16 elements; offsets in elements either way).
+#ifdef __HIPCC__
+typedef float vq_f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 vq_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t bf16x2_rn(float e0, float e1) {      // round to nearest even, element 0 in the low half
+    const vq_f32x2_t v = {e0, e1};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, vq_bf16x2_t));
+}
+__device__ __forceinline__ void store4_out(float* __restrict__ base, int64_t off, float a, float b, float c, float d, int out16) {
+    if (out16)
+        *reinterpret_cast<uint2*>(reinterpret_cast<unsigned short*>(base) + off) = make_uint2(bf16x2_rn(a, b), bf16x2_rn(c, d));
+    else
+        *reinterpret_cast<float4*>(base + off) = make_float4(a, b, c, d);
+}
+__device__ __forceinline__ void store1_out(float* __restrict__ base, int64_t off, float a, int out16) {
+    if (out16) reinterpret_cast<unsigned short*>(base)[off] = (unsigned short)(bf16x2_rn(a, 0.0f) & 0xFFFFu);
+    else base[off] = a;
+}
+#endif
+
 // L = 16 attention on the fp32 matrix cores (relattn16.hip); tokens != nullptr = block-table indirection
 bool relattn16_supported(int H, int hd);
 int64_t relattn16_bwd_workspace(int64_t n_blocks, int H, int hd);
@@ -119,5 +140,10 @@ int relattn16_fwd_b16(const float* qkv, int64_t ldq, const int64_t* tokens, cons
 int relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens, const float* probs,
                       const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* ws, int64_t n_blocks, int H, int hd,
                       float drop_p, uint64_t seed, hipStream_t s, int* nsplit);
+int relattn16_fwd_b16io(const void* qkv_b16, int64_t ldq, const float* e1, const float* e2, void* ctx_b16, int64_t ldo,
+                        float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, hipStream_t s);
+int relattn16_bwd_b16io(const void* d_ctx_b16, int64_t ldo, const void* qkv_b16, int64_t ldq, const float* probs,
+                        const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* ws, int64_t n_blocks, int H,
+                        int hd, float drop_p, uint64_t seed, hipStream_t s, int* nsplit);
 
 }  // namespace vq

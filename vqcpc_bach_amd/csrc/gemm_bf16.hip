@@ -578,6 +578,7 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     BL(E_GATE, B_OUT_F32 | B_GATE_BF16)
     BL(E_ADD, B_OUT_F32)
     BL(0, B_OUT_BF16)
+    BL(E_BIAS, B_OUT_BF16)                           // in_proj output for the all-bf16 attention kernels
     BL(E_BIAS | E_ADD, B_OUT_F32)                    // residual sums for LayerNorm (see gemm.hip)
     BL(E_BIAS | E_DROP | E_ADD, B_OUT_F32)
 #undef BL

@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kAttThreads) void relattn_fwd_kernel(const float* _
                                                                   int64_t ldo, float* __restrict__ probs,
                                                                   int64_t n_blocks, int H, float scale, uint32_t thr,
                                                                   float inv_keep, uint64_t seed,
-                                                                  const int64_t* __restrict__ tokens) {
+                                                                  const int64_t* __restrict__ tokens, int o16) {
     // Persistent slots: slot g of the grid keeps head g % H (the host makes the slot count a multiple of H) and walks the
     // blocks g / H, + slots / H, ...: the relative rows are staged once, the q | k | v rows of the next block are fetched
     // into registers while the current one is processed.  A slot's LDS region is private to its 4 L lanes of one wave.
@@ -205,10 +205,10 @@ __global__ __launch_bounds__(kAttThreads) void relattn_fwd_kernel(const float* _
                     o[c4 * 4 + 3] += p * v.w;
                 }
             }
-            float* op = ctx + (n * L + i) * ldo + h * HD + jg * C::CPL;
+            const int64_t oo = (n * L + i) * ldo + h * HD + jg * C::CPL;
 #pragma unroll
             for (int c4 = 0; c4 < C::CPL / 4; ++c4)
-                *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+                store4_out(ctx, oo + c4 * 4, o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3], o16);
         }
     }
 }
@@ -222,7 +222,7 @@ __global__ __launch_bounds__(kAttThreads) void relattn_bwd_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ qkv, int64_t ldq,
     const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
     float* __restrict__ d_qkv, int64_t ldg, float* __restrict__ ws, int64_t n_blocks, int H, int blocks_per_wg,
-    float scale, uint32_t thr, float inv_keep, uint64_t seed, const int64_t* __restrict__ tokens) {
+    float scale, uint32_t thr, float inv_keep, uint64_t seed, const int64_t* __restrict__ tokens, int g16) {
     using C = AttCfg<L, HD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -355,13 +355,13 @@ __global__ __launch_bounds__(kAttThreads) void relattn_bwd_kernel(
                     dq[c4 * 4 + 2] += ds * (k.z + e.z); dq[c4 * 4 + 3] += ds * (k.w + e.w);
                 }
             }
-            float* gp = d_qkv + (n * L + i) * ldg + h * HD + jg * C::CPL;
+            const int64_t go = (n * L + i) * ldg + h * HD + jg * C::CPL;
 #pragma unroll
             for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
-                *reinterpret_cast<float4*>(gp + c4 * 4) =
-                    make_float4(dq[c4 * 4] * scale, dq[c4 * 4 + 1] * scale, dq[c4 * 4 + 2] * scale, dq[c4 * 4 + 3] * scale);
-                *reinterpret_cast<float4*>(gp + d + c4 * 4) = make_float4(dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3]);
-                *reinterpret_cast<float4*>(gp + 2 * d + c4 * 4) = make_float4(dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3]);
+                store4_out(d_qkv, go + c4 * 4, dq[c4 * 4] * scale, dq[c4 * 4 + 1] * scale, dq[c4 * 4 + 2] * scale,
+                           dq[c4 * 4 + 3] * scale, g16);
+                store4_out(d_qkv, go + d + c4 * 4, dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3], g16);
+                store4_out(d_qkv, go + 2 * d + c4 * 4, dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3], g16);
             }
             // dErel[r] += sum_{i', j: j - i' + L - 1 = r} dS[i'][j] * qs[i']      rows r = i and r = i + L
 #pragma unroll
@@ -421,7 +421,7 @@ static int att_blocks_per_wg(int64_t n_blocks, int slots, int H) {
 template <int L, int HD>
 static int launch_fwd(const float* qkv, int64_t ldq, const float* e1, const float* e2, float* ctx, int64_t ldo,
                       float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s,
-                      const int64_t* tokens = nullptr) {
+                      const int64_t* tokens = nullptr, int o16 = 0) {
     using C = AttCfg<L, HD>;
     const size_t lds = (size_t)C::SLOTS * C::FWD_FLOATS * sizeof(float);
     auto kern = relattn_fwd_kernel<L, HD>;
@@ -433,7 +433,7 @@ static int launch_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
     const int64_t unit = H / gcd;
     grid = ceil_div(grid, unit) * unit;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(kAttThreads), lds, s, qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks,
-                       H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, tokens);
+                       H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, tokens, o16);
     VQ_CHECK_LAUNCH("relattn_fwd");
     return VQCPC_OK;
 }
@@ -441,7 +441,7 @@ static int launch_fwd(const float* qkv, int64_t ldq, const float* e1, const floa
 template <int L, int HD>
 static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
                       const float* e2, float* d_qkv, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int H,
-                      float drop_p, uint64_t seed, float* ws, hipStream_t s, const int64_t* tokens = nullptr) {
+                      float drop_p, uint64_t seed, float* ws, hipStream_t s, const int64_t* tokens = nullptr, int g16 = 0) {
     using C = AttCfg<L, HD>;
     const size_t lds = (size_t)C::SLOTS * C::BWD_FLOATS * sizeof(float);
     auto kern = relattn_bwd_kernel<L, HD>;
@@ -451,7 +451,7 @@ static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
     const int gy = C::SLOTS >= H ? 1 : H / C::SLOTS;
     const int NS = C::SLOTS >= H ? C::SLOTS / H : 1;
     hipLaunchKernelGGL(kern, dim3(chunks, gy), dim3(kAttThreads), lds, s, d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg,
-                       ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, tokens);
+                       ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, tokens, g16);
     VQ_CHECK_LAUNCH("relattn_bwd");
     const int total = H * C::NE * HD;
     float* tot = ws + (int64_t)chunks * NS * total;            // tail of the workspace
@@ -614,6 +614,91 @@ int vqcpc_relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, i
     int nsplit = 0;
     int rc = relattn16_bwd_b16(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, d_qkv_b16, ldg, (float*)workspace, n_blocks, H, hd,
                                drop_p, seed, s, &nsplit);
+    return rc ? rc : finish_de16((float*)workspace, nsplit, H, hd, d_e1, d_e2, s);
+}
+
+/* bf16-output forms for the other block lengths of the encoder stacks (L = 4; L = 16 is forwarded to the matrix-core kernels). */
+int vqcpc_relattn_b16_supported(int L, int H, int hd) { return (!g_force_general && att_supported(L, H, hd)) ? 1 : 0; }
+
+int vqcpc_relattn_fwd_b16(const float* qkv, int64_t ldq, const float* e1, const float* e2, void* ctx_b16, int64_t ldo,
+                          float* probs, int64_t n_blocks, int L, int H, int hd, float drop_p, uint64_t seed, void* stream) {
+    if (n_blocks == 0) return VQCPC_OK;
+    VQ_REQUIRE(qkv && e1 && e2 && ctx_b16 && probs, "relattn_fwd_b16: null pointer");
+    VQ_REQUIRE(!g_force_general && att_supported(L, H, hd), "relattn_fwd_b16: unsupported L=%d H=%d hd=%d (L in {16,4})", L, H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldq >= 3 * H * hd && ldo >= H * hd && aligned16(qkv) && aligned16(ctx_b16),
+               "relattn_fwd_b16: bad strides / alignment");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_fwd_b16: bad dropout probability");
+    hipStream_t s = (hipStream_t)stream;
+    if (use_mfma16(L, H, hd) && aligned16(e1) && aligned16(e2))
+        return relattn16_fwd_b16(qkv, ldq, nullptr, e1, e2, ctx_b16, ldo, probs, n_blocks, H, hd, drop_p, seed, s);
+    float* ctx = reinterpret_cast<float*>(ctx_b16);
+#define CALL(LL, DD) launch_fwd<LL, DD>(qkv, ldq, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s, nullptr, 1)
+    VQ_ATT_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+int vqcpc_relattn_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const float* probs, const float* e1,
+                          const float* e2, void* d_qkv_b16, int64_t ldg, float* d_e1, float* d_e2, int64_t n_blocks, int L,
+                          int H, int hd, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(d_ctx && qkv && probs && e1 && e2 && d_qkv_b16 && d_e1 && d_e2 && workspace, "relattn_bwd_b16: null pointer");
+    VQ_REQUIRE(!g_force_general && att_supported(L, H, hd), "relattn_bwd_b16: unsupported L=%d H=%d hd=%d (L in {16,4})", L, H, hd);
+    VQ_REQUIRE(ldq % 4 == 0 && ldo % 4 == 0 && ldg % 4 == 0 && ldq >= 3 * H * hd && ldg >= 3 * H * hd && ldo >= H * hd &&
+                   n_blocks >= 1 && aligned16(qkv) && aligned16(d_ctx) && aligned16(d_qkv_b16),
+               "relattn_bwd_b16: bad strides / alignment");
+    if (workspace_bytes < vqcpc_relattn_bwd_workspace(n_blocks, L, H, hd)) {
+        set_error("relattn_bwd_b16: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (use_mfma16(L, H, hd) && aligned16(e1) && aligned16(e2)) {
+        int nsplit = 0;
+        int rc = relattn16_bwd_b16(d_ctx, ldo, qkv, ldq, nullptr, probs, e1, e2, d_qkv_b16, ldg, (float*)workspace, n_blocks, H,
+                                   hd, drop_p, seed, s, &nsplit);
+        return rc ? rc : finish_de16((float*)workspace, nsplit, H, hd, d_e1, d_e2, s);
+    }
+    float* d_qkv = reinterpret_cast<float*>(d_qkv_b16);
+#define CALL(LL, DD)                                                                                                   \
+    launch_bwd<LL, DD>(d_ctx, ldo, qkv, ldq, probs, e1, e2, d_qkv, ldg, d_e1, d_e2, n_blocks, H, drop_p, seed, (float*)workspace, s, \
+                       nullptr, 1)
+    VQ_ATT_DISPATCH(CALL)
+#undef CALL
+    return VQCPC_EINVAL;
+}
+
+/* all-bf16 forms: q | k | v (written as bf16 by the in_proj GEMM epilogue) and, in the backward, d ctx (out-proj dgrad epilogue)
+ * are bf16 too -- half the bytes of the two kernels' dominant streams.  Leading dimensions in elements, multiples of 8. */
+int vqcpc_relattn16_fwd_b16io(const void* qkv_b16, int64_t ldq, const float* e1, const float* e2, void* ctx_b16, int64_t ldo,
+                              float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* stream) {
+    if (n_blocks == 0) return VQCPC_OK;
+    VQ_REQUIRE(qkv_b16 && e1 && e2 && ctx_b16 && probs, "relattn16_fwd_b16io: null pointer");
+    VQ_REQUIRE(vqcpc_relattn16_b16_supported(16, H, hd), "relattn16_fwd_b16io: unsupported H=%d hd=%d", H, hd);
+    VQ_REQUIRE(ldq % 8 == 0 && ldo % 4 == 0 && ldq >= 3 * H * hd && ldo >= H * hd && n_blocks >= 0 && aligned16(qkv_b16) &&
+                   aligned16(e1) && aligned16(e2) && aligned16(ctx_b16),
+               "relattn16_fwd_b16io: bad strides / alignment");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn16_fwd_b16io: bad dropout probability");
+    return relattn16_fwd_b16io(qkv_b16, ldq, e1, e2, ctx_b16, ldo, probs, n_blocks, H, hd, drop_p, seed, (hipStream_t)stream);
+}
+
+int vqcpc_relattn16_bwd_b16io(const void* d_ctx_b16, int64_t ldo, const void* qkv_b16, int64_t ldq, const float* probs,
+                              const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* d_e1, float* d_e2,
+                              int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    VQ_REQUIRE(d_ctx_b16 && qkv_b16 && probs && e1 && e2 && d_qkv_b16 && d_e1 && d_e2 && workspace,
+               "relattn16_bwd_b16io: null pointer");
+    VQ_REQUIRE(vqcpc_relattn16_b16_supported(16, H, hd), "relattn16_bwd_b16io: unsupported H=%d hd=%d", H, hd);
+    VQ_REQUIRE(ldq % 8 == 0 && ldo % 8 == 0 && ldg % 4 == 0 && ldq >= 3 * H * hd && ldg >= 3 * H * hd && ldo >= H * hd &&
+                   n_blocks >= 1 && aligned16(qkv_b16) && aligned16(d_ctx_b16) && aligned16(e1) && aligned16(e2) &&
+                   aligned16(d_qkv_b16),
+               "relattn16_bwd_b16io: bad strides / alignment");
+    if (workspace_bytes < vqcpc_relattn_bwd_workspace(n_blocks, 16, H, hd)) {
+        set_error("relattn16_bwd_b16io: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    int nsplit = 0;
+    int rc = relattn16_bwd_b16io(d_ctx_b16, ldo, qkv_b16, ldq, probs, e1, e2, d_qkv_b16, ldg, (float*)workspace, n_blocks, H, hd,
+                                 drop_p, seed, s, &nsplit);
     return rc ? rc : finish_de16((float*)workspace, nsplit, H, hd, d_e1, d_e2, s);
 }
 

@@ -86,6 +86,50 @@ __device__ __forceinline__ void store_out(float* __restrict__ base, int64_t off,
     else store_ct<CT>(base + off, v);
 }
 
+
+// bf16 INPUTS of the bf16 training path (IN16): q | k | v and d ctx are bf16 in HBM (written so by the in_proj / out-proj-dgrad
+// GEMM epilogues); offsets and leading dimensions are in elements either way.
+__device__ __forceinline__ float bf16_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16_hi(uint32_t w) { return __uint_as_float(w & 0xFFFF0000u); }
+template <int N, bool IN16>
+__device__ __forceinline__ void load_vec(float (&dst)[N], const float* __restrict__ base, int64_t off, float mul) {
+    if constexpr (!IN16) {
+        load_f4<N>(dst, base + off, mul);
+    } else {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + off;
+        if constexpr (N == 4) {
+            const uint2 t = *reinterpret_cast<const uint2*>(p);
+            dst[0] = bf16_lo(t.x) * mul; dst[1] = bf16_hi(t.x) * mul; dst[2] = bf16_lo(t.y) * mul; dst[3] = bf16_hi(t.y) * mul;
+        } else {
+#pragma unroll
+            for (int v = 0; v < N / 8; ++v) {
+                const uint4 t = *reinterpret_cast<const uint4*>(p + 8 * v);
+                dst[8 * v] = bf16_lo(t.x) * mul; dst[8 * v + 1] = bf16_hi(t.x) * mul;
+                dst[8 * v + 2] = bf16_lo(t.y) * mul; dst[8 * v + 3] = bf16_hi(t.y) * mul;
+                dst[8 * v + 4] = bf16_lo(t.z) * mul; dst[8 * v + 5] = bf16_hi(t.z) * mul;
+                dst[8 * v + 6] = bf16_lo(t.w) * mul; dst[8 * v + 7] = bf16_hi(t.w) * mul;
+            }
+        }
+    }
+}
+template <int CT, bool IN16>
+__device__ __forceinline__ void load_cols(float (&dst)[CT], const float* __restrict__ base, int64_t off, float mul) {
+    if constexpr (!IN16) {
+        load_ct<CT>(dst, base + off, mul);
+    } else {
+        const unsigned short* p = reinterpret_cast<const unsigned short*>(base) + off;
+        if constexpr (CT == 4) {
+            const uint2 t = *reinterpret_cast<const uint2*>(p);
+            dst[0] = bf16_lo(t.x) * mul; dst[1] = bf16_hi(t.x) * mul; dst[2 % CT] = bf16_lo(t.y) * mul; dst[3 % CT] = bf16_hi(t.y) * mul;
+        } else if constexpr (CT == 2) {
+            const uint32_t t = *reinterpret_cast<const uint32_t*>(p);
+            dst[0] = bf16_lo(t) * mul; dst[1 % CT] = bf16_hi(t) * mul;
+        } else {
+            dst[0] = __uint_as_float((uint32_t)p[0] << 16) * mul;
+        }
+    }
+}
+
 __device__ __forceinline__ float grp16_sum(float v) {
     v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
     return v;
@@ -97,7 +141,7 @@ __device__ __forceinline__ float grp16_max(float v) {
 }
 
 // =====================================================================================================================
-template <int HD, bool B16 = false>      // B16: `ctx` points to bf16 elements (ldo in elements)
+template <int HD, bool B16 = false, bool IN16 = false>      // B16: `ctx` points to bf16 elements (ldo in elements); IN16: `qkv` too
 __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const float* __restrict__ qkv, int64_t ldq,
                                                                        const int64_t* __restrict__ tokens,
                                                                        const float* __restrict__ e1,
@@ -116,11 +160,11 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
     const int d = H * HD;
     const int64_t tokv = tokens ? tokens[n * 16 + c] : 0;
     const int64_t row_c = tokens ? tokv * 16 + c : n * 16 + c;                         // qkv / table row of token c
-    const float* rp = qkv + row_c * ldq + h * HD + g * KH;
+    const int64_t ro = row_c * ldq + h * HD + g * KH;
 
     float qa[KH], kb[KH];
-    load_f4<KH>(qa, rp, scale);
-    load_f4<KH>(kb, rp + d, 1.0f);
+    load_vec<KH, IN16>(qa, qkv, ro, scale);
+    load_vec<KH, IN16>(kb, qkv, ro + d, 1.0f);
     floatx4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < KH; ++k) s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[k], kb[k], s, 0, 0, 0);
@@ -163,7 +207,7 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
         const int64_t tj = __shfl(tokv, j, 16);
         const int64_t row_j = tokens ? tj * 16 + j : n * 16 + j;
         float vb[CT];
-        load_ct<CT>(vb, qkv + row_j * ldq + 2 * d + h * HD + CT * c, 1.0f);
+        load_cols<CT, IN16>(vb, qkv, row_j * ldq + 2 * d + h * HD + CT * c, 1.0f);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) o[ct] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa, vb[ct], o[ct], 0, 0, 0);
     }
@@ -181,7 +225,7 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
 // =====================================================================================================================
 // grid = (chunks, H).  Wave w of a workgroup walks the blocks chunk*bpc + w, + 4, ... of head blockIdx.y and keeps the
 // relative-embedding gradient of its head in registers; partials ws[(chunk*4 + w)][H][31][HD] (deterministic reduce).
-template <int HD, bool B16 = false>      // B16: `d_qkv` points to bf16 elements (ldg in elements)
+template <int HD, bool B16 = false, bool IN16 = false>      // B16: `d_qkv` points to bf16 elements (ldg in elements); IN16: `qkv`, `d_ctx` too
 __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ qkv, int64_t ldq,
     const int64_t* __restrict__ tokens, const float* __restrict__ probs, const float* __restrict__ e1,
@@ -214,8 +258,8 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
     auto load_blk = [&](Blk& B, int64_t n, int64_t tokv) {
         const int64_t prob = n * H + h;
         const int64_t row_c = tokens ? tokv * 16 + c : n * 16 + c;
-        load_f4<KH>(B.doa, d_ctx + (n * 16 + c) * ldo + h * HD + g * KH, 1.0f);
-        load_f4<KH>(B.vb, qkv + row_c * ldq + h * HD + 2 * d + g * KH, 1.0f);
+        load_vec<KH, IN16>(B.doa, d_ctx, (n * 16 + c) * ldo + h * HD + g * KH, 1.0f);
+        load_vec<KH, IN16>(B.vb, qkv, row_c * ldq + h * HD + 2 * d + g * KH, 1.0f);
 #pragma unroll
         for (int r = 0; r < 4; ++r) B.p[r] = probs[(prob * 16 + 4 * g + r) * 16 + c];
 #pragma unroll
@@ -223,9 +267,9 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
             const int j = 4 * g + sidx;
             const int64_t tj = __shfl(tokv, j, 16);
             const int64_t row = tokens ? tj * 16 + j : n * 16 + j;
-            load_ct<CT>(B.dob[sidx], d_ctx + (n * 16 + j) * ldo + h * HD + CT * c, 1.0f);
-            load_ct<CT>(B.qb[sidx], qkv + row * ldq + h * HD + CT * c, scale);
-            load_ct<CT>(B.kb[sidx], qkv + row * ldq + d + h * HD + CT * c, 1.0f);
+            load_cols<CT, IN16>(B.dob[sidx], d_ctx, (n * 16 + j) * ldo + h * HD + CT * c, 1.0f);
+            load_cols<CT, IN16>(B.qb[sidx], qkv, row * ldq + h * HD + CT * c, scale);
+            load_cols<CT, IN16>(B.kb[sidx], qkv, row * ldq + d + h * HD + CT * c, 1.0f);
         }
     };
     Blk cur;
@@ -353,24 +397,24 @@ int64_t relattn16_bwd_workspace(int64_t n_blocks, int H, int hd) {
     return (chunks * kA16Waves + 1) * H * 31 * hd * (int64_t)sizeof(float);
 }
 
-template <int HD, bool B16 = false>
+template <int HD, bool B16 = false, bool IN16 = false>
 static int a16_fwd_t(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
                      int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
     const int64_t total = n_blocks * H;
-    hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64), 0, s, qkv,
+    hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16, IN16>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64), 0, s, qkv,
                        ldq, tokens, e1, e2, ctx, ldo, probs, total, H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed);
     VQ_CHECK_LAUNCH("relattn16_fwd");
     return VQCPC_OK;
 }
 
-template <int HD, bool B16 = false>
+template <int HD, bool B16 = false, bool IN16 = false>
 static int a16_bwd_t(const float* d_ctx, int64_t ldo, const float* qkv, int64_t ldq, const int64_t* tokens,
                      const float* probs, const float* e1, const float* e2, float* d_qkv, int64_t ldg, float* ws,
                      int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s, int* nsplit) {
     const int bpc = a16_blocks_per_chunk(n_blocks, H);
     const int chunks = (int)ceil_div(n_blocks, bpc);
-    hipLaunchKernelGGL((relattn16_bwd_kernel<HD, B16>), dim3(chunks, H), dim3(kA16Waves * 64), 0, s, d_ctx, ldo, qkv, ldq, tokens,
+    hipLaunchKernelGGL((relattn16_bwd_kernel<HD, B16, IN16>), dim3(chunks, H), dim3(kA16Waves * 64), 0, s, d_ctx, ldo, qkv, ldq, tokens,
                        probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, bpc, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed);
     VQ_CHECK_LAUNCH("relattn16_bwd");
@@ -414,6 +458,29 @@ int relattn16_bwd_b16(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
     if (hd == 32)
         return a16_bwd_t<32, true>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
     return a16_bwd_t<64, true>(d_ctx, ldo, qkv, ldq, tokens, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+}
+
+// all-bf16 forms: q | k | v (and d ctx in the backward) are bf16 as well; no token indirection (the first layer's table is fp32)
+int relattn16_fwd_b16io(const void* qkv_b16, int64_t ldq, const float* e1, const float* e2, void* ctx_b16, int64_t ldo,
+                        float* probs, int64_t n_blocks, int H, int hd, float drop_p, uint64_t seed, hipStream_t s) {
+    const float* q = reinterpret_cast<const float*>(qkv_b16);
+    float* c = reinterpret_cast<float*>(ctx_b16);
+    if (hd == 16) return a16_fwd_t<16, true, true>(q, ldq, nullptr, e1, e2, c, ldo, probs, n_blocks, H, drop_p, seed, s);
+    if (hd == 32) return a16_fwd_t<32, true, true>(q, ldq, nullptr, e1, e2, c, ldo, probs, n_blocks, H, drop_p, seed, s);
+    return a16_fwd_t<64, true, true>(q, ldq, nullptr, e1, e2, c, ldo, probs, n_blocks, H, drop_p, seed, s);
+}
+
+int relattn16_bwd_b16io(const void* d_ctx_b16, int64_t ldo, const void* qkv_b16, int64_t ldq, const float* probs,
+                        const float* e1, const float* e2, void* d_qkv_b16, int64_t ldg, float* ws, int64_t n_blocks, int H,
+                        int hd, float drop_p, uint64_t seed, hipStream_t s, int* nsplit) {
+    const float* dc = reinterpret_cast<const float*>(d_ctx_b16);
+    const float* q = reinterpret_cast<const float*>(qkv_b16);
+    float* g = reinterpret_cast<float*>(d_qkv_b16);
+    if (hd == 16)
+        return a16_bwd_t<16, true, true>(dc, ldo, q, ldq, nullptr, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+    if (hd == 32)
+        return a16_bwd_t<32, true, true>(dc, ldo, q, ldq, nullptr, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
+    return a16_bwd_t<64, true, true>(dc, ldo, q, ldq, nullptr, probs, e1, e2, g, ldg, ws, n_blocks, H, drop_p, seed, s, nsplit);
 }
 
 }  // namespace vq

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(64) void relattn_sub_fwd_kernel(const float* __rest
                                                              const float* __restrict__ e1, const float* __restrict__ e2,
                                                              float* __restrict__ ctx, int64_t ldo,
                                                              float* __restrict__ probs, int64_t n_blocks, int H,
-                                                             float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+                                                             float scale, uint32_t thr, float inv_keep, uint64_t seed, int o16) {
     // Persistent slots: slot g of the grid keeps head g % H (the host makes the slot count a multiple of H) and walks the
     // blocks g / H, + slots / H, ...: the relative rows are staged once, the q / k / v rows of the next block are fetched
     // into registers while the current one is processed.  A slot's LDS region is private to its 4 LQ lanes of one wave.
@@ -189,10 +189,10 @@ __global__ __launch_bounds__(64) void relattn_sub_fwd_kernel(const float* __rest
                     o[c4 * 4 + 0] += p * v.x; o[c4 * 4 + 1] += p * v.y; o[c4 * 4 + 2] += p * v.z; o[c4 * 4 + 3] += p * v.w;
                 }
             }
-            float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + jg * C::CPL;
+            const int64_t oo = (n * C::LQ + iq) * ldo + h * HD + jg * C::CPL;
 #pragma unroll
             for (int c4 = 0; c4 < C::CPL / 4; ++c4)
-                *reinterpret_cast<float4*>(op + c4 * 4) = make_float4(o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3]);
+                store4_out(ctx, oo + c4 * 4, o[c4 * 4], o[c4 * 4 + 1], o[c4 * 4 + 2], o[c4 * 4 + 3], o16);
         }
     }
 }
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(64) void relattn_sub_bwd_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ q, int64_t ldq, const float* __restrict__ kv,
     int64_t ldkv, const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
     float* __restrict__ d_q, int64_t ldgq, float* __restrict__ d_kv, int64_t ldgkv, float* __restrict__ ws,
-    int64_t n_blocks, int H, int blocks_per_wg, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    int64_t n_blocks, int H, int blocks_per_wg, float scale, uint32_t thr, float inv_keep, uint64_t seed, int g16) {
     using C = SubCfg<L, HD, F>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x;
@@ -321,11 +321,11 @@ __global__ __launch_bounds__(64) void relattn_sub_bwd_kernel(
                         dk[c4 * 4 + 0] += ds * qq.x; dk[c4 * 4 + 1] += ds * qq.y; dk[c4 * 4 + 2] += ds * qq.z; dk[c4 * 4 + 3] += ds * qq.w;
                     }
                 }
-                float* gp = d_kv + (n * L + j) * ldgkv + h * HD + jg * C::CPL;
+                const int64_t go = (n * L + j) * ldgkv + h * HD + jg * C::CPL;
 #pragma unroll
                 for (int c4 = 0; c4 < C::CPL / 4; ++c4) {
-                    *reinterpret_cast<float4*>(gp + c4 * 4) = make_float4(dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3]);
-                    *reinterpret_cast<float4*>(gp + d + c4 * 4) = make_float4(dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3]);
+                    store4_out(d_kv, go + c4 * 4, dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3], g16 & 1);
+                    store4_out(d_kv, go + d + c4 * 4, dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3], g16 & 1);
                 }
             }
             // dq_iq = scale * sum_j dS[iq][j] (k_j + Erel[j - i + L - 1])
@@ -343,11 +343,11 @@ __global__ __launch_bounds__(64) void relattn_sub_bwd_kernel(
                     dq[c4 * 4 + 2] += ds * (k.z + e.z); dq[c4 * 4 + 3] += ds * (k.w + e.w);
                 }
             }
-            float* gq = d_q + (n * C::LQ + iq) * ldgq + h * HD + jg * C::CPL;
+            const int64_t gqo = (n * C::LQ + iq) * ldgq + h * HD + jg * C::CPL;
 #pragma unroll
             for (int c4 = 0; c4 < C::CPL / 4; ++c4)
-                *reinterpret_cast<float4*>(gq + c4 * 4) =
-                    make_float4(dq[c4 * 4] * scale, dq[c4 * 4 + 1] * scale, dq[c4 * 4 + 2] * scale, dq[c4 * 4 + 3] * scale);
+                store4_out(d_q, gqo + c4 * 4, dq[c4 * 4] * scale, dq[c4 * 4 + 1] * scale, dq[c4 * 4 + 2] * scale,
+                           dq[c4 * 4 + 3] * scale, g16 & 2);
             // dErel[r] += sum_{i'} dS[i'][jx] * qs[i'],  jx = F*i' + r - (L-1);  this lane owns rows r = iq + LQ*a
 #pragma unroll
             for (int a = 0; a < C::NER; ++a) {
@@ -449,7 +449,7 @@ __global__ __launch_bounds__(256) void relattn_sub16_fwd_kernel(const float* __r
                                                                 const float* __restrict__ e1, const float* __restrict__ e2,
                                                                 float* __restrict__ ctx, int64_t ldo,
                                                                 float* __restrict__ probs, int64_t n_blocks, int H,
-                                                                float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+                                                                float scale, uint32_t thr, float inv_keep, uint64_t seed, int o16) {
     // Persistent workgroups: wave w of the grid keeps head w % H (the host makes the wave count a multiple of H), so the 31
     // relative rows -- 45 % of the bytes a problem stages -- go to LDS once, and the q / k / v rows of the wave's next block
     // are fetched into registers while the current one is processed.  The LDS regions are private to a wavefront: only
@@ -523,9 +523,14 @@ __global__ __launch_bounds__(256) void relattn_sub16_fwd_kernel(const float* __r
 #pragma unroll
                 for (int c = 0; c < C::C16; ++c) o[c] += p * Vs[jj * C::RS + j * C::C16 + c];
             }
-            float* op = ctx + (n * C::LQ + iq) * ldo + h * HD + j * C::C16;
+            const int64_t oo = (n * C::LQ + iq) * ldo + h * HD + j * C::C16;
+            if constexpr (C::C16 % 4 == 0) {
 #pragma unroll
-            for (int c = 0; c < C::C16; ++c) op[c] = o[c];
+                for (int c = 0; c < C::C16; c += 4) store4_out(ctx, oo + c, o[c], o[(c + 1) % C::C16], o[(c + 2) % C::C16], o[(c + 3) % C::C16], o16);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C::C16; ++c) store1_out(ctx, oo + c, o[c], o16);
+            }
         }
     }
 }
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(256) void relattn_sub16_bwd_kernel(
     const float* __restrict__ d_ctx, int64_t ldo, const float* __restrict__ q, int64_t ldq, const float* __restrict__ kv,
     int64_t ldkv, const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
     float* __restrict__ d_q, int64_t ldgq, float* __restrict__ d_kv, int64_t ldgkv, float* __restrict__ ws,
-    int64_t n_blocks, int H, int blocks_per_wg, float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    int64_t n_blocks, int H, int blocks_per_wg, float scale, uint32_t thr, float inv_keep, uint64_t seed, int g16) {
     using C = Sub16<HD>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -642,11 +647,11 @@ __global__ __launch_bounds__(256) void relattn_sub16_bwd_kernel(
                     dk[c4 * 4 + 0] += ds * qq.x; dk[c4 * 4 + 1] += ds * qq.y; dk[c4 * 4 + 2] += ds * qq.z; dk[c4 * 4 + 3] += ds * qq.w;
                 }
             }
-            float* gp = d_kv + (n * C::L + j) * ldgkv + h * HD + cg4 * C::C4;
+            const int64_t go = (n * C::L + j) * ldgkv + h * HD + cg4 * C::C4;
 #pragma unroll
             for (int c4 = 0; c4 < C::C4 / 4; ++c4) {
-                *reinterpret_cast<float4*>(gp + c4 * 4) = make_float4(dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3]);
-                *reinterpret_cast<float4*>(gp + d + c4 * 4) = make_float4(dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3]);
+                store4_out(d_kv, go + c4 * 4, dk[c4 * 4], dk[c4 * 4 + 1], dk[c4 * 4 + 2], dk[c4 * 4 + 3], g16 & 1);
+                store4_out(d_kv, go + d + c4 * 4, dv[c4 * 4], dv[c4 * 4 + 1], dv[c4 * 4 + 2], dv[c4 * 4 + 3], g16 & 1);
             }
             // dq: lane (iq, column group j of C16 columns)
             float dq[C::C16];
@@ -660,9 +665,16 @@ __global__ __launch_bounds__(256) void relattn_sub16_bwd_kernel(
 #pragma unroll
                 for (int c = 0; c < C::C16; ++c) dq[c] += ds * (kr[c] + er[c]);
             }
-            float* gq = d_q + (n * C::LQ + iq) * ldgq + h * HD + j * C::C16;
+            const int64_t gqo = (n * C::LQ + iq) * ldgq + h * HD + j * C::C16;
+            if constexpr (C::C16 % 4 == 0) {
 #pragma unroll
-            for (int c = 0; c < C::C16; ++c) gq[c] = dq[c] * scale;
+                for (int c = 0; c < C::C16; c += 4)
+                    store4_out(d_q, gqo + c, dq[c] * scale, dq[(c + 1) % C::C16] * scale, dq[(c + 2) % C::C16] * scale,
+                               dq[(c + 3) % C::C16] * scale, g16 & 2);
+            } else {
+#pragma unroll
+                for (int c = 0; c < C::C16; ++c) store1_out(d_q, gqo + c, dq[c] * scale, g16 & 2);
+            }
             // dErel rows rr and rr + 16, columns [cgE*C4, +C4):  r = jx - 4 i' + 15
 #pragma unroll
             for (int a = 0; a < 2; ++a) {
@@ -724,7 +736,7 @@ static bool sub_supported(int L, int F, int H, int hd) {
 template <int L, int HD, int F>
 static int sub_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
                           float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed,
-                          hipStream_t s) {
+                          hipStream_t s, int b16) {
     using C = SubCfg<L, HD, F>;
     const size_t lds = (size_t)C::PPW * C::FWD_FLOATS * sizeof(float);
     auto kern = relattn_sub_fwd_kernel<L, HD, F>;
@@ -736,7 +748,7 @@ static int sub_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_t 
     const int64_t unit = H / gcd;
     grid = ceil_div(grid, unit) * unit;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(64), lds, s, q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H,
-                       1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+                       1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, b16);
     VQ_CHECK_LAUNCH("relattn_sub_fwd");
     return VQCPC_OK;
 }
@@ -745,7 +757,7 @@ template <int L, int HD, int F>
 static int sub_launch_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
                           const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
                           int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int H, float drop_p, uint64_t seed,
-                          float* ws, hipStream_t s) {
+                          float* ws, hipStream_t s, int b16) {
     using C = SubCfg<L, HD, F>;
     const size_t lds = (size_t)C::PPW * C::BWD_FLOATS * sizeof(float);
     auto kern = relattn_sub_bwd_kernel<L, HD, F>;
@@ -756,7 +768,7 @@ static int sub_launch_bwd(const float* d_ctx, int64_t ldo, const float* q, int64
     const int NS = C::PPW >= H ? C::PPW / H : 1;
     hipLaunchKernelGGL(kern, dim3(chunks, gy), dim3(64), lds, s, d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq,
                        d_kv, ldgkv, ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
-                       1.0f / (1.0f - drop_p), seed);
+                       1.0f / (1.0f - drop_p), seed, b16);
     VQ_CHECK_LAUNCH("relattn_sub_bwd");
     const int total = H * C::NE * HD;
     float* tot = ws + (int64_t)chunks * NS * total;
@@ -776,7 +788,7 @@ static int sub16_blocks_per_wg(int64_t n_blocks, int H) {
 template <int HD>
 static int sub16_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
                             float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed,
-                            hipStream_t s) {
+                            hipStream_t s, int b16) {
     using C = Sub16<HD>;
     const size_t lds = (size_t)4 * C::FWD_FLOATS * sizeof(float);
     auto kern = relattn_sub16_fwd_kernel<HD>;
@@ -788,7 +800,7 @@ static int sub16_launch_fwd(const float* q, int64_t ldq, const float* kv, int64_
     const int64_t unit = H / gcd;
     grid = ceil_div(grid, unit) * unit;
     hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H,
-                       1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+                       1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, b16);
     VQ_CHECK_LAUNCH("relattn_sub16_fwd");
     return VQCPC_OK;
 }
@@ -797,7 +809,7 @@ template <int HD>
 static int sub16_launch_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
                             const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
                             int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int H, float drop_p, uint64_t seed,
-                            float* ws, hipStream_t s) {
+                            float* ws, hipStream_t s, int b16) {
     using C = Sub16<HD>;
     const size_t lds = (size_t)4 * C::BWD_FLOATS * sizeof(float);
     auto kern = relattn_sub16_bwd_kernel<HD>;
@@ -808,7 +820,7 @@ static int sub16_launch_bwd(const float* d_ctx, int64_t ldo, const float* q, int
     const int NS = 4 >= H ? 4 / H : 1;
     hipLaunchKernelGGL(kern, dim3(chunks, gy), dim3(256), lds, s, d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv,
                        ldgkv, ws, n_blocks, H, bpw, 1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p),
-                       seed);
+                       seed, b16);
     VQ_CHECK_LAUNCH("relattn_sub16_bwd");
     const int total = H * C::NE * HD;
     float* tot = ws + (int64_t)chunks * NS * total;
@@ -833,9 +845,9 @@ using namespace vq;
 
 extern "C" {
 
-int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
-                          float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd,
-                          float drop_p, uint64_t seed, void* stream) {
+static int sub_fwd_impl(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                        float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd, float drop_p,
+                        uint64_t seed, void* stream, int b16) {
     if (n_blocks == 0) return VQCPC_OK;
     VQ_REQUIRE(q && kv && e1 && e2 && ctx && probs, "relattn_sub_fwd: null pointer");
     VQ_REQUIRE(sub_supported(L, F, H, hd), "relattn_sub_fwd: unsupported L=%d F=%d H=%d hd=%d", L, F, H, hd);
@@ -845,11 +857,11 @@ int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t 
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "relattn_sub_fwd: bad dropout probability");
     hipStream_t s = (hipStream_t)stream;
     if (L == 16 && (4 % H == 0 || H % 4 == 0)) {
-        if (hd == 16) return sub16_launch_fwd<16>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
-        if (hd == 32) return sub16_launch_fwd<32>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
-        if (hd == 64) return sub16_launch_fwd<64>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s);
+        if (hd == 16) return sub16_launch_fwd<16>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s, b16);
+        if (hd == 32) return sub16_launch_fwd<32>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s, b16);
+        if (hd == 64) return sub16_launch_fwd<64>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s, b16);
     }
-#define CALL(LL, DD, FF) sub_launch_fwd<LL, DD, FF>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s)
+#define CALL(LL, DD, FF) sub_launch_fwd<LL, DD, FF>(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, H, drop_p, seed, s, b16)
     VQ_SUB_DISPATCH(CALL)
 #undef CALL
     return VQCPC_EINVAL;
@@ -869,10 +881,10 @@ int64_t vqcpc_relattn_sub_bwd_workspace(int64_t n_blocks, int L, int F, int H, i
     return (chunks * NS + 1) * H * (2 * L - 1) * hd * (int64_t)sizeof(float);
 }
 
-int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
-                          const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
-                          int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd,
-                          float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+static int sub_bwd_impl(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                        const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
+                        int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd, float drop_p,
+                        uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream, int b16) {
     VQ_REQUIRE(d_ctx && q && kv && probs && e1 && e2 && d_q && d_kv && d_e1 && d_e2 && workspace,
                "relattn_sub_bwd: null pointer");
     VQ_REQUIRE(sub_supported(L, F, H, hd), "relattn_sub_bwd: unsupported L=%d F=%d H=%d hd=%d", L, F, H, hd);
@@ -887,7 +899,7 @@ int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64
     if (L == 16 && (4 % H == 0 || H % 4 == 0)) {
 #define CALL16(DD)                                                                                                     \
     sub16_launch_bwd<DD>(d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv, ldgkv, d_e1, d_e2, n_blocks, H, drop_p, \
-                         seed, (float*)workspace, s)
+                         seed, (float*)workspace, s, b16)
         if (hd == 16) return CALL16(16);
         if (hd == 32) return CALL16(32);
         if (hd == 64) return CALL16(64);
@@ -895,10 +907,44 @@ int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64
     }
 #define CALL(LL, DD, FF)                                                                                                \
     sub_launch_bwd<LL, DD, FF>(d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv, ldgkv, d_e1, d_e2, n_blocks, H, \
-                               drop_p, seed, (float*)workspace, s)
+                               drop_p, seed, (float*)workspace, s, b16)
     VQ_SUB_DISPATCH(CALL)
 #undef CALL
     return VQCPC_EINVAL;
+}
+
+int vqcpc_relattn_sub_fwd(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                          float* ctx, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd,
+                          float drop_p, uint64_t seed, void* stream) {
+    return sub_fwd_impl(q, ldq, kv, ldkv, e1, e2, ctx, ldo, probs, n_blocks, L, F, H, hd, drop_p, seed, stream, 0);
+}
+
+int vqcpc_relattn_sub_bwd(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                          const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, float* d_kv,
+                          int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd,
+                          float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+    return sub_bwd_impl(d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq, d_kv, ldgkv, d_e1, d_e2, n_blocks, L, F, H, hd,
+                        drop_p, seed, workspace, workspace_bytes, stream, 0);
+}
+
+/* bf16-output forms (the bf16 training path, configs[4]): ctx_b16 / d_kv_b16 hold bf16 elements (leading dimensions in elements);
+ * d_q -- 1/8 of the gradient bytes, and an operand of an fp32 GEMM with two residual inputs -- stays fp32. */
+int vqcpc_relattn_sub_b16_supported(int L, int F, int H, int hd) { return sub_supported(L, F, H, hd) ? 1 : 0; }
+
+int vqcpc_relattn_sub_fwd_b16(const float* q, int64_t ldq, const float* kv, int64_t ldkv, const float* e1, const float* e2,
+                              void* ctx_b16, int64_t ldo, float* probs, int64_t n_blocks, int L, int F, int H, int hd,
+                              float drop_p, uint64_t seed, void* stream) {
+    return sub_fwd_impl(q, ldq, kv, ldkv, e1, e2, reinterpret_cast<float*>(ctx_b16), ldo, probs, n_blocks, L, F, H, hd, drop_p,
+                        seed, stream, 1);
+}
+
+int vqcpc_relattn_sub_bwd_b16(const float* d_ctx, int64_t ldo, const float* q, int64_t ldq, const float* kv, int64_t ldkv,
+                              const float* probs, const float* e1, const float* e2, float* d_q, int64_t ldgq, void* d_kv_b16,
+                              int64_t ldgkv, float* d_e1, float* d_e2, int64_t n_blocks, int L, int F, int H, int hd,
+                              float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+    return sub_bwd_impl(d_ctx, ldo, q, ldq, kv, ldkv, probs, e1, e2, d_q, ldgq,
+                        reinterpret_cast<float*>(d_kv_b16), ldgkv, d_e1, d_e2, n_blocks, L, F, H, hd, drop_p, seed, workspace,
+                        workspace_bytes, stream, 1);
 }
 
 }  // extern "C"

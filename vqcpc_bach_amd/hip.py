@@ -80,6 +80,17 @@ SIGNATURES = {
     'vqcpc_relattn_sub_bwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
                                       c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64,
                                       c_ptr]),
+    'vqcpc_relattn_b16_supported': (c_int, [c_int, c_int, c_int]),
+    'vqcpc_relattn_sub_b16_supported': (c_int, [c_int, c_int, c_int, c_int]),
+    'vqcpc_relattn_fwd_b16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_int, c_f32,
+                                      c_u64, c_ptr]),
+    'vqcpc_relattn_bwd_b16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
+                                      c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_relattn_sub_fwd_b16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int,
+                                          c_int, c_int, c_f32, c_u64, c_ptr]),
+    'vqcpc_relattn_sub_bwd_b16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr,
+                                          c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_int, c_f32, c_u64, c_ptr, c_i64,
+                                          c_ptr]),
     'vqcpc_relattn_x_fwd': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int,
                                     c_int, c_int, c_int, c_int, c_f32, c_u64, c_ptr]),
     'vqcpc_relattn_x_bwd_workspace': (c_i64, [c_i64, c_int, c_int, c_int, c_int]),
@@ -123,6 +134,9 @@ SIGNATURES = {
                                         c_ptr]),
     'vqcpc_relattn16_bwd_b16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
                                         c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_relattn16_fwd_b16io': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64, c_int, c_int, c_f32, c_u64, c_ptr]),
+    'vqcpc_relattn16_bwd_b16io': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_i64,
+                                          c_int, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
     'vqcpc_gru_step_supported': (c_int, [c_i64, c_int]),
     'vqcpc_gru_step_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64, c_ptr]),
     'vqcpc_gru_step_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64,

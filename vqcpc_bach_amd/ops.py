@@ -632,16 +632,30 @@ class EncoderLayerFn(torch.autograd.Function):
         xsb = None
         if f == 1:
             Mq, xs, ldxs = M, x, ldx
-            qkv = lin(xb if nat else x, wqkv, bias=bqkv) if qkv_in is None else _f32(qkv_in).contiguous()
             probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
             # bf16 path at L = 16: the attention context only feeds the out-proj GEMM, which reads bf16 -> the kernel writes
-            # bf16 directly (no fp32 tensor, no cast pass)
+            # bf16 directly (no fp32 tensor, no cast pass); where the projection runs here (no block table) q | k | v are
+            # bf16 as well -- the in_proj epilogue writes them so and the attention kernels read half the bytes
             b16_att = nat and ATT_B16_OUT and bool(hip.query('vqcpc_relattn16_b16_supported', L, H, hd))
+            b16_qkv = b16_att and ATT_B16_IN and qkv_in is None
+            if qkv_in is not None:
+                qkv = _f32(qkv_in).contiguous()
+            elif b16_qkv:
+                qkv = gemm_nt_bf16(xb, wqkv, bias=bqkv, out_f32=False, out_bf16=True)
+            else:
+                qkv = lin(xb if nat else x, wqkv, bias=bqkv)
             attb_direct = None
             if b16_att:
                 attb_direct = torch.empty(M, d, dtype=torch.bfloat16, device=dev)
                 att = None
-                hip.call('vqcpc_relattn16_fwd_b16', qkv, 3 * d, qkv_tokens, e1, e2, attb_direct, d, probs, nblk, H, hd, p, s[0])
+                if b16_qkv:
+                    hip.call('vqcpc_relattn16_fwd_b16io', qkv, 3 * d, e1, e2, attb_direct, d, probs, nblk, H, hd, p, s[0])
+                else:
+                    hip.call('vqcpc_relattn16_fwd_b16', qkv, 3 * d, qkv_tokens, e1, e2, attb_direct, d, probs, nblk, H, hd, p, s[0])
+            elif (nat and ATT_B16_OUT and qkv_tokens is None and hip.query('vqcpc_relattn_b16_supported', L, H, hd)):
+                attb_direct = torch.empty(M, d, dtype=torch.bfloat16, device=dev)      # the other block lengths (L = 4)
+                att = None
+                hip.call('vqcpc_relattn_fwd_b16', qkv, 3 * d, e1, e2, attb_direct, d, probs, nblk, L, H, hd, p, s[0])
             else:
                 att = torch.empty(M, d, dtype=torch.float32, device=dev)
                 if qkv_tokens is not None:
@@ -657,10 +671,15 @@ class EncoderLayerFn(torch.autograd.Function):
             xsb = xb[::f].contiguous() if nat else None
             qkv = lin(xb if nat else x, wqkv[d:], bias=bqkv[d:])           # k | v for every token   (M, 2d)
             qproj = lin(xsb if nat else xs, wqkv[:d], bias=bqkv[:d])       # q for the kept rows     (Mq, d)
-            att = torch.empty(Mq, d, dtype=torch.float32, device=dev)
             probs = torch.empty(nblk, H, L // f, L, dtype=torch.float32, device=dev)
-            hip.call('vqcpc_relattn_sub_fwd', qproj, d, qkv, 2 * d, e1, e2, att, d, probs, nblk, L, f, H, hd, p, s[0])
-        attb = (attb_direct if (f == 1 and attb_direct is not None) else cast_bf16(att)) if nat else None
+            if nat and ATT_B16_OUT and hip.query('vqcpc_relattn_sub_b16_supported', L, f, H, hd):
+                attb_direct = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev)
+                att = None
+                hip.call('vqcpc_relattn_sub_fwd_b16', qproj, d, qkv, 2 * d, e1, e2, attb_direct, d, probs, nblk, L, f, H, hd, p, s[0])
+            else:
+                att = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+                hip.call('vqcpc_relattn_sub_fwd', qproj, d, qkv, 2 * d, e1, e2, att, d, probs, nblk, L, f, H, hd, p, s[0])
+        attb = (attb_direct if attb_direct is not None else cast_bf16(att)) if nat else None
         # s1 = x + dropout(att Wo^T + bo): the residual sum is formed by the out-proj epilogue (bias -> dropout -> + x), so the
         # LayerNorm kernels read ONE input stream and the backward needs neither x nor the projection output again
         sform1 = _residual_sum_in_epilogue(Mq, d, d, nat)
@@ -771,9 +790,10 @@ class EncoderLayerFn(torch.autograd.Function):
             ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, mean1, rstd1, s[1])
         else:
             ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, xs, ldxs, s1, g1, mean1, rstd1, s[1])
+        b16_io = nat and f == 1 and qkv.dtype == torch.bfloat16       # the all-bf16 attention backward reads d ctx as bf16
         if nat:
             dwo, dbo = wgrad(dAb, attb, wo, bo)
-            datt = gemm_nt_bf16(dAb, transpose(wo))
+            datt = gemm_nt_bf16(dAb, transpose(wo), out_f32=not b16_io, out_bf16=b16_io)
         else:
             dwo, dbo = wgrad(dA, att, wo, bo)
             datt = gemm_nt(dA, transpose(wo))
@@ -788,8 +808,21 @@ class EncoderLayerFn(torch.autograd.Function):
                     and hip.query('vqcpc_relattn16_b16_supported', L, H, hd)):
                 # bf16 path: d qkv only feeds the two GEMMs below -> written as bf16 by the attention backward itself
                 dqkvb = torch.empty(M, 3 * d, dtype=torch.bfloat16, device=dev)
-                hip.call('vqcpc_relattn16_bwd_b16', datt, d, qkv, 3 * d, None, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk, H, hd,
-                         p, s[0], ws, nbytes)
+                if b16_io:
+                    hip.call('vqcpc_relattn16_bwd_b16io', datt, d, qkv, 3 * d, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk, H,
+                             hd, p, s[0], ws, nbytes)
+                else:
+                    hip.call('vqcpc_relattn16_bwd_b16', datt, d, qkv, 3 * d, None, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk,
+                             H, hd, p, s[0], ws, nbytes)
+                dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
+                dx = gemm_nt_bf16(dqkvb, transpose(wqkv), add=ds1) if need_dx else None
+                de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
+                return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
+                        dbe1, dg2, dbe2)
+            if (nat and not ext_qkv and tok is None and ATT_B16_OUT and hip.query('vqcpc_relattn_b16_supported', L, H, hd)):
+                dqkvb = torch.empty(M, 3 * d, dtype=torch.bfloat16, device=dev)        # the other block lengths (L = 4)
+                hip.call('vqcpc_relattn_bwd_b16', datt, d, qkv, 3 * d, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk, L, H, hd, p,
+                         s[0], ws, nbytes)
                 dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
                 dx = gemm_nt_bf16(dqkvb, transpose(wqkv), add=ds1) if need_dx else None
                 de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
@@ -821,14 +854,16 @@ class EncoderLayerFn(torch.autograd.Function):
                 dwqkv, dbqkv = wgrad(dqkv, x, wqkv, bqkv)
                 dx = gemm_nt(dqkv, transpose(wqkv), add=ds1) if need_dx else None
         else:
-            dq = torch.empty(Mq, d, dtype=torch.float32, device=dev)
-            dkv = torch.empty(M, 2 * d, dtype=torch.float32, device=dev)
             nbytes = hip.query('vqcpc_relattn_sub_bwd_workspace', nblk, L, f, H, hd)
             ws = hip.workspace(nbytes, dev)
-            hip.call('vqcpc_relattn_sub_bwd', datt, d, qproj, d, qkv, 2 * d, probs, e1, e2, dq, d, dkv, 2 * d, de1, de2, nblk,
-                     L, f, H, hd, p, s[0], ws, nbytes)
+            sub_b16 = nat and ATT_B16_OUT and bool(hip.query('vqcpc_relattn_sub_b16_supported', L, f, H, hd))
+            dq = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+            # bf16 path: d k | v (8 x the bytes of d q) only feeds GEMMs that read bf16 -> written so by the kernel
+            dkv = torch.empty(M, 2 * d, dtype=torch.bfloat16 if sub_b16 else torch.float32, device=dev)
+            hip.call('vqcpc_relattn_sub_bwd_b16' if sub_b16 else 'vqcpc_relattn_sub_bwd', datt, d, qproj, d, qkv, 2 * d, probs, e1,
+                     e2, dq, d, dkv, 2 * d, de1, de2, nblk, L, f, H, hd, p, s[0], ws, nbytes)
             if nat:
-                dkv = cast_bf16(dkv)
+                dkv = cast_bf16(dkv)                                   # a no-op on a bf16 tensor
                 dwq, dbq = wgrad(cast_bf16(dq), xsb, wqkv, bqkv, rows=slice(0, d))
                 dwkv, dbkv = wgrad(dkv, xb, wqkv, bqkv, rows=slice(d, 3 * d))
             else:
@@ -1106,6 +1141,7 @@ class DropoutSeluFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------------
 # A15: GRU layer of the context network (time-major rows: row = t * B + b)
 # ------------------------------------------------------------------------------------------------------------------
+ATT_B16_IN = os.environ.get('VQCPC_ATT_B16_IN', '1') != '0'          # A/B switch: bf16 q | k | v and d ctx INTO the L = 16 attention kernels
 ATT_B16_OUT = os.environ.get('VQCPC_ATT_B16_OUT', '1') != '0'        # A/B switch: bf16 outputs straight from the L = 16 attention
 GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)
 

@@ -362,12 +362,15 @@ def test_encoder_layer_bf16_native_path_matches_the_rounded_operand_path(ops):
     x = torch.randn(nblk * L, d, device='cuda', requires_grad=True)
     g = torch.randn(nblk * L, d, device='cuda')
     res = {}
-    real = ops.bf16_native
+    real, real_in = ops.bf16_native, ops.ATT_B16_IN
     try:
         hip.set_gemm_mode(8)
-        for native in (True, False):
+        # 'io': the product's native path (q | k | v and d ctx bf16 into the attention kernels as well); True: native GEMMs with
+        # fp32 attention inputs; False: rounded-operand path
+        for native in ('io', True, False):
             ops.bf16_native = real if native else (lambda *shapes: False)
-            assert ops.bf16_native((1024, 512, 256)) == native
+            ops.ATT_B16_IN = native == 'io'
+            assert ops.bf16_native((1024, 512, 256)) == bool(native)
             for p_ in layer.parameters():
                 p_.grad = None
             x.grad = None
@@ -375,11 +378,18 @@ def test_encoder_layer_bf16_native_path_matches_the_rounded_operand_path(ops):
             (y * g).sum().backward()
             res[native] = [y.detach().clone(), x.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()]
     finally:
-        ops.bf16_native = real
+        ops.bf16_native, ops.ATT_B16_IN = real, real_in
         hip.set_gemm_mode(0)
     for a_, b_ in zip(res[True], res[False]):
         assert rel_err(a_, b_) < 5e-3, rel_err(a_, b_)          # bf16 roundings of near-identical fp32 values may flip
     assert rel_err(res[True][0], res[False][0]) < 2e-4
+    # bf16 q | k | v / d ctx: one more rounding (2^-9 relative) of the attention operands, as in any bf16 training stack.  With
+    # this test's N(0, 1) activations the logits reach +-10, so 2^-9 on q and k moves single probabilities by a few per cent
+    # and the gradients that pass through the softmax follow (5.8 % max-norm measured): bounded here, switched off by
+    # VQCPC_ATT_B16_IN=0, and pinned statistically at the model level by test_c4_bf16_mode_vs_bf16_cast_oracle
+    for a_, b_ in zip(res['io'], res[False]):
+        assert rel_err(a_, b_) < 0.12, rel_err(a_, b_)
+    assert rel_err(res['io'][0], res[False][0]) < 2e-2
 
 
 def test_gemm_nt_bf16x6_256_tile_is_transpose_detecting(ops, bf16x6):

@@ -106,10 +106,26 @@ class GemmTimer:
             e0.record()
             out = raw_tn(a, b, *args, **kw)
             e1.record()
+            if getattr(ops, 'LAST_TN_DEFERRED', False):      # collected for the grouped launch at the end of backward (below)
+                return out
             timer.records['gemm_tn'].append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1],
                                              4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[1] * b.shape[1]),
                                              (a.shape[0], a.shape[1], b.shape[1], 'wgrad')))
             return out
+
+        raw_flush = ops.flush_wgrads
+
+        def flush_wgrads():
+            flops = ops.pending_wgrad_flops()
+            if not timer.enabled or flops == 0:
+                return raw_flush()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            raw_flush()
+            e1.record()
+            timer.records['gemm_tn'].append((e0, e1, flops, 0.0, (0, 0, 0, 'wgrad:grouped')))
+
+        ops.flush_wgrads = flush_wgrads
 
         raw_ntb, raw_cast, raw_tnb = ops.gemm_nt_bf16, ops.cast_bf16, ops.gemm_tn_bf16
 

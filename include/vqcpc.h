@@ -126,6 +126,18 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 int64_t vqcpc_gemm_tn_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
+/* Grouped weight gradients: n independent products dW_i (+)= A_i^T B_i, db_i (+)= column sums of A_i in a few launches (32
+ * problems per launch pair: products + partial-sum reduction).  For the student / decoder steps, whose ~100 weight gradients
+ * per backward pass (3072 rows x 512 ... 2048) cannot fill the chip one at a time; torch.autograd issues them one by one
+ * (decoders/decoder.py:431-543, student_encoder_trainer.py:256-296), the trainers of this library defer them to the end of
+ * loss.backward().  Arrays are HOST arrays of length n (device pointers inside); db[i] may be NULL; a gradient buffer that
+ * occurs twice is accumulated in problem order.  vqcpc_gemm_tn_groupable: the product is one the grouped kernel serves in the
+ * current GEMM mode (bf16x6 / rounded-operand modes, shapes that do not take the 256-tile kernel). */
+int vqcpc_gemm_tn_groupable(int64_t M, int N, int K);
+int64_t vqcpc_gemm_tn_grouped_workspace(int n, const int64_t* M, const int* N, const int* K);
+int vqcpc_gemm_tn_grouped(int n, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb,
+                          void* const* dW, void* const* db, const int64_t* M, const int* N, const int* K, int accumulate,
+                          void* workspace, int64_t workspace_bytes, void* stream);
 /* out[C][R] = in[R][C]^T (weight transposes for the dgrad form of vqcpc_gemm_nt) */
 int vqcpc_transpose(const float* in, float* out, int R, int C, void* stream);
 /* The transposes of n row-major matrices that live in one buffer, in one launch: matrix i = base_in + desc[4 i] with

@@ -349,6 +349,73 @@ def test_gemm_tn_bf16_native_kernel(ops, M, N, K):
     assert torch.equal(dw3.cpu(), bi[torch.arange(N) * (M // N)])
 
 
+@pytest.mark.parametrize('mode', [1, 8])
+def test_grouped_weight_gradients_equal_the_single_launches(ops, mode):
+    """vqcpc_gemm_tn_grouped (the deferred small weight gradients of a trainer's backward pass) against one vqcpc_gemm_tn per
+    product and against fp64: 70 products of mixed shapes (full and ragged tiles, strided operands, no bias, a row block of a
+    larger gradient) incl. a gradient buffer that occurs three times -- accumulated in problem order on top of what the buffers
+    held."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(11 + mode)
+    shapes = [(3072, 512, 512), (3072, 2048, 512), (3072, 512, 2048), (768, 512, 512), (3072, 1536, 512), (1000, 132, 260),
+              (256, 32, 1536), (3072, 512, 512)]
+    hip.set_gemm_mode(mode)
+    try:
+        with torch.no_grad():
+            probs = []
+            for i in range(70):
+                M, N, K = shapes[i % len(shapes)]
+                assert hip.query('vqcpc_gemm_tn_groupable', M, N, K)
+                a = torch.randn(M, N, generator=gen).cuda()
+                b = torch.randn(M, K + 8, generator=gen).cuda()[:, :K] if i % 5 == 0 else torch.randn(M, K, generator=gen).cuda()
+                probs.append((a, b, i % 7 != 3))
+            shared_w = torch.randn(512, 512, generator=gen).cuda()
+            shared_b = torch.randn(512, generator=gen).cuda()
+            big = torch.randn(1536 + 512, 512, generator=gen).cuda()         # problem 4's gradient is rows 512.. of this one
+            def buffers():
+                out = []
+                for i, (a, b, wb) in enumerate(probs):
+                    N, K = a.shape[1], b.shape[1]
+                    if i in (0, 7, 8):                                       # the same (512, 512) gradient three times
+                        out.append((shared_w_c, shared_b_c if wb else None))
+                    elif i == 4:
+                        out.append((big_c[512:], None))
+                    else:
+                        out.append((torch.full((N, K), 0.5, device='cuda'), torch.full((N,), -1.0, device='cuda') if wb else None))
+                return out
+            # reference: one launch pair per product
+            shared_w_c, shared_b_c, big_c = shared_w.clone(), shared_b.clone(), big.clone()
+            ref = buffers()
+            real = ops.GROUP_WGRADS
+            for (a, b, wb), (dw, db) in zip(probs, ref):
+                ops.gemm_tn(a, b, into=(dw, db))
+            ref_shared, ref_big = (shared_w_c, shared_b_c), big_c
+            # grouped: deferred inside a gradient scope, issued at its end
+            shared_w_c, shared_b_c, big_c = shared_w.clone(), shared_b.clone(), big.clone()
+            got = buffers()
+            with ops.direct_weight_gradients():
+                for (a, b, wb), (dw, db) in zip(probs, got):
+                    ops.gemm_tn(a, b, into=(dw, db))
+                    assert ops.LAST_TN_DEFERRED
+                assert float((got[1][0] - 0.5).abs().max()) == 0.0          # nothing has been issued yet
+            torch.cuda.synchronize()
+            for i, ((dw0, db0), (dw1, db1)) in enumerate(zip(ref, got)):
+                scale = float(dw0.abs().max())
+                assert float((dw0 - dw1).abs().max()) <= 2e-5 * scale, i
+                if db0 is not None:
+                    assert float((db0 - db1).abs().max()) <= 2e-5 * float(db0.abs().max()), i
+            a0, b0, _ = probs[1]
+            w64 = a0.double().t() @ b0.double() + 0.5
+            tol = 1e-5 if mode == 1 else 2e-2
+            assert rel_err(got[1][0].cpu(), w64.cpu()) < tol
+            assert rel_err(got[1][1].cpu(), (a0.double().sum(0) - 1.0).cpu()) < 1e-5
+            tri = sum(probs[i][0].double().t() @ probs[i][1].double() for i in (0, 7, 8)) + shared_w.double()
+            assert rel_err(shared_w_c.cpu(), tri.cpu()) < tol
+            assert torch.equal(big_c[:512], big[:512])                       # rows outside the block untouched
+    finally:
+        hip.set_gemm_mode(0)
+
+
 def test_encoder_layer_bf16_native_path_matches_the_rounded_operand_path(ops):
     """hip.set_gemm_mode(8): a layer whose shapes fit the 256-tile bf16 kernel takes bf16 operands from HBM (cast passes,
     bf16 FFN hidden activation); a layer that does not fit rounds fp32 operands inside the 128-tile kernels.  Same

@@ -928,18 +928,18 @@ __device__ __forceinline__ void split3_pair4(const float4& r0, const float4& r1,
 #undef TN_SPLIT_E
 }
 
+// (bx, by) = (output tile, split of the contraction): blockIdx of the plain launch, looked up per problem in the grouped one
 template <bool FULL, int MODE>
-__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float* __restrict__ A, int64_t lda,
-                                                                    const float* __restrict__ B, int64_t ldb, int64_t M,
-                                                                    int N, int K, int tiles_k, int64_t rows_per_split,
-                                                                    float* __restrict__ ws, float* __restrict__ ws_bias) {
+__device__ __forceinline__ void gemm_tn_x6_tile(const float* __restrict__ A, int64_t lda, const float* __restrict__ B,
+                                                int64_t ldb, int64_t M, int N, int K, int tiles_k, int64_t rows_per_split,
+                                                float* __restrict__ ws, float* __restrict__ ws_bias, int bx, int by) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[6 * kTnPlane];   // A_h A_m A_l B_h B_m B_l
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, kh = lane >> 5;
-    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int tn = bx / tiles_k, tk = bx % tiles_k;
     const int n0 = tn * BM, k0 = tk * BN;
-    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_begin = (int64_t)by * rows_per_split;
     const int64_t m_end = min(m_begin + rows_per_split, M);
     const bool want_bias = (ws_bias != nullptr) && tk == 0;
 
@@ -1045,7 +1045,7 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
 #undef X6_ST
 #undef X6_STORE
 
-    float* out = ws + (int64_t)blockIdx.y * N * K;
+    float* out = ws + (int64_t)by * N * K;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
 #pragma unroll
@@ -1069,9 +1069,89 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float
             float tot = 0.0f;
 #pragma unroll
             for (int g = 0; g < 8; ++g) tot += red[g * BM + tid];
-            if (n0 + tid < N) ws_bias[(int64_t)blockIdx.y * N + n0 + tid] = tot;
+            if (n0 + tid < N) ws_bias[(int64_t)by * N + n0 + tid] = tot;
         }
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_kernel(const float* __restrict__ A, int64_t lda,
+                                                                    const float* __restrict__ B, int64_t ldb, int64_t M,
+                                                                    int N, int K, int tiles_k, int64_t rows_per_split,
+                                                                    float* __restrict__ ws, float* __restrict__ ws_bias) {
+    gemm_tn_x6_tile<FULL, MODE>(A, lda, B, ldb, M, N, K, tiles_k, rows_per_split, ws, ws_bias, (int)blockIdx.x, (int)blockIdx.y);
+}
+
+// GROUPED weight gradients (student / decoder steps: ~100 products of 3072 x 512 x 512 ... 2048 per step, each too small to
+// fill the chip: 27 us + a 6 us partial-sum launch apiece).  The weight gradients of a backward pass are independent of each
+// other and only the optimiser reads them, so the host defers them (ops.direct_weight_gradients) and issues up to kTnGroup
+// products per launch: the problem table travels BY VALUE in the kernel arguments (graph-capturable, no device table to keep
+// alive), a workgroup finds its problem by a scalar scan of the workgroup prefix.
+constexpr int kTnGroup = 32;
+struct TnGroupArgs {
+    const float* A[kTnGroup];
+    const float* B[kTnGroup];
+    float* ws[kTnGroup];
+    float* wsb[kTnGroup];
+    int lda[kTnGroup], ldb[kTnGroup], M[kTnGroup], N[kTnGroup], K[kTnGroup], tiles_k[kTnGroup], tiles[kTnGroup], rows_per_split[kTnGroup];
+    int wg_begin[kTnGroup + 1];
+    int n;
+};
+
+template <bool FULL, int MODE>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_tn_x6_grouped_kernel(const TnGroupArgs g) {
+    const int b = (int)blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < g.n; ++i) p += (b >= g.wg_begin[i]) ? 1 : 0;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int local = b - g.wg_begin[p];
+    gemm_tn_x6_tile<FULL, MODE>(g.A[p], g.lda[p], g.B[p], g.ldb[p], g.M[p], g.N[p], g.K[p], g.tiles_k[p], g.rows_per_split[p],
+                                g.ws[p], g.wsb[p], local % g.tiles[p], local / g.tiles[p]);
+}
+
+// partial sums of a group -> the gradient buffers (fixed split order; accumulate = add to what the buffer holds)
+struct RedGroupArgs {
+    const float* ws[kTnGroup];
+    float* out[kTnGroup];
+    const float* ws2[kTnGroup];
+    float* out2[kTnGroup];
+    int count[kTnGroup], count2[kTnGroup], nsplit[kTnGroup];
+    int blk_begin[kTnGroup + 1];
+    int n, accumulate;
+};
+
+__global__ __launch_bounds__(256) void reduce_splits_grouped_kernel(const RedGroupArgs g) {
+    const int b = (int)blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < g.n; ++i) p += (b >= g.blk_begin[i]) ? 1 : 0;
+    p = __builtin_amdgcn_readfirstlane(p);
+    int64_t q = (int64_t)(b - g.blk_begin[p]) * 256 + threadIdx.x;                       // float4 index
+    const float* ws = g.ws[p];
+    float* out = g.out[p];
+    int64_t count = g.count[p];
+    const int64_t first = (count / 4 + 255) / 256 * 256;                                 // segment 2 (bias): workgroup boundary
+    if (q >= first) {
+        q -= first;
+        ws = g.ws2[p];
+        out = g.out2[p];
+        count = g.count2[p];
+    }
+    if (q * 4 >= count) return;
+    const int nsplit = g.nsplit[p];
+    const float4* src = reinterpret_cast<const float4*>(ws) + q;
+    const int64_t st4 = count / 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int s_ = 0; s_ < nsplit; ++s_) {
+        const float4 v = src[s_ * st4];
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    float4* o = reinterpret_cast<float4*>(out) + q;
+    if (g.accumulate) {
+        const float4 prev = *o;
+        acc.x += prev.x; acc.y += prev.y; acc.z += prev.z; acc.w += prev.w;
+    }
+    *o = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -2220,6 +2300,124 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                            tiles_k, rows_per_split, ws, ws_bias);
     VQ_CHECK_LAUNCH("gemm_tn");
     return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
+}
+
+
+// ---- grouped weight gradients (see gemm_tn_x6_grouped_kernel) ---------------------------------------------------------
+// A product is "groupable" when the single launch would take the 128-tile bf16x6 kernel (few rows: student / decoder steps);
+// the large products of the CPC step fill the chip on their own and keep their launches.
+int vqcpc_gemm_tn_groupable(int64_t M, int N, int K) {
+    const int mode = gemm_mode();
+    if (mode != 1 && mode != 2) return 0;
+    if (M < 1 || N < 4 || K < 4 || (N % 4) || (K % 4)) return 0;
+    if (mode == 1 && g_use_t2.load(std::memory_order_relaxed) && tn_can_use_256(M, N, K)) return 0;
+    return M <= (1 << 20) ? 1 : 0;
+}
+
+// split count of a problem inside a group: by its own shape only (results do not depend on what else is in the group);
+// ~64 workgroups per problem, at least 256 rows per split
+static int tn_group_splits(int64_t M, int N, int K) {
+    const int64_t tiles = ceil_div(N, BM) * ceil_div(K, BN);
+    int64_t s = ceil_div(64, tiles);
+    s = std::min<int64_t>(s, std::max<int64_t>(1, M / 256));
+    return (int)std::max<int64_t>(s, 1);
+}
+
+int64_t vqcpc_gemm_tn_grouped_workspace(int n, const int64_t* M, const int* N, const int* K) {
+    int64_t floats = 0;
+    for (int i = 0; i < n; ++i)
+        floats += (int64_t)tn_group_splits(std::max<int64_t>(M[i], 1), N[i], K[i]) * ((int64_t)N[i] * K[i] + N[i]);
+    return floats * (int64_t)sizeof(float);
+}
+
+int vqcpc_gemm_tn_grouped(int n, const void* const* A, const int64_t* lda, const void* const* B, const int64_t* ldb,
+                          void* const* dW, void* const* db, const int64_t* M, const int* N, const int* K, int accumulate,
+                          void* workspace, int64_t workspace_bytes, void* stream) {
+    if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(n > 0 && A && lda && B && ldb && dW && db && M && N && K && workspace, "gemm_tn_grouped: null pointer");
+    if (workspace_bytes < vqcpc_gemm_tn_grouped_workspace(n, M, N, K)) {
+        set_error("gemm_tn_grouped: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    const int mode = gemm_mode();
+    for (int i = 0; i < n; ++i) {
+        VQ_REQUIRE(A[i] && B[i] && dW[i], "gemm_tn_grouped: null operand in problem %d", i);
+        VQ_REQUIRE(vqcpc_gemm_tn_groupable(M[i], N[i], K[i]), "gemm_tn_grouped: problem %d (M=%lld N=%d K=%d) is not groupable in "
+                   "this GEMM mode (query vqcpc_gemm_tn_groupable first)", i, (long long)M[i], N[i], K[i]);
+        VQ_REQUIRE(lda[i] % 4 == 0 && ldb[i] % 4 == 0 && lda[i] >= N[i] && ldb[i] >= K[i] && lda[i] < (1ll << 31) &&
+                       ldb[i] < (1ll << 31),
+                   "gemm_tn_grouped: bad leading dimensions in problem %d", i);
+        VQ_REQUIRE(aligned16(A[i]) && aligned16(B[i]) && aligned16(dW[i]) && (!db[i] || aligned16(db[i])),
+                   "gemm_tn_grouped: operands of problem %d must be 16-byte aligned", i);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    int i = 0;
+    while (i < n) {
+        // a chunk: up to kTnGroup problems with pairwise distinct gradient buffers (a repeated buffer waits for the next
+        // launch pair, which is stream-ordered behind this one: accumulation order = problem order)
+        TnGroupArgs g;
+        RedGroupArgs r;
+        int c = 0, wg = 0, rb = 0;
+        bool full = true;
+        while (i < n && c < kTnGroup) {
+            bool dup = false;
+            for (int j = 0; j < c; ++j) dup = dup || r.out[j] == (float*)dW[i] || (db[i] && r.out2[j] == (float*)db[i]);
+            if (dup) break;
+            const int splits = tn_group_splits(M[i], N[i], K[i]);
+            const int tiles_k = (int)ceil_div(K[i], BN);
+            const int tiles = (int)ceil_div(N[i], BM) * tiles_k;
+            g.A[c] = (const float*)A[i];
+            g.B[c] = (const float*)B[i];
+            g.ws[c] = ws;
+            g.wsb[c] = db[i] ? ws + (int64_t)splits * N[i] * K[i] : nullptr;
+            g.lda[c] = (int)lda[i];
+            g.ldb[c] = (int)ldb[i];
+            g.M[c] = (int)M[i];
+            g.N[c] = N[i];
+            g.K[c] = K[i];
+            g.tiles_k[c] = tiles_k;
+            g.tiles[c] = tiles;
+            g.rows_per_split[c] = (int)round_up(ceil_div(M[i], splits), TM);
+            g.wg_begin[c] = wg;
+            wg += tiles * splits;
+            full = full && (N[i] % BM == 0) && (K[i] % BN == 0) && (M[i] % TM == 0);
+            r.ws[c] = g.ws[c];
+            r.out[c] = (float*)dW[i];
+            r.ws2[c] = g.wsb[c];
+            r.out2[c] = (float*)db[i];
+            r.count[c] = N[i] * K[i];
+            r.count2[c] = db[i] ? N[i] : 0;
+            r.nsplit[c] = splits;
+            r.blk_begin[c] = rb;
+            rb += (int)(ceil_div((int64_t)N[i] * K[i] / 4, 256) + (db[i] ? ceil_div(N[i] / 4, 256) : 0));
+            ws += (int64_t)splits * ((int64_t)N[i] * K[i] + N[i]);
+            ++c;
+            ++i;
+        }
+        for (int j = c; j <= kTnGroup; ++j) g.wg_begin[j] = wg, r.blk_begin[j] = rb;
+        for (int j = c; j < kTnGroup; ++j) {          // unused slots: never selected (their prefix equals the total)
+            g.A[j] = g.B[j] = nullptr; g.ws[j] = g.wsb[j] = nullptr;
+            g.lda[j] = g.ldb[j] = g.M[j] = g.N[j] = g.K[j] = g.tiles_k[j] = g.tiles[j] = g.rows_per_split[j] = 1;
+            r.ws[j] = r.ws2[j] = nullptr; r.out[j] = r.out2[j] = nullptr;
+            r.count[j] = r.count2[j] = r.nsplit[j] = 0;
+        }
+        g.n = c;
+        r.n = c;
+        r.accumulate = accumulate;
+        const dim3 grid((unsigned)wg), block(kGemmThreads);
+        if (mode == 1) {
+            if (full) hipLaunchKernelGGL((gemm_tn_x6_grouped_kernel<true, 1>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_tn_x6_grouped_kernel<false, 1>), grid, block, 0, s, g);
+        } else {
+            if (full) hipLaunchKernelGGL((gemm_tn_x6_grouped_kernel<true, 2>), grid, block, 0, s, g);
+            else hipLaunchKernelGGL((gemm_tn_x6_grouped_kernel<false, 2>), grid, block, 0, s, g);
+        }
+        VQ_CHECK_LAUNCH("gemm_tn_grouped");
+        hipLaunchKernelGGL(reduce_splits_grouped_kernel, dim3((unsigned)rb), dim3(256), 0, s, r);
+        VQ_CHECK_LAUNCH("reduce_splits_grouped");
+    }
+    return VQCPC_OK;
 }
 
 

@@ -62,6 +62,10 @@ SIGNATURES = {
     'vqcpc_gemm_gradient_scope': (c_int, [c_int]),
     'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'vqcpc_gemm_tn_groupable': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_tn_grouped_workspace': (c_i64, [c_int, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_gemm_tn_grouped': (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr, c_i64,
+                                      c_ptr]),
     'vqcpc_transpose': (c_int, [c_ptr, c_ptr, c_int, c_int, c_ptr]),
     'vqcpc_transpose_many': (c_int, [c_ptr, c_ptr, c_ptr, c_int, c_i64, c_ptr]),
     'vqcpc_relattn_force_general': (c_int, [c_int]),

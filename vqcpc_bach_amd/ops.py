@@ -141,10 +141,49 @@ def gemm_tn(a, b, want_bias=True, into=None):
     else:
         dw = torch.empty(N, K, dtype=torch.float32, device=a.device)
         db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
+    global LAST_TN_DEFERRED
+    LAST_TN_DEFERRED = False
+    if into is not None and _DIRECT_WGRAD and GROUP_WGRADS and hip.query('vqcpc_gemm_tn_groupable', M, N, K):
+        # inside a trainer's backward pass: small weight gradients are collected and issued together when the pass ends
+        # (flush_wgrads, called by direct_weight_gradients.__exit__): a few grouped launches instead of two per weight
+        _PENDING_WGRADS.append((a, lda, b, ldb, dw, db, M, N, K))
+        LAST_TN_DEFERRED = True
+        return dw, db
     nbytes = hip.query('vqcpc_gemm_tn_workspace', M, N, K)
     ws = hip.workspace(nbytes, a.device)
     hip.call('vqcpc_gemm_tn', a, lda, b, ldb, dw, db, M, N, K, 0 if into is None else 1, ws, nbytes)
     return dw, db
+
+
+GROUP_WGRADS = os.environ.get('VQCPC_GROUP_WGRADS', '1') != '0'      # A/B switch: grouped launches of the small weight gradients
+LAST_TN_DEFERRED = False
+_PENDING_WGRADS = []           # (a, lda, b, ldb, dw, db, M, N, K): operands stay alive until the flush
+
+
+def pending_wgrad_flops():
+    return sum(2.0 * M * N * K for (_, _, _, _, _, _, M, N, K) in _PENDING_WGRADS)
+
+
+def flush_wgrads():
+    """Issues the weight gradients deferred by gemm_tn(into=...) since the last flush: vqcpc_gemm_tn_grouped accumulates
+    each into its gradient buffer (fixed split order per shape, problems in the order they were deferred)."""
+    import ctypes
+    items = list(_PENDING_WGRADS)
+    _PENDING_WGRADS.clear()
+    if not items:
+        return
+    n = len(items)
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    A = vp(*[it[0].data_ptr() for it in items])
+    lda = i64(*[it[1] for it in items])
+    B = vp(*[it[2].data_ptr() for it in items])
+    ldb = i64(*[it[3] for it in items])
+    dW = vp(*[it[4].data_ptr() for it in items])
+    dB = vp(*[(it[5].data_ptr() if it[5] is not None else None) for it in items])
+    M, N, K = i64(*[it[6] for it in items]), i32(*[it[7] for it in items]), i32(*[it[8] for it in items])
+    nbytes = hip.query('vqcpc_gemm_tn_grouped_workspace', n, M, N, K)
+    ws = hip.workspace(nbytes, items[0][0].device)
+    hip.call('vqcpc_gemm_tn_grouped', n, A, lda, B, ldb, dW, dB, M, N, K, 1, ws, nbytes)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -282,8 +321,14 @@ class direct_weight_gradients:
     def __exit__(self, *exc):
         global _DIRECT_WGRAD
         _DIRECT_WGRAD = self.prev
-        hip.gradient_scope(False)
-        WEIGHT_T.end()
+        try:
+            if exc[0] is None:
+                flush_wgrads()                  # the deferred small weight gradients, still inside the gradient scope
+            else:
+                _PENDING_WGRADS.clear()
+        finally:
+            hip.gradient_scope(False)
+            WEIGHT_T.end()
         return False
 
 

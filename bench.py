@@ -115,13 +115,13 @@ class GemmTimer:
 
         raw_flush = ops.flush_wgrads
 
-        def flush_wgrads():
+        def flush_wgrads(*fa, **fkw):
             flops = ops.pending_wgrad_flops()
             if not timer.enabled or flops == 0:
-                return raw_flush()
+                return raw_flush(*fa, **fkw)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            raw_flush()
+            raw_flush(*fa, **fkw)
             e1.record()
             timer.records['gemm_tn'].append((e0, e1, flops, 0.0, (0, 0, 0, 'wgrad:grouped')))
 

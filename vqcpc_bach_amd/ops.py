@@ -161,17 +161,21 @@ _PENDING_WGRADS = []           # (a, lda, b, ldb, dw, db, M, N, K): operands sta
 
 
 def pending_wgrad_flops():
-    return sum(2.0 * M * N * K for (_, _, _, _, _, _, M, N, K) in _PENDING_WGRADS)
+    return sum(2.0 * it[6] * it[7] * it[8] for it in _PENDING_WGRADS)
 
 
 def flush_wgrads():
     """Issues the weight gradients deferred by gemm_tn(into=...) since the last flush: vqcpc_gemm_tn_grouped accumulates
-    each into its gradient buffer (fixed split order per shape, problems in the order they were deferred)."""
-    import ctypes
+    each into its gradient buffer (fixed split order per shape, problems in the order they were deferred).  Called when the
+    trainers' gradient scope closes, i.e. after backward() has joined the streams it ran on.
+    Measured and NOT kept (profiles/r03_perf_log.md): issuing the groups on a side stream every 8 / 16 deferred products while the
+    input-gradient chain continues -- the 1000-workgroup grouped launches take the CUs the chain's small kernels are waiting
+    for: C3 12.4 -> 14.2-14.9 ms/step, DEC 10.1 -> 10.4."""
     items = list(_PENDING_WGRADS)
     _PENDING_WGRADS.clear()
     if not items:
         return
+    import ctypes
     n = len(items)
     vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
     A = vp(*[it[0].data_ptr() for it in items])

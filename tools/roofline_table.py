@@ -7,7 +7,7 @@ import csv, sys
 ROWS_LN = 2 * (557056 + 139264 + 139264 + 34816)           # LayerNorm rows per step (8 instances), d = 256
 FAMILIES = [   # (label, match substrings, algorithmic work per step, unit, peak, note)
     ('NT GEMMs (`gemm_nt_x6_pp` incl. mask-out / gate-bits / residual-sum epilogues, 128-tile + split-K planes, skinny / narrow)', ('gemm_nt', 'splitk'), 2.59e12, 'TFLOP/s', 416.7e12, 'forward + input gradients after dead-row elimination and the first-layer table'),
-    ('TN GEMMs (`gemm_tn_x6_pq`: ping-pong wave groups, quad-row LDS image; `gemm_tn_x6` 128-tile)', ('gemm_tn',), 1.30e12, 'TFLOP/s', 416.7e12, 'weight / bias gradients'),
+    ('TN GEMMs (`gemm_tn_x6_pq`: ping-pong wave groups, quad-row LDS image; `gemm_tn_x6_grouped`: the small products of the step in grouped launches)', ('gemm_tn',), 1.30e12, 'TFLOP/s', 416.7e12, 'weight / bias gradients'),
     ('`add_ln_bwd` (reads dy, s; writes d_s, d_r; mask regenerated)', ('add_ln_bwd',), 4.0 * ROWS_LN * 1024, 'TB/s', 8e12, '4 streams of rows x 1 KB'),
     ('`add_ln_fwd` (reads the residual sum s, writes y)', ('add_ln_fwd',), 2.0 * ROWS_LN * 1024, 'TB/s', 8e12, '2 streams'),
     ('`relattn16_bwd`', ('relattn16_bwd',), 2.57e9, 'TB/s', 8e12, ''),

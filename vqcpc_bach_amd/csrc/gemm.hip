@@ -262,6 +262,109 @@ __global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_kernel(const float* _
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// bf16x6 NT GEMM on 64 x 64 x 32 tiles for UNDER-FILLED launches (student / decoder steps: 3072 x 512 x 512 is 96 tiles of
+// 128 x 128 -- one workgroup on a third of the CUs, each walking its 16 K tiles alone with a serial stage / multiply rhythm:
+// 38 us for 1.6 GFLOP).  Four times the workgroups, a quarter of the MFMA chain each, two LDS buffers (one barrier per K tile).
+// Same operand split, same term order per k16 step and the same K order into ONE accumulator per 32 x 32 MFMA tile as
+// gemm_nt_kernel<MODE 1>: results are bit-identical to the 128-tile kernel's.  M, N % 64 == 0, K % 32 == 0.
+constexpr int kS64 = 64;
+constexpr int kS64Plane = kS64 * kX6Stride * 2;      // 5 120 B
+constexpr int kS64Buf = 6 * kS64Plane;               // 30 720 B; two buffers 61 440 B
+
+template <int EPI>
+__global__ __launch_bounds__(kGemmThreads, 2) void gemm_nt_x6_s64_kernel(const float* __restrict__ A, int64_t lda,
+                                                                        const float* __restrict__ B, int64_t ldb,
+                                                                        float* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                                        int K, int tiles_n, EpiParams ep) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * kS64Buf];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, kh = lane >> 5;
+    const int t = xcd_swizzle(blockIdx.x, gridDim.x);
+    const int64_t m0 = (int64_t)(t / tiles_n) * kS64;
+    const int n0 = (t % tiles_n) * kS64;
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+    // staging: thread -> rows ld_row and ld_row + 32 of both operands, one float4 of k each
+    const int ld_row = tid >> 3, ld_c4 = (tid & 7) * 4;
+    const float* a_src = A + (m0 + ld_row) * lda + ld_c4;
+    const float* b_src = B + (int64_t)(n0 + ld_row) * ldb + ld_c4;
+    float4 ra0, ra1, rb0, rb1;
+#define S64_LOAD(K0)                                                                 \
+    ra0 = *reinterpret_cast<const float4*>(a_src + (K0));                            \
+    ra1 = *reinterpret_cast<const float4*>(a_src + (int64_t)32 * lda + (K0));        \
+    rb0 = *reinterpret_cast<const float4*>(b_src + (K0));                            \
+    rb1 = *reinterpret_cast<const float4*>(b_src + (int64_t)32 * ldb + (K0));
+#define S64_ST1(R, PLANE0, ROW, BUFP)                                                \
+    {                                                                                \
+        uint2 h_, m_, l_;                                                            \
+        split3x4(R, h_, m_, l_);                                                     \
+        const int o_ = ((ROW) * kX6Stride + ld_c4) * 2;                              \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 0) * kS64Plane + o_) = h_;    \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 1) * kS64Plane + o_) = m_;    \
+        *reinterpret_cast<uint2*>((BUFP) + ((PLANE0) + 2) * kS64Plane + o_) = l_;    \
+    }
+#define S64_STORE(BUFP) \
+    S64_ST1(ra0, 0, ld_row, BUFP) S64_ST1(ra1, 0, ld_row + 32, BUFP) S64_ST1(rb0, 3, ld_row, BUFP) S64_ST1(rb1, 3, ld_row + 32, BUFP)
+    S64_LOAD(0)
+    S64_STORE(smem)
+    __syncthreads();
+    const int a_off = ((wm * 32 + li) * kX6Stride + kh * 8) * 2;
+    const int b_off = 3 * kS64Plane + ((wn * 32 + li) * kX6Stride + kh * 8) * 2;
+    int cur = 0;
+    for (int k0 = 0; k0 < K; k0 += BK) {
+        const bool more = k0 + BK < K;
+        if (more) { S64_LOAD(k0 + BK) }
+        const unsigned char* buf = smem + cur * kS64Buf;
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            bf16x8 a[3], b[3];
+#pragma unroll
+            for (int pc = 0; pc < 3; ++pc) {
+                a[pc] = *reinterpret_cast<const bf16x8*>(buf + a_off + pc * kS64Plane + ks * 32);
+                b[pc] = *reinterpret_cast<const bf16x8*>(buf + b_off + pc * kS64Plane + ks * 32);
+            }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[2], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[2], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[1], b[0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[0], b[0], acc, 0, 0, 0);
+        }
+        if (more) {
+            S64_STORE(smem + (cur ^ 1) * kS64Buf)      // the other buffer: its last readers passed the previous barrier
+            __syncthreads();
+            cur ^= 1;
+        }
+    }
+#undef S64_LOAD
+#undef S64_ST1
+#undef S64_STORE
+    // epilogue (order of operations as in gemm_nt_kernel): row = (reg & 3) + 8 (reg >> 2) + 4 kh, col = lane & 31
+    const int64_t row_base = m0 + wm * 32 + 4 * kh;
+    const int col = n0 + wn * 32 + li;
+    const float bv = (EPI & E_BIAS) ? ep.bias[col] : 0.0f;
+    float aux[16];
+    if (EPI & (E_GATE | E_ADD)) {
+        const float* src = (EPI & E_GATE) ? ep.gate : ep.add;
+        const int64_t lds_ = (EPI & E_GATE) ? ep.ldgate : ep.ldadd;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) aux[r] = src[(row_base + (r & 3) + 8 * (r >> 2)) * lds_ + col];
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+        float v = acc[r] + bv;
+        if (EPI & E_RELU) v = fmaxf(v, 0.0f);
+        if (EPI & E_DROP) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * N + col, ep.thr, ep.inv_keep);
+        if (EPI & E_GATE) v *= (aux[r] > 0.0f ? ep.gate_scale : 0.0f);
+        if (EPI & E_ADD) v += aux[r];
+        C[row * ldc + col] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // bf16x6 NT GEMM, 256 x 256 x 16 tile, 8 waves (2 x 4, wave tile 128 x 64), one workgroup per CU, two LDS buffers.
 // At 128 x 128 the bf16x6 kernel is bound by operand delivery (32 FLOP per operand byte -> ~5.5 TB/s of L2->CU traffic at
 // 175 TFLOP/s); the 256^2 tile doubles the arithmetic intensity.  Shapes must be full tiles (M, N % 256, K % 16).
@@ -1886,6 +1989,29 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
                                ldadd);
         VQ_CHECK_LAUNCH("gemm_nt_skinny");
         return VQCPC_OK;
+    }
+    // under-filled bf16x6 launches (at most one 128-tile per CU): 64 x 64 tiles, four times the workgroups
+    static const int s64_max_tiles = getenv("VQCPC_S64_MAX_TILES") ? atoi(getenv("VQCPC_S64_MAX_TILES")) : 256;
+    if (mode == 1 && tiles <= s64_max_tiles && (M % kS64 == 0) && (N % kS64 == 0) && (K % BK == 0) && M >= kS64) {
+        const int tn64 = N / kS64;
+        const dim3 g64((unsigned)((M / kS64) * tn64));
+#define S64_CASE(EPIV)                                                                                                     \
+    case EPIV:                                                                                                             \
+        hipLaunchKernelGGL((gemm_nt_x6_s64_kernel<EPIV>), g64, block, 0, st, A, lda, B, ldb, C, ldc, M, N, K, tn64, ep);   \
+        VQ_CHECK_LAUNCH("gemm_nt_x6_s64");                                                                                 \
+        return VQCPC_OK;
+        switch (flags) {
+            S64_CASE(0)
+            S64_CASE(E_BIAS)
+            S64_CASE(E_BIAS | E_RELU)
+            S64_CASE(E_BIAS | E_RELU | E_DROP)
+            S64_CASE(E_GATE)
+            S64_CASE(E_ADD)
+            S64_CASE(E_BIAS | E_ADD)
+            S64_CASE(E_BIAS | E_DROP | E_ADD)
+            default: break;
+        }
+#undef S64_CASE
     }
     // bf16x6, full 256 x 256 tiles: the high-arithmetic-intensity kernel (one workgroup of 8 waves per CU)
     // the 256-tile kernel runs ONE workgroup per CU: pick it only when its last (partial) round of tiles does not waste

@@ -131,7 +131,7 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
  * per backward pass (3072 rows x 512 ... 2048) cannot fill the chip one at a time; torch.autograd issues them one by one
  * (decoders/decoder.py:431-543, student_encoder_trainer.py:256-296), the trainers of this library defer them to the end of
  * loss.backward().  Arrays are HOST arrays of length n (device pointers inside); db[i] may be NULL; a gradient buffer that
- * occurs twice is accumulated in problem order.  vqcpc_gemm_tn_groupable: the product is one the grouped kernel serves in the
+ * occurs twice is accumulated in issue order (full-tile problems first, then the ragged ones, each class in the caller's order).  vqcpc_gemm_tn_groupable: the product is one the grouped kernel serves in the
  * current GEMM mode (bf16x6 / rounded-operand modes, shapes that do not take the 256-tile kernel). */
 int vqcpc_gemm_tn_groupable(int64_t M, int N, int K);
 int64_t vqcpc_gemm_tn_grouped_workspace(int n, const int64_t* M, const int* N, const int* K);

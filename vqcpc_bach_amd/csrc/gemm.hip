@@ -10,6 +10,7 @@
 //           (consecutive lanes -> consecutive banks).  M is split over blockIdx.y; partials are reduced deterministically.
 //           The bias gradient (column sums of A) is accumulated from the A operand registers for free.
 #include <atomic>
+#include <vector>
 #include <stdlib.h>
 
 #include <string.h>
@@ -2478,15 +2479,25 @@ int vqcpc_gemm_tn_grouped(int n, const void* const* A, const int64_t* lda, const
     }
     hipStream_t s = (hipStream_t)stream;
     float* ws = (float*)workspace;
-    int i = 0;
-    while (i < n) {
-        // a chunk: up to kTnGroup problems with pairwise distinct gradient buffers (a repeated buffer waits for the next
-        // launch pair, which is stream-ordered behind this one: accumulation order = problem order)
+    // full-tile problems first (they share the kernel without bounds checks), the ragged ones after them; the order inside
+    // each class is the caller's
+    std::vector<int> order;
+    order.reserve(n);
+    auto is_full = [&](int q) { return (N[q] % BM == 0) && (K[q] % BN == 0) && (M[q] % TM == 0); };
+    for (int q = 0; q < n; ++q) if (is_full(q)) order.push_back(q);
+    const int n_full = (int)order.size();
+    for (int q = 0; q < n; ++q) if (!is_full(q)) order.push_back(q);
+    int pos = 0;
+    while (pos < n) {
+        // a chunk: up to kTnGroup problems of one class with pairwise distinct gradient buffers (a repeated buffer waits for the
+        // next launch pair, which is stream-ordered behind this one: accumulation order = issue order)
         TnGroupArgs g;
         RedGroupArgs r;
         int c = 0, wg = 0, rb = 0;
         bool full = true;
-        while (i < n && c < kTnGroup) {
+        const int class_end = pos < n_full ? n_full : n;
+        while (pos < class_end && c < kTnGroup) {
+            const int i = order[pos];
             bool dup = false;
             for (int j = 0; j < c; ++j) dup = dup || r.out[j] == (float*)dW[i] || (db[i] && r.out2[j] == (float*)db[i]);
             if (dup) break;
@@ -2519,7 +2530,7 @@ int vqcpc_gemm_tn_grouped(int n, const void* const* A, const int64_t* lda, const
             rb += (int)(ceil_div((int64_t)N[i] * K[i] / 4, 256) + (db[i] ? ceil_div(N[i] / 4, 256) : 0));
             ws += (int64_t)splits * ((int64_t)N[i] * K[i] + N[i]);
             ++c;
-            ++i;
+            ++pos;
         }
         for (int j = c; j <= kTnGroup; ++j) g.wg_begin[j] = wg, r.blk_begin[j] = rb;
         for (int j = c; j < kTnGroup; ++j) {          // unused slots: never selected (their prefix equals the total)

@@ -1231,6 +1231,43 @@ def test_bad_arguments_raise_with_the_library_message(ops):
                  torch.empty(16, device='cuda'), 16)
 
 
+def test_grouped_weight_gradient_argument_checks(ops, bf16x6):
+    """vqcpc_gemm_tn_grouped refuses what it cannot serve (a product of the 256-tile class, a short workspace, the exact fp32
+    mode) with the library's message instead of computing something else; n = 0 is a no-op."""
+    import ctypes
+    from vqcpc_bach_amd import hip
+    a, b = torch.randn(3072, 512, device='cuda'), torch.randn(3072, 512, device='cuda')
+    dw = torch.zeros(512, 512, device='cuda')
+
+    def call(M, N, K, ws_bytes=None):
+        vp, i64, i32 = ctypes.c_void_p * 1, ctypes.c_int64 * 1, ctypes.c_int * 1
+        Ms, Ns, Ks = i64(M), i32(N), i32(K)
+        need = hip.query('vqcpc_gemm_tn_grouped_workspace', 1, Ms, Ns, Ks)
+        ws = hip.workspace(need, 'cuda')
+        hip.call('vqcpc_gemm_tn_grouped', 1, vp(a.data_ptr()), i64(N), vp(b.data_ptr()), i64(K), vp(dw.data_ptr()), vp(None), Ms, Ns,
+                 Ks, 0, ws, need if ws_bytes is None else ws_bytes)
+
+    assert hip.query('vqcpc_gemm_tn_groupable', 3072, 512, 512) == 1
+    assert hip.query('vqcpc_gemm_tn_groupable', 557056, 1024, 256) == 0        # fills the chip alone: 256-tile kernel
+    assert hip.query('vqcpc_gemm_tn_groupable', 3072, 510, 512) == 0           # N % 4
+    call(3072, 512, 512)
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), (a.double().t() @ b.double()).cpu()) < 1e-5
+    with pytest.raises(hip.VqcpcHipError, match='workspace too small'):
+        call(3072, 512, 512, ws_bytes=16)
+    with pytest.raises(hip.VqcpcHipError, match='not groupable'):
+        call(557056, 1024, 256)
+    hip.call('vqcpc_gemm_tn_grouped', 0, None, None, None, None, None, None, None, None, None, 0, None, 0)
+    hip.set_gemm_mode(0)
+    try:
+        assert hip.query('vqcpc_gemm_tn_groupable', 3072, 512, 512) == 0       # exact fp32 MFMA mode: single launches only
+        with ops.direct_weight_gradients():
+            ops.gemm_tn(a, b, into=(dw, None))
+            assert not ops.LAST_TN_DEFERRED
+    finally:
+        hip.set_gemm_mode(1)
+
+
 # ----------------------------------------------------------------------------------------------------------------
 # bf16x6 GEMM on pre-split (P3) operands: csrc/gemm_planes.hip
 # ----------------------------------------------------------------------------------------------------------------

@@ -580,7 +580,11 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
                                 const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
                                 float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
-    VQ_REQUIRE(dy && x && gamma && mean && rstd && d_s && d_gamma && d_beta && workspace, "add_layernorm_bwd: null pointer");
+    // d_gamma == d_beta == NULL: the column partials stay in `workspace` ([vqcpc_add_layernorm_bwd_partials(M)][2 d]: d gamma | d beta)
+    // for the caller to reduce later (vqcpc_reduce_grouped: the trainers sum the partials of every LayerNorm of a backward pass
+    // in one launch)
+    VQ_REQUIRE(dy && x && gamma && mean && rstd && d_s && workspace && ((d_gamma != nullptr) == (d_beta != nullptr)),
+               "add_layernorm_bwd: null pointer");
     VQ_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_bwd: bad shape");
     if (workspace_bytes < vqcpc_add_layernorm_bwd_workspace(M, d)) {
         set_error("add_layernorm_bwd: workspace too small");
@@ -600,8 +604,11 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
         hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
                            d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
     VQ_CHECK_LAUNCH("add_layernorm_bwd");
+    if (!d_gamma) return VQCPC_OK;
     return launch_reduce_splits2((const float*)workspace, (int64_t)2 * d, blocks, d_gamma, d, (const float*)workspace + d,
                                  (int64_t)2 * d, d_beta, d, 0, s);
 }
+
+int vqcpc_add_layernorm_bwd_partials(int64_t M) { return ln_bwd_blocks(std::max<int64_t>(M, 1)); }
 
 }  // extern "C"

@@ -132,6 +132,51 @@ int launch_reduce_splits2(const float* ws, int64_t stride, int nsplit, float* ou
     return VQCPC_OK;
 }
 
+// n independent "sum nsplit partial rows" reductions in one launch (32 per launch): out_i[c] (+)= sum_s ws_i[s * stride_i + c].
+// The table travels by value in the kernel arguments.  Same summation order per column as reduce_splits_kernel.
+constexpr int kRedMany = 32;
+struct RedManyArgs {
+    const float* ws[kRedMany];
+    float* out[kRedMany];
+    int stride[kRedMany], nsplit[kRedMany], count[kRedMany];
+    int blk_begin[kRedMany + 1];
+    int n, accumulate;
+};
+
+__global__ __launch_bounds__(kRedCols * kRedGroups) void reduce_many_kernel(const RedManyArgs g) {
+    __shared__ float part[kRedGroups][kRedCols];
+    const int b = (int)blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < g.n; ++i) p += (b >= g.blk_begin[i]) ? 1 : 0;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const float* __restrict__ ws = g.ws[p];
+    const int64_t stride = g.stride[p];
+    const int nsplit = g.nsplit[p], count = g.count[p];
+    const int tx = threadIdx.x % kRedCols, ty = threadIdx.x / kRedCols;
+    const int col = (b - g.blk_begin[p]) * kRedCols + tx;
+    float acc = 0.0f;
+    if (col < count) {
+        int s = ty;
+        for (; s + 3 * kRedGroups < nsplit; s += 4 * kRedGroups) {
+            const float a = ws[(int64_t)s * stride + col];
+            const float b2 = ws[(int64_t)(s + kRedGroups) * stride + col];
+            const float c = ws[(int64_t)(s + 2 * kRedGroups) * stride + col];
+            const float d = ws[(int64_t)(s + 3 * kRedGroups) * stride + col];
+            acc = ((acc + a) + b2) + (c + d);
+        }
+        for (; s < nsplit; s += kRedGroups) acc += ws[(int64_t)s * stride + col];
+    }
+    part[ty][tx] = acc;
+    __syncthreads();
+    if (ty == 0 && col < count) {
+        float* out = g.out[p];
+        float tot = g.accumulate ? out[col] : 0.0f;
+#pragma unroll
+        for (int q = 0; q < kRedGroups; ++q) tot += part[q][tx];
+        out[col] = tot;
+    }
+}
+
 int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
                          hipStream_t stream) {
     return launch_reduce_splits2(ws, stride, nsplit, out, count, nullptr, 0, nullptr, 0, accumulate, stream);
@@ -623,6 +668,45 @@ int vqcpc_count_distinct_codes(const int64_t* idx_a, int64_t rows_a, const int64
     hipLaunchKernelGGL(count_distinct_codes_kernel, dim3(1), dim3(kCountThreads), (size_t)words * 4, (hipStream_t)stream, idx_a,
                        rows_a, idx_b, rows_b, num_codebooks, codebook_size, words, out);
     VQ_CHECK_LAUNCH("count_distinct_codes");
+    return VQCPC_OK;
+}
+
+int vqcpc_reduce_grouped(int n, const void* const* ws, const int64_t* stride, const int* nsplit, void* const* out,
+                         const int64_t* count, int accumulate, void* stream) {
+    if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(n > 0 && ws && stride && nsplit && out && count, "reduce_grouped: null pointer");
+    for (int i = 0; i < n; ++i)
+        VQ_REQUIRE(ws[i] && out[i] && nsplit[i] >= 1 && count[i] >= 1 && stride[i] >= count[i] && stride[i] < (1ll << 31) &&
+                       count[i] < (1ll << 31),
+                   "reduce_grouped: bad segment %d", i);
+    hipStream_t s = (hipStream_t)stream;
+    int i = 0;
+    while (i < n) {
+        RedManyArgs g;
+        int c = 0, rb = 0;
+        while (i < n && c < kRedMany) {
+            bool dup = false;                      // a repeated output waits for the next launch (stream-ordered accumulation)
+            for (int j = 0; j < c; ++j) dup = dup || g.out[j] == (float*)out[i];
+            if (dup) break;
+            g.ws[c] = (const float*)ws[i];
+            g.out[c] = (float*)out[i];
+            g.stride[c] = (int)stride[i];
+            g.nsplit[c] = nsplit[i];
+            g.count[c] = (int)count[i];
+            g.blk_begin[c] = rb;
+            rb += (int)ceil_div(count[i], kRedCols);
+            ++c;
+            ++i;
+        }
+        for (int j = c; j <= kRedMany; ++j) g.blk_begin[j] = rb;
+        for (int j = c; j < kRedMany; ++j) {
+            g.ws[j] = nullptr; g.out[j] = nullptr; g.stride[j] = g.nsplit[j] = g.count[j] = 0;
+        }
+        g.n = c;
+        g.accumulate = accumulate;
+        hipLaunchKernelGGL(reduce_many_kernel, dim3((unsigned)rb), dim3(kRedCols * kRedGroups), 0, s, g);
+        VQ_CHECK_LAUNCH("reduce_grouped");
+    }
     return VQCPC_OK;
 }
 

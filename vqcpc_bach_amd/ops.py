@@ -160,6 +160,36 @@ LAST_TN_DEFERRED = False
 _PENDING_WGRADS = []           # (a, lda, b, ldb, dw, db, M, N, K): operands stay alive until the flush
 
 
+_PENDING_REDUCTIONS = []       # (workspace tensor, byte offset, stride, nsplit, out tensor, count): partial sums -> gradient buffers
+
+
+def defer_ln_param_grads(ws, M, d, gamma, beta):
+    """LayerNorm backward inside a trainer's gradient scope: the [partials][2 d] column sums of `ws` are added into the live
+    gradient buffers of gamma / beta by ONE grouped launch when the scope closes.  Returns False when the parameters own no
+    gradient buffers (plain autograd use): the caller reduces as before."""
+    if not (_DIRECT_WGRAD and GROUP_WGRADS):
+        return False
+    gg, bg = _live_grad(gamma), _live_grad(beta)
+    if gg is None or bg is None or gg.numel() != d or bg.numel() != d:
+        return False
+    n = hip.query('vqcpc_add_layernorm_bwd_partials', M)
+    _PENDING_REDUCTIONS.append((ws, 0, 2 * d, n, gg, d))
+    _PENDING_REDUCTIONS.append((ws, 4 * d, 2 * d, n, bg, d))
+    return True
+
+
+def flush_reductions():
+    import ctypes
+    items = list(_PENDING_REDUCTIONS)
+    _PENDING_REDUCTIONS.clear()
+    if not items:
+        return
+    n = len(items)
+    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+    hip.call('vqcpc_reduce_grouped', n, vp(*[it[0].data_ptr() + it[1] for it in items]), i64(*[it[2] for it in items]),
+             i32(*[it[3] for it in items]), vp(*[it[4].data_ptr() for it in items]), i64(*[it[5] for it in items]), 1)
+
+
 def pending_wgrad_flops():
     return sum(2.0 * it[6] * it[7] * it[8] for it in _PENDING_WGRADS)
 
@@ -328,8 +358,10 @@ class direct_weight_gradients:
         try:
             if exc[0] is None:
                 flush_wgrads()                  # the deferred small weight gradients, still inside the gradient scope
+                flush_reductions()              # ... and the LayerNorm weight / bias partial sums
             else:
                 _PENDING_WGRADS.clear()
+                _PENDING_REDUCTIONS.clear()
         finally:
             hip.gradient_scope(False)
             WEIGHT_T.end()
@@ -798,25 +830,28 @@ class EncoderLayerFn(torch.autograd.Function):
 
         nat = ctx.bf16 is not None
 
-        def ln_bwd(dyv, xin, ldxin, r, gamma, mean, rstd, seed):
+        def ln_bwd(dyv, xin, ldxin, r, gamma, beta, mean, rstd, seed):
             # r None: xin is the residual sum itself (s-form, include/vqcpc.h); the mask of d_r is regenerated from `seed`
             ds = torch.empty(Mq, d, dtype=torch.float32, device=dev)
             # bf16 path: the gradient of the sub-layer output only feeds GEMMs, which read its bf16 copy -> no fp32 d_r stream
             dr = torch.empty(Mq, d, dtype=torch.float32, device=dev) if (p > 0 and not nat) else None
             drb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None    # GEMM-operand copy of dr
-            dg = torch.empty(d, dtype=torch.float32, device=dev)
-            db = torch.empty(d, dtype=torch.float32, device=dev)
             nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', Mq, d)
             ws = hip.workspace(nbytes, dev)
+            if defer_ln_param_grads(ws, Mq, d, gamma, beta):     # gamma / beta partial sums: reduced with all the others later
+                dg = db = None
+            else:
+                dg = torch.empty(d, dtype=torch.float32, device=dev)
+                db = torch.empty(d, dtype=torch.float32, device=dev)
             hip.call('vqcpc_add_layernorm_bwd_b16', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed,
                      ws, nbytes)
             return ds, (dr if dr is not None else (None if (nat and p > 0) else ds)), dg, db, drb
 
         sform1, sform2 = ctx.sform
         if sform2:
-            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, mean2, rstd2, s[3])
+            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, be2, mean2, rstd2, s[3])
         else:
-            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, x1, d, s2, g2, mean2, rstd2, s[3])
+            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, x1, d, s2, g2, be2, mean2, rstd2, s[3])
         lin = gemm_nt_bf16 if nat else gemm_nt
         if nat:
             xb, xsb, attb, x1b, h2b = ctx.bf16
@@ -836,9 +871,9 @@ class EncoderLayerFn(torch.autograd.Function):
             dx1 = gemm_nt(da, transpose(w1), add=ds2)
         del da, df, ds2
         if sform1:
-            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, mean1, rstd1, s[1])
+            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, be1, mean1, rstd1, s[1])
         else:
-            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, xs, ldxs, s1, g1, mean1, rstd1, s[1])
+            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, xs, ldxs, s1, g1, be1, mean1, rstd1, s[1])
         b16_io = nat and f == 1 and qkv.dtype == torch.bfloat16       # the all-bf16 attention backward reads d ctx as bf16
         if nat:
             dwo, dbo = wgrad(dAb, attb, wo, bo)
@@ -1016,13 +1051,17 @@ class AddLayerNormFn(torch.autograd.Function):
         dev = x.device
         ds = torch.empty(M, d, dtype=torch.float32, device=dev)
         dr = torch.empty(M, d, dtype=torch.float32, device=dev) if p > 0 else None
-        dg = torch.empty(d, dtype=torch.float32, device=dev)
-        db = torch.empty(d, dtype=torch.float32, device=dev)
         nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', M, d)
         ws = hip.workspace(nbytes, dev)
+        if defer_ln_param_grads(ws, M, d, gamma, ctx.beta):         # trainers: summed with every other LayerNorm's partials later
+            dg = db = None
+        else:
+            dg = torch.empty(d, dtype=torch.float32, device=dev)
+            db = torch.empty(d, dtype=torch.float32, device=dev)
         hip.call('vqcpc_add_layernorm_bwd', dy.contiguous(), x, ldx, r, gamma, mean, rstd, ds, dr, dg, db, M, d, p, seed, ws,
                  nbytes)
-        dg, db = accumulate_small([gamma, ctx.beta], [dg, db])       # one launch into the live gradient buffers (trainers)
+        if dg is not None:
+            dg, db = accumulate_small([gamma, ctx.beta], [dg, db])   # one launch into the live gradient buffers
         return ds, (dr if dr is not None else ds), dg, db, None, None
 
 

@@ -279,12 +279,12 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
                                 const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
                                 float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
                                 int64_t workspace_bytes, void* stream);
-/* d_gamma == d_beta == NULL in either backward form: the [vqcpc_add_layernorm_bwd_partials(M)][2 d] column partials (d gamma | d beta)
+/* d_gamma == d_beta == NULL in either backward form: the [vqcpc_add_layernorm_bwd_partials(M, d, r != NULL)][2 d] column partials (d gamma | d beta)
  * stay in `workspace` for a later vqcpc_reduce_grouped.  vqcpc_reduce_grouped: n independent reductions out_i[c] (+)= sum over
  * s < nsplit_i of ws_i[s * stride_i + c], c < count_i, 32 per launch (host arrays of device pointers; a repeated output is
  * accumulated in argument order).  The trainers sum the LayerNorm weight / bias partials of a whole backward pass this way
  * (one launch instead of one reduction + one accumulation per LayerNorm). */
-int vqcpc_add_layernorm_bwd_partials(int64_t M);
+int vqcpc_add_layernorm_bwd_partials(int64_t M, int d, int has_r);   /* has_r: the call passes a separate r (two-input form) */
 int vqcpc_reduce_grouped(int n, const void* const* ws, const int64_t* stride, const int* nsplit, void* const* out,
                          const int64_t* count, int accumulate, void* stream);
 

@@ -188,7 +188,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // HAS_R: x and r are separate inputs (s = x + dropout(r) is rebuilt here).  MASKED (and !HAS_R): `x` IS the residual sum s (the
 // producing GEMM's epilogue formed it); the dropout mask of the sub-layer output is still regenerated from (seed, index)
 // for d_r = d_s . mask -- one input stream fewer.
-template <bool HAS_R, bool MASKED = HAS_R>
+// NIT = 256-column groups per row (d <= 256 NIT): with the generic 4 the kernel holds 152 registers (3 waves per SIMD); NIT = 1
+// (d <= 256) and 2 (d <= 512) keep the per-row arrays small enough for 8 / 5 waves -- more rows in flight per CU
+template <bool HAS_R, bool MASKED = HAS_R, int NIT = kLnMaxIt>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          int64_t ldx, const float* __restrict__ r,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -196,13 +198,14 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          float* __restrict__ d_r, float* __restrict__ ws, int64_t M, int d,
                                                          uint32_t thr, float inv_keep, uint64_t seed,
                                                          unsigned short* __restrict__ dr_b16) {
-    __shared__ float red[4 * 2 * 1024];
+    constexpr int kRedW = NIT * 256;                    // columns a wave's partials span
+    __shared__ float red[4 * 2 * kRedW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nit = (d + 255) >> 8;
+    constexpr int nit = NIT;
     const float inv_d = 1.0f / (float)d;
-    float4 dg[kLnMaxIt], db[kLnMaxIt], gm[kLnMaxIt];
+    float4 dg[NIT], db[NIT], gm[NIT];
 #pragma unroll
-    for (int it = 0; it < kLnMaxIt; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         dg[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         db[it] = make_float4(0.f, 0.f, 0.f, 0.f);
         const int col = lane * 4 + it * 256;
@@ -210,10 +213,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
     }
     for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
         const float mu = mean[row], rs = rstd[row];
-        float4 xh[kLnMaxIt], gy[kLnMaxIt], msk[kLnMaxIt];
+        float4 xh[NIT], gy[NIT], msk[NIT];
         float s1 = 0.0f, s2 = 0.0f;   // sum(g), sum(g * xhat) with g = dy * gamma
 #pragma unroll
-        for (int it = 0; it < kLnMaxIt; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int col = lane * 4 + it * 256;
             if (it < nit && col < d) {
                 float4 xv = nt_load4(x + row * ldx + col);
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         }
         const float m1 = wave_sum(s1) * inv_d, m2 = wave_sum(s2) * inv_d;
 #pragma unroll
-        for (int it = 0; it < kLnMaxIt; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int col = lane * 4 + it * 256;
             if (it < nit && col < d) {
                 float4 o;
@@ -272,11 +275,11 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
     }
     // reduce the 4 waves' column partials through LDS, then one partial per workgroup
 #pragma unroll
-    for (int it = 0; it < kLnMaxIt; ++it) {
+    for (int it = 0; it < NIT; ++it) {
         const int col = lane * 4 + it * 256;
         if (it < nit && col < d) {
-            *reinterpret_cast<float4*>(&red[(wave * 2 + 0) * 1024 + col]) = dg[it];
-            *reinterpret_cast<float4*>(&red[(wave * 2 + 1) * 1024 + col]) = db[it];
+            *reinterpret_cast<float4*>(&red[(wave * 2 + 0) * kRedW + col]) = dg[it];
+            *reinterpret_cast<float4*>(&red[(wave * 2 + 1) * kRedW + col]) = db[it];
         }
     }
     __syncthreads();
@@ -284,7 +287,7 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         const int which = i / d, col = i % d;
         float acc = 0.0f;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) acc += red[(w * 2 + which) * 1024 + col];
+        for (int w = 0; w < 4; ++w) acc += red[(w * 2 + which) * kRedW + col];
         ws[(int64_t)blockIdx.x * 2 * d + i] = acc;
     }
 }
@@ -314,10 +317,16 @@ __global__ __launch_bounds__(256) void embed_pos_scatter_kernel(const float* __r
 static int ln_blocks(int64_t M) { return (int)std::min<int64_t>(ceil_div(M, 4), 2048); }
 // backward: 512 workgroups (2 per CU) stream faster than 2048 and leave a quarter of the column partials to reduce:
 // 573 -> 488 us at 557 056 x 256, 522 -> 516 us at 278 528 x 512 (tools/bench_ln.py; 384 and fewer fall off again)
-static int ln_bwd_blocks(int64_t M) {
-    static const int cap = getenv("VQCPC_LN_BWD_BLOCKS") ? atoi(getenv("VQCPC_LN_BWD_BLOCKS")) : 512;
+// round 3, with the per-width specialisations of the backward kernel (72 / 98 registers at d <= 256 / 512 instead of 152): the
+// one-input form (x is the residual sum) streams best from 1024 workgroups -- 471 -> 432 us at 557 056 x 256, 423 -> 366 us at
+// 278 528 x 512 -- the two-input form still from 512 (513 vs 557 us)
+// (at d = 1024, the generic kernel: 303 us from 512 workgroups, 318 from 1024)
+static int ln_bwd_blocks(int64_t M, bool has_r, int d) {
+    static const int cap_env = getenv("VQCPC_LN_BWD_BLOCKS") ? atoi(getenv("VQCPC_LN_BWD_BLOCKS")) : 0;
+    const int cap = cap_env > 0 ? cap_env : ((has_r || d > 512) ? 512 : 1024);
     return (int)std::min<int64_t>(ceil_div(M, 4), cap);
 }
+static int ln_bwd_blocks_max(int64_t M, int d) { return std::max(ln_bwd_blocks(M, true, d), ln_bwd_blocks(M, false, d)); }
 
 // =====================================================================================================================
 // Block-table gather / segment sum.  The input of the FIRST encoder layer takes only vmax * L distinct values (token id x
@@ -565,7 +574,7 @@ int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, con
 }
 
 int64_t vqcpc_add_layernorm_bwd_workspace(int64_t M, int d) {
-    return (int64_t)ln_bwd_blocks(std::max<int64_t>(M, 1)) * 2 * d * (int64_t)sizeof(float);
+    return (int64_t)ln_bwd_blocks_max(std::max<int64_t>(M, 1), d) * 2 * d * (int64_t)sizeof(float);
 }
 
 int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
@@ -580,7 +589,7 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
                                 const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
                                 float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
                                 int64_t workspace_bytes, void* stream) {
-    // d_gamma == d_beta == NULL: the column partials stay in `workspace` ([vqcpc_add_layernorm_bwd_partials(M)][2 d]: d gamma | d beta)
+    // d_gamma == d_beta == NULL: the column partials stay in `workspace` ([vqcpc_add_layernorm_bwd_partials(M, d, r != NULL)][2 d]: d gamma | d beta)
     // for the caller to reduce later (vqcpc_reduce_grouped: the trainers sum the partials of every LayerNorm of a backward pass
     // in one launch)
     VQ_REQUIRE(dy && x && gamma && mean && rstd && d_s && workspace && ((d_gamma != nullptr) == (d_beta != nullptr)),
@@ -593,22 +602,29 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
     hipStream_t s = (hipStream_t)stream;
     const uint32_t thr = drop_threshold(drop_p);
     const float ik = 1.0f / (1.0f - drop_p);
-    const int blocks = ln_bwd_blocks(M);
-    if (r)
-        hipLaunchKernelGGL(add_ln_bwd_kernel<true>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
-                           d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
-    else if (thr && (d_r || d_r_bf16))     // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
-        hipLaunchKernelGGL((add_ln_bwd_kernel<false, true>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd,
-                           d_s, d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
-    else
-        hipLaunchKernelGGL(add_ln_bwd_kernel<false>, dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s,
-                           d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16);
+    const int blocks = ln_bwd_blocks(M, r != nullptr, d);
+#define LN_BWD(HR, MK, NITV)                                                                                              \
+    hipLaunchKernelGGL((add_ln_bwd_kernel<HR, MK, NITV>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s, \
+                       d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16)
+#define LN_BWD_D(HR, MK)                     \
+    if (d <= 256) LN_BWD(HR, MK, 1);         \
+    else if (d <= 512) LN_BWD(HR, MK, 2);    \
+    else LN_BWD(HR, MK, 4)
+    if (r) {
+        LN_BWD_D(true, true);
+    } else if (thr && (d_r || d_r_bf16)) {   // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
+        LN_BWD_D(false, true);
+    } else {
+        LN_BWD_D(false, false);
+    }
+#undef LN_BWD_D
+#undef LN_BWD
     VQ_CHECK_LAUNCH("add_layernorm_bwd");
     if (!d_gamma) return VQCPC_OK;
     return launch_reduce_splits2((const float*)workspace, (int64_t)2 * d, blocks, d_gamma, d, (const float*)workspace + d,
                                  (int64_t)2 * d, d_beta, d, 0, s);
 }
 
-int vqcpc_add_layernorm_bwd_partials(int64_t M) { return ln_bwd_blocks(std::max<int64_t>(M, 1)); }
+int vqcpc_add_layernorm_bwd_partials(int64_t M, int d, int has_r) { return ln_bwd_blocks(std::max<int64_t>(M, 1), has_r != 0, d); }
 
 }  // extern "C"

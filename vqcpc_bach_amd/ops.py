@@ -163,7 +163,7 @@ _PENDING_WGRADS = []           # (a, lda, b, ldb, dw, db, M, N, K): operands sta
 _PENDING_REDUCTIONS = []       # (workspace tensor, byte offset, stride, nsplit, out tensor, count): partial sums -> gradient buffers
 
 
-def defer_ln_param_grads(ws, M, d, gamma, beta):
+def defer_ln_param_grads(ws, M, d, gamma, beta, has_r):
     """LayerNorm backward inside a trainer's gradient scope: the [partials][2 d] column sums of `ws` are added into the live
     gradient buffers of gamma / beta by ONE grouped launch when the scope closes.  Returns False when the parameters own no
     gradient buffers (plain autograd use): the caller reduces as before."""
@@ -172,7 +172,7 @@ def defer_ln_param_grads(ws, M, d, gamma, beta):
     gg, bg = _live_grad(gamma), _live_grad(beta)
     if gg is None or bg is None or gg.numel() != d or bg.numel() != d:
         return False
-    n = hip.query('vqcpc_add_layernorm_bwd_partials', M)
+    n = hip.query('vqcpc_add_layernorm_bwd_partials', M, d, 1 if has_r else 0)
     _PENDING_REDUCTIONS.append((ws, 0, 2 * d, n, gg, d))
     _PENDING_REDUCTIONS.append((ws, 4 * d, 2 * d, n, bg, d))
     return True
@@ -838,7 +838,7 @@ class EncoderLayerFn(torch.autograd.Function):
             drb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None    # GEMM-operand copy of dr
             nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', Mq, d)
             ws = hip.workspace(nbytes, dev)
-            if defer_ln_param_grads(ws, Mq, d, gamma, beta):     # gamma / beta partial sums: reduced with all the others later
+            if defer_ln_param_grads(ws, Mq, d, gamma, beta, r is not None):     # gamma / beta partial sums: reduced with all the others later
                 dg = db = None
             else:
                 dg = torch.empty(d, dtype=torch.float32, device=dev)
@@ -1053,7 +1053,7 @@ class AddLayerNormFn(torch.autograd.Function):
         dr = torch.empty(M, d, dtype=torch.float32, device=dev) if p > 0 else None
         nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', M, d)
         ws = hip.workspace(nbytes, dev)
-        if defer_ln_param_grads(ws, M, d, gamma, ctx.beta):         # trainers: summed with every other LayerNorm's partials later
+        if defer_ln_param_grads(ws, M, d, gamma, ctx.beta, r is not None):         # trainers: summed with every other LayerNorm's partials later
             dg = db = None
         else:
             dg = torch.empty(d, dtype=torch.float32, device=dev)

@@ -30,6 +30,8 @@ for M, d in [(557056, 256), (139264, 256), (278528, 512), (98304, 1024)]:
     tb = timeit(lambda: hip.call('vqcpc_add_layernorm_bwd', dy, x, d, r, g, mean, rstd, ds, dr, dg, db, M, d, 0.1, 7, ws, nbytes))
     # the form the encoder layers of C1 / C4 use: x IS the residual sum (r = None), the mask of d_r is regenerated
     ts = timeit(lambda: hip.call('vqcpc_add_layernorm_bwd', dy, x, d, None, g, mean, rstd, ds, dr, dg, db, M, d, 0.1, 7, ws, nbytes))
+    tfs = timeit(lambda: hip.call('vqcpc_add_layernorm_fwd', x, d, None, g, b, y, mean, rstd, M, d, 1e-5, 0.0, 0))
+    print(f'M={M} d={d}: s-form forward {tfs:.1f} us ({2 * 4.0 * M * d / tfs / 1e6:.2f} TB/s of 2 tensors)', flush=True)
     print(f'M={M} d={d}: s-form backward {ts:.1f} us ({4 * 4.0 * M * d / ts / 1e6:.2f} TB/s of 4 tensors)', flush=True)
     print(f'M={M} d={d}: forward {tf:.1f} us ({3 * 4.0 * M * d / tf / 1e6:.2f} TB/s of 3 tensors), backward {tb:.1f} us '
           f'({5 * 4.0 * M * d / tb / 1e6:.2f} TB/s of 5 tensors)', flush=True)

@@ -122,7 +122,10 @@ __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
     __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
 }
 
-template <bool HAS_R>
+// NIT = 256-column groups per row (as in the backward): gamma / beta stay in registers for the whole row loop, and the NEXT row of
+// the wave is requested before the current one is reduced and written (a row is two dependent wave reductions: without the
+// prefetch a wave has one 1 KB load in flight)
+template <bool HAS_R, int NIT = kLnMaxIt>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ r, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
@@ -130,52 +133,66 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                                                          int d, float eps, uint32_t thr, float inv_keep, uint64_t seed,
                                                          unsigned short* __restrict__ y_b16) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int nit = (d + 255) >> 8;
     const float inv_d = 1.0f / (float)d;
-    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < M; row += (int64_t)gridDim.x * 4) {
-        float4 s[kLnMaxIt];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 gm[NIT], bt[NIT];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int col = lane * 4 + it * 256;
+        gm[it] = col < d ? *reinterpret_cast<const float4*>(gamma + col) : zero4;
+        bt[it] = col < d ? *reinterpret_cast<const float4*>(beta + col) : zero4;
+    }
+    const int64_t step = (int64_t)gridDim.x * 4;
+    int64_t row = (int64_t)blockIdx.x * 4 + wave;
+    float4 xn[NIT], rn[NIT];                       // raw operands of the wave's next row
+#define LNF_FETCH(ROW)                                                                   \
+    _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                 \
+        const int col = lane * 4 + it * 256;                                             \
+        const bool ok = (ROW) < M && col < d;                                            \
+        xn[it] = ok ? nt_load4(x + (ROW) * ldx + col) : zero4;                           \
+        if (HAS_R) rn[it] = ok ? nt_load4(r + (ROW) * d + col) : zero4;                  \
+    }
+    LNF_FETCH(row)
+    for (; row < M; row += step) {
+        float4 s[NIT];
         float sum = 0.0f;
 #pragma unroll
-        for (int it = 0; it < kLnMaxIt; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int col = lane * 4 + it * 256;
-            if (it < nit && col < d) {
-                float4 xv = nt_load4(x + row * ldx + col);
-                if (HAS_R) {
-                    const float4 rv = nt_load4(r + row * d + col);
-                    const uint64_t e = (uint64_t)row * d + col;
-                    xv.x += rv.x * drop_scale(seed, e + 0, thr, inv_keep);
-                    xv.y += rv.y * drop_scale(seed, e + 1, thr, inv_keep);
-                    xv.z += rv.z * drop_scale(seed, e + 2, thr, inv_keep);
-                    xv.w += rv.w * drop_scale(seed, e + 3, thr, inv_keep);
-                }
-                s[it] = xv;
-                sum += (xv.x + xv.y) + (xv.z + xv.w);
-            } else {
-                s[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 xv = xn[it];
+            if (HAS_R && col < d) {
+                const float4 rv = rn[it];
+                const uint64_t e = (uint64_t)row * d + col;
+                xv.x += rv.x * drop_scale(seed, e + 0, thr, inv_keep);
+                xv.y += rv.y * drop_scale(seed, e + 1, thr, inv_keep);
+                xv.z += rv.z * drop_scale(seed, e + 2, thr, inv_keep);
+                xv.w += rv.w * drop_scale(seed, e + 3, thr, inv_keep);
             }
+            s[it] = xv;                            // columns past d hold zeros: they add nothing to the sum
+            sum += (xv.x + xv.y) + (xv.z + xv.w);
         }
+        const int64_t nrow = row + step;
+        LNF_FETCH(nrow)
         const float mu = wave_sum(sum) * inv_d;
         float sq = 0.0f;
 #pragma unroll
-        for (int it = 0; it < kLnMaxIt; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int col = lane * 4 + it * 256;
-            if (it < nit && col < d) {
+            if (col < d) {
                 const float a = s[it].x - mu, b = s[it].y - mu, c = s[it].z - mu, e = s[it].w - mu;
                 sq += (a * a + b * b) + (c * c + e * e);
             }
         }
         const float rs = 1.0f / sqrtf(wave_sum(sq) * inv_d + eps);
 #pragma unroll
-        for (int it = 0; it < kLnMaxIt; ++it) {
+        for (int it = 0; it < NIT; ++it) {
             const int col = lane * 4 + it * 256;
-            if (it < nit && col < d) {
-                const float4 gm = *reinterpret_cast<const float4*>(gamma + col);
-                const float4 bt = *reinterpret_cast<const float4*>(beta + col);
+            if (col < d) {
                 float4 o;
-                o.x = (s[it].x - mu) * rs * gm.x + bt.x;
-                o.y = (s[it].y - mu) * rs * gm.y + bt.y;
-                o.z = (s[it].z - mu) * rs * gm.z + bt.z;
-                o.w = (s[it].w - mu) * rs * gm.w + bt.w;
+                o.x = (s[it].x - mu) * rs * gm[it].x + bt[it].x;
+                o.y = (s[it].y - mu) * rs * gm[it].y + bt[it].y;
+                o.z = (s[it].z - mu) * rs * gm[it].z + bt[it].z;
+                o.w = (s[it].w - mu) * rs * gm[it].w + bt[it].w;
                 nt_store4(y + row * d + col, o);
                 if (y_b16) *reinterpret_cast<uint2*>(y_b16 + row * d + col) = round4_bf16(o);   // GEMM operand copy
             }
@@ -185,6 +202,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
             rstd[row] = rs;
         }
     }
+#undef LNF_FETCH
 }
 
 // backward: d_s, d_r and per-workgroup partial d_gamma / d_beta (ws[block][2][d])
@@ -568,12 +586,20 @@ int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, con
     hipStream_t s = (hipStream_t)stream;
     const uint32_t thr = drop_threshold(drop_p);
     const float ik = 1.0f / (1.0f - drop_p);
-    if (r)
-        hipLaunchKernelGGL(add_ln_fwd_kernel<true>, dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean,
-                           rstd, M, d, eps, thr, ik, seed, (unsigned short*)y_bf16);
-    else
-        hipLaunchKernelGGL(add_ln_fwd_kernel<false>, dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean,
-                           rstd, M, d, eps, thr, ik, seed, (unsigned short*)y_bf16);
+#define LN_FWD(HR, NITV)                                                                                                  \
+    hipLaunchKernelGGL((add_ln_fwd_kernel<HR, NITV>), dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean, rstd, \
+                       M, d, eps, thr, ik, seed, (unsigned short*)y_bf16)
+#define LN_FWD_D(HR)                    \
+    if (d <= 256) LN_FWD(HR, 1);        \
+    else if (d <= 512) LN_FWD(HR, 2);   \
+    else LN_FWD(HR, 4)
+    if (r) {
+        LN_FWD_D(true);
+    } else {
+        LN_FWD_D(false);
+    }
+#undef LN_FWD_D
+#undef LN_FWD
     VQ_CHECK_LAUNCH("add_layernorm_fwd");
     return VQCPC_OK;
 }

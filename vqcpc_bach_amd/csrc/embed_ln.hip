@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
         // kEmbU rows in flight per lane, branch-free (the tail re-reads the last row of the voice and adds zero): issue
         // the loads first, then the (ordered) LDS read-modify-writes
         const int64_t last = row0 + v + (row1 - 1 - row0 - v) / nv * nv;         // last row of this voice in the chunk
+        // event index of a row = (row % tpb) / nv.  row0 is a multiple of tpb and the rows of a voice are nv apart, so the index
+        // of consecutive rows of the voice simply counts 0, 1, .., nev - 1, 0, ..: kept as a wrapped counter (the 64-bit
+        // modulo / division per row were ~20 000 scalar instructions per wave: counters in profiles/r03_pmc_kernels_c1.txt)
+        const int nevw = tpb / nv;
+        int ev_next = 0;
         for (int64_t base = row0 + v; base < row1; base += (int64_t)nv * kEmbU) {
             float gv[kEmbU];
             int tk[kEmbU], evi[kEmbU];
@@ -91,7 +96,8 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
                 const float x = g[row * d + col];
                 gv[u] = want < row1 ? x : 0.0f;
                 tk[u] = __builtin_amdgcn_readlane(tokv, u);
-                evi[u] = (int)(row % tpb) / nv;
+                evi[u] = ev_next;                          // rows clamped to `last` add zero: their index is irrelevant
+                ev_next = ev_next + 1 == nevw ? 0 : ev_next + 1;
             }
             // tab | csum | esum are one contiguous LDS array: one branch-free cell index per lane (a per-element
             // if / else-if / else made the wave that holds the 16 positional columns run all three arms for every row:

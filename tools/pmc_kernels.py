@@ -10,7 +10,10 @@ GROUPS = [['SQ_WAVE_CYCLES', 'SQ_BUSY_CYCLES', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY'
            'SQ_WAIT_INST_LDS']]
 FAMILIES = ['relattn16_bwd', 'relattn16_fwd', 'relattn_sub16_bwd', 'relattn_sub16_fwd', 'relattn_bwd_kernel', 'relattn_fwd_kernel',
             'relattn_sub_bwd', 'relattn_sub_fwd', 'block_table_segsum', 'embed_pos_bwd', 'embed_pos_fwd', 'add_ln_bwd', 'add_ln_fwd',
-            'vq_fwd', 'vq_bwd', 'gru_step_fwd', 'gru_step_bwd']
+            'vq_fwd', 'vq_bwd', 'gru_step_fwd', 'gru_step_bwd', 'relattn_x_fwd', 'relattn_x_bwd_dq', 'relattn_x_bwd_dkv',
+            'relattn_x_bwd_de', 'softmax_ce', 'upscale_bwd', 'upscale_fwd', 'embedding_bwd', 'adam_dev', 'sumsq_stage1',
+            'reduce_many', 'reduce_splits', 'splitk_epilogue', 'gemm_nt_skinny', 'transpose_many', 'dropout_selu', 'nce_',
+            'count_distinct', 'accumulate8', 'scale_rows', 'same_seq']
 
 
 def family(name):

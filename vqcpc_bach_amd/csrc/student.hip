@@ -75,12 +75,14 @@ __global__ __launch_bounds__(256) void upscale_fwd_kernel(const float* __restric
 }
 
 // dx[r][c] = sum_u g[r*f+u][c];  ws[chunk][u][c] = sum over the chunk's rows of g[r*f+u][c]
-constexpr int kUpRows = 32;      // input rows per workgroup
+// input rows per workgroup: a thread walks them one after the other (dependent on nothing, but one load round trip each), so
+// few rows per workgroup when there are few rows at all -- the student step's 192 rows took 70 us in 6 workgroups of 32 rows
+static int up_rows_per_wg(int64_t rows) { return (int)std::min<int64_t>(32, std::max<int64_t>(1, rows / 1024)); }
 constexpr int kUpMaxF = 8;
 
 __global__ __launch_bounds__(256) void upscale_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx,
-                                                          float* __restrict__ ws, int64_t rows, int f, int d) {
-    const int64_t r0 = (int64_t)blockIdx.x * kUpRows, r1 = min(r0 + kUpRows, rows);
+                                                          float* __restrict__ ws, int64_t rows, int f, int d, int rows_per_wg) {
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg, r1 = min(r0 + rows_per_wg, rows);
     for (int c = threadIdx.x; c < d; c += blockDim.x) {
         float acc[kUpMaxF];
 #pragma unroll
@@ -184,7 +186,7 @@ int vqcpc_upscale_fwd(const float* x, const float* emb, float* out, int64_t rows
 }
 
 int64_t vqcpc_upscale_bwd_workspace(int64_t rows, int f, int d) {
-    return ceil_div(std::max<int64_t>(rows, 1), kUpRows) * f * d * (int64_t)sizeof(float);
+    return ceil_div(std::max<int64_t>(rows, 1), up_rows_per_wg(std::max<int64_t>(rows, 1))) * f * d * (int64_t)sizeof(float);
 }
 
 int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int f, int d, void* workspace,
@@ -195,9 +197,10 @@ int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int
         set_error("upscale_bwd: workspace too small");
         return VQCPC_EWORKSPACE;
     }
-    const int chunks = (int)ceil_div(rows, kUpRows);
+    const int rpw = up_rows_per_wg(rows);
+    const int chunks = (int)ceil_div(rows, rpw);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(upscale_bwd_kernel, dim3(chunks), dim3(256), 0, s, g, dx, (float*)workspace, rows, f, d);
+    hipLaunchKernelGGL(upscale_bwd_kernel, dim3(chunks), dim3(256), 0, s, g, dx, (float*)workspace, rows, f, d, rpw);
     VQ_CHECK_LAUNCH("upscale_bwd");
     return launch_reduce_splits((const float*)workspace, (int64_t)f * d, chunks, d_emb, (int64_t)f * d, 0, s);
 }

@@ -11,12 +11,19 @@ name = sys.argv[1] if len(sys.argv) > 1 else 'C1'
 hip.load(); hip.set_gemm_mode(1)
 dp = DataParallelContext()
 torch.manual_seed(0)
-config = configs.make_config(name, dropout=0.1)
+config = configs.make_config(name, dropout=0.2 if name == 'DEC' else 0.1)
 dlg = getters.get_dataloader_generator(config['dataset'], config['training_method'],
                                        dict(config['dataloader_generator_kwargs'], seed=1, rank=0, device=dp.device))
-assert config['training_method'].lower() != 'decoder', 'encoder / student steps only'
-enc = getters.get_encoder('/tmp/vqcpc_trace', dlg, config)
-tr = getters.get_encoder_trainer('/tmp/vqcpc_trace', dlg, config['training_method'], enc, config['auxiliary_networks_kwargs'])
+if config['training_method'].lower() == 'decoder':
+    enc_cfg = config['config_encoder']
+    enc_dlg = getters.get_dataloader_generator(enc_cfg['dataset'], enc_cfg['training_method'],
+                                               dict(enc_cfg['dataloader_generator_kwargs'], seed=1, rank=0, device=dp.device))
+    enc = getters.get_encoder('/tmp/vqcpc_trace', enc_dlg, enc_cfg)
+    data_processor = getters.get_data_processor(dlg, config['data_processor_type'], config['data_processor_kwargs'])
+    tr = getters.get_decoder('/tmp/vqcpc_trace', dlg, data_processor, enc, config['decoder_type'], config['decoder_kwargs'])
+else:
+    enc = getters.get_encoder('/tmp/vqcpc_trace', dlg, config)
+    tr = getters.get_encoder_trainer('/tmp/vqcpc_trace', dlg, config['training_method'], enc, config['auxiliary_networks_kwargs'])
 tr.to(dp.device); tr.init_optimizers(lr=config['lr'], schedule_lr=False, dp=dp); tr.train()
 stream = dlg.dataloaders(batch_size=config['batch_size'])[0]
 batches = [next(stream) for _ in range(4)]

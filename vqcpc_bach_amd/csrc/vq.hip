@@ -204,9 +204,14 @@ __global__ __launch_bounds__(kVqThreads) void vq_bwd_kernel(const float* __restr
         const int kgroups = kVqThreads / dsub;      // dsub <= 256 checked on the host
         const int my_t = threadIdx.x % dsub, my_g = threadIdx.x / dsub;
         if (my_g < kgroups) {
+            // k % kgroups per row is a scalar division (8 600 scalar instructions per wave at 256 rows x 2 codebooks:
+            // profiles/r03_pmc_kernels_c1.txt); kgroups is a power of two for every dsub that divides 256
+            const bool pow2 = (kgroups & (kgroups - 1)) == 0;
+            const int kmask = kgroups - 1;
             for (int row = 0; row < rows_here; ++row) {
                 const int k = sidx[row];
-                if (k % kgroups == my_g) acc[k * dsub + my_t] += val[row * dsub + my_t];
+                const int kg = pow2 ? (k & kmask) : (k % kgroups);
+                if (kg == my_g) acc[k * dsub + my_t] += val[row * dsub + my_t];
             }
         }
         __syncthreads();

@@ -1955,6 +1955,9 @@ static bool skinny_ok(int64_t M, int N, int K, int flags, int* nw) {
     // (34 816 x 32 x 512: 69 us, 2048 x 32 x 1536: 115 us); 32 x 32 tiles with the K range over the waves: 3-6x faster
     const bool narrow = N <= 64 && K >= 128 && M <= (1 << 21);          // gridDim.y = M / 32
     if (!narrow && (M > 1024 || ceil_div(M, BM) * ceil_div(N, BN) >= 128)) return false;     // enough big tiles: use them
+    // bf16x6 mode, >= 96 tiles of 64 x 64: the LDS-staged 64-tile kernel reads full lines and beats the fragment-shaped global
+    // loads of this kernel from there on (768 x 1536 x 512: 37.7 -> 18.5 us, 768 x 512 x 512: 16.1 -> 14.7; tools/bench_s64.py)
+    if (!narrow && gemm_mode() == 1 && M % 64 == 0 && N % 64 == 0 && K % BK == 0 && (M / 64) * (N / 64) >= 96) return false;
     *nw = K >= 1024 ? 8 : 4;
     return K % (8 * *nw) == 0;
 }

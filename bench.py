@@ -68,6 +68,9 @@ def parse():
                          'and the code assignment are unaffected.  Default 6 = the exact split everywhere (the headline)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra (non-headline) measurement of the opt-in three-product gradient arithmetic')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the short runs of the other configurations (C3 student step, DEC decoder step, C4 in bf16) that '
+                         'the default N = 1 / C1 run reports under "secondary" after -- and outside -- the headline measurement')
     ap.add_argument('--gemm-breakdown', action='store_true', help='per-shape GEMM times of the sampled steps, to stderr')
     ap.add_argument('--cpu-baseline-only', action='store_true', help=argparse.SUPPRESS)
     return ap.parse_args()
@@ -241,7 +244,7 @@ def live_pmc(args, B, timeout_s=100):
     inner = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(steps), '--warmup', str(warm),
              '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-products',
              str(args.grad_products), '--no-graph',
-             '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc', '--no-extras']
+             '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc', '--no-extras', '--no-secondary']
     out = {'steps': n_steps}
     tmp = tempfile.mkdtemp(prefix='vqcpc_pmc_', dir='/tmp')
     env = dict(os.environ, TMPDIR='/tmp')
@@ -457,6 +460,35 @@ def cpu_baseline(cfg_name, dropout, batch, steps, timeout_s=240):
                     sample=f'cpu baseline failed: {type(e).__name__}: {str(e)[:200]}')
 
 
+SECONDARY = (('C3', ['--config', 'C3', '--steps', '300', '--warmup', '4']),
+             ('DEC', ['--config', 'DEC', '--steps', '300', '--warmup', '4']),
+             ('C4_bf16', ['--config', 'C4', '--gemm-mode', 'bf16', '--steps', '40', '--warmup', '3']))
+
+
+def secondary_runs(timeout_s=240):
+    """The other measured configurations, each a short run of THIS script in a child process after the headline's timed
+    region (they never touch `value`): BASELINE configs[3] (student step), the decoder step and
+    configs[4] in its named precision.  Same timing contract as the headline (epoch(train=True) over graph replays, barrier
+    + synchronize on both sides); the per-launch GEMM samples of each child give its gemm_nt fraction of the MFMA peak."""
+    import subprocess
+    out = {}
+    for name, extra in SECONDARY:
+        cmd = [sys.executable, os.path.abspath(__file__)] + extra + ['--no-cpu-baseline', '--no-live-pmc', '--no-extras',
+                                                                     '--no-secondary']
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+            rf = line.get('roofline') or {}
+            out[name] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': line['steps'],
+                         'dtype': line['dtype'], 'gemm_nt_frac': rf.get('frac'), 'gemm_nt_tflops': rf.get('achieved'),
+                         'gemm_nt_peak': rf.get('peak'), 'gemm_tn_tflops': (line.get('gemm_tn') or {}).get('achieved'),
+                         'workload': line['config']['workload'], 'wall_s': round(time.perf_counter() - t0, 1)}
+        except Exception as e:                          # never lose the headline line to a secondary run
+            out[name] = {'error': f'{type(e).__name__}: {str(e)[:200]}', 'wall_s': round(time.perf_counter() - t0, 1)}
+    return out
+
+
 def flush_c_stdio():
     """RCCL prints its version banner with printf; on a pipe that text sits in libc's buffer until exit and would land
     AFTER the JSON line.  Flushing libc's streams on every rank before rank 0 prints keeps the JSON line last."""
@@ -468,12 +500,41 @@ def flush_c_stdio():
     sys.stdout.flush()
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: start the N ranks HERE (one process per GPU,
+    torch.distributed.run on 127.0.0.1 and a free port) and hand their exit status back.  Rank 0 of the children prints
+    the JSON line on the inherited stdout.  Refuses to start when the node has fewer than N GPUs (VQCPC_DP_SHARE_GPU=1,
+    the 1-GPU test harness, puts every rank on device 0 instead)."""
+    import subprocess
+    share = os.environ.get('VQCPC_DP_SHARE_GPU', '0') == '1'
+    have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if have < (1 if share else args.gpus):
+        sys.exit(f'bench.py: --gpus {args.gpus} needs {args.gpus} visible GPUs, this node has {have} '
+                 f'(VQCPC_DP_SHARE_GPU=1 VQCPC_DP_BACKEND=gloo runs every rank on GPU 0: a test harness, not a measurement)')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}',
+           '--master-addr', '127.0.0.1', '--master-port', str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, OMP_NUM_THREADS=os.environ.get('OMP_NUM_THREADS', '4'), VQCPC_BENCH_SELF_LAUNCHED='1')
+    sys.exit(subprocess.call(cmd, env=env))
+
+
 def main():
     args = parse()
     if args.dropout is None:
         args.dropout = 0.2 if args.config == 'DEC' else 0.1
     if args.cpu_baseline_only:
         return cpu_baseline_worker(args.config, args.dropout, args.cpu_batch, args.cpu_steps)
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        return launch_ranks(args)
+    world_env = int(os.environ.get('WORLD_SIZE', 1))
+    if world_env != args.gpus:            # never a mislabelled line: the ranks that run ARE the --gpus that are reported
+        sys.exit(f'bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world_env} ranks')
     from vqcpc_bach_amd import configs, getters, hip, ops
     from vqcpc_bach_amd.parallel import DataParallelContext
     from vqcpc_bach_amd.utils import SEEDS
@@ -482,8 +543,10 @@ def main():
     gemm_mode = 2 if args.gemm_mode in ('bf16', '8') else (1 if args.gemm_mode in ('bf16x6', '1') else 0)
     hip.set_gemm_mode(8 if gemm_mode == 2 else gemm_mode)
     hip.set_gradient_products(args.grad_products)
+    if args.gpus > 1 and os.environ.get('VQCPC_DP_SHARE_GPU', '0') != '1' and torch.cuda.device_count() < args.gpus:
+        sys.exit(f'bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPUs are visible to this rank')
     dp = DataParallelContext()
-    assert dp.world_size == args.gpus or dp.world_size == 1, f'--gpus {args.gpus} but WORLD_SIZE={dp.world_size}'
+    assert dp.world_size == args.gpus, f'--gpus {args.gpus} but {dp.world_size} ranks joined the process group'
     dev = dp.device
     torch.manual_seed(0)                                           # identical initial weights on every rank
     SEEDS.manual_seed(1000 + dp.rank)
@@ -597,6 +660,30 @@ def main():
         graphs_per_step = 2 if (g is not None and g.finish_fn is not None) else 1
         trainer.enable_step_graph(False)
         timed_steps = max(1, sampled_eager_steps)
+    # the collective of the data-parallel step alone: the flat gradient bucket (what every step all-reduces), back to back
+    allreduce = None
+    if dp.distributed:
+        import torch.distributed as dist
+        bucket = torch.zeros_like(trainer.flat.flat_grad)
+        for _ in range(3):
+            dp.all_reduce_sum_(bucket)
+        torch.cuda.synchronize()
+        dp.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        n_ar = 20
+        for _ in range(n_ar):
+            dp.all_reduce_sum_(bucket)
+        torch.cuda.synchronize()
+        ar_ms = dp.max_over_ranks((time.perf_counter() - t0) * 1e3 / n_ar)
+        nbytes = bucket.numel() * 4
+        allreduce = {'ms_per_step': round(ar_ms, 4), 'bucket_bytes': nbytes, 'calls_per_step': 1,
+                     'bus_gb_s': round(2.0 * (dp.world_size - 1) / dp.world_size * nbytes / (ar_ms * 1e-3) / 1e9, 2),
+                     'share_of_step': round(ar_ms / (1e3 * dt / args.steps), 4),
+                     'backend': dp.backend, 'rccl_ranks': dist.get_world_size(),
+                     'note': f'{n_ar} back-to-back all-reduces of the flat fp32 gradient bucket after the timed region (max over '
+                             'ranks); inside the step the same call sits between the two graph replays'}
+        del bucket
     # Extra, NOT the headline: the same steps with the opt-in three-product gradient arithmetic (include/vqcpc.h), measured
     # after the timed region so that it cannot touch `value`.  Forward (losses, code assignment) identical; gradients carry
     # ~2^-17 per product instead of ~2^-24.  Under the socket's power cap the MFMA count is what the GEMM rate follows
@@ -699,7 +786,8 @@ def main():
                                      'HIP events around every GEMM launch of every 4th step of the timed region'))
         line = {
             'metric': f'encoder-train windows/sec (Bach 4-voice, seq={seq_len})', 'value': round(value, 2), 'unit': 'windows/s',
-            'n_gpus': dp.world_size, 'steps': args.steps, 'warmup': args.warmup,
+            'n_gpus': dp.world_size, 'rccl_ranks': (allreduce['rccl_ranks'] if allreduce else 1),
+            'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(1e3 * dt / args.steps, 3), 'higher_is_better': True, 'scaling': 'weak',
             'vs_baseline': None, 'dtype': 'bf16' if gemm_mode == 2 else 'f32',
             'data': 'synthetic' + (' (host-resident inputs: PCIe-inclusive)' if args.host_inputs else ''),
@@ -717,6 +805,7 @@ def main():
                        'gemm': ('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else
                                 'bf16 operands, fp32 accumulate (reduced precision)' if gemm_mode == 2 else 'fp32 MFMA')},
             'roofline': roofline,
+            'allreduce': allreduce,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
                          'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
                          'effective_clock_mhz': (pmc or {}).get('gemm_tn', {}).get('effective_clock_mhz'),
@@ -763,6 +852,9 @@ def main():
                 line['speedup_vs_cpu'] = round(value / line['cpu_baseline']['value'], 1)
         else:
             line['cpu_baseline'] = None
+        if (dp.world_size == 1 and args.config == 'C1' and not args.no_secondary and not args.host_inputs
+                and args.batch is None and gemm_mode == 1):
+            line['secondary'] = secondary_runs()
         print(json.dumps(line), flush=True)
     dp.shutdown()
 

@@ -174,6 +174,10 @@ def _full_size_c4_properties(bf16):
             assert torch.equal(idx, out['idx_negative'].reshape(-1, 4))
             assert idx.unique().numel() > 256                      # the check is not vacuous: many codes in use
         tr.train()
+        from test_trainer_gpu import gradient_additivity_error
+        err = gradient_additivity_error(tr, batch, B)          # full-size gradients: g(batch) == mean of g(halves)
+        print('C4 full-size gradient additivity error', err, 'bf16' if bf16 else 'f32-class')
+        assert err < (5e-3 if bf16 else 2e-5), err
         SEEDS.manual_seed(5)
         tr.train_step(batch, train=True)
         assert bool(torch.isfinite(tr.flat.flat_grad).all()) and bool(torch.isfinite(tr.flat.flat).all())

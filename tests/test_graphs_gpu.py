@@ -156,3 +156,62 @@ def test_decoder_step_graph():
         hip.set_gemm_mode(0)
     assert np.allclose(res[False][0], res[True][0], rtol=1e-6)
     assert float((res[False][1] - res[True][1]).abs().max()) < 1e-6 * float(res[False][1].abs().max())
+
+
+@pytest.mark.parametrize('graph_a,graph_b', [(True, False), (True, True), (False, False)])
+def test_two_trainers_interleaved_in_one_process_equal_each_run_apart(graph_a, graph_b):
+    """the library keeps process-wide state (GEMM mode, the device-side RNG salt of graph replays,
+    the deferred weight-gradient lists and the transposed-weight cache of a gradient scope, the dropout-seed source).
+    None of it may leak from one trainer into another at STEP granularity: two trainers of different shapes whose steps
+    alternate in one process -- eager and replayed, both with dropout -- end with parameters bit-identical to the ones
+    each reaches when it runs alone."""
+    from vqcpc_bach_amd import hip
+    from vqcpc_bach_amd.utils import SEEDS
+    hip.load()
+    cfg_a, sd_a, batches_a = _cpc_setup(0.2)
+    cfg_b = O.make_cfg(emb=32, vocab=[56] * 4, d=128, H=4, layers=[1, 1], ff=256, D=32, K=16, ncb=1, zdim=32, up_hidden=64,
+                       cdim=32, gru_hidden=64, B=4, N=5, Kl=2, Kr=2)
+    sd_b = O.init_state(cfg_b, seed=33)
+    batches_b = [O.synthetic_batch(cfg_b, seed=90 + i) for i in range(6)]
+    st = {}
+    O.encoder_forward(batches_b[0]['negative_samples'].reshape(-1, 4, 4), sd_b, cfg_b, stages=st)
+    sd_b['encoder.quantizer.embeddings.0'] = st['z'].reshape(-1, cfg_b['D'])[:cfg_b['K']].clone() + 0.01
+
+    def make(cfg, sd, seed, dropout, graph):
+        SEEDS.manual_seed(seed)
+        tr = build_trainer(cfg, sd, lr=2e-3, dropout=dropout)
+        tr.train()
+        tr.enable_step_graph(graph)
+        return tr
+
+    def steps(tr, batches):
+        for b in batches:
+            yield tr.train_step({k: v.cuda() for k, v in b.items()}, train=True)
+
+    hip.set_gemm_mode(1)
+    try:
+        apart = []
+        for cfg, sd, batches, seed, p, graph in ((cfg_a, sd_a, batches_a, 7, 0.2, graph_a), (cfg_b, sd_b, batches_b, 8, 0.1, graph_b)):
+            tr = make(cfg, sd, seed, p, graph)
+            losses = [float(o['loss']) for o in steps(tr, batches)]
+            apart.append((losses, tr.flat.flat.detach().clone()))
+            tr.enable_step_graph(False)
+        ta = make(cfg_a, sd_a, 7, 0.2, graph_a)
+        # trainer B is seeded and built AFTER trainer A took its first steps: its stream forks from its own seeding
+        la, lb = [], []
+        ga = steps(ta, batches_a)
+        la.append(float(next(ga)['loss']))
+        tb = make(cfg_b, sd_b, 8, 0.1, graph_b)
+        gb = steps(tb, batches_b)
+        for _ in range(len(batches_a) - 1):
+            lb.append(float(next(gb)['loss']))
+            la.append(float(next(ga)['loss']))
+        lb.append(float(next(gb)['loss']))
+        assert la == apart[0][0] and lb == apart[1][0], (la, apart[0][0], lb, apart[1][0])
+        assert torch.equal(ta.flat.flat, apart[0][1]) and torch.equal(tb.flat.flat, apart[1][1])
+        if graph_a:
+            assert ta._graph.replays == len(batches_a) - ta.graph_warmup_steps
+        ta.enable_step_graph(False)
+        tb.enable_step_graph(False)
+    finally:
+        hip.set_gemm_mode(0)

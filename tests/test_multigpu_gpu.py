@@ -138,21 +138,40 @@ def test_two_ranks_share_this_gpu_over_gloo(tmp_path):
 
 
 def test_bench_contract_with_two_ranks_sharing_this_gpu():
-    """bench.py under torch.distributed.run with 2 ranks (both on device 0, gloo): ONE JSON line from rank 0, n_gpus = 2,
-    whole-job value = global batch * steps / max-over-ranks time; the timed steps are graph replays (two per step around the
-    all-reduce), as on one rank."""
+    """PLAIN `python bench.py --gpus 2` (the driver's command form, no launcher): bench.py starts the two ranks itself (both
+    on device 0 here, gloo): ONE JSON line from rank 0, n_gpus = rccl_ranks = 2, whole-job value = global batch * steps /
+    max-over-ranks time; the timed steps are graph replays (two per step around the all-reduce), as on one rank."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_SHARE_GPU='1', VQCPC_DP_BACKEND='gloo',
                PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2',
-           '--batch', '32']
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        env.pop(k, None)
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '2', '--batch', '32']
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith('{')]
     assert len(lines) == 1, lines
     line = json.loads(lines[0])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['cpu_baseline'] is None
+    assert line['rccl_ranks'] == 2 and line['allreduce']['rccl_ranks'] == 2 and line['allreduce']['ms_per_step'] > 0
+    assert line['allreduce']['bucket_bytes'] == 4 * line['config']['params']
     assert line['step_graph'] is not None and line['step_graph']['replays_in_run'] >= 8 and line['step_graph']['graphs_per_step'] == 2
     assert line['config']['global_batch'] == 64 and line['config']['parallelism'] == 'dp2'
     assert abs(line['value'] - 64 * 4 / (line['ms_per_step'] * 4e-3)) < 0.01 * line['value']
     assert line['roofline'] is not None and line['roofline']['achieved'] > 0
+
+
+def test_bench_refuses_a_rank_count_that_differs_from_gpus():
+    """A launcher that starts 1 rank for `--gpus 2` must not produce a (mislabelled) line."""
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(_free_port()))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+@pytest.mark.skipif(_world() != 1, reason='the refusal for too few GPUs is only observable on a 1-GPU box')
+def test_bench_refuses_more_gpus_than_the_node_has():
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'VQCPC_DP_SHARE_GPU')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and 'needs 2 visible GPUs' in r.stderr

@@ -227,3 +227,25 @@ def test_decoder_dp_gradient_mean_with_frozen_encoder(tmp_path):
         res = torch.load(tmp_path / f'd{r}.pt')
         assert res['worst'] < 2e-4, res['worst']
         assert abs(res['norm'] - res['refn']) < 1e-4 * res['refn']
+
+
+def test_bench_gpus_2_without_gpus_exits_nonzero_with_a_message():
+    """`python bench.py --gpus 2` starts its own ranks; on a node without two GPUs it must refuse (non-zero, a message, no
+    JSON line) instead of benchmarking one rank under a multi-GPU label."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'VQCPC_DP_SHARE_GPU')}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0
+    assert 'needs 2 visible GPUs' in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_bench_rejects_a_launcher_whose_world_differs_from_gpus():
+    import subprocess
+    import sys
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '4', '--steps', '2', '--warmup', '1'],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
+    assert r.returncode != 0 and 'WORLD_SIZE=1' in r.stderr

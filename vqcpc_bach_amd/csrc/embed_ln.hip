@@ -71,7 +71,12 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     const int64_t row0 = (int64_t)chunk * chunk_rows;
     const int64_t row1 = min(row0 + chunk_rows, n_rows);
     // rows of this voice: row % tpb % nv == v.  chunk_rows is a multiple of tpb (checked on the host).
-    for (int col = threadIdx.x; col < d; col += blockDim.x) {
+    // The column loop runs over WAVE-UNIFORM bases with every lane active: the token ids of a batch are handed out with
+    // v_readlane from lanes 0..15, which must have executed the load even when the last wave owns fewer than 16 columns
+    // (d % 64 in [1, 15]); lanes past the last column read column 0 and skip the LDS update.
+    for (int colb = (int)(threadIdx.x & ~63u); colb < d; colb += blockDim.x) {
+        const bool cok = colb + (int)(threadIdx.x & 63) < d;
+        const int col = cok ? colb + (int)(threadIdx.x & 63) : 0;
         const int kind = col < dlin ? 0 : (col < dlin + pos ? 1 : 2);                 // table column | channel | event
         const int cbase = kind == 0 ? col : (kind == 1 ? vmax * dlin + (col - dlin) : vmax * dlin + pos + (col - dlin - pos));
         const int cmul = kind == 0 ? dlin : (kind == 2 ? pos : 0);
@@ -94,7 +99,7 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
                 const int64_t want = base + (int64_t)u * nv;
                 const int64_t row = min(want, last);
                 const float x = g[row * d + col];
-                gv[u] = want < row1 ? x : 0.0f;
+                gv[u] = (cok && want < row1) ? x : 0.0f;
                 tk[u] = __builtin_amdgcn_readlane(tokv, u);
                 evi[u] = ev_next;                          // rows clamped to `last` add zero: their index is irrelevant
                 ev_next = ev_next + 1 == nevw ? 0 : ev_next + 1;
@@ -103,7 +108,8 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
             // if / else-if / else made the wave that holds the 16 positional columns run all three arms for every row:
             // 465 -> 324 us at C1; requesting the next batch before these read-modify-writes was slower again, 423 us)
 #pragma unroll
-            for (int u = 0; u < kEmbU; ++u) lds[cbase + (kind == 2 ? evi[u] : tk[u]) * cmul] += gv[u];
+            for (int u = 0; u < kEmbU; ++u)
+                if (cok) lds[cbase + (kind == 2 ? evi[u] : tk[u]) * cmul] += gv[u];
         }
     }
     __syncthreads();

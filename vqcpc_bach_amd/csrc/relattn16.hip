@@ -67,6 +67,7 @@ __device__ __forceinline__ void store_ct(float* __restrict__ p, const float (&v)
 // there, which read bf16 from HBM -- the kernels round on the way out instead of writing fp32 for a cast pass to re-read.
 __device__ __forceinline__ unsigned short bf16_rn(float x) {
     const uint32_t u = __float_as_uint(x);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x40u);   // NaN stays NaN (quiet), never +-Inf
     return (unsigned short)((u + 0x7FFFu + ((u >> 16) & 1u)) >> 16);
 }
 template <int CT>

@@ -290,9 +290,10 @@ class Decoder(GraphedTraining, nn.Module):
             codes = self.encode(tensor_dict['x'])
             with torch.no_grad():
                 return self.compute_loss(codes, x)[0].detach()
-        out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
-        if out is None:
-            out = self._train_step_body(tensor_dict)
+        with SEEDS.stream_of(self):            # this trainer's own dropout-seed stream (utils.DropoutSeeds.stream_of)
+            out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
+            if out is None:
+                out = self._train_step_body(tensor_dict)
         self.global_step += 1
         return out
 

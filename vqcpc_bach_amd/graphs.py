@@ -82,7 +82,11 @@ class StepGraph:
 
     def _body(self, static):
         hip.call('vqcpc_rng_salt_advance', self.counter, self.seed_base)
-        return self.step_fn(static)
+        out = self.step_fn(static)
+        # the salt is process-wide device state: the graph's last node puts it back to 0, so that whatever runs after a
+        # replay -- an eager step of ANOTHER trainer, an evaluation pass -- sees the seeds it was given
+        hip.call('vqcpc_rng_salt_set', 0)
+        return out
 
     def capture(self, batch):
         """Records one step on `batch`'s shapes.  Nothing is executed: the caller replays afterwards."""
@@ -160,6 +164,11 @@ class GraphedTraining:
         if not self._graph_explicit and os.environ.get('VQCPC_STEP_GRAPH', '1') != '0':
             self.enable_step_graph(True)
             self._graph_explicit = False
+
+    def seed_dropout(self, base):
+        """Re-seeds THIS trainer's dropout-seed stream (utils.DropoutSeeds.stream_of): the per-trainer counterpart of
+        SEEDS.manual_seed(), which only reaches trainers that have not taken a step yet."""
+        self._dropout_stream = (int(base) & 0xFFFFFFFF, 0)
 
     def enable_step_graph(self, enabled=True):
         self._graph_on = bool(enabled)

@@ -347,6 +347,8 @@ class direct_weight_gradients:
     def __enter__(self):
         global _DIRECT_WGRAD
         self.prev, _DIRECT_WGRAD = _DIRECT_WGRAD, True
+        if self.prev:                      # nested scope: the outermost one owns the deferred work and the transposed weights
+            return self
         hip.gradient_scope(True)           # the GEMMs launched from here on are gradient GEMMs (hip.set_gradient_products)
         if self.flat is not None and BATCHED_TRANSPOSES:
             WEIGHT_T.begin(self.flat)
@@ -355,6 +357,8 @@ class direct_weight_gradients:
     def __exit__(self, *exc):
         global _DIRECT_WGRAD
         _DIRECT_WGRAD = self.prev
+        if self.prev:                      # an inner scope neither flushes nor discards what the outer scope deferred
+            return False
         try:
             if exc[0] is None:
                 flush_wgrads()                  # the deferred small weight gradients, still inside the gradient scope

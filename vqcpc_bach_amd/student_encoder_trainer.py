@@ -269,10 +269,11 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         x = tensor_dict['x']
         self._graph_m = self.draw_masked_event(x.shape[1]) if masked_event_index is None else int(masked_event_index)
         out = None
-        if not self.encoder.quantizer_needs_init():
-            out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
-        if out is None:
-            out = self._train_step_body(tensor_dict, self._graph_m)
+        with SEEDS.stream_of(self):            # this trainer's own dropout-seed stream (utils.DropoutSeeds.stream_of)
+            if not self.encoder.quantizer_needs_init():
+                out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
+            if out is None:
+                out = self._train_step_body(tensor_dict, self._graph_m)
         self.global_step += 1
         return out
 

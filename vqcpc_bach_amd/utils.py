@@ -24,6 +24,32 @@ class DropoutSeeds:
         self.counter += 1
         return (((self.base + self.rank_salt) & 0xFFFFFFFF) << 32) + self.counter * 0x10000
 
+    def stream_of(self, owner):
+        """Context manager around one training step of `owner` (a trainer): inside it the seeds come from the owner's OWN
+        stream, forked from this object's (base, counter) at the owner's FIRST step (seed, build, step -- as with one trainer
+        -- gives the sequence it always gave; `trainer.seed_dropout(base)` re-seeds a trainer that has already stepped).
+        Two trainers stepping alternately in one process therefore draw exactly the seeds each would draw alone."""
+        return _OwnedStream(self, owner)
+
+
+class _OwnedStream:
+    def __init__(self, seeds, owner):
+        self.seeds, self.owner = seeds, owner
+
+    def __enter__(self):
+        s, st = self.seeds, getattr(self.owner, '_dropout_stream', None)
+        self.outer = (s.base, s.counter)
+        if st is None:
+            st = (s.base, s.counter)
+        s.base, s.counter = st
+        return s
+
+    def __exit__(self, *exc):
+        s = self.seeds
+        self.owner._dropout_stream = (s.base, s.counter)
+        s.base, s.counter = self.outer
+        return False
+
 
 SEEDS = DropoutSeeds()
 

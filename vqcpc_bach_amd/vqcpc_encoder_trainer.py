@@ -257,10 +257,11 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
                 out['metrics'] = self._step_metrics(out)
                 return out
         out = None
-        if not corrupt_labels and not self.encoder.quantizer_needs_init():
-            out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
-        if out is None:
-            out = self._train_step_body(tensor_dict, corrupt_labels)
+        with SEEDS.stream_of(self):            # this trainer's own dropout-seed stream (utils.DropoutSeeds.stream_of)
+            if not corrupt_labels and not self.encoder.quantizer_needs_init():
+                out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
+            if out is None:
+                out = self._train_step_body(tensor_dict, corrupt_labels)
         self.global_step += 1
         return out
 

@@ -61,6 +61,143 @@ struct Bf16Out {
                             // variant without the epilogue's global stores (VQCPC_BF16_STAGGER=-1, tools/bench_gemm_bf16.py)
 };
 
+// =====================================================================================================================
+// Epilogue of the 256 x 256 bf16 NT kernels (shared by gemm_nt_bf16_kernel and gemm_nt_bf16_k64_kernel; expands inside the
+// kernel body and uses its locals: smem, wave, lane, li, kh, wm, wn, o, ep, N, tiles, tiles_n, acc, EPI, OUT).
+// One 32 x 32 accumulator tile at a time goes through a 4 KB LDS scratch of its wave (16 ds_write_b32, 4 ds_read_b128:
+// lane -> row lane >> 3 (+ 8 j), columns 4 (lane & 7) ..) and leaves as dwordx4 stores of fp32 and / or dwordx2 stores of
+// bf16 (8 row segments of 128 / 64 bytes per instruction); bias / gate / residual operands are fetched in the same shape
+// (fp32: 4 x dwordx4; bf16 gate: 4 x dwordx2 kept RAW, only the sign is looked at).  Software-pipelined: while tile t is
+// finished (bias / activation / dropout / gate / residual, stores) the scratch round trip of tile t + 1 and the operand
+// loads of tile t + 3 are in flight.  A bf16 gate operand (24 VGPRs for three tiles) is requested one whole phase pair
+// earlier (B_AUX_PREFETCH in the last memory phase of the tile); fp32 operands (48 VGPRs) only in the epilogue itself.
+// LDS accesses and stores are inline asm (see gemm_dma.hip: no compiler-inserted vmcnt(0), explicit wait states).
+// SCR_OFF = byte offset of the 8 x 4 KB scratch area inside the kernel's dynamic LDS.
+#define B_EPI_DECLS(SCR_OFF)                                                                                           \
+    int ep_tile = blockIdx.x;                                                                                          \
+    constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;                                                            \
+    constexpr bool AUX_B16 = (OUT & B_GATE_BF16) != 0;             /* gate operand is bf16 (sign only) */              \
+    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;                 \
+    const unsigned scr = lds0 + (SCR_OFF) + wave * 4096;                                                               \
+    const unsigned scr_w = scr + ((4 * kh) * 32 + li) * 4;                                                             \
+    const unsigned scr_r = scr + ((lane >> 3) * 32 + (lane & 7) * 4) * 4;                                              \
+    const int e_row = wm * 128 + (lane >> 3), e_col = wn * 64 + 4 * (lane & 7);                                        \
+    const int ldci = (int)o.ldc, ldcbi = (int)o.ldcb;                                                                  \
+    const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;                                                             \
+    const int ldxi = (int)(AUX_B16 ? o.ldgate_b : ((EPI & E_GATE) ? ep.ldgate : ep.ldadd));                            \
+    union AuxT {                                                                                                       \
+        fx4 f[4];                                                                                                      \
+        u32x2 h[4];                                                                                                    \
+    };                                                                                                                 \
+    AuxT aux0, aux1, aux2;
+#define B_SCR_WRITE(MT, NT)                                                                                            \
+    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                     \
+        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(scr_w), "v"(acc[MT][NT][r]), "i"(((r & 3) + 8 * (r >> 2)) * 128));
+#define B_SCR_READ(V)                                                                                                  \
+    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(V[0]) : "v"(scr_r));                                            \
+    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(V[1]) : "v"(scr_r));                                         \
+    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(V[2]) : "v"(scr_r));                                         \
+    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(V[3]) : "v"(scr_r));
+#define B_SCR_WAIT(V) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]));
+#define B_AUX_LOAD(DST, TILE)                                                                                          \
+    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
+        if (AUX_B16)                                                                                                   \
+            DST.h[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                                 \
+                rx, voff_x, ((((TILE) >> 1) * 32 + 8 * j) * ldxi + ((TILE) & 1) * 32) * 2, 0));                        \
+        else                                                                                                           \
+            DST.f[j] = __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(                                  \
+                rx, voff_x, ((((TILE) >> 1) * 32 + 8 * j) * ldxi + ((TILE) & 1) * 32) * 4, 0));                        \
+    }
+#define B_EPI_TILE(V, AUX, TILE)                                                                                       \
+    {                                                                                                                  \
+        constexpr int MT = (TILE) >> 1, NT = (TILE) & 1;                                                               \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
+            const int64_t row = m0 + e_row + MT * 32 + 8 * j;                                                          \
+            const int col = n0 + e_col + NT * 32;                                                                      \
+            fx4 ov;                                                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
+                float v = V[j][c];                                                                                     \
+                if (EPI & E_BIAS) v += bias4[NT][c];                                                                   \
+                if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
+                if (EPI & E_DROP)   /* == drop_scale(ep.seed, (row + ep.row0) * N + col + c, ..); thr > 0 on this path */  \
+                    v *= rng_u24_from_x0(x0_lane + (uint32_t)((MT * 32 + 8 * j) * N + NT * 32 + c) * kRngMul, drop_sh) >= ep.thr \
+                             ? ep.inv_keep : 0.0f;                                                                     \
+                if (EPI & E_GATE) {                                                                                    \
+                    bool pos;                                                                                          \
+                    if (AUX_B16) {                                                                                     \
+                        const unsigned hw = (AUX.h[j][c >> 1] >> (16 * (c & 1))) & 0xFFFFu;       /* bf16 > 0 */       \
+                        pos = hw != 0 && hw < 0x8000u;                                                                 \
+                    } else {                                                                                           \
+                        pos = AUX.f[j][c] > 0.0f;                                                                      \
+                    }                                                                                                  \
+                    v *= pos ? ep.gate_scale : 0.0f;                                                                   \
+                }                                                                                                      \
+                if (EPI & E_ADD) v += AUX.f[j][c];                                                                     \
+                ov[c] = v;                                                                                             \
+            }                                                                                                          \
+            if ((OUT & B_OUT_F32) && o.stagger != -1)                                                                  \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(ov), "v"(voff_c), \
+                             "s"(rc), "s"(((MT * 32 + 8 * j) * ldci + NT * 32) * 4) : "memory");                       \
+            if ((OUT & B_OUT_BF16) && o.stagger != -1) {                                                               \
+                u32x2 pk;                                                                                              \
+                pk[0] = cvt_pk_bf16(ov[0], ov[1]);                                                                     \
+                pk[1] = cvt_pk_bf16(ov[2], ov[3]);                                                                     \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(pk), "v"(voff_cb), \
+                             "s"(rcb), "s"(((MT * 32 + 8 * j) * ldcbi + NT * 32) * 2) : "memory");                     \
+            }                                                                                                          \
+        }                                                                                                              \
+        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[MT][NT][r] = 0.0f;                                          \
+    }
+#define B_EPI_DESC()                                                                                                   \
+    const int t_ = xcd_swizzle(ep_tile, tiles);                                                                        \
+    const int64_t m0 = (int64_t)(t_ / tiles_n) * kB;                                                                   \
+    const int n0 = (t_ % tiles_n) * kB;                                                                                \
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                               \
+        (void*)(!HAS_AUX ? (const void*)smem                                                                           \
+                         : AUX_B16 ? (const void*)(o.gate_b + m0 * (int64_t)ldxi + n0)                                 \
+                                   : (const void*)(xsrc + m0 * (int64_t)ldxi + n0)),                                   \
+        0, 0x7FFFFFFF, 0x00020000);                                                                                    \
+    const int voff_x = (e_row * ldxi + e_col) * (AUX_B16 ? 2 : 4);
+#define B_AUX_PREFETCH()                                                                                               \
+    {                                                                                                                  \
+        B_EPI_DESC()                                                                                                   \
+        B_AUX_LOAD(aux0, 0) B_AUX_LOAD(aux1, 1) B_AUX_LOAD(aux2, 2)                                                    \
+    }
+#define B_EPI_STEP(TILE, VCUR, VNXT, AUXC)                                                                             \
+    B_SCR_WAIT(VCUR)                                                                                                   \
+    if ((TILE) + 1 < 8) {                                                                                              \
+        B_SCR_WRITE(((TILE) + 1) >> 1, ((TILE) + 1) & 1)                                                               \
+        B_SCR_READ(VNXT)                                                                                               \
+    }                                                                                                                  \
+    B_EPI_TILE(VCUR, AUXC, TILE)                                                                                       \
+    if (HAS_AUX && (TILE) + 3 < 8) { B_AUX_LOAD(AUXC, (TILE) + 3) }
+#define B_EPILOGUE()                                                                                                   \
+    {                                                                                                                  \
+        B_EPI_DESC()                                                                                                   \
+        /* dropout hash input of this lane's first element of the output tile; the others are constant offsets away */ \
+        const uint64_t drop_se = rng_seed_eff(ep.seed);                                                                \
+        const uint32_t drop_sh = (uint32_t)(drop_se >> 32);                                                            \
+        const uint32_t x0_lane = rng_x0(drop_se, (uint32_t)(m0 + e_row + ep.row0) * (uint32_t)N + (uint32_t)(n0 + e_col)); \
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)((OUT & B_OUT_F32) ? o.c + m0 * o.ldc + n0 : (float*)smem), 0, 0x7FFFFFFF, 0x00020000);             \
+        const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(                                          \
+            (void*)((OUT & B_OUT_BF16) ? o.cb + m0 * o.ldcb + n0 : (bf16_t*)smem), 0, 0x7FFFFFFF, 0x00020000);         \
+        const int voff_c = (e_row * ldci + e_col) * 4;                                                                 \
+        const int voff_cb = (e_row * ldcbi + e_col) * 2;                                                               \
+        fx4 bias4[2];                                                                                                  \
+        if (EPI & E_BIAS) {                                                                                            \
+            bias4[0] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col);                                            \
+            bias4[1] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col + 32);                                       \
+        }                                                                                                              \
+        if (HAS_AUX && !AUX_B16) { B_AUX_LOAD(aux0, 0) B_AUX_LOAD(aux1, 1) B_AUX_LOAD(aux2, 2) }                        \
+        fx4 va[4], vb[4];                                                                                              \
+        B_SCR_WRITE(0, 0)                                                                                              \
+        B_SCR_READ(va)                                                                                                 \
+        B_EPI_STEP(0, va, vb, aux0) B_EPI_STEP(1, vb, va, aux1) B_EPI_STEP(2, va, vb, aux2) B_EPI_STEP(3, vb, va, aux0) \
+        B_EPI_STEP(4, va, vb, aux1) B_EPI_STEP(5, vb, va, aux2) B_EPI_STEP(6, va, vb, aux0) B_EPI_STEP(7, vb, va, aux1) \
+        ep_tile += gridDim.x;                                                                                          \
+    }
+
 template <int EPI, int OUT>
 __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
                                                                    const bf16_t* __restrict__ B, int64_t ldb, Bf16Out o,
@@ -152,138 +289,8 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  \
     __builtin_amdgcn_sched_barrier(0);
 
-    // ---- epilogue through the wave's LDS scratch (see gemm_dma.hip for the layout and for why stores are inline asm) ----
-    int ep_tile = blockIdx.x;
-    constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;
-    constexpr bool AUX_B16 = (OUT & B_GATE_BF16) != 0;             // gate operand is bf16 (sign only)
-    const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const unsigned scr = lds0 + 2 * kBStage + wave * 4096;
-    const unsigned scr_w = scr + ((4 * kh) * 32 + li) * 4;
-    const unsigned scr_r = scr + ((lane >> 3) * 32 + (lane & 7) * 4) * 4;
-    const int e_row = wm * 128 + (lane >> 3), e_col = wn * 64 + 4 * (lane & 7);
-    const int ldci = (int)o.ldc, ldcbi = (int)o.ldcb;
-    const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;
-    const int ldxi = (int)(AUX_B16 ? o.ldgate_b : ((EPI & E_GATE) ? ep.ldgate : ep.ldadd));
-#define B_SCR_WRITE(MT, NT)                                                                                            \
-    _Pragma("unroll") for (int r = 0; r < 16; ++r)                                                                     \
-        asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(scr_w), "v"(acc[MT][NT][r]), "i"(((r & 3) + 8 * (r >> 2)) * 128));
-#define B_SCR_READ(V)                                                                                                  \
-    asm volatile("ds_read_b128 %0, %1 offset:0" : "=v"(V[0]) : "v"(scr_r));                                            \
-    asm volatile("ds_read_b128 %0, %1 offset:1024" : "=v"(V[1]) : "v"(scr_r));                                         \
-    asm volatile("ds_read_b128 %0, %1 offset:2048" : "=v"(V[2]) : "v"(scr_r));                                         \
-    asm volatile("ds_read_b128 %0, %1 offset:3072" : "=v"(V[3]) : "v"(scr_r));
-#define B_SCR_WAIT(V) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(V[0]), "+v"(V[1]), "+v"(V[2]), "+v"(V[3]));
-    // operand of the gate / residual epilogues for one 32 x 32 tile, in the shape of the transposed values: 4 row groups x
-    // 4 columns per lane -- fp32: 4 x dwordx4; bf16 gate: 4 x dwordx2 kept RAW (only the sign is looked at)
-#define B_AUX_LOAD(DST, TILE)                                                                                          \
-    _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                    \
-        if (AUX_B16)                                                                                                   \
-            DST.h[j] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                                 \
-                rx, voff_x, ((((TILE) >> 1) * 32 + 8 * j) * ldxi + ((TILE) & 1) * 32) * 2, 0));                        \
-        else                                                                                                           \
-            DST.f[j] = __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(                                  \
-                rx, voff_x, ((((TILE) >> 1) * 32 + 8 * j) * ldxi + ((TILE) & 1) * 32) * 4, 0));                        \
-    }
-#define B_EPI_TILE(V, AUX, TILE)                                                                                       \
-    {                                                                                                                  \
-        constexpr int MT = (TILE) >> 1, NT = (TILE) & 1;                                                               \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                                \
-            const int64_t row = m0 + e_row + MT * 32 + 8 * j;                                                          \
-            const int col = n0 + e_col + NT * 32;                                                                      \
-            fx4 ov;                                                                                                    \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
-                float v = V[j][c];                                                                                     \
-                if (EPI & E_BIAS) v += bias4[NT][c];                                                                   \
-                if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
-                if (EPI & E_DROP)   /* == drop_scale(ep.seed, (row + ep.row0) * N + col + c, ..); thr > 0 on this path */  \
-                    v *= rng_u24_from_x0(x0_lane + (uint32_t)((MT * 32 + 8 * j) * N + NT * 32 + c) * kRngMul, drop_sh) >= ep.thr \
-                             ? ep.inv_keep : 0.0f;                                                                     \
-                if (EPI & E_GATE) {                                                                                    \
-                    bool pos;                                                                                          \
-                    if (AUX_B16) {                                                                                     \
-                        const unsigned hw = (AUX.h[j][c >> 1] >> (16 * (c & 1))) & 0xFFFFu;       /* bf16 > 0 */       \
-                        pos = hw != 0 && hw < 0x8000u;                                                                 \
-                    } else {                                                                                           \
-                        pos = AUX.f[j][c] > 0.0f;                                                                      \
-                    }                                                                                                  \
-                    v *= pos ? ep.gate_scale : 0.0f;                                                                   \
-                }                                                                                                      \
-                if (EPI & E_ADD) v += AUX.f[j][c];                                                                     \
-                ov[c] = v;                                                                                             \
-            }                                                                                                          \
-            if ((OUT & B_OUT_F32) && o.stagger != -1)                                                                  \
-                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(ov), "v"(voff_c), \
-                             "s"(rc), "s"(((MT * 32 + 8 * j) * ldci + NT * 32) * 4) : "memory");                       \
-            if ((OUT & B_OUT_BF16) && o.stagger != -1) {                                                               \
-                u32x2 pk;                                                                                              \
-                pk[0] = cvt_pk_bf16(ov[0], ov[1]);                                                                     \
-                pk[1] = cvt_pk_bf16(ov[2], ov[3]);                                                                     \
-                asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(pk), "v"(voff_cb), \
-                             "s"(rcb), "s"(((MT * 32 + 8 * j) * ldcbi + NT * 32) * 2) : "memory");                     \
-            }                                                                                                          \
-        }                                                                                                              \
-        _Pragma("unroll") for (int r = 0; r < 16; ++r) acc[MT][NT][r] = 0.0f;                                          \
-    }
-    // descriptors of the output tile with linear index ep_tile (wave-uniform)
-#define B_EPI_DESC()                                                                                                   \
-    const int t_ = xcd_swizzle(ep_tile, tiles);                                                                        \
-    const int64_t m0 = (int64_t)(t_ / tiles_n) * kB;                                                                   \
-    const int n0 = (t_ % tiles_n) * kB;                                                                                \
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                               \
-        (void*)(!HAS_AUX ? (const void*)smem                                                                           \
-                         : AUX_B16 ? (const void*)(o.gate_b + m0 * (int64_t)ldxi + n0)                                 \
-                                   : (const void*)(xsrc + m0 * (int64_t)ldxi + n0)),                                   \
-        0, 0x7FFFFFFF, 0x00020000);                                                                                    \
-    const int voff_x = (e_row * ldxi + e_col) * (AUX_B16 ? 2 : 4);
-    // One 32 x 32 tile at a time goes through the scratch, software-pipelined: while tile t is finished (bias / activation /
-    // dropout / gate / residual, stores) the scratch round trip of tile t + 1 and the operand loads of tile t + 3 are in
-    // flight.  A bf16 gate operand (24 VGPRs for three tiles) is requested one whole phase pair earlier (B_AUX_PREFETCH in
-    // the last memory phase of the tile); fp32 operands (48 VGPRs) only here.
-    union AuxT {
-        fx4 f[4];
-        u32x2 h[4];
-    };
-    AuxT aux0, aux1, aux2;
-#define B_AUX_PREFETCH()                                                                                               \
-    {                                                                                                                  \
-        B_EPI_DESC()                                                                                                   \
-        B_AUX_LOAD(aux0, 0) B_AUX_LOAD(aux1, 1) B_AUX_LOAD(aux2, 2)                                                    \
-    }
-#define B_EPI_STEP(TILE, VCUR, VNXT, AUXC)                                                                             \
-    B_SCR_WAIT(VCUR)                                                                                                   \
-    if ((TILE) + 1 < 8) {                                                                                              \
-        B_SCR_WRITE(((TILE) + 1) >> 1, ((TILE) + 1) & 1)                                                               \
-        B_SCR_READ(VNXT)                                                                                               \
-    }                                                                                                                  \
-    B_EPI_TILE(VCUR, AUXC, TILE)                                                                                       \
-    if (HAS_AUX && (TILE) + 3 < 8) { B_AUX_LOAD(AUXC, (TILE) + 3) }
-#define B_EPILOGUE()                                                                                                   \
-    {                                                                                                                  \
-        B_EPI_DESC()                                                                                                   \
-        /* dropout hash input of this lane's first element of the output tile; the others are constant offsets away */ \
-        const uint64_t drop_se = rng_seed_eff(ep.seed);                                                                \
-        const uint32_t drop_sh = (uint32_t)(drop_se >> 32);                                                            \
-        const uint32_t x0_lane = rng_x0(drop_se, (uint32_t)(m0 + e_row + ep.row0) * (uint32_t)N + (uint32_t)(n0 + e_col)); \
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(                                           \
-            (void*)((OUT & B_OUT_F32) ? o.c + m0 * o.ldc + n0 : (float*)smem), 0, 0x7FFFFFFF, 0x00020000);             \
-        const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(                                          \
-            (void*)((OUT & B_OUT_BF16) ? o.cb + m0 * o.ldcb + n0 : (bf16_t*)smem), 0, 0x7FFFFFFF, 0x00020000);         \
-        const int voff_c = (e_row * ldci + e_col) * 4;                                                                 \
-        const int voff_cb = (e_row * ldcbi + e_col) * 2;                                                               \
-        fx4 bias4[2];                                                                                                  \
-        if (EPI & E_BIAS) {                                                                                            \
-            bias4[0] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col);                                            \
-            bias4[1] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col + 32);                                       \
-        }                                                                                                              \
-        if (HAS_AUX && !AUX_B16) { B_AUX_LOAD(aux0, 0) B_AUX_LOAD(aux1, 1) B_AUX_LOAD(aux2, 2) }                        \
-        fx4 va[4], vb[4];                                                                                              \
-        B_SCR_WRITE(0, 0)                                                                                              \
-        B_SCR_READ(va)                                                                                                 \
-        B_EPI_STEP(0, va, vb, aux0) B_EPI_STEP(1, vb, va, aux1) B_EPI_STEP(2, va, vb, aux2) B_EPI_STEP(3, vb, va, aux0) \
-        B_EPI_STEP(4, va, vb, aux1) B_EPI_STEP(5, vb, va, aux2) B_EPI_STEP(6, va, vb, aux0) B_EPI_STEP(7, vb, va, aux1) \
-        ep_tile += gridDim.x;                                                                                          \
-    }
-
+    // ---- epilogue through the wave's LDS scratch: macros B_EPILOGUE / B_AUX_PREFETCH at file scope above ----
+    B_EPI_DECLS(2 * kBStage)
     // one phase pair for stream position s: RB_ = LDS buffer with K tile s, WB_ = buffer for tile s+1; register set SET_
     // holds tile s+1 (requested two phase pairs ago), is written to LDS and re-used for the request of tile s+3
 #define B_PHASES(RB_, WB_, SET_)                                                  \
@@ -320,15 +327,6 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
     if (wm == 0) { B_BARRIER() }                         // pairs with group 1's last barrier
     B_EPILOGUE()
 #undef B_PHASES
-#undef B_EPILOGUE
-#undef B_EPI_STEP
-#undef B_AUX_PREFETCH
-#undef B_EPI_DESC
-#undef B_EPI_TILE
-#undef B_AUX_LOAD
-#undef B_SCR_WAIT
-#undef B_SCR_READ
-#undef B_SCR_WRITE
 #undef B_BARRIER
 #undef B_MFMA
 #undef B_READ_FRAGS

@@ -21,6 +21,7 @@ def timeit(f, n=5, reps=5):
     return statistics.median(ts)
 
 
+VARIANTS = [int(v) for v in os.environ.get('VQCPC_BF16_VARIANTS', '0,1').split(',')]
 for N, K in [(2048, 512), (512, 2048), (512, 512), (1536, 512)]:
     a = ops.cast_bf16(torch.randn(M, K, device='cuda')); b = ops.cast_bf16(torch.randn(N, K, device='cuda') * 0.05)
     bias = torch.randn(N, device='cuda')
@@ -35,8 +36,17 @@ for N, K in [(2048, 512), (512, 2048), (512, 512), (1536, 512)]:
              ('gate_b -> bf16', dict(gate_b=gate_b, gate_scale=1.1, out_f32=False, out_bf16=True)),
              ('add -> f32', dict(add=res, out=out32))]
     for name, kw in forms:
-        t = timeit(lambda: ops.gemm_nt_bf16(a, b, **kw))
-        print(f'M={M} N={N} K={K} {name:24s} {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.0f} TFLOP/s', flush=True)
+        res_ = []
+        outs = []
+        for v in VARIANTS:
+            hip.call('vqcpc_gemm_bf16_set_variant', v)
+            r_ = ops.gemm_nt_bf16(a, b, **kw)
+            outs.append([x.clone() for x in (r_ if isinstance(r_, (tuple, list)) else [r_]) if torch.is_tensor(x)])
+            t = timeit(lambda: ops.gemm_nt_bf16(a, b, **kw))
+            res_.append(f'v{v}: {t:8.1f} us {2.0 * M * N * K / t / 1e6:6.0f} TFLOP/s')
+        same = all(torch.equal(x, y) for o in outs[1:] for x, y in zip(outs[0], o))
+        print(f'M={M} N={N} K={K} {name:24s} ' + ' | '.join(res_) + ('' if len(VARIANTS) < 2 else f'  bit-identical: {same}'), flush=True)
+    hip.call('vqcpc_gemm_bf16_set_variant', 1)
 hip.set_gemm_mode(0)
 
 # weight-gradient (TN) bf16 kernel

@@ -17,6 +17,8 @@
 //                        dwordx2 stores of bf16.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include "gemm_common.h"
 
 namespace vq {
@@ -150,7 +152,7 @@ struct Bf16Out {
     }
 #define B_EPI_DESC()                                                                                                   \
     const int t_ = xcd_swizzle(ep_tile, tiles);                                                                        \
-    const int64_t m0 = (int64_t)(t_ / tiles_n) * kB;                                                                   \
+    const int64_t m0 = (int64_t)(t_ / tiles_n) * kTileRows;                                                            \
     const int n0 = (t_ % tiles_n) * kB;                                                                                \
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                               \
         (void*)(!HAS_AUX ? (const void*)smem                                                                           \
@@ -290,6 +292,7 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
     __builtin_amdgcn_sched_barrier(0);
 
     // ---- epilogue through the wave's LDS scratch: macros B_EPILOGUE / B_AUX_PREFETCH at file scope above ----
+    constexpr int kTileRows = kB;
     B_EPI_DECLS(2 * kBStage)
     // one phase pair for stream position s: RB_ = LDS buffer with K tile s, WB_ = buffer for tile s+1; register set SET_
     // holds tile s+1 (requested two phase pairs ago), is written to LDS and re-used for the request of tile s+3
@@ -333,6 +336,295 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
 #undef B_STORE
 #undef B_LOAD
 #undef B_SET_SRC
+}
+
+
+// =====================================================================================================================
+// Epilogue WITHOUT LDS, for kernels that accumulate the TRANSPOSED product (the B fragment is the MFMA's first operand):
+// the 32 x 32 accumulator layout then gives a lane ONE output row (mt * 32 + li) and, per register quad q, FOUR CONSECUTIVE
+// columns nt * 32 + 8 q + 4 kh + 0..3 -- a dwordx4 store of fp32 / a dwordx2 store of bf16 straight from the accumulator,
+// no transposition.  The LDS-transposed form above costs 16 ds_write_b32 + 4 ds_read_b128 per 32 x 32 tile and wave:
+// 4 096 + 1 024 LDS-array cycles per 256 x 256 output next to the 6 144 of a K = 512 main loop's fragment reads and the DMA
+// writes, i.e. the LDS -- not the stores -- paced the K = 512 products (two independent workgroups per CU did not overlap
+// their epilogues for that reason: profiles/r04_gemm_bf16.md).  A store instruction covers 32 rows x 32 bytes (fp32); the
+// four instructions of a tile complete each row's 128-byte line in the L2 before it is written back.
+// Bias is per column: 8 float4 per lane (columns of its quads), loaded once.  Gate / residual operands are fetched in the
+// shape of the stores, two tiles ahead.  Uses the kernel's locals as B_EPI_DECLS' macros do (wm, wn, li, kh, o, ep, acc ..).
+#define T_EPI_DECLS()                                                                                                  \
+    int ep_tile = blockIdx.x;                                                                                          \
+    constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;                                                            \
+    constexpr bool AUX_B16 = (OUT & B_GATE_BF16) != 0;             /* gate operand is bf16 (sign only) */              \
+    const int t_row = wm * 128 + li, t_col = wn * 64 + 4 * kh;     /* + 32 mt, + 32 nt + 8 q */                        \
+    const int ldci = (int)o.ldc, ldcbi = (int)o.ldcb;                                                                  \
+    const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;                                                             \
+    const int ldxi = (int)(AUX_B16 ? o.ldgate_b : ((EPI & E_GATE) ? ep.ldgate : ep.ldadd));                            \
+    union AuxT {                                                                                                       \
+        fx4 f[4];                                                                                                      \
+        u32x2 h[4];                                                                                                    \
+    };                                                                                                                 \
+    AuxT aux0, aux1;
+#define T_EPI_DESC()                                                                                                   \
+    const int t_ = xcd_swizzle(ep_tile, tiles);                                                                        \
+    const int64_t m0 = (int64_t)(t_ / tiles_n) * kTileRows;                                                            \
+    const int n0 = (t_ % tiles_n) * kB;                                                                                \
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                               \
+        (void*)(!HAS_AUX ? (const void*)smem                                                                           \
+                         : AUX_B16 ? (const void*)(o.gate_b + m0 * (int64_t)ldxi + n0)                                 \
+                                   : (const void*)(xsrc + m0 * (int64_t)ldxi + n0)),                                   \
+        0, 0x7FFFFFFF, 0x00020000);                                                                                    \
+    const int voff_x = (t_row * ldxi + t_col) * (AUX_B16 ? 2 : 4);
+#define T_AUX_LOAD(DST, TILE)                                                                                          \
+    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
+        if (AUX_B16)                                                                                                   \
+            DST.h[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                                 \
+                rx, voff_x, ((((TILE) >> 1) * 32) * ldxi + ((TILE) & 1) * 32 + 8 * q) * 2, 0));                        \
+        else                                                                                                           \
+            DST.f[q] = __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(                                  \
+                rx, voff_x, ((((TILE) >> 1) * 32) * ldxi + ((TILE) & 1) * 32 + 8 * q) * 4, 0));                        \
+    }
+#define T_AUX_PREFETCH()                                                                                               \
+    {                                                                                                                  \
+        T_EPI_DESC()                                                                                                   \
+        T_AUX_LOAD(aux0, 0) T_AUX_LOAD(aux1, 1)                                                                        \
+    }
+#define T_EPI_TILE(AUX, TILE)                                                                                          \
+    {                                                                                                                  \
+        constexpr int MT = (TILE) >> 1, NT = (TILE) & 1;                                                               \
+        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
+            fx4 ov;                                                                                                    \
+            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
+                float v = acc[MT][NT][4 * q + c];                                                                      \
+                if (EPI & E_BIAS) v += bias4[NT][q][c];                                                                \
+                if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
+                if (EPI & E_DROP)   /* == drop_scale(ep.seed, (row + ep.row0) * N + col, ..); thr > 0 on this path */  \
+                    v *= rng_u24_from_x0(x0_lane + (uint32_t)((MT * 32) * N + NT * 32 + 8 * q + c) * kRngMul, drop_sh) >= ep.thr \
+                             ? ep.inv_keep : 0.0f;                                                                     \
+                if (EPI & E_GATE) {                                                                                    \
+                    bool pos;                                                                                          \
+                    if (AUX_B16) {                                                                                     \
+                        const unsigned hw = (AUX.h[q][c >> 1] >> (16 * (c & 1))) & 0xFFFFu;       /* bf16 > 0 */       \
+                        pos = hw != 0 && hw < 0x8000u;                                                                 \
+                    } else {                                                                                           \
+                        pos = AUX.f[q][c] > 0.0f;                                                                      \
+                    }                                                                                                  \
+                    v *= pos ? ep.gate_scale : 0.0f;                                                                   \
+                }                                                                                                      \
+                if (EPI & E_ADD) v += AUX.f[q][c];                                                                     \
+                ov[c] = v;                                                                                             \
+            }                                                                                                          \
+            if (OUT & B_OUT_F32)                                                                                       \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" ::"v"(ov),    \
+                             "v"(voff_c), "s"(rc), "s"((MT * 32) * ldci * 4), "i"((NT * 32 + 8 * q) * 4) : "memory");   \
+            if (OUT & B_OUT_BF16) {                                                                                    \
+                u32x2 pk;                                                                                              \
+                pk[0] = cvt_pk_bf16(ov[0], ov[1]);                                                                     \
+                pk[1] = cvt_pk_bf16(ov[2], ov[3]);                                                                     \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" ::"v"(pk),    \
+                             "v"(voff_cb), "s"(rcb), "s"((MT * 32) * ldcbi * 2), "i"((NT * 32 + 8 * q) * 2) : "memory"); \
+            }                                                                                                          \
+        }                                                                                                              \
+    }
+#define T_EPI_STEP(TILE, AUXC)                                                                                         \
+    T_EPI_TILE(AUXC, TILE)                                                                                             \
+    if (HAS_AUX && (TILE) + 2 < 8) { T_AUX_LOAD(AUXC, (TILE) + 2) }
+// PREFETCHED: the operands of tiles 0 and 1 were requested by T_AUX_PREFETCH
+#define T_EPILOGUE(PREFETCHED)                                                                                         \
+    {                                                                                                                  \
+        T_EPI_DESC()                                                                                                   \
+        const uint64_t drop_se = rng_seed_eff(ep.seed);                                                                \
+        const uint32_t drop_sh = (uint32_t)(drop_se >> 32);                                                            \
+        const uint32_t x0_lane = rng_x0(drop_se, (uint32_t)(m0 + t_row + ep.row0) * (uint32_t)N + (uint32_t)(n0 + t_col)); \
+        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)((OUT & B_OUT_F32) ? o.c + m0 * o.ldc + n0 : (float*)smem), 0, 0x7FFFFFFF, 0x00020000);             \
+        const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(                                          \
+            (void*)((OUT & B_OUT_BF16) ? o.cb + m0 * o.ldcb + n0 : (bf16_t*)smem), 0, 0x7FFFFFFF, 0x00020000);         \
+        const int voff_c = (t_row * ldci + t_col) * 4;                                                                 \
+        const int voff_cb = (t_row * ldcbi + t_col) * 2;                                                               \
+        fx4 bias4[2][4];                                                                                               \
+        if (EPI & E_BIAS) {                                                                                            \
+            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                           \
+                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
+                    bias4[nt][q] = *reinterpret_cast<const fx4*>(ep.bias + n0 + t_col + nt * 32 + 8 * q);              \
+        }                                                                                                              \
+        if (HAS_AUX && !(PREFETCHED)) { T_AUX_LOAD(aux0, 0) T_AUX_LOAD(aux1, 1) }                                      \
+        T_EPI_STEP(0, aux0) T_EPI_STEP(1, aux1) T_EPI_STEP(2, aux0) T_EPI_STEP(3, aux1)                                \
+        T_EPI_STEP(4, aux0) T_EPI_STEP(5, aux1) T_EPI_STEP(6, aux0) T_EPI_STEP(7, aux1)                                \
+    }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_nt_bf16_w4_kernel: the same product on a 128 (rows of A) x 256 (rows of B) output tile per workgroup of FOUR waves
+// (1 x 4, wave tile 128 x 64: the accumulator / fragment economy of the 8-wave kernel), TWO workgroups resident per CU,
+// operands delivered global -> LDS by DMA (buffer_load_dwordx4 ... lds), no staging registers and no LDS stores.
+//
+// Why: in the 8-wave ping-pong kernel the two wave groups are coupled by the workgroup barrier of every phase, so the
+// epilogue of an output tile (LDS transposition, bias / relu / dropout hash / gate / residual, 32-64 stores per wave) is
+// exposed: the partner group can run ONE MFMA phase ahead and then waits.  At K = 512 an output tile is only 16 phase
+// pairs long and the exposed epilogues were 22-48 % of the time (none -> bf16: 838, bias+relu+drop -> bf16: 628,
+// add -> f32: 553 TFLOP/s against 1020 at K = 2048; profiles/r04_gemm_bf16.md).  Two INDEPENDENT workgroups per CU share
+// nothing but the hardware: while one is in its epilogue (VALU, LDS, stores) the other one's waves own the matrix pipes.
+//
+// K tiles of 32 (64-byte operand rows) in a ring of three 24 KB LDS slots [A 128 rows | B 256 rows]; 16-byte chunk c of row
+// r sits at chunk position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments); a DMA instruction writes 1 KB = 16
+// rows lane-linearly, so the swizzle is applied to the per-lane SOURCE address.  Software pipeline of a wave, phase p:
+//     s_waitcnt vmcnt(6)     this wave's pieces of K tile p+1 have landed (tile p+2 may be in flight)
+//     s_barrier              everybody's have; and every wave has finished reading slot p % 3 (its reads were waited for
+//                            at the end of phase p-1)
+//     DMA  tile p+3 -> slot p % 3                       (6 instructions per wave: 2 of A, 4 of B)
+//     ds_read fragments of tile p+1 -> register set (p+1) & 1   (12 x ds_read_b128)
+//     16 MFMAs on register set p & 1
+//     s_waitcnt lgkmcnt(0)
+// One barrier per 16 MFMAs among four waves; the LDS reads of the next phase and the DMA issue run under this phase's
+// MFMAs, the other workgroup's waves fill what is left.  Not persistent: a workgroup owns one output tile, its epilogue
+// scratch aliases the operand ring (idle by then), and the CU's other workgroup covers its prologue.
+constexpr int kWTM = 128, kWTN = 256;        // output tile
+constexpr int kWSlotA = kWTM * kBRowB;       // 8 KB
+constexpr int kWSlot = (kWTM + kWTN) * kBRowB;   // 24 KB
+constexpr int kWLds = 3 * kWSlot;            // 72 KB: two workgroups per CU
+constexpr int kWThreads = 256;
+
+template <int EPI, int OUT>
+__global__ __launch_bounds__(kWThreads, 2) void gemm_nt_bf16_w4_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                      const bf16_t* __restrict__ B, int64_t ldb, Bf16Out o,
+                                                                      int64_t M, int N, int K, int tiles_n, int tiles,
+                                                                      EpiParams ep) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    constexpr int wm = 0;
+    const int wn = wave;
+    const int li = lane & 31, kh = lane >> 5;
+    const int P = K / kBBK;                                        // K tiles (K % 64 == 0: P even, >= 2)
+    const int t_own = xcd_swizzle((int)blockIdx.x, tiles);
+    const int64_t m_own = (int64_t)(t_own / tiles_n) * kWTM;
+    const int n_own = (t_own % tiles_n) * kWTN;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // ---- DMA: wave w delivers A rows [32 w, 32 w + 32) and B rows [64 w, 64 w + 64) of a K tile ----
+    // lane l of an instruction -> row l >> 2 of its 16-row block, chunk position l & 3 <- logical chunk (l & 3) ^ ((l >> 4) & 3)
+    const int dl_row = lane >> 2, dl_c = (lane & 3) ^ ((lane >> 4) & 3);
+    const int voff_a = (dl_row * (int)lda + dl_c * 8) * 2;
+    const int voff_b = (dl_row * (int)ldb + dl_c * 8) * 2;
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(A + (m_own + 32 * wave) * lda), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(B + ((int64_t)n_own + 64 * wave) * ldb), 0, 0x7FFFFFFF, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int ldai = (int)lda, ldbi = (int)ldb;
+#define W_ISSUE(SOFF, KT)                                                                                               \
+    {                                                                                                                   \
+        unsigned char* da_ = smem + (SOFF) + wave * 2048;                                                               \
+        unsigned char* db_ = smem + (SOFF) + kWSlotA + wave * 4096;                                                     \
+        const int k_ = (KT) * kBBK;                                                                                     \
+        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(da_ + j * 1024), 16, voff_a,                     \
+                                                     (j * 16 * ldai + k_) * 2, 0, 0);                                   \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(db_ + j * 1024), 16, voff_b,                     \
+                                                     (j * 16 * ldbi + k_) * 2, 0, 0);                                   \
+    }
+
+    // ---- fragments: lane (row li, k group kh) of k16 step ks reads chunk 2 ks + kh of its row (inline asm: for a C++ LDS
+    // load hipcc would wait vmcnt(0) as soon as an LDS-DMA is in flight) ----
+    const unsigned ldsb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int fsw = (li >> 2) & 3;
+    const unsigned a_ad0 = ldsb + li * kBRowB + (((0 + kh) ^ fsw) << 4);
+    const unsigned a_ad1 = ldsb + li * kBRowB + (((2 + kh) ^ fsw) << 4);
+    const unsigned b_ad0 = a_ad0 + kWSlotA + wn * 64 * kBRowB;
+    const unsigned b_ad1 = a_ad1 + kWSlotA + wn * 64 * kBRowB;
+    fx4 xb[2][2], xa[2][4], yb[2][2], ya[2][4];                    // two register sets, [ks][tile]
+#define W_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
+#define W_READ_FRAGS(S_, SOFF)                                                                                          \
+    {                                                                                                                   \
+        const unsigned a0_ = a_ad0 + (SOFF), a1_ = a_ad1 + (SOFF), b0_ = b_ad0 + (SOFF), b1_ = b_ad1 + (SOFF);          \
+        W_RD(S_##b[0][0], b0_, 0);                                                                                      \
+        W_RD(S_##b[0][1], b0_, 32 * kBRowB);                                                                            \
+        W_RD(S_##a[0][0], a0_, 0);                                                                                      \
+        W_RD(S_##a[0][1], a0_, 32 * kBRowB);                                                                            \
+        W_RD(S_##a[0][2], a0_, 64 * kBRowB);                                                                            \
+        W_RD(S_##a[0][3], a0_, 96 * kBRowB);                                                                            \
+        W_RD(S_##b[1][0], b1_, 0);                                                                                      \
+        W_RD(S_##b[1][1], b1_, 32 * kBRowB);                                                                            \
+        W_RD(S_##a[1][0], a1_, 0);                                                                                      \
+        W_RD(S_##a[1][1], a1_, 32 * kBRowB);                                                                            \
+        W_RD(S_##a[1][2], a1_, 64 * kBRowB);                                                                            \
+        W_RD(S_##a[1][3], a1_, 96 * kBRowB);                                                                            \
+    }
+    // the wait names every destination read-write: no consumer can be scheduled above it
+#define W_LGKM_WAIT(S_)                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                 : "+v"(S_##b[0][0]), "+v"(S_##b[0][1]), "+v"(S_##b[1][0]), "+v"(S_##b[1][1]), "+v"(S_##a[0][0]),       \
+                   "+v"(S_##a[0][1]), "+v"(S_##a[0][2]), "+v"(S_##a[0][3]), "+v"(S_##a[1][0]), "+v"(S_##a[1][1]),       \
+                   "+v"(S_##a[1][2]), "+v"(S_##a[1][3]));
+#define W_MFMA(S_)                                                                                                      \
+    _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                    \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                              \
+            /* B fragment first: the accumulator holds the TRANSPOSED tile (lane = output row, registers = columns) */  \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##b[ks][0]),              \
+                                                                 __builtin_bit_cast(bf16x8, S_##a[ks][mt]), acc[mt][0], 0, 0, 0); \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##b[ks][1]),              \
+                                                                 __builtin_bit_cast(bf16x8, S_##a[ks][mt]), acc[mt][1], 0, 0, 0); \
+        }
+    // vmcnt(6): this wave's pieces of the NEXT tile have landed, the one after it (6 instructions) may be in flight
+#define W_SYNC(VMC)                                                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    asm volatile("s_waitcnt vmcnt(" #VMC ")\n\ts_barrier" ::: "memory");                                                \
+    __builtin_amdgcn_sched_barrier(0);
+
+    constexpr int kTileRows = kWTM;
+    T_EPI_DECLS()
+
+    // one phase for K tile p: CUR_ = register set holding its fragments, NXT_ = set that receives tile p+1.
+    // so0 / so1 / so2 = byte offsets of the slots of tiles p, p+1, p+2 (rotated at the end of the phase)
+#define W_PHASE(CUR_, NXT_, VMC, ISSUE_, READ_, PREFETCH_)                                                              \
+    {                                                                                                                   \
+        W_SYNC(VMC)                                                                                                     \
+        if (ISSUE_) W_ISSUE(so0, p + 3)                                                                                 \
+        if ((PREFETCH_) && HAS_AUX && AUX_B16) T_AUX_PREFETCH()                                                          \
+        if (READ_) W_READ_FRAGS(NXT_, so1)                                                                              \
+        __builtin_amdgcn_s_setprio(1);                                                                                  \
+        W_MFMA(CUR_)                                                                                                    \
+        __builtin_amdgcn_s_setprio(0);                                                                                  \
+        if (READ_) { W_LGKM_WAIT(NXT_) }                                                                                \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+        ++p;                                                                                                            \
+        { const int t_ = so0; so0 = so1; so1 = so2; so2 = t_; }                                                         \
+    }
+
+    // prologue: tiles 0, 1, 2 requested; tile 0 landed for everybody -> fragments of tile 0 in set x  (P >= 4, host)
+    int so0 = 0, so1 = kWSlot, so2 = 2 * kWSlot;
+    int p = 0;
+    W_ISSUE(0, 0)
+    W_ISSUE(kWSlot, 1)
+    W_ISSUE(2 * kWSlot, 2)
+    W_SYNC(12)
+    W_READ_FRAGS(x, 0)
+    W_LGKM_WAIT(x)
+    // steady state, two phases per trip (the register sets alternate); the last four phases are peeled: they stop issuing
+    // (tile p+3 does not exist), wait for everything, request the epilogue's bf16 gate operand and stop reading
+#pragma unroll 1
+    while (p < P - 4) {
+        W_PHASE(x, y, 6, true, true, false)
+        W_PHASE(y, x, 6, true, true, false)
+    }
+    W_PHASE(x, y, 6, true, true, false)          // p = P - 4: requests the last tile
+    W_PHASE(y, x, 6, false, true, false)         // p = P - 3
+    W_PHASE(x, y, 0, false, true, true)          // p = P - 2: nothing in flight behind tile P - 1
+    W_PHASE(y, x, 0, false, false, false)        // p = P - 1
+    T_EPILOGUE(HAS_AUX && AUX_B16)
+#undef W_PHASE
+#undef W_SYNC
+#undef W_MFMA
+#undef W_LGKM_WAIT
+#undef W_READ_FRAGS
+#undef W_RD
+#undef W_ISSUE
 }
 
 
@@ -517,6 +809,14 @@ int vqcpc_cast_bf16(const float* in, int64_t ld_in, void* out, int64_t rows, int
     return VQCPC_OK;
 }
 
+static std::atomic<int> g_bf16_nt_variant{1};      // 1: four-wave workgroups, two per CU (gemm_nt_bf16_w4_kernel); 0: 8-wave ping-pong
+
+int vqcpc_gemm_bf16_set_variant(int variant) {
+    VQ_REQUIRE(variant == 0 || variant == 1, "gemm_bf16_set_variant: 0 (8-wave ping-pong kernel) or 1 (two 4-wave workgroups per CU)");
+    g_bf16_nt_variant.store(variant, std::memory_order_relaxed);
+    return VQCPC_OK;
+}
+
 int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K) { return (M % kB == 0 && N % kB == 0 && K % (2 * kBBK) == 0) ? 1 : 0; }
 
 int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, void* Cb, int64_t ldcb,
@@ -547,7 +847,21 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     const int tiles = (int)((M / kB) * tn);
     const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kBThreads);
     hipStream_t st = (hipStream_t)stream;
+    const bool w4 = g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && K >= 4 * kBBK;
+    const int tiles_w4 = (int)((M / kWTM) * tn);
 #define BL(EPIV, OUTV)                                                                                                 \
+    if (flags == (EPIV) && out == (OUTV) && w4) {                                                                      \
+        static bool attr_w4 = false;                                                                                   \
+        if (!attr_w4) {                                                                                                \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_w4_kernel<EPIV, OUTV>,                                 \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWLds);                              \
+            attr_w4 = true;                                                                                            \
+        }                                                                                                              \
+        hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<EPIV, OUTV>), dim3((unsigned)tiles_w4), dim3(kWThreads), kWLds, st, \
+                           (const bf16_t*)A, lda, (const bf16_t*)B, ldb, o, M, N, K, tn, tiles_w4, ep);                \
+        VQ_CHECK_LAUNCH("gemm_nt_bf16_w4");                                                                            \
+        return VQCPC_OK;                                                                                               \
+    }                                                                                                                  \
     if (flags == (EPIV) && out == (OUTV)) {                                                                            \
         static bool attr_done = false;                                                                                 \
         if (!attr_done) {                                                                                              \

@@ -287,8 +287,18 @@ def test_gemm_nt_bf16x6_dma_kernel_is_bit_identical_to_the_register_staged_kerne
     assert float(outs[17][6][1::2].abs().max()) == 0.0
 
 
-@pytest.mark.parametrize('M,N,K', [(512, 256, 64), (1024, 768, 512), (256 * 260, 256, 128), (2048, 512, 2048)])
-def test_gemm_nt_bf16_native_kernel(ops, M, N, K):
+@pytest.fixture(params=[1, 0], ids=['k64-dma', 'k32-pingpong'])
+def bf16_nt_variant(request):
+    """Both kernels behind vqcpc_gemm_nt_bf16: 1 = K tiles of 64 by LDS-DMA (default, K % 128 == 0), 0 = ping-pong, K tiles of 32."""
+    from vqcpc_bach_amd import hip
+    hip.load()
+    hip.call('vqcpc_gemm_bf16_set_variant', request.param)
+    yield request.param
+    hip.call('vqcpc_gemm_bf16_set_variant', 1)
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 256, 64), (1024, 768, 512), (256 * 260, 256, 128), (2048, 512, 2048), (256 * 300, 512, 256)])
+def test_gemm_nt_bf16_native_kernel(ops, bf16_nt_variant, M, N, K):
     """vqcpc_gemm_nt_bf16 (bf16 operands in HBM, fp32 accumulation) against the fp64 product of the bf16-rounded operands:
     every epilogue / output combination the training step uses, several output tiles per persistent workgroup."""
     gen = torch.Generator().manual_seed(M + N + K)
@@ -324,6 +334,33 @@ def test_gemm_nt_bf16_native_kernel(ops, M, N, K):
     n = 512
     eye, bb2 = torch.eye(n), (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)
     assert torch.equal(ops.gemm_nt_bf16(dev(eye), dev(bb2)).cpu(), bb2.t().contiguous())
+
+
+@pytest.mark.parametrize('M,N,K', [(512, 256, 128), (256 * 260, 256, 256), (2048, 512, 2048), (256 * 300, 512, 512)])
+def test_gemm_nt_bf16_kernels_are_bit_identical(ops, M, N, K):
+    """The LDS-DMA kernel (K tiles of 64) sums every output element over k in the order of the ping-pong kernel (K tiles of
+    32): both give the same bits for every epilogue / output form of the training step (persistent workgroups with several
+    output tiles each at the larger shapes: tile-boundary handling of the DMA ring)."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + K)
+    a, b = ops.cast_bf16(dev(torch.randn(M, K, generator=gen))), ops.cast_bf16(dev(torch.randn(N, K, generator=gen)))
+    bias, add = dev(torch.randn(N, generator=gen)), dev(torch.randn(M, N, generator=gen))
+    gate, gb = dev(torch.randn(M, N, generator=gen)), dev(torch.randn(M, N, generator=gen)).bfloat16()
+    forms = [dict(), dict(out_f32=False, out_bf16=True), dict(bias=bias), dict(bias=bias, out_f32=True, out_bf16=True),
+             dict(bias=bias, act=1, out_f32=False, out_bf16=True), dict(bias=bias, act=1, drop_p=0.25, seed=7, out_f32=False, out_bf16=True),
+             dict(bias=bias, act=1, drop_p=0.25, seed=7, out_f32=True, out_bf16=True), dict(gate=gate, gate_scale=1.5),
+             dict(gate_b=gb, gate_scale=1.5, out_f32=False, out_bf16=True), dict(gate_b=gb, gate_scale=1.5, out_f32=True, out_bf16=True),
+             dict(add=add), dict(bias=bias, add=add), dict(bias=bias, drop_p=0.1, seed=3, add=add), dict(bias=bias, out_f32=False, out_bf16=True)]
+    try:
+        for kw in forms:
+            outs = []
+            for v in (0, 1):
+                hip.call('vqcpc_gemm_bf16_set_variant', v)
+                r = ops.gemm_nt_bf16(a, b, **kw)
+                outs.append([x.clone() for x in (r if isinstance(r, tuple) else (r,))])
+            assert all(torch.equal(x, y) for x, y in zip(*outs)), sorted(kw)
+    finally:
+        hip.call('vqcpc_gemm_bf16_set_variant', 1)
 
 
 @pytest.mark.parametrize('M,N,K', [(512, 256, 256), (4096, 512, 256), (128 * 700, 256, 768), (33280, 1024, 512)])

@@ -22,7 +22,11 @@ def timeit(f, n=5, reps=5):
 
 
 VARIANTS = [int(v) for v in os.environ.get('VQCPC_BF16_VARIANTS', '0,1').split(',')]
-for N, K in [(2048, 512), (512, 2048), (512, 512), (1536, 512)]:
+SHAPES = [(2048, 512), (512, 2048), (512, 512), (1536, 512)]
+if os.environ.get('VQCPC_BF16_SHAPES'):
+    SHAPES = [tuple(int(x) for x in sh.split('x')) for sh in os.environ['VQCPC_BF16_SHAPES'].split(',')]
+FORMS = os.environ.get('VQCPC_BF16_FORMS')
+for N, K in SHAPES:
     a = ops.cast_bf16(torch.randn(M, K, device='cuda')); b = ops.cast_bf16(torch.randn(N, K, device='cuda') * 0.05)
     bias = torch.randn(N, device='cuda')
     gate_b = torch.randn(M, N, device='cuda').bfloat16()
@@ -36,6 +40,8 @@ for N, K in [(2048, 512), (512, 2048), (512, 512), (1536, 512)]:
              ('gate_b -> bf16', dict(gate_b=gate_b, gate_scale=1.1, out_f32=False, out_bf16=True)),
              ('add -> f32', dict(add=res, out=out32))]
     for name, kw in forms:
+        if FORMS and name not in FORMS.split(','):
+            continue
         res_ = []
         outs = []
         for v in VARIANTS:
@@ -51,7 +57,7 @@ hip.set_gemm_mode(0)
 
 # weight-gradient (TN) bf16 kernel
 hip.set_gemm_mode(8)
-for N, K in [(2048, 512), (512, 2048), (1536, 512), (512, 512)]:
+for N, K in ([] if os.environ.get('VQCPC_BF16_NO_TN') else [(2048, 512), (512, 2048), (1536, 512), (512, 512)]):
     a = ops.cast_bf16(torch.randn(M, N, device='cuda')); b = ops.cast_bf16(torch.randn(M, K, device='cuda'))
     t = timeit(lambda: ops.gemm_tn_bf16(a, b))
     print(f'M={M} N={N} K={K} wgrad (TN, incl. reduction) {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.0f} TFLOP/s', flush=True)

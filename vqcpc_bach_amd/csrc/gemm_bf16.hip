@@ -51,6 +51,10 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 
 // extra epilogue features of the bf16 kernel (on top of gemm_common.h's E_*)
 enum { B_OUT_F32 = 1, B_OUT_BF16 = 2, B_GATE_BF16 = 4 };
+// cache policy of the output stores (" nt", " sc1", ..: measurement builds, tools/build_lab_variants.sh)
+#ifndef VQ_BF16_STORE_POL
+#define VQ_BF16_STORE_POL ""
+#endif
 
 struct Bf16Out {
     float* c;            // fp32 output (B_OUT_F32)
@@ -138,13 +142,13 @@ struct Bf16Out {
                 ov[c] = v;                                                                                             \
             }                                                                                                          \
             if ((OUT & B_OUT_F32) && o.stagger != -1)                                                                  \
-                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(ov), "v"(voff_c), \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen" VQ_BF16_STORE_POL "\n\ts_nop 1" ::"v"(ov), "v"(voff_c), \
                              "s"(rc), "s"(((MT * 32 + 8 * j) * ldci + NT * 32) * 4) : "memory");                       \
             if ((OUT & B_OUT_BF16) && o.stagger != -1) {                                                               \
                 u32x2 pk;                                                                                              \
                 pk[0] = cvt_pk_bf16(ov[0], ov[1]);                                                                     \
                 pk[1] = cvt_pk_bf16(ov[2], ov[3]);                                                                     \
-                asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen\n\ts_nop 1" ::"v"(pk), "v"(voff_cb), \
+                asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen" VQ_BF16_STORE_POL "\n\ts_nop 1" ::"v"(pk), "v"(voff_cb), \
                              "s"(rcb), "s"(((MT * 32 + 8 * j) * ldcbi + NT * 32) * 2) : "memory");                     \
             }                                                                                                          \
         }                                                                                                              \
@@ -173,7 +177,7 @@ struct Bf16Out {
     }                                                                                                                  \
     B_EPI_TILE(VCUR, AUXC, TILE)                                                                                       \
     if (HAS_AUX && (TILE) + 3 < 8) { B_AUX_LOAD(AUXC, (TILE) + 3) }
-#define B_EPILOGUE()                                                                                                   \
+#define B_EPILOGUE_P(PREFETCHED)                                                                                       \
     {                                                                                                                  \
         B_EPI_DESC()                                                                                                   \
         /* dropout hash input of this lane's first element of the output tile; the others are constant offsets away */ \
@@ -191,7 +195,7 @@ struct Bf16Out {
             bias4[0] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col);                                            \
             bias4[1] = *reinterpret_cast<const fx4*>(ep.bias + n0 + e_col + 32);                                       \
         }                                                                                                              \
-        if (HAS_AUX && !AUX_B16) { B_AUX_LOAD(aux0, 0) B_AUX_LOAD(aux1, 1) B_AUX_LOAD(aux2, 2) }                        \
+        if (HAS_AUX && !(PREFETCHED)) { B_AUX_LOAD(aux0, 0) B_AUX_LOAD(aux1, 1) B_AUX_LOAD(aux2, 2) }                   \
         fx4 va[4], vb[4];                                                                                              \
         B_SCR_WRITE(0, 0)                                                                                              \
         B_SCR_READ(va)                                                                                                 \
@@ -199,6 +203,7 @@ struct Bf16Out {
         B_EPI_STEP(4, va, vb, aux1) B_EPI_STEP(5, vb, va, aux2) B_EPI_STEP(6, va, vb, aux0) B_EPI_STEP(7, vb, va, aux1) \
         ep_tile += gridDim.x;                                                                                          \
     }
+#define B_EPILOGUE() B_EPILOGUE_P(AUX_B16)   /* callers that request a bf16 gate operand with B_AUX_PREFETCH */
 
 template <int EPI, int OUT>
 __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t* __restrict__ A, int64_t lda,
@@ -339,164 +344,50 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_kernel(const bf16_t
 }
 
 
-// =====================================================================================================================
-// Epilogue WITHOUT LDS, for kernels that accumulate the TRANSPOSED product (the B fragment is the MFMA's first operand):
-// the 32 x 32 accumulator layout then gives a lane ONE output row (mt * 32 + li) and, per register quad q, FOUR CONSECUTIVE
-// columns nt * 32 + 8 q + 4 kh + 0..3 -- a dwordx4 store of fp32 / a dwordx2 store of bf16 straight from the accumulator,
-// no transposition.  The LDS-transposed form above costs 16 ds_write_b32 + 4 ds_read_b128 per 32 x 32 tile and wave:
-// 4 096 + 1 024 LDS-array cycles per 256 x 256 output next to the 6 144 of a K = 512 main loop's fragment reads and the DMA
-// writes, i.e. the LDS -- not the stores -- paced the K = 512 products (two independent workgroups per CU did not overlap
-// their epilogues for that reason: profiles/r04_gemm_bf16.md).  A store instruction covers 32 rows x 32 bytes (fp32); the
-// four instructions of a tile complete each row's 128-byte line in the L2 before it is written back.
-// Bias is per column: 8 float4 per lane (columns of its quads), loaded once.  Gate / residual operands are fetched in the
-// shape of the stores, two tiles ahead.  Uses the kernel's locals as B_EPI_DECLS' macros do (wm, wn, li, kh, o, ep, acc ..).
-#define T_EPI_DECLS()                                                                                                  \
-    int ep_tile = blockIdx.x;                                                                                          \
-    constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;                                                            \
-    constexpr bool AUX_B16 = (OUT & B_GATE_BF16) != 0;             /* gate operand is bf16 (sign only) */              \
-    const int t_row = wm * 128 + li, t_col = wn * 64 + 4 * kh;     /* + 32 mt, + 32 nt + 8 q */                        \
-    const int ldci = (int)o.ldc, ldcbi = (int)o.ldcb;                                                                  \
-    const float* xsrc = (EPI & E_GATE) ? ep.gate : ep.add;                                                             \
-    const int ldxi = (int)(AUX_B16 ? o.ldgate_b : ((EPI & E_GATE) ? ep.ldgate : ep.ldadd));                            \
-    union AuxT {                                                                                                       \
-        fx4 f[4];                                                                                                      \
-        u32x2 h[4];                                                                                                    \
-    };                                                                                                                 \
-    AuxT aux0, aux1;
-#define T_EPI_DESC()                                                                                                   \
-    const int t_ = xcd_swizzle(ep_tile, tiles);                                                                        \
-    const int64_t m0 = (int64_t)(t_ / tiles_n) * kTileRows;                                                            \
-    const int n0 = (t_ % tiles_n) * kB;                                                                                \
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                               \
-        (void*)(!HAS_AUX ? (const void*)smem                                                                           \
-                         : AUX_B16 ? (const void*)(o.gate_b + m0 * (int64_t)ldxi + n0)                                 \
-                                   : (const void*)(xsrc + m0 * (int64_t)ldxi + n0)),                                   \
-        0, 0x7FFFFFFF, 0x00020000);                                                                                    \
-    const int voff_x = (t_row * ldxi + t_col) * (AUX_B16 ? 2 : 4);
-#define T_AUX_LOAD(DST, TILE)                                                                                          \
-    _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                    \
-        if (AUX_B16)                                                                                                   \
-            DST.h[q] = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(                                 \
-                rx, voff_x, ((((TILE) >> 1) * 32) * ldxi + ((TILE) & 1) * 32 + 8 * q) * 2, 0));                        \
-        else                                                                                                           \
-            DST.f[q] = __builtin_bit_cast(fx4, __builtin_amdgcn_raw_buffer_load_b128(                                  \
-                rx, voff_x, ((((TILE) >> 1) * 32) * ldxi + ((TILE) & 1) * 32 + 8 * q) * 4, 0));                        \
-    }
-#define T_AUX_PREFETCH()                                                                                               \
-    {                                                                                                                  \
-        T_EPI_DESC()                                                                                                   \
-        T_AUX_LOAD(aux0, 0) T_AUX_LOAD(aux1, 1)                                                                        \
-    }
-#define T_EPI_TILE(AUX, TILE)                                                                                          \
-    {                                                                                                                  \
-        constexpr int MT = (TILE) >> 1, NT = (TILE) & 1;                                                               \
-        _Pragma("unroll") for (int q = 0; q < 4; ++q) {                                                                \
-            fx4 ov;                                                                                                    \
-            _Pragma("unroll") for (int c = 0; c < 4; ++c) {                                                            \
-                float v = acc[MT][NT][4 * q + c];                                                                      \
-                if (EPI & E_BIAS) v += bias4[NT][q][c];                                                                \
-                if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
-                if (EPI & E_DROP)   /* == drop_scale(ep.seed, (row + ep.row0) * N + col, ..); thr > 0 on this path */  \
-                    v *= rng_u24_from_x0(x0_lane + (uint32_t)((MT * 32) * N + NT * 32 + 8 * q + c) * kRngMul, drop_sh) >= ep.thr \
-                             ? ep.inv_keep : 0.0f;                                                                     \
-                if (EPI & E_GATE) {                                                                                    \
-                    bool pos;                                                                                          \
-                    if (AUX_B16) {                                                                                     \
-                        const unsigned hw = (AUX.h[q][c >> 1] >> (16 * (c & 1))) & 0xFFFFu;       /* bf16 > 0 */       \
-                        pos = hw != 0 && hw < 0x8000u;                                                                 \
-                    } else {                                                                                           \
-                        pos = AUX.f[q][c] > 0.0f;                                                                      \
-                    }                                                                                                  \
-                    v *= pos ? ep.gate_scale : 0.0f;                                                                   \
-                }                                                                                                      \
-                if (EPI & E_ADD) v += AUX.f[q][c];                                                                     \
-                ov[c] = v;                                                                                             \
-            }                                                                                                          \
-            if (OUT & B_OUT_F32)                                                                                       \
-                asm volatile("s_nop 4\n\tbuffer_store_dwordx4 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" ::"v"(ov),    \
-                             "v"(voff_c), "s"(rc), "s"((MT * 32) * ldci * 4), "i"((NT * 32 + 8 * q) * 4) : "memory");   \
-            if (OUT & B_OUT_BF16) {                                                                                    \
-                u32x2 pk;                                                                                              \
-                pk[0] = cvt_pk_bf16(ov[0], ov[1]);                                                                     \
-                pk[1] = cvt_pk_bf16(ov[2], ov[3]);                                                                     \
-                asm volatile("s_nop 4\n\tbuffer_store_dwordx2 %0, %1, %2, %3 offen offset:%4\n\ts_nop 1" ::"v"(pk),    \
-                             "v"(voff_cb), "s"(rcb), "s"((MT * 32) * ldcbi * 2), "i"((NT * 32 + 8 * q) * 2) : "memory"); \
-            }                                                                                                          \
-        }                                                                                                              \
-    }
-#define T_EPI_STEP(TILE, AUXC)                                                                                         \
-    T_EPI_TILE(AUXC, TILE)                                                                                             \
-    if (HAS_AUX && (TILE) + 2 < 8) { T_AUX_LOAD(AUXC, (TILE) + 2) }
-// PREFETCHED: the operands of tiles 0 and 1 were requested by T_AUX_PREFETCH
-#define T_EPILOGUE(PREFETCHED)                                                                                         \
-    {                                                                                                                  \
-        T_EPI_DESC()                                                                                                   \
-        const uint64_t drop_se = rng_seed_eff(ep.seed);                                                                \
-        const uint32_t drop_sh = (uint32_t)(drop_se >> 32);                                                            \
-        const uint32_t x0_lane = rng_x0(drop_se, (uint32_t)(m0 + t_row + ep.row0) * (uint32_t)N + (uint32_t)(n0 + t_col)); \
-        const __amdgpu_buffer_rsrc_t rc = __builtin_amdgcn_make_buffer_rsrc(                                           \
-            (void*)((OUT & B_OUT_F32) ? o.c + m0 * o.ldc + n0 : (float*)smem), 0, 0x7FFFFFFF, 0x00020000);             \
-        const __amdgpu_buffer_rsrc_t rcb = __builtin_amdgcn_make_buffer_rsrc(                                          \
-            (void*)((OUT & B_OUT_BF16) ? o.cb + m0 * o.ldcb + n0 : (bf16_t*)smem), 0, 0x7FFFFFFF, 0x00020000);         \
-        const int voff_c = (t_row * ldci + t_col) * 4;                                                                 \
-        const int voff_cb = (t_row * ldcbi + t_col) * 2;                                                               \
-        fx4 bias4[2][4];                                                                                               \
-        if (EPI & E_BIAS) {                                                                                            \
-            _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                                                           \
-                _Pragma("unroll") for (int q = 0; q < 4; ++q)                                                          \
-                    bias4[nt][q] = *reinterpret_cast<const fx4*>(ep.bias + n0 + t_col + nt * 32 + 8 * q);              \
-        }                                                                                                              \
-        if (HAS_AUX && !(PREFETCHED)) { T_AUX_LOAD(aux0, 0) T_AUX_LOAD(aux1, 1) }                                      \
-        T_EPI_STEP(0, aux0) T_EPI_STEP(1, aux1) T_EPI_STEP(2, aux0) T_EPI_STEP(3, aux1)                                \
-        T_EPI_STEP(4, aux0) T_EPI_STEP(5, aux1) T_EPI_STEP(6, aux0) T_EPI_STEP(7, aux1)                                \
-    }
-
 // ---------------------------------------------------------------------------------------------------------------------
-// gemm_nt_bf16_w4_kernel: the same product on a 128 (rows of A) x 256 (rows of B) output tile per workgroup of FOUR waves
-// (1 x 4, wave tile 128 x 64: the accumulator / fragment economy of the 8-wave kernel), TWO workgroups resident per CU,
-// operands delivered global -> LDS by DMA (buffer_load_dwordx4 ... lds), no staging registers and no LDS stores.
+// gemm_nt_bf16_k64_kernel: 256 x 256 tile, 8 waves (2 x 4, wave tile 128 x 64), persistent, K tiles of 64 (128-byte operand
+// rows = whole cache lines per request) delivered global -> LDS by DMA into a ring of TWO 64 KB slots.
 //
-// Why: in the 8-wave ping-pong kernel the two wave groups are coupled by the workgroup barrier of every phase, so the
-// epilogue of an output tile (LDS transposition, bias / relu / dropout hash / gate / residual, 32-64 stores per wave) is
-// exposed: the partner group can run ONE MFMA phase ahead and then waits.  At K = 512 an output tile is only 16 phase
-// pairs long and the exposed epilogues were 22-48 % of the time (none -> bf16: 838, bias+relu+drop -> bf16: 628,
-// add -> f32: 553 TFLOP/s against 1020 at K = 2048; profiles/r04_gemm_bf16.md).  Two INDEPENDENT workgroups per CU share
-// nothing but the hardware: while one is in its epilogue (VALU, LDS, stores) the other one's waves own the matrix pipes.
+// Counters and ablations of the K-tile-32 kernels (profiles/r04_gemm_bf16.md): every L1 -> L2 read request is a 64-byte
+// half line (2.9e8 requests for 17 GB), waves sit in issue stalls for half of their cycles while the matrix pipes are busy
+// 50-59 %, and a DMA variant of the same loop WITHOUT its operand delivery ran at 1 450 TFLOP/s (with it: 930): the request
+// stream, not the MFMAs, paces them.  128-byte rows halve the requests per byte.  (The same round measured a 128 x 256 tile on
+// two independent four-wave workgroups per CU, meant to overlap one workgroup's epilogue with the other's K loop: it moves a
+// third more operand bytes per MFMA and was slower for that reason; and an LDS-free epilogue on transposed accumulators,
+// whose 32-byte row pieces per store were slower than the LDS-transposed full-line stores.)
 //
-// K tiles of 32 (64-byte operand rows) in a ring of three 24 KB LDS slots [A 128 rows | B 256 rows]; 16-byte chunk c of row
-// r sits at chunk position c ^ ((r >> 2) & 3) (conflict-free ds_read_b128 fragments); a DMA instruction writes 1 KB = 16
-// rows lane-linearly, so the swizzle is applied to the per-lane SOURCE address.  Software pipeline of a wave, phase p:
-//     s_waitcnt vmcnt(6)     this wave's pieces of K tile p+1 have landed (tile p+2 may be in flight)
-//     s_barrier              everybody's have; and every wave has finished reading slot p % 3 (its reads were waited for
-//                            at the end of phase p-1)
-//     DMA  tile p+3 -> slot p % 3                       (6 instructions per wave: 2 of A, 4 of B)
-//     ds_read fragments of tile p+1 -> register set (p+1) & 1   (12 x ds_read_b128)
-//     16 MFMAs on register set p & 1
-//     s_waitcnt lgkmcnt(0)
-// One barrier per 16 MFMAs among four waves; the LDS reads of the next phase and the DMA issue run under this phase's
-// MFMAs, the other workgroup's waves fill what is left.  Not persistent: a workgroup owns one output tile, its epilogue
-// scratch aliases the operand ring (idle by then), and the CU's other workgroup covers its prologue.
-constexpr int kWTM = 128, kWTN = 256;        // output tile
-constexpr int kWSlotA = kWTM * kBRowB;       // 8 KB
-constexpr int kWSlot = (kWTM + kWTN) * kBRowB;   // 24 KB
-constexpr int kWLds = 3 * kWSlot;            // 72 KB: two workgroups per CU
-constexpr int kWThreads = 256;
+// LDS: A slot 0 | A slot 1 | B slot 0 | B slot 1 (32 KB each) | 8 x 4 KB epilogue scratch.  16-byte chunk c of row r at chunk
+// position c ^ ((r >> 1) & 7): a fragment read (ds_read_b128, lane = row li, chunk 2 ks + kh) touches 16 distinct 16-byte
+// slots of the 256-byte bank row in every lane group.  A DMA instruction writes 1 KB = 8 rows lane-linearly, so the swizzle is
+// applied to the per-lane SOURCE address.
+// No ping-pong: all eight waves run the same stream, ONE workgroup barrier per K tile.  A K tile is consumed in two halves
+// (k16 steps 0-1 from register set X, 2-3 from set Y: 48 registers each, the 24 fragments of a whole tile would not fit):
+//   half 0 of tile s:  read Y <- (s, steps 2-3);  16 MFMAs on X;  lgkmcnt(0)
+//   half 1 of tile s:  vmcnt: own DMA pieces of tile s+1 landed;  s_barrier  (now everybody's have, and everybody has
+//                      finished reading tile s);  DMA tile s+2 -> the slot of tile s;  read X <- (s+1, steps 0-1);
+//                      16 MFMAs on Y;  lgkmcnt(0)
+// so the LDS reads of the next half and the DMA issue always run under 16 MFMAs of the same wave, and a requested tile has
+// 32 MFMAs (~2 000 cycles at two waves per SIMD) to land.  At an output-tile boundary the epilogue (B_EPILOGUE above) runs
+// first and X is read after it (its registers are the epilogue's); the DMA of the next tile's first two K tiles is in flight
+// meanwhile, and the wait that follows allows for the epilogue's own stores (vmcnt counts in order).
+constexpr int kKRowB = 128;                    // bytes per operand row per K tile
+constexpr int kKBK = 64;
+constexpr int kKOperand = kB * kKRowB;         // 32 KB
+constexpr int kKLds = 4 * kKOperand + 8 * 4096;   // 160 KB
 
 template <int EPI, int OUT>
-__global__ __launch_bounds__(kWThreads, 2) void gemm_nt_bf16_w4_kernel(const bf16_t* __restrict__ A, int64_t lda,
-                                                                      const bf16_t* __restrict__ B, int64_t ldb, Bf16Out o,
-                                                                      int64_t M, int N, int K, int tiles_n, int tiles,
-                                                                      EpiParams ep) {
+__global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_k64_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                       const bf16_t* __restrict__ B, int64_t ldb, Bf16Out o,
+                                                                       int64_t M, int N, int K, int tiles_n, int tiles,
+                                                                       EpiParams ep) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int wm = 0;
-    const int wn = wave;
+    const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, kh = lane >> 5;
-    const int P = K / kBBK;                                        // K tiles (K % 64 == 0: P even, >= 2)
-    const int t_own = xcd_swizzle((int)blockIdx.x, tiles);
-    const int64_t m_own = (int64_t)(t_own / tiles_n) * kWTM;
-    const int n_own = (t_own % tiles_n) * kWTN;
+    const int T = K / kKBK;                                        // K tiles per output tile
+    const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * T;
 
     floatx16 acc[4][2];
 #pragma unroll
@@ -506,125 +397,145 @@ __global__ __launch_bounds__(kWThreads, 2) void gemm_nt_bf16_w4_kernel(const bf1
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
-    // ---- DMA: wave w delivers A rows [32 w, 32 w + 32) and B rows [64 w, 64 w + 64) of a K tile ----
-    // lane l of an instruction -> row l >> 2 of its 16-row block, chunk position l & 3 <- logical chunk (l & 3) ^ ((l >> 4) & 3)
-    const int dl_row = lane >> 2, dl_c = (lane & 3) ^ ((lane >> 4) & 3);
-    const int voff_a = (dl_row * (int)lda + dl_c * 8) * 2;
-    const int voff_b = (dl_row * (int)ldb + dl_c * 8) * 2;
-    const __amdgpu_buffer_rsrc_t rs_a =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(A + (m_own + 32 * wave) * lda), 0, 0x7FFFFFFF, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_b =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(B + ((int64_t)n_own + 64 * wave) * ldb), 0, 0x7FFFFFFF, 0x00020000);
-    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    // ---- DMA: wave w delivers rows [32 w, 32 w + 32) of A and of B: 4 + 4 instructions of 8 rows x 128 bytes ----
+    // lane l -> row l >> 3 of the 8-row block j, chunk position l & 7 <- logical chunk (l & 7) ^ (((8 j + (l >> 3)) >> 1) & 7)
+    //        = (l & 7) ^ ((4 (j & 1) + (l >> 4)) & 7): one per-lane offset for even j, one for odd j
+    const int dl_row = lane >> 3;
+    const int dl_ce = (lane & 7) ^ (lane >> 4), dl_co = (lane & 7) ^ (4 + (lane >> 4));
     const int ldai = (int)lda, ldbi = (int)ldb;
-#define W_ISSUE(SOFF, KT)                                                                                               \
+    const int voff_ae = (dl_row * ldai + dl_ce * 8) * 2, voff_ao = (dl_row * ldai + dl_co * 8) * 2;
+    const int voff_be = (dl_row * ldbi + dl_ce * 8) * 2, voff_bo = (dl_row * ldbi + dl_co * 8) * 2;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    int ld_tile = blockIdx.x, ld_k = 0;
+    __amdgpu_buffer_rsrc_t rs_a, rs_b;
+#define K_SET_SRC()                                                                                                     \
     {                                                                                                                   \
-        unsigned char* da_ = smem + (SOFF) + wave * 2048;                                                               \
-        unsigned char* db_ = smem + (SOFF) + kWSlotA + wave * 4096;                                                     \
-        const int k_ = (KT) * kBBK;                                                                                     \
-        _Pragma("unroll") for (int j = 0; j < 2; ++j)                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(da_ + j * 1024), 16, voff_a,                     \
-                                                     (j * 16 * ldai + k_) * 2, 0, 0);                                   \
+        const int t_ = xcd_swizzle(min(ld_tile, tiles - 1), tiles);                                                     \
+        rs_a = __builtin_amdgcn_make_buffer_rsrc((void*)(A + ((int64_t)(t_ / tiles_n) * kB + 32 * wave) * lda), 0,       \
+                                                 0x7FFFFFFF, 0x00020000);                                               \
+        rs_b = __builtin_amdgcn_make_buffer_rsrc((void*)(B + ((int64_t)(t_ % tiles_n) * kB + 32 * wave) * ldb), 0,       \
+                                                 0x7FFFFFFF, 0x00020000);                                               \
+    }
+    K_SET_SRC()
+#define K_ISSUE(SLOT)                                                                                                   \
+    {                                                                                                                   \
+        unsigned char* da_ = smem + (SLOT) * kKOperand + wave * 4096;                                                   \
+        unsigned char* db_ = smem + (2 + (SLOT)) * kKOperand + wave * 4096;                                             \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(db_ + j * 1024), 16, voff_b,                     \
-                                                     (j * 16 * ldbi + k_) * 2, 0, 0);                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(da_ + j * 1024), 16, (j & 1) ? voff_ao : voff_ae, \
+                                                     (j * 8 * ldai + ld_k) * 2, 0, 0);                                  \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(db_ + j * 1024), 16, (j & 1) ? voff_bo : voff_be, \
+                                                     (j * 8 * ldbi + ld_k) * 2, 0, 0);                                  \
+        ld_k += kKBK;                                                                                                   \
+        if (ld_k == K) {                                                                                                \
+            ld_k = 0;                                                                                                   \
+            ld_tile += gridDim.x;            /* past the end: re-reads the last tile, never used */                     \
+            K_SET_SRC()                                                                                                 \
+        }                                                                                                               \
     }
 
-    // ---- fragments: lane (row li, k group kh) of k16 step ks reads chunk 2 ks + kh of its row (inline asm: for a C++ LDS
-    // load hipcc would wait vmcnt(0) as soon as an LDS-DMA is in flight) ----
+    // ---- fragments (inline asm: no compiler-inserted vmcnt(0) while DMA is in flight) ----
     const unsigned ldsb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    const int fsw = (li >> 2) & 3;
-    const unsigned a_ad0 = ldsb + li * kBRowB + (((0 + kh) ^ fsw) << 4);
-    const unsigned a_ad1 = ldsb + li * kBRowB + (((2 + kh) ^ fsw) << 4);
-    const unsigned b_ad0 = a_ad0 + kWSlotA + wn * 64 * kBRowB;
-    const unsigned b_ad1 = a_ad1 + kWSlotA + wn * 64 * kBRowB;
-    fx4 xb[2][2], xa[2][4], yb[2][2], ya[2][4];                    // two register sets, [ks][tile]
-#define W_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
-#define W_READ_FRAGS(S_, SOFF)                                                                                          \
-    {                                                                                                                   \
-        const unsigned a0_ = a_ad0 + (SOFF), a1_ = a_ad1 + (SOFF), b0_ = b_ad0 + (SOFF), b1_ = b_ad1 + (SOFF);          \
-        W_RD(S_##b[0][0], b0_, 0);                                                                                      \
-        W_RD(S_##b[0][1], b0_, 32 * kBRowB);                                                                            \
-        W_RD(S_##a[0][0], a0_, 0);                                                                                      \
-        W_RD(S_##a[0][1], a0_, 32 * kBRowB);                                                                            \
-        W_RD(S_##a[0][2], a0_, 64 * kBRowB);                                                                            \
-        W_RD(S_##a[0][3], a0_, 96 * kBRowB);                                                                            \
-        W_RD(S_##b[1][0], b1_, 0);                                                                                      \
-        W_RD(S_##b[1][1], b1_, 32 * kBRowB);                                                                            \
-        W_RD(S_##a[1][0], a1_, 0);                                                                                      \
-        W_RD(S_##a[1][1], a1_, 32 * kBRowB);                                                                            \
-        W_RD(S_##a[1][2], a1_, 64 * kBRowB);                                                                            \
-        W_RD(S_##a[1][3], a1_, 96 * kBRowB);                                                                            \
-    }
-    // the wait names every destination read-write: no consumer can be scheduled above it
-#define W_LGKM_WAIT(S_)                                                                                                 \
+    const int fsw = (li >> 1) & 7;
+    const unsigned a_row = ldsb + (wm * 128 + li) * kKRowB;
+    const unsigned b_row = ldsb + 2 * kKOperand + (wn * 64 + li) * kKRowB;
+    const unsigned a_ad0 = a_row + (((0 + kh) ^ fsw) << 4), a_ad1 = a_row + (((2 + kh) ^ fsw) << 4);
+    const unsigned a_ad2 = a_row + (((4 + kh) ^ fsw) << 4), a_ad3 = a_row + (((6 + kh) ^ fsw) << 4);
+    const unsigned b_ad0 = b_row + (((0 + kh) ^ fsw) << 4), b_ad1 = b_row + (((2 + kh) ^ fsw) << 4);
+    const unsigned b_ad2 = b_row + (((4 + kh) ^ fsw) << 4), b_ad3 = b_row + (((6 + kh) ^ fsw) << 4);
+    fx4 xb[2][2], xa[2][4], yb[2][2], ya[2][4];                    // X: k16 steps 0, 1; Y: steps 2, 3; [step][tile]
+#define K_RD(DST, ADDR, OFF) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
+#define K_READ(S_, SLOT, AD0A, AD1A, AD0B, AD1B)                                                                        \
+    K_RD(S_##b[0][0], AD0B, (SLOT) * kKOperand);                                                                        \
+    K_RD(S_##b[0][1], AD0B, (SLOT) * kKOperand + 32 * kKRowB);                                                          \
+    K_RD(S_##a[0][0], AD0A, (SLOT) * kKOperand);                                                                        \
+    K_RD(S_##a[0][1], AD0A, (SLOT) * kKOperand + 32 * kKRowB);                                                          \
+    K_RD(S_##a[0][2], AD0A, (SLOT) * kKOperand + 64 * kKRowB);                                                          \
+    K_RD(S_##a[0][3], AD0A, (SLOT) * kKOperand + 96 * kKRowB);                                                          \
+    K_RD(S_##b[1][0], AD1B, (SLOT) * kKOperand);                                                                        \
+    K_RD(S_##b[1][1], AD1B, (SLOT) * kKOperand + 32 * kKRowB);                                                          \
+    K_RD(S_##a[1][0], AD1A, (SLOT) * kKOperand);                                                                        \
+    K_RD(S_##a[1][1], AD1A, (SLOT) * kKOperand + 32 * kKRowB);                                                          \
+    K_RD(S_##a[1][2], AD1A, (SLOT) * kKOperand + 64 * kKRowB);                                                          \
+    K_RD(S_##a[1][3], AD1A, (SLOT) * kKOperand + 96 * kKRowB);
+#define K_READ_X(SLOT) K_READ(x, SLOT, a_ad0, a_ad1, b_ad0, b_ad1)
+#define K_READ_Y(SLOT) K_READ(y, SLOT, a_ad2, a_ad3, b_ad2, b_ad3)
+#define K_LGKM_WAIT(S_)                                                                                                 \
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
                  : "+v"(S_##b[0][0]), "+v"(S_##b[0][1]), "+v"(S_##b[1][0]), "+v"(S_##b[1][1]), "+v"(S_##a[0][0]),       \
                    "+v"(S_##a[0][1]), "+v"(S_##a[0][2]), "+v"(S_##a[0][3]), "+v"(S_##a[1][0]), "+v"(S_##a[1][1]),       \
                    "+v"(S_##a[1][2]), "+v"(S_##a[1][3]));
-#define W_MFMA(S_)                                                                                                      \
+#define K_MFMA(S_)                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                                      \
     _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                                                    \
         _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                              \
-            /* B fragment first: the accumulator holds the TRANSPOSED tile (lane = output row, registers = columns) */  \
-            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##b[ks][0]),              \
-                                                                 __builtin_bit_cast(bf16x8, S_##a[ks][mt]), acc[mt][0], 0, 0, 0); \
-            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##b[ks][1]),              \
-                                                                 __builtin_bit_cast(bf16x8, S_##a[ks][mt]), acc[mt][1], 0, 0, 0); \
-        }
-    // vmcnt(6): this wave's pieces of the NEXT tile have landed, the one after it (6 instructions) may be in flight
-#define W_SYNC(VMC)                                                                                                     \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##a[ks][mt]),             \
+                                                                 __builtin_bit_cast(bf16x8, S_##b[ks][0]), acc[mt][0], 0, 0, 0); \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##a[ks][mt]),             \
+                                                                 __builtin_bit_cast(bf16x8, S_##b[ks][1]), acc[mt][1], 0, 0, 0); \
+        }                                                                                                               \
+    __builtin_amdgcn_s_setprio(0);
+    // stores of the epilogue issued by this wave since its last DMA: the wait for that DMA may leave them outstanding
+    constexpr int kEpiStores = ((OUT & B_OUT_F32) ? 32 : 0) + ((OUT & B_OUT_BF16) ? 32 : 0);
+    constexpr int kBoundaryVm = kEpiStores > 63 ? 63 : kEpiStores;
+#define K_SYNC(AFTER_EPILOGUE)                                                                                          \
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
-    asm volatile("s_waitcnt vmcnt(" #VMC ")\n\ts_barrier" ::: "memory");                                                \
+    if (AFTER_EPILOGUE) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(kBoundaryVm) : "memory");                 \
+    else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                                  \
     __builtin_amdgcn_sched_barrier(0);
 
-    constexpr int kTileRows = kWTM;
-    T_EPI_DECLS()
+    constexpr int kTileRows = kB;
+    B_EPI_DECLS(4 * kKOperand)
 
-    // one phase for K tile p: CUR_ = register set holding its fragments, NXT_ = set that receives tile p+1.
-    // so0 / so1 / so2 = byte offsets of the slots of tiles p, p+1, p+2 (rotated at the end of the phase)
-#define W_PHASE(CUR_, NXT_, VMC, ISSUE_, READ_, PREFETCH_)                                                              \
+    // stream position s (K tile kt of the current output tile): RB_ = its slot, WB_ = the other one
+#define K_TILE(RB_, WB_)                                                                                                \
     {                                                                                                                   \
-        W_SYNC(VMC)                                                                                                     \
-        if (ISSUE_) W_ISSUE(so0, p + 3)                                                                                 \
-        if ((PREFETCH_) && HAS_AUX && AUX_B16) T_AUX_PREFETCH()                                                          \
-        if (READ_) W_READ_FRAGS(NXT_, so1)                                                                              \
-        __builtin_amdgcn_s_setprio(1);                                                                                  \
-        W_MFMA(CUR_)                                                                                                    \
-        __builtin_amdgcn_s_setprio(0);                                                                                  \
-        if (READ_) { W_LGKM_WAIT(NXT_) }                                                                                \
+        const bool boundary = (kt == 0 && s > 0);                                                                       \
+        if (boundary) {                                                                                                 \
+            B_EPILOGUE_P(false)                                                                                         \
+            K_READ_X(RB_)                                                                                               \
+        }                                                                                                               \
+        K_READ_Y(RB_)                                                                                                   \
+        if (boundary) { K_LGKM_WAIT(x) }                                                                                \
+        K_MFMA(x)                                                                                                       \
+        K_LGKM_WAIT(y)                                                                                                  \
+        K_SYNC(boundary)                                                                                                \
+        K_ISSUE(RB_)                                                                                                    \
+        ++s;                                                                                                            \
+        kt = (kt + 1 == T) ? 0 : kt + 1;                                                                                \
+        if (kt != 0) { K_READ_X(WB_) }                                                                                  \
+        K_MFMA(y)                                                                                                       \
+        if (kt != 0) { K_LGKM_WAIT(x) }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
-        ++p;                                                                                                            \
-        { const int t_ = so0; so0 = so1; so1 = so2; so2 = t_; }                                                         \
     }
 
-    // prologue: tiles 0, 1, 2 requested; tile 0 landed for everybody -> fragments of tile 0 in set x  (P >= 4, host)
-    int so0 = 0, so1 = kWSlot, so2 = 2 * kWSlot;
-    int p = 0;
-    W_ISSUE(0, 0)
-    W_ISSUE(kWSlot, 1)
-    W_ISSUE(2 * kWSlot, 2)
-    W_SYNC(12)
-    W_READ_FRAGS(x, 0)
-    W_LGKM_WAIT(x)
-    // steady state, two phases per trip (the register sets alternate); the last four phases are peeled: they stop issuing
-    // (tile p+3 does not exist), wait for everything, request the epilogue's bf16 gate operand and stop reading
+    // prologue: K tiles 0 and 1 requested, tile 0 landed for everybody, X <- (0, steps 0-1)
+    K_ISSUE(0)
+    K_ISSUE(1)
+    __builtin_amdgcn_sched_barrier(0);
+    asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    K_READ_X(0)
+    K_LGKM_WAIT(x)
+    int s = 0, kt = 0;
 #pragma unroll 1
-    while (p < P - 4) {
-        W_PHASE(x, y, 6, true, true, false)
-        W_PHASE(y, x, 6, true, true, false)
+    while (s < S) {                                      // S is even (T is: K % 128 == 0, host)
+        K_TILE(0, 1)
+        K_TILE(1, 0)
     }
-    W_PHASE(x, y, 6, true, true, false)          // p = P - 4: requests the last tile
-    W_PHASE(y, x, 6, false, true, false)         // p = P - 3
-    W_PHASE(x, y, 0, false, true, true)          // p = P - 2: nothing in flight behind tile P - 1
-    W_PHASE(y, x, 0, false, false, false)        // p = P - 1
-    T_EPILOGUE(HAS_AUX && AUX_B16)
-#undef W_PHASE
-#undef W_SYNC
-#undef W_MFMA
-#undef W_LGKM_WAIT
-#undef W_READ_FRAGS
-#undef W_RD
-#undef W_ISSUE
+    B_EPILOGUE_P(false)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the run-ahead DMAs must not outlive the workgroup's LDS
+#undef K_TILE
+#undef K_SYNC
+#undef K_MFMA
+#undef K_LGKM_WAIT
+#undef K_READ_Y
+#undef K_READ_X
+#undef K_READ
+#undef K_RD
+#undef K_ISSUE
+#undef K_SET_SRC
 }
 
 
@@ -809,10 +720,10 @@ int vqcpc_cast_bf16(const float* in, int64_t ld_in, void* out, int64_t rows, int
     return VQCPC_OK;
 }
 
-static std::atomic<int> g_bf16_nt_variant{1};      // 1: four-wave workgroups, two per CU (gemm_nt_bf16_w4_kernel); 0: 8-wave ping-pong
+static std::atomic<int> g_bf16_nt_variant{1};      // 1: K tiles of 64 by LDS-DMA (gemm_nt_bf16_k64_kernel, K % 128 == 0); 0: ping-pong kernel, K tiles of 32
 
 int vqcpc_gemm_bf16_set_variant(int variant) {
-    VQ_REQUIRE(variant == 0 || variant == 1, "gemm_bf16_set_variant: 0 (8-wave ping-pong kernel) or 1 (two 4-wave workgroups per CU)");
+    VQ_REQUIRE(variant == 0 || variant == 1, "gemm_bf16_set_variant: 0 (ping-pong kernel, K tiles of 32) or 1 (K tiles of 64 by LDS-DMA)");
     g_bf16_nt_variant.store(variant, std::memory_order_relaxed);
     return VQCPC_OK;
 }
@@ -847,19 +758,18 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     const int tiles = (int)((M / kB) * tn);
     const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kBThreads);
     hipStream_t st = (hipStream_t)stream;
-    const bool w4 = g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && K >= 4 * kBBK;
-    const int tiles_w4 = (int)((M / kWTM) * tn);
+    const bool k64 = g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && K % (2 * kKBK) == 0;
 #define BL(EPIV, OUTV)                                                                                                 \
-    if (flags == (EPIV) && out == (OUTV) && w4) {                                                                      \
-        static bool attr_w4 = false;                                                                                   \
-        if (!attr_w4) {                                                                                                \
-            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_w4_kernel<EPIV, OUTV>,                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, kWLds);                              \
-            attr_w4 = true;                                                                                            \
+    if (flags == (EPIV) && out == (OUTV) && k64) {                                                                     \
+        static bool attr_k64 = false;                                                                                  \
+        if (!attr_k64) {                                                                                               \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_bf16_k64_kernel<EPIV, OUTV>,                                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kKLds);                              \
+            attr_k64 = true;                                                                                           \
         }                                                                                                              \
-        hipLaunchKernelGGL((gemm_nt_bf16_w4_kernel<EPIV, OUTV>), dim3((unsigned)tiles_w4), dim3(kWThreads), kWLds, st, \
-                           (const bf16_t*)A, lda, (const bf16_t*)B, ldb, o, M, N, K, tn, tiles_w4, ep);                \
-        VQ_CHECK_LAUNCH("gemm_nt_bf16_w4");                                                                            \
+        hipLaunchKernelGGL((gemm_nt_bf16_k64_kernel<EPIV, OUTV>), grid, block, kKLds, st, (const bf16_t*)A, lda,       \
+                           (const bf16_t*)B, ldb, o, M, N, K, tn, tiles, ep);                                          \
+        VQ_CHECK_LAUNCH("gemm_nt_bf16_k64");                                                                           \
         return VQCPC_OK;                                                                                               \
     }                                                                                                                  \
     if (flags == (EPIV) && out == (OUTV)) {                                                                            \

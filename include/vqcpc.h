@@ -32,6 +32,25 @@ extern "C" {
 #define VQCPC_ELAUNCH (-2)   /* HIP launch / runtime error */
 #define VQCPC_EWORKSPACE (-3) /* workspace too small */
 
+/* ------------------------------------------------------------------------------------------------------------------
+ * PROCESS-WIDE STATE.  Every compute entry point is a pure function of its arguments, re-entrant and stream-ordered (work is
+ * enqueued on the `stream` argument, nothing is synchronised), EXCEPT for the following settings, which are plain
+ * process-wide values read at launch time.  They are configuration, not data: set them before the work they apply to is
+ * enqueued and do not change them from a second thread while another one launches.
+ *   vqcpc_gemm_set_mode / vqcpc_gemm_bf16_set_variant   which GEMM arithmetic / kernel vqcpc_gemm_* launch (read by vqcpc_gemm_nt,
+ *                              _tn, _tn_grouped, _nt_splitk, _nt_relu_mask, _nt_gatebits, _nt_bf16 and by the *_workspace /
+ *                              *_supported / *_groupable queries, whose answers belong to the mode they were asked in)
+ *   vqcpc_gemm_set_gradient_products / vqcpc_gemm_gradient_scope   the opt-in gradient arithmetic of the bf16x6 mode: the scope
+ *                              is a counter, opened and closed by ONE thread around its backward pass
+ *   vqcpc_relattn_force_general                         A/B switch of the attention dispatch (tests)
+ *   vqcpc_rng_salt_set / vqcpc_rng_salt_advance         a DEVICE-side value (one copy per translation unit) XOR-ed into every
+ *                              dropout seed: 0 outside a replayed step graph; a captured step sets it in its first node and
+ *                              puts it back to 0 in its last, so work enqueued after a replay on the same stream sees 0
+ *   vqcpc_last_error                                    thread-local message of the last failing call of the calling thread
+ * Several trainers in one process may therefore interleave their steps at STEP granularity on one thread (tested:
+ * tests/test_graphs_gpu.py::test_two_trainers_interleaved_in_one_process_equal_each_run_apart); concurrent steps from two
+ * threads must agree on the settings above.
+ * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_abi_version(void);
 const char* vqcpc_last_error(void);
 
@@ -473,6 +492,29 @@ int vqcpc_gemm_nt_splitk(const float* A, int64_t lda, const float* B, int64_t ld
                          void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------------
+ * Whole-step HIP-graph replay (vqcpc_bach_amd/graphs.py).  A captured step freezes its kernel ARGUMENTS, so the values
+ * that must change every step live on the device:
+ *   - dropout: every seed is XOR-ed with a step salt (0 outside graph replay).  vqcpc_rng_salt_advance is the first node
+ *     of a captured step: counter[0] += 1, salt = splitmix64(base ^ counter[0]); vqcpc_rng_salt_set writes it directly
+ *     (value 0 restores eager behaviour).  This is the ONE piece of library state: a process-wide device value.
+ *   - Adam (vqcpc_adam_step_dev = vqcpc_adam_step with lr read from lr_dev[0] and the step count t -- the bias
+ *     corrections 1 - beta^t -- from step_dev[0], the counter that vqcpc_rng_salt_advance increments).
+ * ------------------------------------------------------------------------------------------------------------------ */
+int vqcpc_rng_salt_set(uint64_t value, void* stream);
+int vqcpc_rng_salt_advance(uint64_t* counter, uint64_t base, void* stream);
+int vqcpc_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
+                        float eps, const uint64_t* step_dev, float grad_scale, float max_norm, const double* sumsq,
+                        void* stream);
+
+#ifdef VQCPC_LAB
+/* ==================================================================================================================
+ * LAB BUILDS ONLY (`VQCPC_LAB=1 python -m vqcpc_bach_amd.build` -> libvqcpc_hip_lab.so; never loaded by the training steps).
+ * Rejected kernel designs kept for A/B measurements by the tools under tools/; the lab library additionally honours the
+ * tools' environment switches (VQCPC_PP_ABL, VQCPC_PP_GRID, VQCPC_TN_PQ, VQCPC_S64_MAX_TILES, VQCPC_SPLITK_MIN_K / _KS,
+ * VQCPC_BF16_STAGGER, VQCPC_LN_BWD_BLOCKS, VQCPC_RELATTN16_LDS, VQCPC_GEMM_ABL) and the vqcpc_gemm_set_mode bits +16
+ * (gemm_dma.hip) and +32 (gemm_sw.hip).  The product library reads none of them.
+ * ================================================================================================================== */
+/* ------------------------------------------------------------------------------------------------------------------
  * bf16x6 GEMM on pre-split operands (csrc/gemm_planes.hip; no reference counterpart: the same F.linear products as
  * vqcpc_gemm_nt in mode 1, bit-identical results, with the exact 3-way bf16 split done once by the producer).
  *   "P3" format of an fp32 matrix X[rows][cols], cols % 16 == 0: three bf16 planes p = 0 (high), 1 (mid), 2 (low) with
@@ -490,20 +532,7 @@ int vqcpc_gemm_nt_planes(const void* a_planes, const void* b_planes, float* C, i
                          const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                          float gate_scale, const float* add, int64_t ldadd, void* stream);
 
-/* ------------------------------------------------------------------------------------------------------------------
- * Whole-step HIP-graph replay (vqcpc_bach_amd/graphs.py).  A captured step freezes its kernel ARGUMENTS, so the values
- * that must change every step live on the device:
- *   - dropout: every seed is XOR-ed with a step salt (0 outside graph replay).  vqcpc_rng_salt_advance is the first node
- *     of a captured step: counter[0] += 1, salt = splitmix64(base ^ counter[0]); vqcpc_rng_salt_set writes it directly
- *     (value 0 restores eager behaviour).  This is the ONE piece of library state: a process-wide device value.
- *   - Adam (vqcpc_adam_step_dev = vqcpc_adam_step with lr read from lr_dev[0] and the step count t -- the bias
- *     corrections 1 - beta^t -- from step_dev[0], the counter that vqcpc_rng_salt_advance increments).
- * ------------------------------------------------------------------------------------------------------------------ */
-int vqcpc_rng_salt_set(uint64_t value, void* stream);
-int vqcpc_rng_salt_advance(uint64_t* counter, uint64_t base, void* stream);
-int vqcpc_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
-                        float eps, const uint64_t* step_dev, float grad_scale, float max_norm, const double* sumsq,
-                        void* stream);
+#endif /* VQCPC_LAB */
 
 #ifdef __cplusplus
 }

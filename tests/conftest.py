@@ -15,6 +15,11 @@ def pytest_configure(config):
     config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
 
 
+# tests of rejected kernel designs / A/B switches that exist in the LAB library only (VQCPC_LAB=1 python -m vqcpc_bach_amd.build;
+# run them with VQCPC_LAB=1 python -m pytest tests -m gpu -k lab)
+lab_only = pytest.mark.skipif(os.environ.get('VQCPC_LAB', '0') != '1', reason='needs the lab build (VQCPC_LAB=1)')
+
+
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + '.npz'), allow_pickle=False)
     return {k: z[k] for k in z.files}

@@ -8,8 +8,12 @@ import pytest
 from conftest import ROOT
 
 
-def header_symbols():
+def header_symbols(lab=False):
+    """Entry points declared by include/vqcpc.h: the product ABI, or (lab=True) the `#ifdef VQCPC_LAB` section only."""
     text = open(os.path.join(ROOT, 'include', 'vqcpc.h')).read()
+    m = re.search(r'#ifdef VQCPC_LAB\n(.*?)#endif /\* VQCPC_LAB \*/', text, flags=re.S)
+    assert m, 'include/vqcpc.h must keep its lab section'
+    text = m.group(1) if lab else text[:m.start()] + text[m.end():]
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     return sorted(set(re.findall(r'\b(vqcpc_[a-z0-9_]+)\s*\(', text)))
 
@@ -33,6 +37,22 @@ def test_every_declared_symbol_is_exported(lib):
 def test_binding_covers_header_exactly():
     from vqcpc_bach_amd import hip
     assert sorted(hip.SIGNATURES) == header_symbols()
+    assert sorted(hip.LAB_SIGNATURES) == header_symbols(lab=True)
+
+
+def test_product_library_is_not_the_lab_bench(lib):
+    """Rejected kernel designs and measurement switches live in the lab build only (`VQCPC_LAB=1 python -m
+    vqcpc_bach_amd.build`): the product library exports none of their entry points, contains none of their kernels and
+    does not know the tools' environment variables."""
+    from vqcpc_bach_amd import hip
+    if os.environ.get('VQCPC_LAB', '0') == '1':
+        pytest.skip('the lab library is loaded')
+    for s in header_symbols(lab=True):
+        assert not hasattr(lib, s), f'{s} is a lab entry point'
+    blob = open(hip.LIB_PATH, 'rb').read()
+    for needle in (b'gemm_nt_x6_dma_kernel', b'gemm_nt_x6_sw', b'planes_kernel', b'VQCPC_PP_ABL', b'VQCPC_TN_PQ', b'VQCPC_PP_GRID',
+                   b'VQCPC_S64_MAX_TILES', b'VQCPC_BF16_STAGGER', b'VQCPC_GEMM_ABL'):
+        assert needle not in blob, needle
 
 
 def test_abi_version_and_error_string(lib):

@@ -5,6 +5,7 @@ import numpy as np
 import pytest
 import torch
 
+from conftest import lab_only  # noqa: F401
 from conftest import load_golden, rel_err, sub_state
 from oracle import vqcpc_oracle as O
 
@@ -256,6 +257,7 @@ def test_gemm_nt_bf16x6_epilogues(ops, bf16x6, M, N, K):
     assert float(dst[1::4].abs().max()) == 0.0
 
 
+@lab_only
 @pytest.mark.parametrize('M,N,K', [(512, 256, 64), (1024, 768, 256), (256 * 300, 256, 128), (2048, 1024, 1024), (256 * 130, 512, 64)])
 def test_gemm_nt_bf16x6_dma_kernel_is_bit_identical_to_the_register_staged_kernel(ops, M, N, K):
     """gemm_nt_x6_dma_kernel (operands global -> LDS by DMA, fragments split per wave) against gemm_nt_x6_pp_kernel
@@ -1308,8 +1310,9 @@ def test_grouped_weight_gradient_argument_checks(ops, bf16x6):
 
 
 # ----------------------------------------------------------------------------------------------------------------
-# bf16x6 GEMM on pre-split (P3) operands: csrc/gemm_planes.hip
+# bf16x6 GEMM on pre-split (P3) operands: csrc/gemm_planes.hip (lab build only)
 # ----------------------------------------------------------------------------------------------------------------
+@lab_only
 def test_split3_planes_round_trip_is_exact(ops):
     gen = torch.Generator().manual_seed(11)
     for rows, cols in [(256, 64), (1000, 256), (37, 1024), (16, 16)]:
@@ -1322,6 +1325,7 @@ def test_split3_planes_round_trip_is_exact(ops):
         assert torch.equal(ops.join3_planes(ops.split3_planes(wide[:, 16:16 + cols]), rows, cols), wide[:, 16:16 + cols])
 
 
+@lab_only
 @pytest.mark.parametrize('M,N,K,epi', [(512, 256, 64, 'bias'), (2048, 768, 256, 'bias'), (1536, 256, 1024, 'none'),
                                        (4096, 1024, 256, 'relu_drop'), (2560, 1024, 256, 'gate'), (1280, 256, 1024, 'add'),
                                        (65536 + 256, 512, 160, 'bias')])
@@ -1417,6 +1421,7 @@ def test_ffn_uses_the_bit_gate_in_bf16x6_mode_and_matches_the_fp32_gate(ops):
         assert rel_err(a, b) < 5e-6
 
 
+@lab_only
 @pytest.mark.parametrize('M,N,K,with_bias', [(512, 256, 64, True), (65536, 768, 256, True), (66048, 256, 1024, False),
                                              (131072, 512, 96, True)])
 def test_gemm_nt_one_wave_per_simd_kernel_is_bitwise_the_ping_pong_kernel(ops, M, N, K, with_bias):
@@ -1722,6 +1727,7 @@ def test_gru_fused_steps_equal_the_gemm_plus_gate_launches(ops):
         assert rel_err(a.cpu(), b.cpu()) < 2e-6
 
 
+@lab_only
 @pytest.mark.parametrize('M,N,K', [(65536, 256, 256), (131072, 1024, 256), (557056, 256, 512)])
 def test_gemm_tn_quad_row_lds_image_is_bit_identical_to_the_row_pair_image(ops, bf16x6, M, N, K):
     """gemm_tn_x6_pq_kernel (four consecutive rows per staging thread, fragments by two ds_read_b64) against

@@ -1,6 +1,7 @@
 """Micro-benchmark: bf16x6 NT GEMM on pre-split (P3) operands vs the fp32-in kernel (mode 1) on the C1 shapes (GPU only).
     python tools/bench_gemm_planes.py [reps]"""
 import os
+import os as _os; _os.environ.setdefault('VQCPC_LAB', '1')   # measurement switches live in the lab build (vqcpc_bach_amd/build.py)
 import statistics
 import sys
 

@@ -2,6 +2,7 @@
 split-K entry point, per shape and epilogue.  A/B inside one process is not possible (the tile limit is read once):
     VQCPC_S64_MAX_TILES=0 python tools/bench_s64.py ; python tools/bench_s64.py"""
 import os, sys, statistics, torch
+import os as _os; _os.environ.setdefault('VQCPC_LAB', '1')   # measurement switches live in the lab build (vqcpc_bach_amd/build.py)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vqcpc_bach_amd import hip, ops
 hip.load()

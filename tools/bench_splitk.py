@@ -1,6 +1,7 @@
 """Split-K NT GEMM (vqcpc_gemm_nt_splitk) against the single-launch path at the student / decoder step's under-filled
 shapes, and the vectorised partial-sum reduction of the weight-gradient GEMM.    python tools/bench_splitk.py"""
 import os, sys, statistics, torch
+import os as _os; _os.environ.setdefault('VQCPC_LAB', '1')   # measurement switches live in the lab build (vqcpc_bach_amd/build.py)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vqcpc_bach_amd import hip, ops
 hip.load()

@@ -2,6 +2,7 @@
 fragment) vs 0 (row-pair image, two ds_read2_b32); prints TFLOP/s and a digest of the result (must be identical).
     VQCPC_TN_PQ=0 python tools/bench_tn_pq.py; VQCPC_TN_PQ=1 python tools/bench_tn_pq.py"""
 import hashlib, os, statistics, sys, torch
+import os as _os; _os.environ.setdefault('VQCPC_LAB', '1')   # measurement switches live in the lab build (vqcpc_bach_amd/build.py)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vqcpc_bach_amd import hip, ops
 hip.load(); hip.set_gemm_mode(1)

@@ -1,4 +1,5 @@
 import os, sys, torch
+import os as _os; _os.environ.setdefault('VQCPC_LAB', '1')   # measurement switches live in the lab build (vqcpc_bach_amd/build.py)
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vqcpc_bach_amd import hip, ops
 hip.load(); hip.set_gemm_mode(int(os.environ.get('VQCPC_ONE_GEMM_MODE', '1')))

@@ -4,6 +4,7 @@ fewer workgroups than CUs (VQCPC_PP_GRID, measurement only) with and without its
 Per-CU throughput rises 1.5-1.7x when a quarter of the CUs or fewer are active (the clock is no longer held at ~1.4 GHz by the
 1.24 kW the full chip draws), see profiles/r03_gemm_power_limit.txt."""
 import os, sys, statistics, torch
+import os as _os; _os.environ.setdefault('VQCPC_LAB', '1')   # measurement switches live in the lab build (vqcpc_bach_amd/build.py)
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 from vqcpc_bach_amd import hip, ops
 hip.load(); hip.set_gemm_mode(1)

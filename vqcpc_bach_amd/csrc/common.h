@@ -1,5 +1,6 @@
 // Shared device/host helpers for libvqcpc_hip.so (gfx950 only, wave64).
 #pragma once
+#include <stdlib.h>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -58,6 +59,20 @@ struct RngSaltRegistrar {
 };
 static RngSaltRegistrar g_rng_salt_registrar;
 }  // namespace
+
+// Measurement switches (environment variables of the tools under tools/) exist in LAB builds only (-DVQCPC_LAB=1,
+// `VQCPC_LAB=1 python -m vqcpc_bach_amd.build` -> libvqcpc_hip_lab.so): the product library reads no tuning variable.
+#ifndef VQCPC_LAB
+#define VQCPC_LAB 0
+#endif
+#if VQCPC_LAB
+inline int lab_env_int(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+constexpr int lab_env_int(const char*, int dflt) { return dflt; }
+#endif
 
 // The hash in two steps, for kernels whose element index advances by a constant stride (GEMM epilogues: rows of one
 // column): x0 = idx * kRngMul + seed_lo is affine in idx, so x0(idx + d) = x0(idx) + d * kRngMul costs one add instead of

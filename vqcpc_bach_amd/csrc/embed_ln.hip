@@ -355,7 +355,7 @@ static int ln_blocks(int64_t M) { return (int)std::min<int64_t>(ceil_div(M, 4), 
 // 278 528 x 512 -- the two-input form still from 512 (513 vs 557 us)
 // (at d = 1024, the generic kernel: 303 us from 512 workgroups, 318 from 1024)
 static int ln_bwd_blocks(int64_t M, bool has_r, int d) {
-    static const int cap_env = getenv("VQCPC_LN_BWD_BLOCKS") ? atoi(getenv("VQCPC_LN_BWD_BLOCKS")) : 0;
+    static const int cap_env = lab_env_int("VQCPC_LN_BWD_BLOCKS", 0);
     const int cap = cap_env > 0 ? cap_env : ((has_r || d > 512) ? 512 : 1024);
     return (int)std::min<int64_t>(ceil_div(M, 4), cap);
 }

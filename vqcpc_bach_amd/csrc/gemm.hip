@@ -1838,8 +1838,10 @@ static int gradient_products_now() {
     return g_grad_scope.load(std::memory_order_relaxed) > 0 ? g_grad_products.load(std::memory_order_relaxed) : 6;
 }
 static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups (A/B switch)
+#if VQCPC_LAB
 static std::atomic<int> g_use_sw{0};   // bf16x6 NT 256-tile: software-pipelined one-wave-per-SIMD kernel (gemm_sw.hip), A/B switch
 static std::atomic<int> g_use_dma{0};  // bf16x6 NT 256-tile: LDS-DMA operand delivery (gemm_dma.hip) instead of register staging
+#endif
 static std::atomic<int> g_use_t2{1};   // bf16x6 NT: use the 256x256 tile kernel where shapes allow (A/B switch)
 static int gemm_mode() {
     int m = g_gemm_mode.load(std::memory_order_relaxed);
@@ -1995,7 +1997,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         return VQCPC_OK;
     }
     // under-filled bf16x6 launches (at most one 128-tile per CU): 64 x 64 tiles, four times the workgroups
-    static const int s64_max_tiles = getenv("VQCPC_S64_MAX_TILES") ? atoi(getenv("VQCPC_S64_MAX_TILES")) : 256;
+    static const int s64_max_tiles = lab_env_int("VQCPC_S64_MAX_TILES", 256);
     if (mode == 1 && tiles <= s64_max_tiles && (M % kS64 == 0) && (N % kS64 == 0) && (K % BK == 0) && M >= kS64) {
         const int tn64 = N / kS64;
         const dim3 g64((unsigned)((M / kS64) * tn64));
@@ -2052,15 +2054,17 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         const double eff256 = r256 / ceil(r256), eff128 = r128 / ceil(r128);
         t2_ok = eff256 * 1.08 >= eff128;
     }
+#if VQCPC_LAB      // rejected designs kept for A/B measurements (gemm_sw.hip, gemm_dma.hip): lab builds only
     if (t2_ok && g_use_sw.load(std::memory_order_relaxed) && gemm_nt_sw_ok(M, N, K, flags))
         return gemm_nt_sw_launch(A, lda, B, ldb, C, ldc, M, N, K, flags, ep, st);
     if (t2_ok && g_use_dma.load(std::memory_order_relaxed) && gemm_nt_dma_ok(M, N, K, flags))
         return gemm_nt_dma_launch(A, lda, B, ldb, C, ldc, M, N, K, flags, ep, st);
+#endif
     if (t2_ok) {
         const int tn2 = N / kT2;
         const int tiles2 = (int)((M / kT2) * tn2);
         // VQCPC_PP_GRID (measurement only): fewer persistent workgroups than CUs, to tell a per-CU store limit from a chip-wide burst
-        static const int grid_cap = getenv("VQCPC_PP_GRID") ? atoi(getenv("VQCPC_PP_GRID")) : kNumCU;
+        static const int grid_cap = lab_env_int("VQCPC_PP_GRID", kNumCU);
         const dim3 grid2((unsigned)std::min(tiles2, grid_cap)), block2(kT2Threads);
         // the gate epilogue (relu / dropout backward: reads an M x N operand, N = 4 K) is HBM-bound; all eight waves storing
         // together (lockstep kernel) keep more bytes in flight than one wave group at a time: 0.92 vs 1.21 ms at C1
@@ -2068,35 +2072,12 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         const size_t lds2 = 2 * kT2Buf;
         const size_t lds_pp = 2 * 6 * kT2 * 32;          // ping-pong kernel: unpadded swizzled planes (96 KB)
         const size_t lds_pp2 = 2 * 4 * kT2 * 32;         // its two-plane gradient variant (64 KB)
-#define T2_LAUNCH(EPIV)                                                                                                    \
+#if VQCPC_LAB
+// ablation variants of the ping-pong kernel (tools/ablate_pp_gemm.py, VQCPC_PP_ABL; bias epilogue only): lab builds only
+#define T2_ABL(EPIV)                                                                                                       \
     {                                                                                                                      \
-        static bool attr_done = false;                                                                                     \
-        if (!attr_done) {                                                                                                  \
-            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_256_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      (int)lds2);                                                                          \
-            attr_done = true;                                                                                              \
-        }                                                                                                                  \
-        static bool attr_pp = false;                                                                                       \
-        if (!attr_pp) {                                                                                                    \
-            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
-                                      (int)lds_pp);                                                                        \
-            attr_pp = true;                                                                                                \
-        }                                                                                                                  \
-        static const int abl = getenv("VQCPC_PP_ABL") ? atoi(getenv("VQCPC_PP_ABL")) : 0;                                  \
-        if (use_pp && ((EPIV) == 0 || (EPIV) == E_ADD || (EPIV) == (E_ADD | E_ADD2)) && gradient_products_now() == 3) {    \
-            /* opt-in gradient arithmetic (input-gradient GEMMs inside a gradient scope): two planes, three products */    \
-            constexpr int EG = ((EPIV) == 0 || (EPIV) == E_ADD || (EPIV) == (E_ADD | E_ADD2)) ? (EPIV) : 0;                \
-            static bool attr_g = false;                                                                                    \
-            if (!attr_g) {                                                                                                 \
-                (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EG, 0, 2>,                                     \
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp2);                       \
-                attr_g = true;                                                                                             \
-            }                                                                                                              \
-            hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EG, 0, 2>), grid2, block2, lds_pp2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
-            VQ_CHECK_LAUNCH("gemm_nt_x6_pp (gradient arithmetic)");                                                        \
-            return VQCPC_OK;                                                                                               \
-        }                                                                                                                  \
-        if (use_pp && abl && (EPIV) == E_BIAS) {                                                                             \
+        static const int abl = lab_env_int("VQCPC_PP_ABL", 0);                                                             \
+        if (use_pp && abl && (EPIV) == E_BIAS) {                                                                           \
             if (abl == 1) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 1>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 2) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 2>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 3) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 3>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
@@ -2112,7 +2093,42 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             if (abl == 4096) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 4096>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 4096>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 512) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 512>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 512>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
             if (abl == 4) { (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<E_BIAS, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp); hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<E_BIAS, 4>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); } \
-        } else if (use_pp)                                                                                                 \
+            VQ_CHECK_LAUNCH("gemm_nt_x6_pp (ablation)");                                                                   \
+            return VQCPC_OK;                                                                                               \
+        }                                                                                                                  \
+    }
+#else
+#define T2_ABL(EPIV)
+#endif
+#define T2_LAUNCH(EPIV)                                                                                                    \
+    {                                                                                                                      \
+        static bool attr_done = false;                                                                                     \
+        if (!attr_done) {                                                                                                  \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_256_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds2);                                                                          \
+            attr_done = true;                                                                                              \
+        }                                                                                                                  \
+        static bool attr_pp = false;                                                                                       \
+        if (!attr_pp) {                                                                                                    \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      (int)lds_pp);                                                                        \
+            attr_pp = true;                                                                                                \
+        }                                                                                                                  \
+        if (use_pp && ((EPIV) == 0 || (EPIV) == E_ADD || (EPIV) == (E_ADD | E_ADD2)) && gradient_products_now() == 3) {    \
+            /* opt-in gradient arithmetic (input-gradient GEMMs inside a gradient scope): two planes, three products */    \
+            constexpr int EG = ((EPIV) == 0 || (EPIV) == E_ADD || (EPIV) == (E_ADD | E_ADD2)) ? (EPIV) : 0;                \
+            static bool attr_g = false;                                                                                    \
+            if (!attr_g) {                                                                                                 \
+                (void)hipFuncSetAttribute((const void*)gemm_nt_x6_pp_kernel<EG, 0, 2>,                                     \
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pp2);                       \
+                attr_g = true;                                                                                             \
+            }                                                                                                              \
+            hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EG, 0, 2>), grid2, block2, lds_pp2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
+            VQ_CHECK_LAUNCH("gemm_nt_x6_pp (gradient arithmetic)");                                                        \
+            return VQCPC_OK;                                                                                               \
+        }                                                                                                                  \
+        T2_ABL(EPIV)                                                                                                       \
+        if (use_pp)                                                                                                        \
             hipLaunchKernelGGL((gemm_nt_x6_pp_kernel<EPIV>), grid2, block2, lds_pp, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
         else                                                                                                               \
             hipLaunchKernelGGL((gemm_nt_x6_256_kernel<EPIV>), grid2, block2, lds2, st, A, lda, B, ldb, C, ldc, M, N, K, tn2, tiles2, ep); \
@@ -2134,6 +2150,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
             default: break;
         }
 #undef T2_LAUNCH
+#undef T2_ABL
     }
 #define NT_LAUNCH(FULLV, EPIV)                                                                                            \
     if (mode == 1)                                                                                                        \
@@ -2190,14 +2207,17 @@ int vqcpc_gemm_set_mode(int mode) {
     // +16: 256-tile NT kernel with LDS-DMA operand delivery (gemm_dma.hip) instead of register staging (A/B switch; the
     // register-staged ping-pong kernel is 3-5 % faster: an LDS-DMA instruction costs ~90 issue cycles on its SIMD)
     // +32: software-pipelined one-wave-per-SIMD 256-tile NT kernel (gemm_sw.hip; A/B switch)
+#if VQCPC_LAB
     const int use_sw = (mode >= 32 && mode < 48) ? 1 : 0;
     if (use_sw) mode -= 32;
     g_use_sw.store(use_sw, std::memory_order_relaxed);
     const int use_dma = (mode >= 16 && mode < 32) ? 1 : 0;
     if (use_dma) mode -= 16;
-    VQ_REQUIRE((mode >= 0 && mode <= 7) || mode == 8,
-               "gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong, +16: LDS-DMA kernel, +32: one-wave-per-SIMD kernel] or 8 (bf16)");
     g_use_dma.store(use_dma, std::memory_order_relaxed);
+#endif
+    VQ_REQUIRE((mode >= 0 && mode <= 7) || mode == 8,
+               "gemm_set_mode: mode must be 0 (fp32 MFMA), 1 (bf16x6) [+2: 128-tile only, +4: no ping-pong; lab builds: +16 LDS-DMA "
+               "kernel, +32 one-wave-per-SIMD kernel] or 8 (bf16)");
     if (mode == 8) {
         g_gemm_mode.store(2, std::memory_order_relaxed);
         return VQCPC_OK;
@@ -2238,7 +2258,7 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 namespace vq {
 
 static int splitk_choose(int64_t M, int N, int K) {
-    static const int min_k = getenv("VQCPC_SPLITK_MIN_K") ? atoi(getenv("VQCPC_SPLITK_MIN_K")) : 768;
+    static const int min_k = lab_env_int("VQCPC_SPLITK_MIN_K", 768);
     if (gemm_mode() != 1 || M % BM || N % BN || K % BK || K < min_k) return 0;
     const int64_t tiles = (M / BM) * (N / BN);
     if (tiles > 160) return 0;
@@ -2246,7 +2266,7 @@ static int splitk_choose(int64_t M, int N, int K) {
     int best = 0;
     // at most 16 tiles (the GRU recurrence: 256 x 512 x 1536, one launch per time step on the critical path): planes of
     // 64 k keep the lone workgroup of a CU to a handful of K tiles (21 -> 15.5 us)
-    static const int min_ks = getenv("VQCPC_SPLITK_MIN_KS") ? atoi(getenv("VQCPC_SPLITK_MIN_KS")) : 64;
+    static const int min_ks = lab_env_int("VQCPC_SPLITK_MIN_KS", 64);
     for (int s = 2; s <= 16; ++s)
         if (kt % s == 0 && K / s >= (tiles <= 16 ? min_ks : 256) && tiles * s <= 512) best = s;
     return best;
@@ -2388,9 +2408,14 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                                           kPQBuf2);
                 attr_pp = true;
             }
-            // A/B switch: VQCPC_TN_PQ=0 keeps the row-pair LDS image of gemm_tn_x6_pp_kernel
-            const char* pq_env = getenv("VQCPC_TN_PQ");          // read per launch: tests flip it inside one process
+#if VQCPC_LAB
+            // A/B switch of lab builds: VQCPC_TN_PQ=0 keeps the row-pair LDS image of gemm_tn_x6_pp_kernel (read per launch:
+            // the lab test flips it inside one process)
+            const char* pq_env = getenv("VQCPC_TN_PQ");
             const bool use_pq = !(pq_env && pq_env[0] == '0');
+#else
+            constexpr bool use_pq = true;                       // the quad-row LDS image (gemm_tn_x6_pq_kernel)
+#endif
             const dim3 g_((N / kT2) * tk2, splits), b_(kT2Threads);
             if (gradient_products_now() == 3) {        // opt-in gradient arithmetic, inside a gradient scope only
                 if (use_pq)

@@ -746,7 +746,7 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     VQ_REQUIRE(act == 0 || act == 1, "gemm_nt_bf16: act must be 0 or 1");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt_bf16: bad dropout probability");
     EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, nullptr, 0, 0};
-    static const int stagger_per_ktile = getenv("VQCPC_BF16_STAGGER") ? atoi(getenv("VQCPC_BF16_STAGGER")) : 0;
+    static const int stagger_per_ktile = lab_env_int("VQCPC_BF16_STAGGER", 0);
     const int tiles_total = (int)((M / kB) * (N / kB));
     Bf16Out o{C, ldc, (bf16_t*)Cb, ldcb, (const bf16_t*)gate_bf16, ldgate_bf16,
               stagger_per_ktile < 0 ? stagger_per_ktile : (tiles_total >= 4 * kNumCU ? stagger_per_ktile * (K / kBBK) : 0)};

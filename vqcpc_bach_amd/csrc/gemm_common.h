@@ -102,6 +102,7 @@ __device__ __forceinline__ void split2_pair4(const float4& r0, const float4& r1,
     split2_pair(r0.w, r1.w, h.w, m.w);
 }
 
+#if VQCPC_LAB
 // software-pipelined one-wave-per-SIMD variant of the 256-tile bf16x6 NT kernel (gemm_sw.hip)
 bool gemm_nt_sw_ok(int64_t M, int N, int K, int flags);
 int gemm_nt_sw_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
@@ -110,5 +111,7 @@ int gemm_nt_sw_launch(const float* A, int64_t lda, const float* B, int64_t ldb, 
 bool gemm_nt_dma_ok(int64_t M, int N, int K, int flags);
 int gemm_nt_dma_launch(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N,
                        int K, int flags, const EpiParams& ep, hipStream_t st);
+
+#endif
 
 }  // namespace vq

@@ -357,7 +357,7 @@ int gemm_nt_dma_launch(const float* A, int64_t lda, const float* B, int64_t ldb,
     const int tn = N / kD;
     const int tiles = (int)((M / kD) * tn);
     const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kDThreads);
-    static const int abl = getenv("VQCPC_GEMM_ABL") ? atoi(getenv("VQCPC_GEMM_ABL")) : 0;   // ablation builds (tools only)
+    static const int abl = lab_env_int("VQCPC_GEMM_ABL", 0);   // ablation builds (tools only)
 #define D_LAUNCH(EPIV)                                                                                                \
     {                                                                                                                 \
         static bool attr_done = false;                                                                                \

@@ -465,7 +465,7 @@ static int launch_bwd(const float* d_ctx, int64_t ldo, const float* qkv, int64_t
 static int g_force_general = 0;   // tests: route L = 16 / 4 through the general-L kernels too
 // L = 16 runs on the matrix cores (relattn16.hip); VQCPC_RELATTN16_LDS=1 keeps the LDS-tiled VALU kernels (A/B, tests)
 static bool use_mfma16(int L, int H, int hd) {
-    static const bool lds_only = getenv("VQCPC_RELATTN16_LDS") && atoi(getenv("VQCPC_RELATTN16_LDS")) != 0;
+    static const bool lds_only = lab_env_int("VQCPC_RELATTN16_LDS", 0) != 0;
     return L == 16 && !lds_only && relattn16_supported(H, hd);
 }
 static int finish_de16(float* ws, int nsplit, int H, int hd, float* d_e1, float* d_e2, hipStream_t s);

@@ -9,6 +9,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libvqcpc_hip.so')
+LAB_LIB_PATH = os.path.join(_HERE, 'libvqcpc_hip_lab.so')
+_is_lab = False
 ABI_VERSION = 1
 
 _lib = None
@@ -50,12 +52,6 @@ SIGNATURES = {
     'vqcpc_gemm_nt_splitk': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_ptr, c_i64, c_ptr,
                                      c_i64, c_ptr]),
     'vqcpc_gemm_nt_gatebits': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_f32, c_ptr]),
-    'vqcpc_planes_bytes': (c_i64, [c_i64, c_int]),
-    'vqcpc_split3_planes': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
-    'vqcpc_join3_planes': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
-    'vqcpc_gemm_nt_planes_supported': (c_int, [c_i64, c_int, c_int]),
-    'vqcpc_gemm_nt_planes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr, c_i64,
-                                     c_f32, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_set_mode': (c_int, [c_int]),
     'vqcpc_gemm_get_mode': (c_int, []),
     'vqcpc_gemm_set_gradient_products': (c_int, [c_int]),
@@ -156,28 +152,52 @@ SIGNATURES = {
     'vqcpc_upscale_bwd': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr]),
 }
 
+# Entry points of LAB builds only (`VQCPC_LAB=1 python -m vqcpc_bach_amd.build` -> libvqcpc_hip_lab.so, the `#ifdef VQCPC_LAB`
+# section of include/vqcpc.h): rejected kernel designs kept for A/B measurements by the tools under tools/
+LAB_SIGNATURES = {
+    'vqcpc_planes_bytes': (c_i64, [c_i64, c_int]),
+    'vqcpc_split3_planes': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
+    'vqcpc_join3_planes': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),
+    'vqcpc_gemm_nt_planes_supported': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_nt_planes': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr, c_i64,
+                                     c_f32, c_ptr, c_i64, c_ptr]),
+}
+
 
 class VqcpcHipError(RuntimeError):
     pass
 
 
 def load(path=None):
-    """dlopen the library (after torch, so that its libamdhip64.so.7 is the one HIP runtime in the process)."""
-    global _lib
+    """dlopen the library (after torch, so that its libamdhip64.so.7 is the one HIP runtime in the process).  The product
+    library unless VQCPC_LAB=1 asks for the lab build (measurement tools; see build.py)."""
+    global _lib, _is_lab
     if _lib is not None:
         return _lib
-    path = path or os.environ.get('VQCPC_HIP_LIB', LIB_PATH)
+    want_lab = os.environ.get('VQCPC_LAB', '0') == '1'
+    path = path or os.environ.get('VQCPC_HIP_LIB', LAB_LIB_PATH if want_lab else LIB_PATH)
     if not os.path.exists(path):
-        raise VqcpcHipError(f'{path} not found: build it with `python -m vqcpc_bach_amd.build` '
+        raise VqcpcHipError(f'{path} not found: build it with `{"VQCPC_LAB=1 " if want_lab else ""}python -m vqcpc_bach_amd.build` '
                             f'(hipcc --offload-arch=gfx950). There is no CPU fallback.')
     lib = ctypes.CDLL(path)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype, fn.argtypes = res, args
+    _is_lab = hasattr(lib, 'vqcpc_gemm_nt_planes')
+    if _is_lab:
+        for name, (res, args) in LAB_SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype, fn.argtypes = res, args
     if lib.vqcpc_abi_version() != ABI_VERSION:
         raise VqcpcHipError(f'ABI version mismatch: library {lib.vqcpc_abi_version()} != binding {ABI_VERSION}')
     _lib = lib
     return lib
+
+
+def is_lab():
+    """True when the loaded library is a lab build (LAB_SIGNATURES are bound, the tools' environment switches are live)."""
+    load()
+    return _is_lab
 
 
 def is_loaded():

@@ -223,9 +223,15 @@ def flush_wgrads():
 # ------------------------------------------------------------------------------------------------------------------
 # bf16 path (BASELINE configs[4]: hip.set_gemm_mode(8)): operands are bf16 IN HBM (vqcpc_gemm_nt_bf16), fp32 accumulate
 # ------------------------------------------------------------------------------------------------------------------
+def _require_lab(what):
+    if not hip.is_lab():
+        raise hip.VqcpcHipError(f'{what} exists in the lab build only: VQCPC_LAB=1 python -m vqcpc_bach_amd.build, then run with VQCPC_LAB=1')
+
+
 def split3_planes(x):
     """fp32 (rows, cols) -> the P3 format of csrc/gemm_planes.hip: three K-tile-major bf16 planes with
     x == high + mid + low exactly.  Returns a uint8 buffer of 6 * rows * cols bytes tagged with its logical shape."""
+    _require_lab('split3_planes')
     x = _f32(x)
     assert x.dim() == 2 and x.stride(1) == 1 and x.shape[1] % 16 == 0
     rows, cols = x.shape
@@ -236,6 +242,7 @@ def split3_planes(x):
 
 
 def join3_planes(planes, rows, cols):
+    _require_lab('join3_planes')
     x = torch.empty(rows, cols, dtype=torch.float32, device=planes.device)
     hip.call('vqcpc_join3_planes', planes, rows, cols, x, cols)
     return x
@@ -244,6 +251,7 @@ def join3_planes(planes, rows, cols):
 def gemm_nt_planes(a_planes, b_planes, M, N, K, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, add=None,
                    out=None):
     """C[M, N] = epi(A . B^T) on pre-split (P3) operands: the same products, in the same order, as ops.gemm_nt in mode 1."""
+    _require_lab('gemm_nt_planes')
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a_planes.device)
     hip.call('vqcpc_gemm_nt_planes', a_planes, b_planes, out, out.stride(0), M, N, K, bias, int(act), float(drop_p), int(seed),

@@ -175,7 +175,8 @@ assert hip.get_gemm_mode() == 0                       # bare library default: ex
 cfg = make_reference_style_config()
 cfg.update(num_batches=6, num_epochs=1)
 tr, _, hist = run_main_encoder(cfg, train=True, load=False, model_root=sys.argv[1])
-assert hip.get_gemm_mode() == 1, hip.get_gemm_mode()  # train_model chose bf16x6
+assert tr.trained_gemm_mode == 1, tr.trained_gemm_mode    # train_model chose bf16x6 for its epochs ...
+assert hip.get_gemm_mode() == 0                       # ... and put the process-wide setting back
 assert tr._graph is not None and tr._graph.replays >= 3, 'training steps are graph replays by default'
 print('REPLAYS', tr._graph.replays)
 # explicit choices win

@@ -811,6 +811,10 @@ __global__ __launch_bounds__(kT2Threads, 2) void gemm_nt_x6_pp_kernel(const floa
         }                                                                                                              \
     }
 
+    // (Round 4, measured and not kept: requesting K tile s+2 BEFORE the epilogue's stores, so that it does not queue behind
+    // them -- as its own code path at tile boundaries it spilled, 2 x slower; as one path (store + request ahead of the
+    // fragment reads in every phase) the memory phase loses the overlap of the fragment-read latency with the split
+    // arithmetic: 5-7 % slower at every K.  profiles/r04_perf_log.md)
     // one phase pair for stream position s (RB_ = LDS buffer with K tile s, WB_ = buffer for tile s+1).  ONE raw-operand
     // register set: tile s+1 (requested in the previous memory phase) is split and stored, then the same registers are
     // reused for the request of tile s+2 -- a full MFMA phase + two barriers of latency cover.
@@ -2466,7 +2470,9 @@ int vqcpc_gemm_tn_groupable(int64_t M, int N, int K) {
     if (mode != 1 && mode != 2) return 0;
     if (M < 1 || N < 4 || K < 4 || (N % 4) || (K % 4)) return 0;
     if (mode == 1 && g_use_t2.load(std::memory_order_relaxed) && tn_can_use_256(M, N, K)) return 0;
-    return M <= (1 << 20) ? 1 : 0;
+    // deferred problems keep both operands alive until the gradient scope closes and run on ~64 workgroups each: only the
+    // genuinely small ones (student / decoder steps, narrow projections) are worth grouping -- at most 64 MB of operands
+    return (M <= (1 << 20) && M * ((int64_t)N + K) * 4 <= (64ll << 20)) ? 1 : 0;
 }
 
 // split count of a problem inside a group: by its own shape only (results do not depend on what else is in the group);

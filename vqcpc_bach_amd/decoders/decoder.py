@@ -315,8 +315,17 @@ class Decoder(GraphedTraining, nn.Module):
         return means
 
     def train_model(self, batch_size, num_batches, num_epochs, lr, schedule_lr, plot=False, num_workers=0, **kwargs):
-        best_val = 1e8
+        from .. import hip
+        mode_before = hip.gemm_mode_state()
         self.use_training_defaults()               # bf16x6 GEMMs + step-graph replay unless the caller chose otherwise
+        self.trained_gemm_mode = hip.get_gemm_mode()
+        try:
+            return self._train_epochs(batch_size, num_batches, num_epochs, lr, schedule_lr, num_workers)
+        finally:
+            hip.restore_gemm_mode_state(mode_before)      # process-wide setting: put back what the caller had (encoder.py)
+
+    def _train_epochs(self, batch_size, num_batches, num_epochs, lr, schedule_lr, num_workers):
+        best_val = 1e8
         self.init_optimizers(lr=lr, schedule_lr=schedule_lr)
         history = []
         for epoch_id in range(num_epochs):

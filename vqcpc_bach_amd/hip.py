@@ -264,6 +264,20 @@ def use_training_default_gemm_mode():
         _gemm_mode_explicit = False          # still "nobody chose": a later explicit choice wins as usual
 
 
+def gemm_mode_state():
+    """(arithmetic in force: 0 fp32 MFMA / 1 bf16x6 / 2 bf16, whether a caller chose it): what restore_gemm_mode_state() puts
+    back (the A/B sub-switches of set_gemm_mode are not part of it)."""
+    return (get_gemm_mode(), _gemm_mode_explicit)
+
+
+def restore_gemm_mode_state(state):
+    global _gemm_mode_explicit
+    mode, explicit = state
+    if mode != get_gemm_mode():
+        set_gemm_mode({0: 0, 1: 1, 2: 8}[mode])
+    _gemm_mode_explicit = explicit
+
+
 def set_gradient_products(products):
     """Opt-in gradient arithmetic of the bf16x6 mode (include/vqcpc.h): 6 (default) or 3 MFMAs per product for the
     256-tile GEMMs launched inside a gradient scope (ops.direct_weight_gradients, i.e. the trainers' loss.backward())."""

@@ -9,28 +9,44 @@ from torch import nn
 from .subsampled_relative_attention import SubsampledRelativeAttention
 
 
+_MASK_CLASS_CACHE = {}
+
+
 def classify_additive_mask(attn_mask):
     """The additive (T, S) masks the reference builds (decoders/decoder.py:294-308: 0 = keep, -inf = masked; T = r S, every
     source position repeated r times along the target axis) -> the index rule the attention kernels evaluate:
     ops.MASK_CAUSAL keeps j <= i // r, ops.MASK_ANTICAUSAL keeps j >= i // r, an all-zero mask is ops.MASK_NONE.
-    Any other pattern raises NotImplementedError (the reference never builds one on the path).  One small host read."""
+    Entries <= -1e4 count as masked (the finite "large negative" masks of user code: exp(-1e4 - max) == 0 in fp32).
+    Any other pattern raises NotImplementedError (the reference never builds one on the path).
+    One small host read per DISTINCT mask: the class is cached on (storage pointer, version counter, shape, strides)."""
     from .. import ops
     assert attn_mask.dim() == 2, 'attn_mask: (target length, source length)'
+    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), tuple(attn_mask.stride()), attn_mask.dtype,
+           str(attn_mask.device))
+    hit = _MASK_CLASS_CACHE.get(key)
+    if hit is not None:
+        return hit
     T, S = attn_mask.shape
     m = attn_mask.detach().to('cpu', torch.float32)
     keep = m == 0
-    if not bool((keep | torch.isinf(m) & (m < 0)).all()):
-        raise NotImplementedError('attn_mask: only 0 / -inf additive masks are supported')
+    if not bool((keep | (m <= -1e4)).all()):
+        raise NotImplementedError('attn_mask: only additive masks of 0 (keep) and -inf / <= -1e4 (masked) are supported')
+    cls = None
     if bool(keep.all()):
-        return ops.MASK_NONE
-    if T % S == 0:
+        cls = ops.MASK_NONE
+    elif T % S == 0:
         p = (torch.arange(T) // (T // S)).unsqueeze(1)
         j = torch.arange(S).unsqueeze(0)
         if torch.equal(keep, j <= p):
-            return ops.MASK_CAUSAL
-        if torch.equal(keep, j >= p):
-            return ops.MASK_ANTICAUSAL
-    raise NotImplementedError('attn_mask: not the causal / anticausal pattern of decoders/decoder.py:294-308')
+            cls = ops.MASK_CAUSAL
+        elif torch.equal(keep, j >= p):
+            cls = ops.MASK_ANTICAUSAL
+    if cls is None:
+        raise NotImplementedError('attn_mask: not the causal / anticausal pattern of decoders/decoder.py:294-308')
+    if len(_MASK_CLASS_CACHE) > 64:
+        _MASK_CLASS_CACHE.clear()
+    _MASK_CLASS_CACHE[key] = cls
+    return cls
 
 
 class MultiheadAttentionCustom(nn.Module):

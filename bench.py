@@ -657,7 +657,7 @@ def main():
     if use_graph:
         g = getattr(trainer, '_graph', None)
         graph_replays = g.replays if g is not None else 0
-        graphs_per_step = 2 if (g is not None and g.finish_fn is not None) else 1
+        graphs_per_step = len(g.stages) if g is not None else 1
         trainer.enable_step_graph(False)
         timed_steps = max(1, sampled_eager_steps)
     # the collective of the data-parallel step alone: the flat gradient bucket (what every step all-reduces), back to back
@@ -818,8 +818,8 @@ def main():
             'timed': 'trainer.epoch(train=True, num_batches=steps): steps + per-step metric bookkeeping + end-of-epoch host read',
             'step_graph': ({'replays_in_run': graph_replays, 'graphs_per_step': graphs_per_step,
                             'note': ('each training step is one HIP-graph replay' if graphs_per_step == 1 else
-                                     'each training step is two HIP-graph replays around the eagerly issued all-reduce of the '
-                                     'gradient bucket') + ' (vqcpc_bach_amd/graphs.py); --no-graph runs the same launches eagerly'}
+                                     f'each training step is {graphs_per_step} HIP-graph replays around the eagerly issued '
+                                     'all-reduce(s) of the gradient bucket') + ' (vqcpc_bach_amd/graphs.py); --no-graph runs the same launches eagerly'}
                            if use_graph else None),
             'train_step_only': {'value': round(B * dp.world_size * args.steps / dt_steps, 2),
                                 'ms_per_step': round(1e3 * dt_steps / args.steps, 3),

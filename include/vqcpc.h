@@ -502,6 +502,9 @@ int vqcpc_gemm_nt_splitk(const float* A, int64_t lda, const float* B, int64_t ld
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_rng_salt_set(uint64_t value, void* stream);
 int vqcpc_rng_salt_advance(uint64_t* counter, uint64_t base, void* stream);
+/* the salt of the CURRENT counter value again, without advancing it: first node of a later captured stage of the same step
+ * (a step cut into several graphs around eagerly issued, bucketed all-reduces) */
+int vqcpc_rng_salt_from_counter(const uint64_t* counter, uint64_t base, void* stream);
 int vqcpc_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const float* lr_dev, float beta1, float beta2,
                         float eps, const uint64_t* step_dev, float grad_scale, float max_norm, const double* sumsq,
                         void* stream);

@@ -137,6 +137,28 @@ def test_two_ranks_share_this_gpu_over_gloo(tmp_path):
     _check_graphed_dp(res)                           # two graph replays per step around the (gloo) all-reduce
 
 
+def test_student_step_bucketed_all_reduce_two_ranks_share_this_gpu(tmp_path):
+    """StudentEncoderTrainer under data parallelism (BASELINE configs[3] with several ranks): the teacher's gradient range is
+    all-reduced asynchronously while the encoder / decoder half runs, the rest afterwards (VQCPC_DP_BUCKETS=1: one call).
+    Two ranks on this GPU over gloo: the bucketed gradients equal the single-call gradients bit for bit, replicas stay
+    bit-identical through eager steps and through replays of the three-graph step, and the trajectories agree."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_SHARE_GPU='1', VQCPC_DP_BACKEND='gloo',
+               PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'multigpu_student_worker.py'), str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [torch.load(tmp_path / f's{k}.pt') for k in range(2)]
+    for k, x in enumerate(res):
+        assert x['world'] == 2 and x['rank'] == k
+        assert x['grads_equal'], ('bucketed vs single-call all-reduce', x['grad_rel'])
+        assert x['stages'] == 3 and x['replays'] == 5, (x['stages'], x['replays'])
+        assert x['graph_vs_eager'] < 2e-6, x['graph_vs_eager']
+        assert x['single_vs_bucketed'] < 2e-6, x['single_vs_bucketed']       # same gradients, other launch order
+    assert res[0]['digest_bucketed'] == res[1]['digest_bucketed'], 'replicas must stay bit-identical (eager)'
+    assert res[0]['digest_graph'] == res[1]['digest_graph'], 'replicas must stay bit-identical (graph replays)'
+
+
 def test_bench_contract_with_two_ranks_sharing_this_gpu():
     """PLAIN `python bench.py --gpus 2` (the driver's command form, no launcher): bench.py starts the two ranks itself (both
     on device 0 here, gloo): ONE JSON line from rank 0, n_gpus = rccl_ranks = 2, whole-job value = global batch * steps /

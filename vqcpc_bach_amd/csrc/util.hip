@@ -377,6 +377,11 @@ __global__ void rng_salt_advance_kernel(SaltAddrs a, uint64_t* counter, uint64_t
     __syncthreads();
     if (threadIdx.x < a.n) *a.p[threadIdx.x] = salt;
 }
+// the same salt again, WITHOUT advancing the counter: a later captured stage of the same step (graphs.py: bucketed all-reduces)
+__global__ void rng_salt_from_counter_kernel(SaltAddrs a, const uint64_t* counter, uint64_t base) {
+    const uint64_t v = splitmix64(base ^ counter[0]);
+    if (threadIdx.x < a.n) *a.p[threadIdx.x] = v ? v : 1;
+}
 
 // Adam with its per-step scalars on the device: lr from lr_dev[0], step count t from step_dev[0] (graph replay)
 __global__ __launch_bounds__(256) void adam_dev_kernel(float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
@@ -602,6 +607,14 @@ int vqcpc_rng_salt_advance(uint64_t* counter, uint64_t base, void* stream) {
     const SaltAddrs a = salt_addrs();
     hipLaunchKernelGGL(rng_salt_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, counter, base);
     VQ_CHECK_LAUNCH("rng_salt_advance");
+    return VQCPC_OK;
+}
+
+int vqcpc_rng_salt_from_counter(const uint64_t* counter, uint64_t base, void* stream) {
+    VQ_REQUIRE(counter != nullptr, "rng_salt_from_counter: null counter");
+    const SaltAddrs a = salt_addrs();
+    hipLaunchKernelGGL(rng_salt_from_counter_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a, counter, base);
+    VQ_CHECK_LAUNCH("rng_salt_from_counter");
     return VQCPC_OK;
 }
 

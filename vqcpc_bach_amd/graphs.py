@@ -46,7 +46,7 @@ def dp_graph_mode():
 
 class StepGraph:
     def __init__(self, step_fn, optimizers, lr_fn, device, key_fn=None, seed_base=0x5EED5A17, between_fn=None,
-                 finish_fn=None):
+                 finish_fn=None, stages=None, betweens=None):
         """step_fn(batch_dict) -> outputs (tensor / dict / tuple of tensors): one full training step on device tensors.
         optimizers: the ops.FlatAdam objects the step uses; lr_fn() -> current learning rate (host float);
         key_fn(batch) -> extra hashable that selects the graph (the student step's masked event index).
@@ -55,6 +55,17 @@ class StepGraph:
         self.step_fn, self.optimizers, self.lr_fn, self.key_fn = step_fn, list(optimizers), lr_fn, key_fn
         self.between_fn, self.finish_fn = between_fn, finish_fn
         assert (between_fn is None) == (finish_fn is None)
+        # General form: `stages` = [f0, f1, .., fk] (f0(batch) -> outputs, fi(outputs) -> outputs), one graph each, and
+        # `betweens` = [b0, .., b(k-1)] run EAGERLY between consecutive replays (bucketed all-reduces).  The two-graph form
+        # above is stages = [step_fn, finish_fn], betweens = [between_fn].
+        if stages is not None:
+            assert step_fn is None and between_fn is None and len(betweens) == len(stages) - 1 >= 1
+            self.step_fn, self.finish_fn, self.between_fn = stages[0], stages[-1], betweens[0]
+            self.stages, self.betweens = list(stages), list(betweens)
+        elif finish_fn is not None:
+            self.stages, self.betweens = [step_fn, finish_fn], [between_fn]
+        else:
+            self.stages, self.betweens = [step_fn], []
         self.device = torch.device(device)
         self.seed_base = int(seed_base)
         self.counter = torch.zeros(1, dtype=torch.int64, device=self.device)       # device step counter (uint64 bits)
@@ -80,12 +91,19 @@ class StepGraph:
             self.lr_dev.fill_(lr)
             self._lr_set = lr
 
-    def _body(self, static):
-        hip.call('vqcpc_rng_salt_advance', self.counter, self.seed_base)
-        out = self.step_fn(static)
-        # the salt is process-wide device state: the graph's last node puts it back to 0, so that whatever runs after a
-        # replay -- an eager step of ANOTHER trainer, an evaluation pass -- sees the seeds it was given
-        hip.call('vqcpc_rng_salt_set', 0)
+    def _stage(self, i, arg):
+        """Stage i of a step.  The salt is process-wide device state: every captured stage that may draw random numbers sets
+        it in its first node (stage 0 advances the step counter, later ones re-derive the same salt from it) and puts it
+        back to 0 in its last, so that whatever runs after a replay -- an eager step of ANOTHER trainer, an evaluation pass,
+        the eager collective between two stages -- sees the seeds it was given."""
+        last = len(self.stages) - 1
+        if i == 0:
+            hip.call('vqcpc_rng_salt_advance', self.counter, self.seed_base)
+        elif i < last:
+            hip.call('vqcpc_rng_salt_from_counter', self.counter, self.seed_base)
+        out = self.stages[i](arg)
+        if i < last or last == 0:
+            hip.call('vqcpc_rng_salt_set', 0)
         return out
 
     def capture(self, batch):
@@ -98,20 +116,22 @@ class StepGraph:
         # with a process group alive its watchdog thread polls events while we capture: only calls of THIS thread may
         # invalidate the capture
         mode = 'thread_local' if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 'global'
+        graphs = [graph]
         try:
             with torch.cuda.graph(graph, pool=self.pool, capture_error_mode=mode):
-                out = self._body(static)
+                out = self._stage(0, static)
             if self.pool is None:
                 self.pool = graph.pool()
-            graph2 = None
-            if self.finish_fn is not None:               # second half: same memory pool, replayed right after the first
-                graph2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph2, pool=self.pool, capture_error_mode=mode):
-                    out = self.finish_fn(out)
+            for i in range(1, len(self.stages)):         # later stages: same memory pool, replayed right after the previous one
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=self.pool, capture_error_mode=mode):
+                    out = self._stage(i, out)
+                graphs.append(g)
         finally:
             for opt, c in zip(self.optimizers, counts):  # capture ran the Python side of optimizer.step(): undo its count
                 opt.step_count = c
-        entry = ((graph, graph2), static, out)
+        graph2 = graphs[1] if len(graphs) > 1 else None
+        entry = (tuple(graphs), static, out)
         self.graphs[self._signature(batch)] = entry
         return entry
 
@@ -119,7 +139,7 @@ class StepGraph:
         entry = self.graphs.get(self._signature(batch))
         if entry is None:
             entry = self.capture(batch)
-        (graph, graph2), static, out = entry
+        graphs, static, out = entry
         for k, v in batch.items():
             if torch.is_tensor(v):
                 static[k].copy_(v, non_blocking=True)
@@ -128,10 +148,10 @@ class StepGraph:
         if want != self._counter_host:
             self.counter.fill_(int(want))
         self._set_lr()
-        graph.replay()
-        if graph2 is not None:
-            self.between_fn()
-            graph2.replay()
+        graphs[0].replay()
+        for g, between in zip(graphs[1:], self.betweens):
+            between()
+            g.replay()
         for opt in self.optimizers:
             opt.step_count += 1
         self._counter_host = want + 1
@@ -187,12 +207,18 @@ class GraphedTraining:
     def _all_reduce_gradients(self):
         self.dp.all_reduce_sum_(self.flat.flat_grad)
 
+    def _dp_stages(self, parts):
+        """(stages, betweens) of the multi-rank step: by default [compute, apply] around ONE all-reduce of the flat gradient
+        bucket.  A trainer whose step has independent halves overrides this (student: bucketed all-reduces)."""
+        return [parts[0], parts[1]], [self._all_reduce_gradients]
+
     def _new_step_graph(self, body, parts):
         """parts = (compute, apply): the halves of `body` before / after the gradient all-reduce."""
         dev = self.flat.flat.device
         if self.dp.distributed and not (dp_graph_mode() == 'capture' and self.dp.backend == 'nccl'):
-            return StepGraph(parts[0], self._graph_optimizers(), self.current_lr, dev, key_fn=self._graph_key,
-                             between_fn=self._all_reduce_gradients, finish_fn=parts[1])
+            stages, betweens = self._dp_stages(parts)
+            return StepGraph(None, self._graph_optimizers(), self.current_lr, dev, key_fn=self._graph_key, stages=stages,
+                             betweens=betweens)
         return StepGraph(body, self._graph_optimizers(), self.current_lr, dev, key_fn=self._graph_key)
 
     def _graphed_step(self, batch, body, parts=None):

@@ -127,6 +127,7 @@ SIGNATURES = {
                                 c_ptr]),
     'vqcpc_rng_salt_set': (c_int, [c_u64, c_ptr]),
     'vqcpc_rng_salt_advance': (c_int, [c_ptr, c_u64, c_ptr]),
+    'vqcpc_rng_salt_from_counter': (c_int, [c_ptr, c_u64, c_ptr]),
     'vqcpc_adam_step_dev': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_f32, c_f32, c_f32, c_ptr, c_f32, c_f32, c_ptr,
                                     c_ptr]),
     'vqcpc_gru_cell_fwd': (c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_u64, c_u64, c_ptr]),

@@ -53,6 +53,8 @@ static int64_t emb_chunk_rows(int64_t n_rows, int tpb) {
     return std::min<int64_t>(r, kEmbRowsPerChunk);
 }
 
+// PARTIAL = the last wave of the column loop owns fewer than 16 columns (d % 64 in [1, 15]): see the loop
+template <bool PARTIAL>
 __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __restrict__ tokens, int64_t n_rows, int tpb,
                                                             int nv, int vmax, int dlin, int pos, int has_ev,
                                                             const float* __restrict__ g, float* __restrict__ ws,
@@ -71,12 +73,14 @@ __global__ __launch_bounds__(256) void embed_pos_bwd_kernel(const int64_t* __res
     const int64_t row0 = (int64_t)chunk * chunk_rows;
     const int64_t row1 = min(row0 + chunk_rows, n_rows);
     // rows of this voice: row % tpb % nv == v.  chunk_rows is a multiple of tpb (checked on the host).
-    // The column loop runs over WAVE-UNIFORM bases with every lane active: the token ids of a batch are handed out with
-    // v_readlane from lanes 0..15, which must have executed the load even when the last wave owns fewer than 16 columns
-    // (d % 64 in [1, 15]); lanes past the last column read column 0 and skip the LDS update.
-    for (int colb = (int)(threadIdx.x & ~63u); colb < d; colb += blockDim.x) {
-        const bool cok = colb + (int)(threadIdx.x & 63) < d;
-        const int col = cok ? colb + (int)(threadIdx.x & 63) : 0;
+    // The token ids of a batch are handed out with v_readlane from lanes 0..15, which must have executed the load.  With
+    // d % 64 in [1, 15] the last wave of the plain column loop has fewer than 16 active lanes: the PARTIAL instantiation runs
+    // the loop over wave-uniform bases with every lane active (lanes past the last column read column 0 and skip the LDS
+    // update).  It is 4 x slower (386 vs 98 us at C1: the all-lanes form keeps 32 more loads per batch in flight and a
+    // branch around every update), so the host selects it only for those widths.
+    for (int colb = PARTIAL ? (int)(threadIdx.x & ~63u) : (int)threadIdx.x; colb < d; colb += blockDim.x) {
+        const bool cok = !PARTIAL || colb + (int)(threadIdx.x & 63) < d;
+        const int col = !PARTIAL ? colb : (cok ? colb + (int)(threadIdx.x & 63) : 0);
         const int kind = col < dlin ? 0 : (col < dlin + pos ? 1 : 2);                 // table column | channel | event
         const int cbase = kind == 0 ? col : (kind == 1 ? vmax * dlin + (col - dlin) : vmax * dlin + pos + (col - dlin - pos));
         const int cmul = kind == 0 ? dlin : (kind == 2 ? pos : 0);
@@ -507,8 +511,11 @@ int vqcpc_embed_pos_bwd(const int64_t* tokens, int64_t n_rows, int tokens_per_bl
     const int nchunks = (int)ceil_div(n_rows, chunk_rows);
     hipStream_t s = (hipStream_t)stream;
     if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)embed_pos_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(embed_pos_bwd_kernel, dim3(nchunks * n_voices), dim3(256), lds, s, tokens, n_rows,
+        (void)hipFuncSetAttribute((const void*)embed_pos_bwd_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds),
+        (void)hipFuncSetAttribute((const void*)embed_pos_bwd_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int d_cols = dlin + (d_event ? 2 : 1) * pos;
+    const bool partial_wave = (d_cols % 64) >= 1 && (d_cols % 64) <= 15;
+    hipLaunchKernelGGL(partial_wave ? embed_pos_bwd_kernel<true> : embed_pos_bwd_kernel<false>, dim3(nchunks * n_voices), dim3(256), lds, s, tokens, n_rows,
                        tokens_per_block, n_voices, vmax, dlin, pos, d_event ? 1 : 0, g_out, (float*)workspace, chunk_rows);
     VQ_CHECK_LAUNCH("embed_pos_bwd");
     // stage 2: partials ws[chunk][voice][table | chan | event] -> parallel deterministic column reductions (a single

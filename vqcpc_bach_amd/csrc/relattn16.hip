@@ -12,7 +12,7 @@
 // Same semantics / buffers as relattn.hip (probs saved before dropout, dropout index ((prob*16 + i)*16 + j),
 // S[i][j] = qs_i.k_j + qs_i.Erel[j - i + 15], Erel[r] = e1[h][r] (r < 16) | e2[h][r - 15] (r >= 16)), optional token
 // indirection into the first layer's block table.
-#include "common.h"
+#include "gemm_common.h"
 
 namespace vq {
 
@@ -131,6 +131,30 @@ __device__ __forceinline__ void load_cols(float (&dst)[CT], const float* __restr
     }
 }
 
+// exact 3-way bf16 split of a lane's 8 contraction elements (gemm_common.h: x == h + m + l): the operand form of
+// v_mfma_f32_16x16x32_bf16, whose lane (row c, k group g) holds k = 8 g .. 8 g + 7 -- the very columns the fp32 kernels
+// assign to lane group g for head_dim 32
+__device__ __forceinline__ void split8x3(const float (&x)[8], bf16x8& h, bf16x8& m, bf16x8& l) {
+    uint2 h0, m0, l0, h1, m1, l1;
+    split3x4(make_float4(x[0], x[1], x[2], x[3]), h0, m0, l0);
+    split3x4(make_float4(x[4], x[5], x[6], x[7]), h1, m1, l1);
+    h = __builtin_bit_cast(bf16x8, make_uint4(h0.x, h0.y, h1.x, h1.y));
+    m = __builtin_bit_cast(bf16x8, make_uint4(m0.x, m0.y, m1.x, m1.y));
+    l = __builtin_bit_cast(bf16x8, make_uint4(l0.x, l0.y, l1.x, l1.y));
+}
+// a . b over 32 contraction elements as six bf16 MFMAs (hl + lh + mm, hm + mh, hh: smallest terms first), fp32 accumulate:
+// fp32-class accuracy (the bf16x6 arithmetic of the GEMMs) at 6 x 16x16x32 instead of 8 dependent 16x16x4 fp32 MFMAs
+__device__ __forceinline__ floatx4 dot32_x6(const bf16x8& ah, const bf16x8& am, const bf16x8& al, const bf16x8& bh,
+                                            const bf16x8& bm, const bf16x8& bl, floatx4 acc) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(am, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bm, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh, acc, 0, 0, 0);
+    return acc;
+}
+
 __device__ __forceinline__ float grp16_sum(float v) {
     v += __shfl_xor(v, 1, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 8, 16);
     return v;
@@ -142,7 +166,8 @@ __device__ __forceinline__ float grp16_max(float v) {
 }
 
 // =====================================================================================================================
-template <int HD, bool B16 = false, bool IN16 = false>      // B16: `ctx` points to bf16 elements (ldo in elements); IN16: `qkv` too
+// X6 (head_dim 32): q . k and q . Erel on the bf16 matrix pipe as six products of the exact 3-way split
+template <int HD, bool B16 = false, bool IN16 = false, bool X6 = false>      // B16: `ctx` points to bf16 elements (ldo in elements); IN16: `qkv` too
 __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const float* __restrict__ qkv, int64_t ldq,
                                                                        const int64_t* __restrict__ tokens,
                                                                        const float* __restrict__ e1,
@@ -167,6 +192,22 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
     load_vec<KH, IN16>(qa, qkv, ro, scale);
     load_vec<KH, IN16>(kb, qkv, ro + d, 1.0f);
     floatx4 s = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (X6 && HD == 32) {
+        bf16x8 qh, qm, ql, kh_, km, kl;
+        split8x3(qa, qh, qm, ql);
+        split8x3(kb, kh_, km, kl);
+        s = dot32_x6(qh, qm, ql, kh_, km, kl, s);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            float eb[KH];
+            load_f4<KH>(eb, erel16(e1, e2, h, HD, 16 * t + c) + g * KH, 1.0f);
+            bf16x8 eh, em, el;
+            split8x3(eb, eh, em, el);
+            const floatx4 qe = dot32_x6(qh, qm, ql, eh, em, el, floatx4{0.f, 0.f, 0.f, 0.f});
+#pragma unroll
+            for (int r = 0; r < 4; ++r) buf[(4 * g + r) * kA16RS + 16 * t + c] = qe[r];
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < KH; ++k) s = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[k], kb[k], s, 0, 0, 0);
     // relative term: QE[i][x] = qs_i . Erel[x], x = 0..30 (two 16-column tiles), skewed into the scores through LDS
@@ -179,6 +220,7 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
         for (int k = 0; k < KH; ++k) qe = __builtin_amdgcn_mfma_f32_16x16x4f32(qa[k], eb[k], qe, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) buf[(4 * g + r) * kA16RS + 16 * t + c] = qe[r];
+    }
     }
     wave_lds_fence();
     float p[4], pd[4];
@@ -402,6 +444,14 @@ template <int HD, bool B16 = false, bool IN16 = false>
 static int a16_fwd_t(const float* qkv, int64_t ldq, const int64_t* tokens, const float* e1, const float* e2, float* ctx,
                      int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
     const int64_t total = n_blocks * H;
+    static const int x6 = lab_env_int("VQCPC_RELATTN16_X6", 1);      // lab builds: =0 keeps the fp32-MFMA contractions (A/B)
+    if (HD == 32 && x6) {
+        hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16, IN16, HD == 32>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64),
+                           0, s, qkv, ldq, tokens, e1, e2, ctx, ldo, probs, total, H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
+                           1.0f / (1.0f - drop_p), seed);
+        VQ_CHECK_LAUNCH("relattn16_fwd (x6)");
+        return VQCPC_OK;
+    }
     hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16, IN16>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64), 0, s, qkv,
                        ldq, tokens, e1, e2, ctx, ldo, probs, total, H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed);

@@ -435,9 +435,11 @@ int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_cast_bf16(const float* in, int64_t ld_in, void* out, int64_t rows, int cols, void* stream);
 int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K);
-/* Kernel selection of vqcpc_gemm_nt_bf16 (process-wide; A/B measurements): 1 (default) = K tiles of 64 (128-byte operand
- * rows) delivered by LDS-DMA, one barrier per K tile (K % 128 == 0, otherwise kernel 0 is used); 0 = the ping-pong kernel
- * with K tiles of 32 staged through registers.  Same results bit for bit (same per-element summation order over k). */
+/* Kernel selection of vqcpc_gemm_nt_bf16 / vqcpc_gemm_tn_bf16 (process-wide; A/B measurements): 1 (default) = operands delivered
+ * global -> LDS by DMA in whole 128-byte lines -- NT: K tiles of 64, one barrier per K tile (K % 128 == 0, otherwise kernel 0);
+ * TN: 64-row slots in their row-major form, fragments by ds_read_b64_tr_b16 -- 0 = the register-staged kernels (NT: ping-pong,
+ * K tiles of 32; TN: row pairs interleaved with v_perm, ds_read_b32 fragments).  NT results are identical bit for bit; TN results
+ * agree to fp32 rounding of the partial sums (the split boundaries differ: multiples of 128 instead of 64 rows). */
 int vqcpc_gemm_bf16_set_variant(int variant);
 int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, void* Cb, int64_t ldcb,
                        int64_t M, int N, int K, const float* bias, int act, float drop_p, uint64_t seed, const float* gate,

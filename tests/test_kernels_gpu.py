@@ -365,10 +365,12 @@ def test_gemm_nt_bf16_kernels_are_bit_identical(ops, M, N, K):
         hip.call('vqcpc_gemm_bf16_set_variant', 1)
 
 
-@pytest.mark.parametrize('M,N,K', [(512, 256, 256), (4096, 512, 256), (128 * 700, 256, 768), (33280, 1024, 512)])
-def test_gemm_tn_bf16_native_kernel(ops, M, N, K):
+@pytest.mark.parametrize('M,N,K', [(512, 256, 256), (4096, 512, 256), (128 * 700, 256, 768), (33280, 1024, 512), (128, 256, 256),
+                                   (128 * 3, 512, 512)])
+def test_gemm_tn_bf16_native_kernel(ops, bf16_nt_variant, M, N, K):
     """vqcpc_gemm_tn_bf16: dW = A^T B and db = column sums of A on bf16 operands, against fp64 on the rounded operands;
-    plain, accumulating into existing buffers, and A = I-like transpose detection."""
+    plain, accumulating into existing buffers, and A = I-like transpose detection -- for both kernels (variant 1: operands by
+    LDS-DMA, fragments by ds_read_b64_tr_b16; variant 0: row pairs interleaved in registers, ds_read_b32 fragments)."""
     gen = torch.Generator().manual_seed(M + N + K)
     a, b = torch.randn(M, N, generator=gen), torch.randn(M, K, generator=gen)
     ab, bb = ops.cast_bf16(dev(a)), ops.cast_bf16(dev(b))

@@ -59,6 +59,13 @@ hip.set_gemm_mode(0)
 hip.set_gemm_mode(8)
 for N, K in ([] if os.environ.get('VQCPC_BF16_NO_TN') else [(2048, 512), (512, 2048), (1536, 512), (512, 512)]):
     a = ops.cast_bf16(torch.randn(M, N, device='cuda')); b = ops.cast_bf16(torch.randn(M, K, device='cuda'))
-    t = timeit(lambda: ops.gemm_tn_bf16(a, b))
-    print(f'M={M} N={N} K={K} wgrad (TN, incl. reduction) {t:8.1f} us  {2.0 * M * N * K / t / 1e6:7.0f} TFLOP/s', flush=True)
+    res_, outs = [], []
+    for v in VARIANTS:
+        hip.call('vqcpc_gemm_bf16_set_variant', v)
+        outs.append(ops.gemm_tn_bf16(a, b)[0].clone())
+        t = timeit(lambda: ops.gemm_tn_bf16(a, b))
+        res_.append(f'v{v}: {t:8.1f} us {2.0 * M * N * K / t / 1e6:6.0f} TFLOP/s')
+    hip.call('vqcpc_gemm_bf16_set_variant', 1)
+    diff = float((outs[0] - outs[-1]).abs().max() / outs[0].abs().max()) if len(outs) > 1 else 0.0
+    print(f'M={M} N={N} K={K} wgrad (TN, incl. reduction) ' + ' | '.join(res_) + f'  max rel diff {diff:.1e}', flush=True)
 hip.set_gemm_mode(0)

@@ -703,6 +703,199 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_tn_bf16_kernel(const bf16_t
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// gemm_tn_bf16_tr_kernel: the same weight gradient with operands delivered global -> LDS by DMA in their natural row-major
+// form and the fragments read with ds_read_b64_tr_b16 (gfx950's transposing LDS read).
+//
+// The kernel above needs 8 consecutive CONTRACTION elements (rows m) per lane while memory holds rows: it interleaves row
+// pairs with v_perm in registers, writes them to LDS and reads a fragment as four ds_read_b32 -- 48 LDS reads per wave and
+// 16 MFMAs at 128 B/clk plus the staging writes: the LDS, not the matrix pipe, paces it (0.33 of the bf16 peak).  Here:
+//   * a slot = 64 rows x 256 columns (512 bytes per row) of A and of B, two slots per operand (128 KB), filled by
+//     buffer_load_dwordx4 ... lds: whole 128-byte lines per request, no staging registers, no v_perm, no LDS writes;
+//   * ds_read_b64_tr_b16 (measured semantics, tools/micro/tr_probe.hip): within a 16-lane group, source lane j = 4 e + c
+//     supplies the address of 4 consecutive bf16, and lane i = 4 c + k receives element k of source lanes c, 4 + c, 8 + c,
+//     12 + c (e = 0..3).  With source lane (e, c) pointing at X[m0 + e][n0 + 4 c ..] the group's lane i holds column n0 + i
+//     for rows m0 .. m0 + 3: two such reads are the 8 contraction elements of a 32 x 32 x 16 MFMA fragment (lane groups
+//     0 / 1 = columns 0-15 / 16-31 at rows m0 .. m0 + 7, groups 2 / 3 the same columns at rows m0 + 8 .. m0 + 15), at
+//     256 B/clk and half the instruction count of the ds_read_b32 form;
+//   * 16-byte chunk c of row r sits at chunk position c ^ (4 (r & 3)) (applied to the DMA's per-lane SOURCE address): the four
+//     rows of a read's 32-lane half then touch four different 64-byte segments of the 256-byte bank row;
+//   * the schedule of gemm_nt_bf16_k64_kernel: fragments of a slot in two 48-register halves (k16 steps 0-1 / 2-3), the next
+//     half's reads and the next slot's DMA under 16 MFMAs of the same wave, ONE barrier per 64 rows.
+// The bias gradient (column sums of A) comes from the A fragments of the waves with wn == 0.
+constexpr int kTRRows = 64;                         // contraction rows per slot
+constexpr int kTRRowB = kB * 2;                     // 512 bytes per operand row
+constexpr int kTROperand = kTRRows * kTRRowB;       // 32 KB
+constexpr int kTRLds = 4 * kTROperand;              // A slot 0 | A slot 1 | B slot 0 | B slot 1
+
+__global__ __launch_bounds__(kBThreads, 2) void gemm_tn_bf16_tr_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                                      const bf16_t* __restrict__ B, int64_t ldb, int64_t M,
+                                                                      int N, int K, int tiles_k, int64_t rows_per_split,
+                                                                      float* __restrict__ ws, float* __restrict__ ws_bias) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    const int tn = blockIdx.x / tiles_k, tk = blockIdx.x % tiles_k;
+    const int n0 = tn * kB, k0 = tk * kB;
+    const int64_t m_begin = (int64_t)blockIdx.y * rows_per_split;
+    const int64_t m_end = min(m_begin + rows_per_split, M);           // (m_end - m_begin) % 128 == 0 (host)
+    const int S = m_end > m_begin ? (int)((m_end - m_begin) / kTRRows) : 0;      // slots of this split: even
+    const bool want_bias = (ws_bias != nullptr) && tk == 0 && wn == 0;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};                             // column sums of A: column 128 wm + 32 mt + li, rows of this lane's kh
+
+    // ---- DMA: wave w delivers rows [8 w, 8 w + 8) of a slot of A and of B: 4 + 4 instructions of 2 rows x 512 bytes ----
+    // lane l -> row l >> 5 of the 2-row block j, chunk position l & 31 <- logical chunk (l & 31) ^ (4 ((2 j + (l >> 5)) & 3))
+    const int dl_row = lane >> 5;
+    const int dl_ce = (lane & 31) ^ (4 * dl_row), dl_co = (lane & 31) ^ (4 * (2 + dl_row));
+    const int ldai = (int)lda, ldbi = (int)ldb;
+    const int voff_ae = (dl_row * ldai + dl_ce * 8) * 2, voff_ao = (dl_row * ldai + dl_co * 8) * 2;
+    const int voff_be = (dl_row * ldbi + dl_ce * 8) * 2, voff_bo = (dl_row * ldbi + dl_co * 8) * 2;
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const __amdgpu_buffer_rsrc_t rs_a = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(A + (m_begin + 8 * wave) * lda + n0), 0, 0x7FFFFFFF, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(B + (m_begin + 8 * wave) * ldb + k0), 0, 0x7FFFFFFF, 0x00020000);
+    int ld_slot = 0;                                                  // next slot to request (clamped to the last one)
+#define R_ISSUE(SLOT)                                                                                                   \
+    {                                                                                                                   \
+        unsigned char* da_ = smem + (SLOT) * kTROperand + wave * 4096;                                                  \
+        unsigned char* db_ = smem + (2 + (SLOT)) * kTROperand + wave * 4096;                                            \
+        const int row0_ = min(ld_slot, S - 1) * kTRRows;                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_a, (lds_ptr_t)(da_ + j * 1024), 16, (j & 1) ? voff_ao : voff_ae, \
+                                                     (row0_ + 2 * j) * ldai * 2, 0, 0);                                 \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                                                   \
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_b, (lds_ptr_t)(db_ + j * 1024), 16, (j & 1) ? voff_bo : voff_be, \
+                                                     (row0_ + 2 * j) * ldbi * 2, 0, 0);                                 \
+        ++ld_slot;                                                                                                      \
+    }
+
+    // ---- fragment addressing: lane = (group g = lane >> 4: column half g & 1, row half kh = g >> 1; source role e = (lane >> 2) & 3
+    // (row m0 + e), c = lane & 3 (columns 4 c ..)) ----
+    const unsigned ldsb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const int te = (lane >> 2) & 3, tc = lane & 3, tg = (lane >> 4) & 1;
+    const unsigned row_off = (unsigned)((8 * kh + te) * kTRRowB + (tc & 1) * 8);
+    unsigned a_ad[4], b_ad[2];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+        a_ad[mt] = ldsb + row_off + ((unsigned)((16 * wm + 4 * mt + 2 * tg + (tc >> 1)) ^ (4 * te)) << 4);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+        b_ad[nt] = ldsb + 2 * kTROperand + row_off + ((unsigned)((8 * wn + 4 * nt + 2 * tg + (tc >> 1)) ^ (4 * te)) << 4);
+    uint2 xa[2][4][2], xb[2][2][2], ya[2][4][2], yb[2][2][2];         // [k16 step of the half][tile][rows 0-3 | 4-7]
+#define R_RD(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "i"(OFF))
+    // k16 step KS (0..3) of slot SLOT: rows 16 KS + 8 kh + 4 r + e
+#define R_READ_STEP(S_, H, SLOT, KS)                                                                                    \
+    _Pragma("unroll") for (int nt = 0; nt < 2; ++nt) {                                                                  \
+        R_RD(S_##b[H][nt][0], b_ad[nt], (SLOT) * kTROperand + (16 * (KS)) * kTRRowB);                                   \
+        R_RD(S_##b[H][nt][1], b_ad[nt], (SLOT) * kTROperand + (16 * (KS) + 4) * kTRRowB);                               \
+    }                                                                                                                   \
+    _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                                  \
+        R_RD(S_##a[H][mt][0], a_ad[mt], (SLOT) * kTROperand + (16 * (KS)) * kTRRowB);                                   \
+        R_RD(S_##a[H][mt][1], a_ad[mt], (SLOT) * kTROperand + (16 * (KS) + 4) * kTRRowB);                               \
+    }
+#define R_READ_X(SLOT) R_READ_STEP(x, 0, SLOT, 0) R_READ_STEP(x, 1, SLOT, 1)
+#define R_READ_Y(SLOT) R_READ_STEP(y, 0, SLOT, 2) R_READ_STEP(y, 1, SLOT, 3)
+#define R_W2(V) "+v"(V[0]), "+v"(V[1])
+#define R_LGKM_WAIT(S_)                                                                                                 \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                 \
+                 : R_W2(S_##b[0][0]), R_W2(S_##b[0][1]), R_W2(S_##b[1][0]), R_W2(S_##b[1][1]), R_W2(S_##a[0][0]),       \
+                   R_W2(S_##a[0][1]), R_W2(S_##a[0][2]), R_W2(S_##a[0][3]), R_W2(S_##a[1][0]), R_W2(S_##a[1][1]),       \
+                   R_W2(S_##a[1][2]), R_W2(S_##a[1][3]));
+#define R_FRAG(V) __builtin_bit_cast(bf16x8, make_uint4(V[0].x, V[0].y, V[1].x, V[1].y))
+#define R_BSUM1(U) (__uint_as_float((U) << 16) + __uint_as_float((U) & 0xFFFF0000u))
+#define R_MFMA(S_)                                                                                                      \
+    __builtin_amdgcn_s_setprio(1);                                                                                      \
+    _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                       \
+        _Pragma("unroll") for (int mt = 0; mt < 4; ++mt) {                                                              \
+            acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R_FRAG(S_##a[h][mt]), R_FRAG(S_##b[h][0]), acc[mt][0], 0, 0, 0); \
+            acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R_FRAG(S_##a[h][mt]), R_FRAG(S_##b[h][1]), acc[mt][1], 0, 0, 0); \
+        }                                                                                                               \
+    __builtin_amdgcn_s_setprio(0);                                                                                      \
+    if (want_bias) {                                                                                                    \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                            \
+                bsum[mt] += (R_BSUM1(S_##a[h][mt][0].x) + R_BSUM1(S_##a[h][mt][0].y)) +                                 \
+                            (R_BSUM1(S_##a[h][mt][1].x) + R_BSUM1(S_##a[h][mt][1].y));                                  \
+    }
+#define R_SYNC()                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                  \
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                                       \
+    __builtin_amdgcn_sched_barrier(0);
+    // slot s (RB_ = its buffer, WB_ = the other one)
+#define R_SLOT(RB_, WB_)                                                                                                \
+    {                                                                                                                   \
+        R_READ_Y(RB_)                                                                                                   \
+        R_MFMA(x)                                                                                                       \
+        R_LGKM_WAIT(y)                                                                                                  \
+        R_SYNC()                        /* own DMA of slot s+1 landed, everybody's after the barrier; slot s fully read */ \
+        R_ISSUE(RB_)                    /* slot s+2 */                                                                  \
+        R_READ_X(WB_)                                                                                                   \
+        R_MFMA(y)                                                                                                       \
+        R_LGKM_WAIT(x)                                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                              \
+    }
+
+    if (S > 0) {
+        R_ISSUE(0)
+        R_ISSUE(1)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        R_READ_X(0)
+        R_LGKM_WAIT(x)
+#pragma unroll 1
+        for (int s = 0; s < S; s += 2) {
+            R_SLOT(0, 1)
+            R_SLOT(1, 0)
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped run-ahead DMAs must not outlive the workgroup's LDS
+    }
+#undef R_SLOT
+#undef R_SYNC
+#undef R_MFMA
+#undef R_BSUM1
+#undef R_FRAG
+#undef R_LGKM_WAIT
+#undef R_W2
+#undef R_READ_Y
+#undef R_READ_X
+#undef R_READ_STEP
+#undef R_RD
+#undef R_ISSUE
+
+    float* out = ws + (int64_t)blockIdx.y * N * K;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = k0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(int64_t)row * K + col] = acc[mt][nt][r];
+            }
+        }
+    }
+    if ((ws_bias != nullptr) && tk == 0 && wn == 0) {
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const float tot = bsum[mt] + __shfl_xor(bsum[mt], 32, 64);
+            if (kh == 0) ws_bias[(int64_t)blockIdx.y * N + n0 + wm * 128 + mt * 32 + li] = tot;
+        }
+    }
+}
+
 }  // namespace vq
 
 using namespace vq;
@@ -831,10 +1024,24 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
         return VQCPC_EWORKSPACE;
     }
     const int splits = tn_bf16_splits(M, N, K);
-    const int64_t rows_per_split = round_up(ceil_div(M, splits), 2 * kTBM);
     float* ws = (float*)workspace;
     float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
     hipStream_t s = (hipStream_t)stream;
+    if (g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && lda < (1 << 20) && ldb < (1 << 20)) {
+        // transposed-read kernel: splits of whole 128-row pairs of slots
+        const int64_t rps = round_up(ceil_div(M, splits), 2 * kTRRows);
+        static bool attr_tr = false;
+        if (!attr_tr) {
+            (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTRLds);
+            attr_tr = true;
+        }
+        const int tkr = K / kB;
+        hipLaunchKernelGGL(gemm_tn_bf16_tr_kernel, dim3((N / kB) * tkr, splits), dim3(kBThreads), kTRLds, s, (const bf16_t*)A, lda,
+                           (const bf16_t*)B, ldb, M, N, K, tkr, rps, ws, ws_bias);
+        VQ_CHECK_LAUNCH("gemm_tn_bf16_tr");
+        return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
+    }
+    const int64_t rows_per_split = round_up(ceil_div(M, splits), 2 * kTBM);
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * kTBBuf);

@@ -543,10 +543,18 @@ def main():
     gemm_mode = 2 if args.gemm_mode in ('bf16', '8') else (1 if args.gemm_mode in ('bf16x6', '1') else 0)
     hip.set_gemm_mode(8 if gemm_mode == 2 else gemm_mode)
     hip.set_gradient_products(args.grad_products)
-    if args.gpus > 1 and os.environ.get('VQCPC_DP_SHARE_GPU', '0') != '1' and torch.cuda.device_count() < args.gpus:
+    share = os.environ.get('VQCPC_DP_SHARE_GPU', '0') == '1'
+    # (a launcher may mask visibility to ONE device per rank: then the check is the PCI-id census below, after the group exists)
+    if args.gpus > 1 and not share and 1 < torch.cuda.device_count() < args.gpus:
         sys.exit(f'bench.py: --gpus {args.gpus} but only {torch.cuda.device_count()} GPUs are visible to this rank')
     dp = DataParallelContext()
     assert dp.world_size == args.gpus, f'--gpus {args.gpus} but {dp.world_size} ranks joined the process group'
+    if dp.world_size > 1 and not share:
+        n_dev = dp.distinct_devices()
+        if n_dev is not None and n_dev != dp.world_size:      # every rank sees the same census: all exit together
+            dp.shutdown()
+            sys.exit(f'bench.py: {dp.world_size} ranks run on {n_dev} distinct GPUs: not a {dp.world_size}-GPU measurement '
+                     f'(VQCPC_DP_SHARE_GPU=1 is the test harness that allows it)')
     dev = dp.device
     torch.manual_seed(0)                                           # identical initial weights on every rank
     SEEDS.manual_seed(1000 + dp.rank)

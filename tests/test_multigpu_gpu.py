@@ -197,3 +197,17 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1'],
                        capture_output=True, text=True, timeout=300, env=env, cwd=ROOT)
     assert r.returncode != 0 and 'needs 2 visible GPUs' in r.stderr
+
+
+@pytest.mark.skipif(_world() != 1, reason='needs a 1-GPU box: two ranks must land on the same physical GPU')
+def test_bench_refuses_ranks_that_share_a_gpu_without_the_harness_flag():
+    """Two ranks whose visible device is the same physical GPU (a launcher masking visibility, or a 1-GPU box) are not a
+    2-GPU measurement: the PCI-id census after the process group is up makes every rank exit non-zero, no JSON line."""
+    env = {k: v for k, v in os.environ.items() if k != 'VQCPC_DP_SHARE_GPU'}
+    env.update(HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_BACKEND='gloo', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '2', '--warmup', '1',
+           '--batch', '16']
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode != 0 and 'distinct GPUs' in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith('{')]

@@ -31,6 +31,9 @@ class DataParallelContext:
             self.local_rank = 0
         if device is None:
             if torch.cuda.is_available():
+                # a launcher that masks device visibility per rank (one visible GPU each) numbers it 0 whatever LOCAL_RANK says
+                if torch.cuda.device_count() == 1 and self.local_rank > 0:
+                    self.local_rank = 0
                 torch.cuda.set_device(self.local_rank)     # mandatory: the reference moves to the DEFAULT device
                 device = torch.device('cuda', self.local_rank)
             else:
@@ -73,6 +76,21 @@ class DataParallelContext:
         if self.distributed:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
+
+    def distinct_devices(self):
+        """Number of DIFFERENT physical GPUs behind the ranks of the group (by PCI domain / bus / device id), or None when it
+        cannot be told.  bench.py refuses a multi-rank measurement whose ranks share a GPU."""
+        if not self.distributed or self.device.type != 'cuda':
+            return 1
+        try:
+            pr = torch.cuda.get_device_properties(self.device)
+            mine = [int(pr.pci_domain_id), int(pr.pci_bus_id), int(pr.pci_device_id)]
+            t = torch.tensor(mine, dtype=torch.int64, device=self.device)
+            got = [torch.empty_like(t) for _ in range(self.world_size)]
+            dist.all_gather(got, t)
+            return len({tuple(g.tolist()) for g in got})
+        except Exception:
+            return None
 
     def shutdown(self):
         if self.owns_group and dist.is_initialized():

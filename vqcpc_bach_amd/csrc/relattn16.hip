@@ -166,7 +166,7 @@ __device__ __forceinline__ float grp16_max(float v) {
 }
 
 // =====================================================================================================================
-// X6 (head_dim 32): q . k and q . Erel on the bf16 matrix pipe as six products of the exact 3-way split
+// X6 (head_dim 32 / 64): q . k and q . Erel on the bf16 matrix pipe as (up to) six products of the exact 3-way split
 template <int HD, bool B16 = false, bool IN16 = false, bool X6 = false>      // B16: `ctx` points to bf16 elements (ldo in elements); IN16: `qkv` too
 __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const float* __restrict__ qkv, int64_t ldq,
                                                                        const int64_t* __restrict__ tokens,
@@ -192,18 +192,52 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_fwd_kernel(const flo
     load_vec<KH, IN16>(qa, qkv, ro, scale);
     load_vec<KH, IN16>(kb, qkv, ro + d, 1.0f);
     floatx4 s = {0.f, 0.f, 0.f, 0.f};
-    if constexpr (X6 && HD == 32) {
-        bf16x8 qh, qm, ql, kh_, km, kl;
-        split8x3(qa, qh, qm, ql);
-        split8x3(kb, kh_, km, kl);
-        s = dot32_x6(qh, qm, ql, kh_, km, kl, s);
+    if constexpr (X6 && (HD == 32 || HD == 64)) {
+        // head_dim 64: a lane holds 16 contraction elements = two chunks of 8 (columns 16 g + 8 ch ..): chunk ch of every lane
+        // is one K = 32 MFMA block (the k index is a summation index: any assignment shared by both operands is valid).
+        // bf16 INPUTS (IN16) are single pieces: k always, q when the scale 1 / sqrt(head_dim) is a power of two (head_dim 64:
+        // q / 8 is a bf16 number): q . k is then ONE exact bf16 MFMA per chunk, q . Erel three (Erel is fp32).
+        constexpr int NCH = KH / 8;
+        constexpr bool Q1 = IN16 && HD == 64, K1 = IN16;
+        bf16x8 qh[NCH], qm[NCH], ql[NCH];
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            float q8[8], k8[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { q8[k] = qa[8 * ch + k]; k8[k] = kb[8 * ch + k]; }
+            bf16x8 kh_, km, kl;
+            split8x3(q8, qh[ch], qm[ch], ql[ch]);
+            split8x3(k8, kh_, km, kl);
+            if constexpr (Q1 && K1) {
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[ch], kh_, s, 0, 0, 0);
+            } else if constexpr (K1) {                  // q: three pieces, k: one
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ql[ch], kh_, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qm[ch], kh_, s, 0, 0, 0);
+                s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[ch], kh_, s, 0, 0, 0);
+            } else {
+                s = dot32_x6(qh[ch], qm[ch], ql[ch], kh_, km, kl, s);
+            }
+        }
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             float eb[KH];
             load_f4<KH>(eb, erel16(e1, e2, h, HD, 16 * t + c) + g * KH, 1.0f);
-            bf16x8 eh, em, el;
-            split8x3(eb, eh, em, el);
-            const floatx4 qe = dot32_x6(qh, qm, ql, eh, em, el, floatx4{0.f, 0.f, 0.f, 0.f});
+            floatx4 qe = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ch = 0; ch < NCH; ++ch) {
+                float e8[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) e8[k] = eb[8 * ch + k];
+                bf16x8 eh, em, el;
+                split8x3(e8, eh, em, el);
+                if constexpr (Q1) {                     // q: one piece, Erel: three
+                    qe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[ch], el, qe, 0, 0, 0);
+                    qe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[ch], em, qe, 0, 0, 0);
+                    qe = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qh[ch], eh, qe, 0, 0, 0);
+                } else {
+                    qe = dot32_x6(qh[ch], qm[ch], ql[ch], eh, em, el, qe);
+                }
+            }
 #pragma unroll
             for (int r = 0; r < 4; ++r) buf[(4 * g + r) * kA16RS + 16 * t + c] = qe[r];
         }
@@ -445,8 +479,8 @@ static int a16_fwd_t(const float* qkv, int64_t ldq, const int64_t* tokens, const
                      int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
     const int64_t total = n_blocks * H;
     static const int x6 = lab_env_int("VQCPC_RELATTN16_X6", 1);      // lab builds: =0 keeps the fp32-MFMA contractions (A/B)
-    if (HD == 32 && x6) {
-        hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16, IN16, HD == 32>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64),
+    if ((HD == 32 || HD == 64) && x6) {
+        hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16, IN16, (HD == 32 || HD == 64)>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64),
                            0, s, qkv, ldq, tokens, e1, e2, ctx, ldo, probs, total, H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                            1.0f / (1.0f - drop_p), seed);
         VQ_CHECK_LAUNCH("relattn16_fwd (x6)");

@@ -68,6 +68,13 @@ __global__ __launch_bounds__(kDThreads, 2) void gemm_nt_x6_dma_kernel(const floa
     const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int S = my_tiles * T;                                    // length of this workgroup's K-tile stream
 
+    // measurement (VQCPC_GEMM_STAGGER, carried in ep.split_plane which this kernel does not use): the persistent workgroups
+    // start 8 phases apart -- phase (blockIdx.x >> 3) & 7, `stagger` x 1024 cycles each -- so that their tile boundaries (the
+    // output-store bursts) are spread over a tile period instead of coinciding chip-wide
+    if (ep.split_plane > 0) {
+        const int n_ = (((int)blockIdx.x >> 3) & 7) * (int)ep.split_plane;
+        for (int i = 0; i < n_; ++i) __builtin_amdgcn_s_sleep(16);
+    }
     floatx16 acc[4][2];
 #pragma unroll
     for (int a = 0; a < 4; ++a)
@@ -358,6 +365,10 @@ int gemm_nt_dma_launch(const float* A, int64_t lda, const float* B, int64_t ldb,
     const int tiles = (int)((M / kD) * tn);
     const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kDThreads);
     static const int abl = lab_env_int("VQCPC_GEMM_ABL", 0);   // ablation builds (tools only)
+    static const int stagger = lab_env_int("VQCPC_GEMM_STAGGER", 0);
+    EpiParams ep_st = ep;
+    ep_st.split_plane = stagger;
+#define ep ep_st
 #define D_LAUNCH(EPIV)                                                                                                \
     {                                                                                                                 \
         static bool attr_done = false;                                                                                \
@@ -399,6 +410,7 @@ int gemm_nt_dma_launch(const float* A, int64_t lda, const float* B, int64_t ldb,
         default: break;
     }
 #undef D_LAUNCH
+#undef ep
     set_error("gemm_nt_dma: unsupported epilogue %d", flags);
     return VQCPC_EINVAL;
 }

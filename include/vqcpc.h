@@ -143,6 +143,15 @@ int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, floa
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                   float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream);
 int64_t vqcpc_gemm_tn_workspace(int64_t M, int N, int K);
+/* Deferred reduction of the weight-gradient partial sums: vqcpc_gemm_tn / vqcpc_gemm_tn_bf16 with accumulate == 2 leave their
+ * `splits` partial sums in the workspace (dW partials at float offset s * N * K, db partials at splits * N * K + s * N) and
+ * vqcpc_reduce_grouped_vec sums many such products in ONE launch (at the end of a backward pass: 17 launches less per CPC step),
+ * with the per-element arithmetic of the immediate reduction.  *_deferred_splits returns the split count, or 0 when the product
+ * is too small for the float4 reduction (then reduce immediately). */
+int vqcpc_gemm_tn_deferred_splits(int64_t M, int N, int K);
+int vqcpc_gemm_tn_bf16_deferred_splits(int64_t M, int N, int K);
+int vqcpc_reduce_grouped_vec(int n, const void* const* ws, const int64_t* stride, const int* nsplit, void* const* out,
+                             const int64_t* count, int accumulate, void* stream);
 int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
                   int accumulate, void* workspace, int64_t workspace_bytes, void* stream);
 /* Grouped weight gradients: n independent products dW_i (+)= A_i^T B_i, db_i (+)= column sums of A_i in a few launches (32

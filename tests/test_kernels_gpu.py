@@ -1765,3 +1765,38 @@ def test_gemm_tn_quad_row_lds_image_is_bit_identical_to_the_row_pair_image(ops, 
     ref = a.double().t() @ b.double()
     assert rel_err(res['1'][0].cpu(), ref.cpu()) < 3e-6
     assert rel_err(res['1'][1].cpu(), a.double().sum(0).cpu()) < 3e-6
+
+
+@pytest.mark.parametrize('mode', [1, 8])
+def test_deferred_grouped_reduction_of_weight_gradient_partials_is_bit_identical(ops, mode):
+    """Inside a trainer's gradient scope the partial sums of the LARGE weight gradients stay in their workspaces and ONE
+    vqcpc_reduce_grouped_vec launch sums them when the scope closes (ops.DEFER_TN_REDUCTIONS): same bits as the reduction each
+    product would have run on its own -- also for a gradient buffer that receives two products (accumulation order = issue order)
+    and next to a small product that keeps its immediate reduction."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    shapes = [(65536, 768, 256), (65536, 256, 256), (32768, 256, 1024), (4096, 64, 64)]
+    hip.set_gemm_mode(mode)
+    try:
+        res = {}
+        for defer in (False, True):
+            ops.DEFER_TN_REDUCTIONS = defer
+            outs = []
+            gen.manual_seed(5)
+            with ops.direct_weight_gradients():
+                for M, N, K in shapes:
+                    a, b = torch.randn(M, N, device='cuda', generator=gen), torch.randn(M, K, device='cuda', generator=gen)
+                    dw, db = torch.full((N, K), 0.5, device='cuda'), torch.full((N,), -1.0, device='cuda')
+                    tn = ops.gemm_tn_bf16 if (mode == 8 and hip.query('vqcpc_gemm_tn_bf16_supported', M, N, K)) else ops.gemm_tn
+                    tn(a, b, into=(dw, db))
+                    if N == 768:                     # a second product into the same buffers
+                        tn(b.new_ones(M, N), b, into=(dw, db))
+                    outs += [dw, db]
+                pending = len(ops._PENDING_VEC_REDUCTIONS)
+            assert (pending > 0) == defer and not ops._PENDING_VEC_REDUCTIONS
+            res[defer] = [o.clone() for o in outs]
+        for x, y in zip(res[False], res[True]):
+            assert torch.equal(x, y)
+    finally:
+        ops.DEFER_TN_REDUCTIONS = False
+        hip.set_gemm_mode(0)

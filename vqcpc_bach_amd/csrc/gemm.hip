@@ -2458,7 +2458,19 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         hipLaunchKernelGGL(gemm_tn_kernel<false>, dim3(tiles, splits), dim3(kGemmThreads), 0, s, A, lda, B, ldb, M, N, K,
                            tiles_k, rows_per_split, ws, ws_bias);
     VQ_CHECK_LAUNCH("gemm_tn");
+    if (accumulate == 2) return VQCPC_OK;       // partial sums stay in `workspace` (vqcpc_gemm_tn_deferred_splits): the caller reduces
     return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
+}
+
+// Deferred reduction (accumulate == 2): vqcpc_gemm_tn leaves its `splits` partial sums in the workspace -- dW partials at
+// float offset s * N * K, db partials at splits * N * K + s * N -- for ONE vqcpc_reduce_grouped_vec launch over many products
+// at the end of a backward pass.  Returns that split count, or 0 when the immediate reduction would not take the float4 kernel
+// (small products): only then is the deferred result bit-identical to the immediate one.
+int vqcpc_gemm_tn_deferred_splits(int64_t M, int N, int K) {
+    if (M < 1 || N < 4 || K < 4 || (N % 4) || (K % 4)) return 0;
+    const bool use256 = gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && tn_can_use_256(M, N, K);
+    const int splits = use256 ? tn_splits_256(M, N, K) : tn_splits(M, N, K);
+    return ((int64_t)N * K >= (1 << 16) && splits <= 64) ? splits : 0;
 }
 
 

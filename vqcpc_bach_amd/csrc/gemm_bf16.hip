@@ -1039,6 +1039,7 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
         hipLaunchKernelGGL(gemm_tn_bf16_tr_kernel, dim3((N / kB) * tkr, splits), dim3(kBThreads), kTRLds, s, (const bf16_t*)A, lda,
                            (const bf16_t*)B, ldb, M, N, K, tkr, rps, ws, ws_bias);
         VQ_CHECK_LAUNCH("gemm_tn_bf16_tr");
+        if (accumulate == 2) return VQCPC_OK;       // deferred reduction: see vqcpc_gemm_tn_bf16_deferred_splits
         return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
     }
     const int64_t rows_per_split = round_up(ceil_div(M, splits), 2 * kTBM);
@@ -1051,7 +1052,15 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     hipLaunchKernelGGL(gemm_tn_bf16_kernel, dim3((N / kB) * tk2, splits), dim3(kBThreads), 2 * kTBBuf, s, (const bf16_t*)A, lda,
                        (const bf16_t*)B, ldb, M, N, K, tk2, rows_per_split, ws, ws_bias);
     VQ_CHECK_LAUNCH("gemm_tn_bf16");
+    if (accumulate == 2) return VQCPC_OK;
     return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
+}
+
+// as vqcpc_gemm_tn_deferred_splits, for vqcpc_gemm_tn_bf16 (accumulate == 2 leaves the partial sums in the workspace)
+int vqcpc_gemm_tn_bf16_deferred_splits(int64_t M, int N, int K) {
+    if (!vqcpc_gemm_tn_bf16_supported(M, N, K)) return 0;
+    const int splits = tn_bf16_splits(M, N, K);
+    return ((int64_t)N * K >= (1 << 16) && splits <= 64) ? splits : 0;
 }
 
 }  // extern "C"

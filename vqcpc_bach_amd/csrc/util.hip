@@ -177,6 +177,43 @@ __global__ __launch_bounds__(kRedCols * kRedGroups) void reduce_many_kernel(cons
     }
 }
 
+// The float4 form for many LARGE segments in one launch (the weight-gradient partial sums of a whole backward pass, deferred to
+// its end): per column group the arithmetic of reduce_splits_vec_kernel, so a deferred reduction gives the bits of the
+// immediate one.  Segment p owns workgroups [blk_begin[p], blk_begin[p + 1]).
+__global__ __launch_bounds__(kRedVecThreads) void reduce_many_vec_kernel(const RedManyArgs g) {
+    const int b = (int)blockIdx.x;
+    int p = 0;
+    for (int i = 1; i < g.n; ++i) p += (b >= g.blk_begin[i]) ? 1 : 0;
+    p = __builtin_amdgcn_readfirstlane(p);
+    const int64_t q = (int64_t)(b - g.blk_begin[p]) * kRedVecThreads + threadIdx.x;      // float4 index inside the segment
+    if (q * 4 >= g.count[p]) return;
+    const float4* ptr = reinterpret_cast<const float4*>(g.ws[p]) + q;
+    const int64_t st4 = g.stride[p] / 4;
+    const int nsplit = g.nsplit[p];
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#define RV_ADD(X, Y) make_float4(X.x + Y.x, X.y + Y.y, X.z + Y.z, X.w + Y.w)
+    int s = 0;
+    for (; s + 7 < nsplit; s += 8) {
+        const float4 v0 = ptr[(s + 0) * st4], v1 = ptr[(s + 1) * st4], v2 = ptr[(s + 2) * st4], v3 = ptr[(s + 3) * st4];
+        const float4 v4 = ptr[(s + 4) * st4], v5 = ptr[(s + 5) * st4], v6 = ptr[(s + 6) * st4], v7 = ptr[(s + 7) * st4];
+        const float4 a = RV_ADD(v0, v1), bb = RV_ADD(v2, v3), c = RV_ADD(v4, v5), d = RV_ADD(v6, v7);
+        const float4 ab = RV_ADD(a, bb), cd = RV_ADD(c, d);
+        const float4 t = RV_ADD(ab, cd);
+        acc = RV_ADD(acc, t);
+    }
+    for (; s < nsplit; ++s) {
+        const float4 v = ptr[s * st4];
+        acc = RV_ADD(acc, v);
+    }
+    float4* o = reinterpret_cast<float4*>(g.out[p]) + q;
+    if (g.accumulate) {
+        const float4 prev = *o;
+        acc = RV_ADD(prev, acc);
+    }
+#undef RV_ADD
+    *o = acc;
+}
+
 int launch_reduce_splits(const float* ws, int64_t stride, int nsplit, float* out, int64_t count, int accumulate,
                          hipStream_t stream) {
     return launch_reduce_splits2(ws, stride, nsplit, out, count, nullptr, 0, nullptr, 0, accumulate, stream);
@@ -681,6 +718,46 @@ int vqcpc_count_distinct_codes(const int64_t* idx_a, int64_t rows_a, const int64
     hipLaunchKernelGGL(count_distinct_codes_kernel, dim3(1), dim3(kCountThreads), (size_t)words * 4, (hipStream_t)stream, idx_a,
                        rows_a, idx_b, rows_b, num_codebooks, codebook_size, words, out);
     VQ_CHECK_LAUNCH("count_distinct_codes");
+    return VQCPC_OK;
+}
+
+int vqcpc_reduce_grouped_vec(int n, const void* const* ws, const int64_t* stride, const int* nsplit, void* const* out,
+                             const int64_t* count, int accumulate, void* stream) {
+    if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(n > 0 && ws && stride && nsplit && out && count, "reduce_grouped_vec: null pointer");
+    for (int i = 0; i < n; ++i)
+        VQ_REQUIRE(ws[i] && out[i] && nsplit[i] >= 1 && count[i] >= 4 && count[i] % 4 == 0 && stride[i] % 4 == 0 &&
+                       stride[i] >= count[i] && stride[i] < (1ll << 31) && count[i] < (1ll << 31) && aligned16(ws[i]) &&
+                       aligned16(out[i]),
+                   "reduce_grouped_vec: bad segment %d (counts and strides multiples of 4, 16-byte aligned)", i);
+    hipStream_t s = (hipStream_t)stream;
+    int i = 0;
+    while (i < n) {
+        RedManyArgs g;
+        int c = 0, rb = 0;
+        while (i < n && c < kRedMany) {
+            bool dup = false;                      // a repeated output waits for the next launch (stream-ordered accumulation)
+            for (int j = 0; j < c; ++j) dup = dup || g.out[j] == (float*)out[i];
+            if (dup) break;
+            g.ws[c] = (const float*)ws[i];
+            g.out[c] = (float*)out[i];
+            g.stride[c] = (int)stride[i];
+            g.nsplit[c] = nsplit[i];
+            g.count[c] = (int)count[i];
+            g.blk_begin[c] = rb;
+            rb += (int)ceil_div(count[i] / 4, (int64_t)kRedVecThreads);
+            ++c;
+            ++i;
+        }
+        for (int j = c; j <= kRedMany; ++j) g.blk_begin[j] = rb;
+        for (int j = c; j < kRedMany; ++j) {
+            g.ws[j] = nullptr; g.out[j] = nullptr; g.stride[j] = g.nsplit[j] = g.count[j] = 0;
+        }
+        g.n = c;
+        g.accumulate = accumulate;
+        hipLaunchKernelGGL(reduce_many_vec_kernel, dim3((unsigned)rb), dim3(kRedVecThreads), 0, s, g);
+        VQ_CHECK_LAUNCH("reduce_grouped_vec");
+    }
     return VQCPC_OK;
 }
 

@@ -108,6 +108,9 @@ SIGNATURES = {
     'vqcpc_add_layernorm_bwd_workspace': (c_i64, [c_i64, c_int]),
     'vqcpc_add_layernorm_bwd_partials': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_reduce_grouped': (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
+    'vqcpc_reduce_grouped_vec': (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),
+    'vqcpc_gemm_tn_deferred_splits': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_tn_bf16_deferred_splits': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_add_layernorm_bwd': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                         c_i64, c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
     'vqcpc_vq_fwd': (c_int, [c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_f32, c_int, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),

@@ -151,11 +151,31 @@ def gemm_tn(a, b, want_bias=True, into=None):
         return dw, db
     nbytes = hip.query('vqcpc_gemm_tn_workspace', M, N, K)
     ws = hip.workspace(nbytes, a.device)
+    if into is not None and _DIRECT_WGRAD and DEFER_TN_REDUCTIONS:
+        # inside a trainer's backward pass the partial sums of the LARGE weight gradients stay in their workspaces and are
+        # reduced by ONE grouped launch when the pass ends (flush_reductions): one launch instead of one per weight
+        splits = hip.query('vqcpc_gemm_tn_deferred_splits', M, N, K)
+        if splits:
+            hip.call('vqcpc_gemm_tn', a, lda, b, ldb, dw, db, M, N, K, 2, ws, nbytes)
+            _defer_tn_reduction(ws, splits, N, K, dw, db)
+            return dw, db
     hip.call('vqcpc_gemm_tn', a, lda, b, ldb, dw, db, M, N, K, 0 if into is None else 1, ws, nbytes)
     return dw, db
 
 
 GROUP_WGRADS = os.environ.get('VQCPC_GROUP_WGRADS', '1') != '0'      # A/B switch: grouped launches of the small weight gradients
+# opt-in (VQCPC_DEFER_TN_REDUCE=1): ONE grouped reduction of the large weight gradients' partial sums at the end of backward instead
+# of one per product.  Bit-identical, 16 launches less per CPC step -- and no faster (27.34 / 27.43 vs 27.36 / 27.39 ms per step at
+# C1, profiles/r04_perf_log.md): the deferred pass reads 270 MB of partials back from HBM that the immediate ones find in the L2 /
+# MALL, which costs what the launches saved.  Off by default.
+DEFER_TN_REDUCTIONS = os.environ.get('VQCPC_DEFER_TN_REDUCE', '0') == '1'
+_PENDING_VEC_REDUCTIONS = []   # (workspace tensor, byte offset, stride, nsplit, out tensor, count): float4 form (large segments)
+
+
+def _defer_tn_reduction(ws, splits, N, K, dw, db):
+    _PENDING_VEC_REDUCTIONS.append((ws, 0, N * K, splits, dw, N * K))
+    if db is not None:
+        _PENDING_VEC_REDUCTIONS.append((ws, 4 * splits * N * K, N, splits, db, N))
 LAST_TN_DEFERRED = False
 _PENDING_WGRADS = []           # (a, lda, b, ldb, dw, db, M, N, K): operands stay alive until the flush
 
@@ -180,14 +200,15 @@ def defer_ln_param_grads(ws, M, d, gamma, beta, has_r):
 
 def flush_reductions():
     import ctypes
-    items = list(_PENDING_REDUCTIONS)
-    _PENDING_REDUCTIONS.clear()
-    if not items:
-        return
-    n = len(items)
-    vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
-    hip.call('vqcpc_reduce_grouped', n, vp(*[it[0].data_ptr() + it[1] for it in items]), i64(*[it[2] for it in items]),
-             i32(*[it[3] for it in items]), vp(*[it[4].data_ptr() for it in items]), i64(*[it[5] for it in items]), 1)
+    for pending, entry in ((_PENDING_VEC_REDUCTIONS, 'vqcpc_reduce_grouped_vec'), (_PENDING_REDUCTIONS, 'vqcpc_reduce_grouped')):
+        items = list(pending)
+        pending.clear()
+        if not items:
+            continue
+        n = len(items)
+        vp, i64, i32 = ctypes.c_void_p * n, ctypes.c_int64 * n, ctypes.c_int * n
+        hip.call(entry, n, vp(*[it[0].data_ptr() + it[1] for it in items]), i64(*[it[2] for it in items]),
+                 i32(*[it[3] for it in items]), vp(*[it[4].data_ptr() for it in items]), i64(*[it[5] for it in items]), 1)
 
 
 def pending_wgrad_flops():
@@ -333,6 +354,12 @@ def gemm_tn_bf16(a, b, want_bias=True, into=None):
         db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
     nbytes = hip.query('vqcpc_gemm_tn_bf16_workspace', M, N, K)
     ws = hip.workspace(nbytes, a.device)
+    if into is not None and _DIRECT_WGRAD and DEFER_TN_REDUCTIONS:
+        splits = hip.query('vqcpc_gemm_tn_bf16_deferred_splits', M, N, K)
+        if splits:
+            hip.call('vqcpc_gemm_tn_bf16', a, N, b, K, dw, db, M, N, K, 2, ws, nbytes)
+            _defer_tn_reduction(ws, splits, N, K, dw, db)
+            return dw, db
     hip.call('vqcpc_gemm_tn_bf16', a, N, b, K, dw, db, M, N, K, 0 if into is None else 1, ws, nbytes)
     return dw, db
 
@@ -374,6 +401,7 @@ class direct_weight_gradients:
             else:
                 _PENDING_WGRADS.clear()
                 _PENDING_REDUCTIONS.clear()
+                _PENDING_VEC_REDUCTIONS.clear()
         finally:
             hip.gradient_scope(False)
             WEIGHT_T.end()

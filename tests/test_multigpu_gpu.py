@@ -139,7 +139,7 @@ def test_two_ranks_share_this_gpu_over_gloo(tmp_path):
 
 def test_student_step_bucketed_all_reduce_two_ranks_share_this_gpu(tmp_path):
     """StudentEncoderTrainer under data parallelism (BASELINE configs[3] with several ranks): the teacher's gradient range is
-    all-reduced asynchronously while the encoder / decoder half runs, the rest afterwards (VQCPC_DP_BUCKETS=1: one call).
+    all-reduced asynchronously while the encoder / decoder half runs, the rest afterwards (opt-in: VQCPC_DP_BUCKETS=2; the default is one call).
     Two ranks on this GPU over gloo: the bucketed gradients equal the single-call gradients bit for bit, replicas stay
     bit-identical through eager steps and through replays of the three-graph step, and the trajectories agree."""
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_SHARE_GPU='1', VQCPC_DP_BACKEND='gloo',

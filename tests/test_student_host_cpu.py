@@ -112,3 +112,48 @@ def test_additive_attention_masks_are_recognised_as_index_rules():
     with pytest.raises(NotImplementedError):
         classify_additive_mask(torch.full((4, 4), -1.0))
     assert mask_code('causal') == ops.MASK_CAUSAL and mask_code(None) == ops.MASK_NONE
+    # masks freed and rebuilt per forward (as the reference does) land at recycled addresses with equal version counters:
+    # the remembered class must belong to the tensor object, not to its address (round-4 advisor finding)
+    for it in range(12):
+        sq = square_subsequent(64)
+        m = sq if it % 2 == 0 else sq.t().contiguous()
+        want = ops.MASK_CAUSAL if it % 2 == 0 else ops.MASK_ANTICAUSAL
+        assert classify_additive_mask(m) == want and classify_additive_mask(m) == want
+        del m, sq
+    kept = square_subsequent(8)
+    assert classify_additive_mask(kept) == ops.MASK_CAUSAL
+    kept.copy_(square_subsequent(8).t())                            # in-place rewrite bumps the version: read again
+    assert classify_additive_mask(kept) == ops.MASK_ANTICAUSAL
+
+
+def test_manual_seed_reaches_trainers_that_have_already_stepped():
+    """utils.DropoutSeeds: a trainer forks its own seed stream at its first step; SEEDS.manual_seed() afterwards bumps a
+    generation counter, so the trainer forks again at its next step (round-4 advisor finding: re-seeding between two runs of
+    one trainer object silently lost reproducibility); seed_dropout() / restore_dropout_stream() pin one trainer."""
+    from vqcpc_bach_amd.utils import DropoutSeeds
+    from vqcpc_bach_amd.graphs import GraphedTraining
+
+    class Owner(GraphedTraining):
+        pass
+
+    def draw(seeds, owner, n=3):
+        with seeds.stream_of(owner) as s:
+            return [s.next() for _ in range(n)]
+
+    seeds, a = DropoutSeeds(), Owner()
+    seeds.manual_seed(7)
+    first = draw(seeds, a) + draw(seeds, a)
+    seeds.manual_seed(7)
+    assert draw(seeds, a) + draw(seeds, a) == first, 'manual_seed must reach a trainer that has already stepped'
+    b = Owner()
+    seeds.manual_seed(7)
+    assert draw(seeds, b) + draw(seeds, b) == first
+    draw(seeds, a)                                    # (re-forks a under the current generation)
+    state = a.dropout_stream_state()                  # checkpointed next to the optimiser state
+    nxt = draw(seeds, a)
+    c = Owner()
+    c.restore_dropout_stream(state)
+    seeds.manual_seed(99)                             # a restored / explicitly seeded stream is not re-forked
+    assert draw(seeds, c) == nxt
+    a.seed_dropout(7)
+    assert draw(seeds, a) + draw(seeds, a) == first

@@ -1027,9 +1027,11 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     float* ws = (float*)workspace;
     float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
     hipStream_t s = (hipStream_t)stream;
-    if (g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && lda < (1 << 20) && ldb < (1 << 20)) {
-        // transposed-read kernel: splits of whole 128-row pairs of slots
-        const int64_t rps = round_up(ceil_div(M, splits), 2 * kTRRows);
+    // transposed-read kernel: splits of whole 128-row pairs of slots.  Its DMA offsets (row within the split) * ld * 2 are
+    // 32-bit against a 2 GB buffer resource based at the split's first row: taken only when a split's rows fit that range
+    const int64_t rps = round_up(ceil_div(M, splits), 2 * kTRRows);
+    if (g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && lda < (1 << 20) && ldb < (1 << 20) &&
+        (rps + 2 * kTRRows) * std::max(lda, ldb) * 2 < ((int64_t)1 << 31)) {
         static bool attr_tr = false;
         if (!attr_tr) {
             (void)hipFuncSetAttribute((const void*)gemm_tn_bf16_tr_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, kTRLds);

@@ -479,7 +479,9 @@ static int a16_fwd_t(const float* qkv, int64_t ldq, const int64_t* tokens, const
                      int64_t ldo, float* probs, int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s) {
     const int64_t total = n_blocks * H;
     static const int x6 = lab_env_int("VQCPC_RELATTN16_X6", 1);      // lab builds: =0 keeps the fp32-MFMA contractions (A/B)
-    if ((HD == 32 || HD == 64) && x6) {
+    // GEMM mode 0 is documented as the exact fp32-MFMA arithmetic (include/vqcpc.h): there the contractions over head_dim
+    // stay on v_mfma_f32_16x16x4_f32 too; the six-product bf16 form belongs to the bf16x6 / bf16 modes
+    if ((HD == 32 || HD == 64) && x6 && vqcpc_gemm_get_mode() != 0) {
         hipLaunchKernelGGL((relattn16_fwd_kernel<HD, B16, IN16, (HD == 32 || HD == 64)>), dim3((unsigned)ceil_div(total, kA16Waves)), dim3(kA16Waves * 64),
                            0, s, qkv, ldq, tokens, e1, e2, ctx, ldo, probs, total, H, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                            1.0f / (1.0f - drop_p), seed);

@@ -186,6 +186,7 @@ class Decoder(GraphedTraining, nn.Module):
             self.optimizer.v.copy_(st['v'])
             self.optimizer.step_count = int(st['step'])
             self.global_step = int(st['global_step'])
+            self.restore_dropout_stream(st.get('dropout_stream'))
         self._resume_state = None
 
     def current_lr(self):
@@ -201,7 +202,7 @@ class Decoder(GraphedTraining, nn.Module):
         torch.save(self.state_dict(), f'{model_dir}/decoder')
         if self.optimizer is not None:       # extension: the reference restarts Adam on every resume
             torch.save(dict(m=self.optimizer.m, v=self.optimizer.v, step=self.optimizer.step_count,
-                            global_step=self.global_step), f'{model_dir}/decoder_optimizer')
+                            global_step=self.global_step, dropout_stream=self.dropout_stream_state()), f'{model_dir}/decoder_optimizer')
 
     def load(self, early_stopped, device):
         print(f'Loading models {self.__repr__()}')

@@ -188,7 +188,16 @@ class GraphedTraining:
     def seed_dropout(self, base):
         """Re-seeds THIS trainer's dropout-seed stream (utils.DropoutSeeds.stream_of): the per-trainer counterpart of
         SEEDS.manual_seed(), which only reaches trainers that have not taken a step yet."""
-        self._dropout_stream = (int(base) & 0xFFFFFFFF, 0)
+        self._dropout_stream = (int(base) & 0xFFFFFFFF, 0)      # two fields: immune to SEEDS.manual_seed() generations
+
+    def dropout_stream_state(self):
+        """(base, counter) of this trainer's dropout-seed stream, for checkpoints (None before the first step)."""
+        st = getattr(self, '_dropout_stream', None)
+        return None if st is None else (int(st[0]), int(st[1]))
+
+    def restore_dropout_stream(self, state):
+        if state is not None:
+            self._dropout_stream = (int(state[0]) & 0xFFFFFFFF, int(state[1]))
 
     def enable_step_graph(self, enabled=True):
         self._graph_on = bool(enabled)

@@ -91,6 +91,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
                 opt.m.copy_(m[a:b])
                 opt.v.copy_(v[a:b])
             self.global_step = int(st['global_step'])
+            self.restore_dropout_stream(st.get('dropout_stream'))
             self._resume_state = None
 
     def current_lr(self):
@@ -114,7 +115,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         if self.optimizer_teacher is not None:      # extension: the reference drops optimiser state on resume
             opts = (self.optimizer_teacher,) + self.optimizer_enc_dec
             torch.save(dict(m=torch.cat([o.m for o in opts]), v=torch.cat([o.v for o in opts]),
-                            step=self.optimizer_teacher.step_count, global_step=self.global_step),
+                            step=self.optimizer_teacher.step_count, global_step=self.global_step, dropout_stream=self.dropout_stream_state()),
                        f'{model_dir}/optimizer')
 
     def load(self, early_stopped, device):
@@ -239,7 +240,11 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         if self._dp_bucketed():
             out = self._step_compute_teacher(tensor_dict, masked_event_index)
             self._all_reduce_teacher_async()
-            out = self._step_compute_encdec(out)
+            try:
+                out = self._step_compute_encdec(out)
+            except BaseException:
+                self._join_teacher_work()     # never leave the asynchronous collective dangling behind an exception
+                raise
             self._all_reduce_encdec_and_join()
             return self._step_apply(out)
         out = self._step_compute(tensor_dict, masked_event_index)
@@ -253,13 +258,18 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
     # the step is  [teacher forward + backward]  ->  all-reduce(teacher range), asynchronously on RCCL's own stream  ->
     # [encoder / decoder forward + backward, under that collective]  ->  all-reduce(rest), join  ->  clip + Adam.
     # Price: the two halves no longer fill the GPU side by side on two streams (compute_losses' overlap_streams).
-    # VQCPC_DP_BUCKETS=1 keeps the single all-reduce.  UNMEASURED: no multi-GPU node was available to the builder; on the
+    # OPT-IN (VQCPC_DP_BUCKETS=2); the default is the single all-reduce.  UNMEASURED: no multi-GPU node was available to the
+    # builder, so the form that has never met RCCL on two physical GPUs is not what a distributed run gets by default; on the
     # two-ranks-on-one-GPU harness (gloo) the replicas stay bit-identical and equal the single-call form's gradients.
     def _dp_bucketed(self):
-        return self.dp is not None and self.dp.distributed and os.environ.get('VQCPC_DP_BUCKETS', '2') != '1'
+        return self.dp is not None and self.dp.distributed and os.environ.get('VQCPC_DP_BUCKETS', '1') == '2'
+
+    _teacher_range_cache = None
 
     def _teacher_range(self):
-        return self.flat.range_of(self.teacher)
+        if self._teacher_range_cache is None or self._teacher_range_cache[0] is not self.flat:
+            self._teacher_range_cache = (self.flat, self.flat.range_of(self.teacher))   # once per flat buffer, not per step
+        return self._teacher_range_cache[1]
 
     def _step_compute_teacher(self, tensor_dict, masked_event_index=None):
         m = self._graph_m if masked_event_index is None else masked_event_index
@@ -292,12 +302,18 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         import torch.distributed as dist
         a, b = self._teacher_range()
         g = self.flat.flat_grad
-        if a > 0:
-            dist.all_reduce(g[:a], op=dist.ReduceOp.SUM)
-        if b < g.numel():
-            dist.all_reduce(g[b:], op=dist.ReduceOp.SUM)
-        self._teacher_work.wait()             # the current stream waits for the collective (no host block with RCCL)
-        self._teacher_work = None
+        try:
+            if a > 0:
+                dist.all_reduce(g[:a], op=dist.ReduceOp.SUM)
+            if b < g.numel():
+                dist.all_reduce(g[b:], op=dist.ReduceOp.SUM)
+        finally:
+            self._join_teacher_work()
+
+    def _join_teacher_work(self):
+        work, self._teacher_work = getattr(self, '_teacher_work', None), None
+        if work is not None:
+            work.wait()                       # the current stream waits for the collective (no host block with RCCL)
 
     def _dp_stages(self, parts):
         if self._dp_bucketed():

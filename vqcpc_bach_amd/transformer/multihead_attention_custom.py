@@ -9,23 +9,21 @@ from torch import nn
 from .subsampled_relative_attention import SubsampledRelativeAttention
 
 
-_MASK_CLASS_CACHE = {}
-
-
 def classify_additive_mask(attn_mask):
     """The additive (T, S) masks the reference builds (decoders/decoder.py:294-308: 0 = keep, -inf = masked; T = r S, every
     source position repeated r times along the target axis) -> the index rule the attention kernels evaluate:
     ops.MASK_CAUSAL keeps j <= i // r, ops.MASK_ANTICAUSAL keeps j >= i // r, an all-zero mask is ops.MASK_NONE.
     Entries <= -1e4 count as masked (the finite "large negative" masks of user code: exp(-1e4 - max) == 0 in fp32).
     Any other pattern raises NotImplementedError (the reference never builds one on the path).
-    One small host read per DISTINCT mask: the class is cached on (storage pointer, version counter, shape, strides)."""
+    One small host read per mask OBJECT and content version: the class is remembered on the tensor object itself (it dies
+    with the tensor; an address-keyed cache would hand a freed mask's class to whatever the allocator puts there next) next
+    to the in-place version counter it was computed at, so a mask rebuilt per forward -- as the reference does -- is read
+    again and a mask kept by the caller is read once."""
     from .. import ops
     assert attn_mask.dim() == 2, 'attn_mask: (target length, source length)'
-    key = (attn_mask.data_ptr(), attn_mask._version, tuple(attn_mask.shape), tuple(attn_mask.stride()), attn_mask.dtype,
-           str(attn_mask.device))
-    hit = _MASK_CLASS_CACHE.get(key)
-    if hit is not None:
-        return hit
+    hit = getattr(attn_mask, '_vqcpc_mask_class', None)
+    if hit is not None and hit[0] == attn_mask._version:
+        return hit[1]
     T, S = attn_mask.shape
     m = attn_mask.detach().to('cpu', torch.float32)
     keep = m == 0
@@ -43,9 +41,7 @@ def classify_additive_mask(attn_mask):
             cls = ops.MASK_ANTICAUSAL
     if cls is None:
         raise NotImplementedError('attn_mask: not the causal / anticausal pattern of decoders/decoder.py:294-308')
-    if len(_MASK_CLASS_CACHE) > 64:
-        _MASK_CLASS_CACHE.clear()
-    _MASK_CLASS_CACHE[key] = cls
+    attn_mask._vqcpc_mask_class = (attn_mask._version, cls)
     return cls
 
 

@@ -9,6 +9,7 @@ class DropoutSeeds:
     def __init__(self, base=0x5EED):
         self.base = int(base) & 0xFFFFFFFF
         self.counter = 0
+        self.generation = 0         # bumped by manual_seed(): invalidates every trainer's forked stream
         self.rank_salt = 0          # set once per process by the trainers' init_optimizers (data-parallel rank)
 
     def set_rank(self, rank):
@@ -17,8 +18,13 @@ class DropoutSeeds:
         self.rank_salt = (int(rank) * 0x9E3779B1) & 0xFFFFFFFF
 
     def manual_seed(self, base):
+        """Re-seeds the process-wide source AND every trainer: a trainer that has already stepped re-forks its stream from
+        the new (base, counter) at its next step (as if it were taking its first), so `SEEDS.manual_seed(s)` between two
+        runs of one trainer object reproduces the masks of the first run.  (`trainer.seed_dropout(base)` re-seeds one
+        trainer only.)"""
         self.base = int(base) & 0xFFFFFFFF
         self.counter = 0
+        self.generation += 1
 
     def next(self):
         self.counter += 1
@@ -39,14 +45,16 @@ class _OwnedStream:
     def __enter__(self):
         s, st = self.seeds, getattr(self.owner, '_dropout_stream', None)
         self.outer = (s.base, s.counter)
+        if st is not None and len(st) > 2 and st[2] != s.generation:
+            st = None                                # SEEDS.manual_seed() since this stream was forked: fork again
         if st is None:
             st = (s.base, s.counter)
-        s.base, s.counter = st
+        s.base, s.counter = st[0], st[1]
         return s
 
     def __exit__(self, *exc):
         s = self.seeds
-        self.owner._dropout_stream = (s.base, s.counter)
+        self.owner._dropout_stream = (s.base, s.counter, s.generation)
         s.base, s.counter = self.outer
         return False
 

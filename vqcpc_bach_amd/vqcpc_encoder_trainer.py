@@ -103,6 +103,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         self.optimizer.v.copy_(st['v'])
         self.optimizer.step_count = int(st['step'])
         self.global_step = int(st['global_step'])
+        self.restore_dropout_stream(st.get('dropout_stream'))
         self._resume_state = None
 
     def current_lr(self):
@@ -128,7 +129,8 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
             torch.save(self.fks_module_back.state_dict(), f'{model_dir}/fks_module_back')
         if self.optimizer is not None:       # extension: the reference drops optimiser state on resume
             torch.save(dict(m=self.optimizer.m, v=self.optimizer.v, step=self.optimizer.step_count,
-                            global_step=self.global_step), f'{model_dir}/optimizer')
+                            global_step=self.global_step, dropout_stream=self.dropout_stream_state()),
+                       f'{model_dir}/optimizer')
 
     def load(self, early_stopped, device):
         print(f'Loading models {self.__repr__()}')

@@ -139,6 +139,30 @@ int vqcpc_gemm_get_mode(void);
 int vqcpc_gemm_set_gradient_products(int products);
 int vqcpc_gemm_get_gradient_products(void);
 int vqcpc_gemm_gradient_scope(int open);
+/* Gradient GEMMs on THREE fp16 MFMAs per product at fp32-class accuracy (round 5; csrc/gemm_grad.hip) -- the dgrad / wgrad of
+ * torch.autograd's backward of F.linear (vqcpc_encoder_trainer.py:311-313 `loss.backward()`, transformer_custom.py:279-289,
+ * multihead_attention_custom.py:171,346) for the 256 x 256-tile shapes.  Each operand element x of a tensor with the
+ * power-of-two scale s is carried as h = rtz_f16(x s) (saturating) and m = rn_f16(x s - h): |x s - h - m| <= 2^-21 |x s|, a
+ * product is hh + hm + mh on v_mfma_f32_32x32x16_f16 with fp32 accumulation, the result is multiplied by 2^-(eA + eB).
+ * Explicit entry points, no process-wide switch: the caller chooses them for its backward pass; the forward pass never does.
+ * `scale_state`: 4 floats per CALL SITE, caller-owned device memory: [0] / [1] = amax |A| / |B| of the PREVIOUS step (read:
+ * the scale maps it into [2^12, 2^13)), [2] / [3] = amax of THIS call's operands (atomic max by the kernel; zero them before).
+ * vqcpc_grad_scale_roll(state, nsites) moves [2], [3] -> [0], [1] (sites that ran) and zeroes [2], [3] for `nsites`
+ * consecutive sites: once per step; vqcpc_grad_amax primes [0] / [1] of a site on its first use (atomic max of |x| into *slot).
+ * vqcpc_gemm_nt_grad: C = epilogue(A . B^T) with epilogue none | + add | + add + add2 | gate-bit mask * gate_scale (the forms
+ *   of the input-gradient GEMMs); M, N multiples of 256, K of 32 (persistent over the tiles: the caller cuts ragged rounds).
+ * vqcpc_gemm_tn_grad: dW = A^T . B (+ db = column sums of A, fp32 exact), as vqcpc_gemm_tn (accumulate 0 | 1); N, K multiples
+ *   of 256, M of 32. */
+int vqcpc_gemm_nt_grad_supported(int64_t M, int N, int K);
+int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                       const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, const void* gate_mask,
+                       float gate_scale, float* scale_state, void* stream);
+int vqcpc_gemm_tn_grad_supported(int64_t M, int N, int K);
+int64_t vqcpc_gemm_tn_grad_workspace(int64_t M, int N, int K);
+int vqcpc_gemm_tn_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
+                       int accumulate, void* workspace, int64_t workspace_bytes, float* scale_state, void* stream);
+int vqcpc_grad_amax(const float* x, int64_t ld, int64_t rows, int cols, float* amax_slot, void* stream);
+int vqcpc_grad_scale_roll(float* state, int nsites, void* stream);
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                   float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream);

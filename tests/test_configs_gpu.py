@@ -211,6 +211,30 @@ def test_c1_model_dimensions_with_three_product_gradient_arithmetic(gemm_mode):
         hip.set_gradient_products(6)
 
 
+@pytest.mark.parametrize('cfg_name,B', [('C1', 8), ('C4', 4)])
+def test_model_dimensions_with_f16x3_gradient_arithmetic(gemm_mode, cfg_name, B):
+    """ops.set_gradient_arithmetic('f16x3') (csrc/gemm_grad.hip: two fp16 planes per operand under a per-tensor power-of-two
+    scale, three MFMAs per product): the forward is untouched -- indices bit-exact, losses within 5e-5 -- and every parameter
+    gradient stays within the UNCHANGED 5e-4 of the oracle's, at the model dimensions of configs[1] / configs[4] with every
+    eligible dgrad / wgrad forced through the new kernels (the tile-count thresholds only say where they are faster)."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('an arithmetic of the bf16x6 mode')
+    from vqcpc_bach_amd import hip, ops
+    calls, raw = [], hip.call
+    prev = ops.set_gradient_arithmetic('f16x3')
+    saved = ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS
+    ops.GRAD_MIN_TILES = ops.GRAD_TN_MIN_ROWS = 0
+    hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+    try:
+        _step_vs_oracle(O.make_cfg(cfg_name, B=B), seed=31, trainer_backward=True)
+    finally:
+        hip.call = raw
+        ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS = saved
+        ops.set_gradient_arithmetic(prev)
+    assert calls.count('vqcpc_gemm_nt_grad') >= 10 and calls.count('vqcpc_gemm_tn_grad') >= 10, (
+        calls.count('vqcpc_gemm_nt_grad'), calls.count('vqcpc_gemm_tn_grad'))
+
+
 def test_c4_model_dimensions_vs_oracle():
     """configs[4] at B = 4: 1088 blocks of 16 tokens through 4 + 4 layers at d_model 512, 4 x 1024 codes."""
     cfg = O.make_cfg('C4', B=4)

@@ -1693,6 +1693,189 @@ def test_three_product_gradient_arithmetic(ops, bf16x6, kind, M, N, K, epi):
     assert float((three.double() - ref).abs().max() / ref.abs().max()) < 2e-5
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# f16x3 gradient arithmetic (round 5, csrc/gemm_grad.hip): two fp16 planes per operand under a per-tensor power-of-two scale
+# ----------------------------------------------------------------------------------------------------------------
+def _grad_state(a, b, stale=1.0):
+    from vqcpc_bach_amd import hip
+    st = torch.zeros(4, device='cuda')
+    hip.call('vqcpc_grad_amax', a, a.stride(0), a.shape[0], a.shape[1], st[0:1])
+    hip.call('vqcpc_grad_amax', b, b.stride(0), b.shape[0], b.shape[1], st[1:2])
+    if stale != 1.0:
+        st[0] *= stale
+    return st
+
+
+def _nt_grad(a, b, st, add=None, add2=None, mask=None, gate_scale=1.0):
+    from vqcpc_bach_amd import hip
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, device='cuda')
+    hip.call('vqcpc_gemm_nt_grad', a, a.stride(0), b, b.stride(0), out, N, M, N, K, add, 0 if add is None else add.stride(0), add2,
+             0 if add2 is None else add2.stride(0), mask, float(gate_scale), st)
+    return out
+
+
+def _rms(x, ref):
+    return float((x.double() - ref).pow(2).mean().sqrt() / ref.pow(2).mean().sqrt())
+
+
+@pytest.mark.parametrize('M,N,K,scale_a,scale_b', [(2048, 256, 64, 1.0, 1.0), (65536, 256, 1024, 1e-5, 0.05), (8192, 1024, 256, 3e-8, 1.0),
+                                                    (512, 512, 32, 1e3, 1e-3)])
+def test_f16x3_input_gradient_gemm_vs_fp64(ops, bf16x6, M, N, K, scale_a, scale_b):
+    """vqcpc_gemm_nt_grad against an fp64 product: fp32-class (rms <= 1e-6 of the result's rms, within 2 x of the exact fp32 MFMA
+    kernel's own error) for operands of any magnitude -- the per-tensor power-of-two scale makes the arithmetic scale free --,
+    deterministic, and the kernel reports the operands' amax (what the next step's scale is taken from)."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn(M, K, device='cuda', generator=gen) * scale_a
+    b = torch.randn(N, K, device='cuda', generator=gen) * scale_b
+    ref = a.double() @ b.double().t()
+    st = _grad_state(a, b)
+    out = _nt_grad(a, b, st)
+    assert torch.equal(out, _nt_grad(a, b, st)), 'deterministic'
+    torch.cuda.synchronize()
+    assert float(st[2]) == float(a.abs().max()) and float(st[3]) == float(b.abs().max()), st
+    hip.set_gemm_mode(0)
+    try:
+        e32 = _rms(ops.gemm_nt(a, b), ref)
+    finally:
+        hip.set_gemm_mode(1)
+    e = _rms(out, ref)
+    assert e < 1e-6 and e < 2.0 * e32 + 1e-7, (e, e32)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 3e-6
+    # the scale may lag: a previous-step amax 8 x smaller or 1000 x larger than this step's changes nothing / little
+    for stale, tol in ((0.125, 1e-6), (1024.0, 1e-6), (2.0 ** 18, 2e-4)):
+        assert _rms(_nt_grad(a, b, _grad_state(a, b, stale)), ref) < tol, stale
+    # roll: this step's amax becomes the next step's scale, the written slots are cleared
+    hip.call('vqcpc_grad_scale_roll', st, 1)
+    torch.cuda.synchronize()
+    assert float(st[0]) == float(a.abs().max()) and float(st[2]) == 0.0 and float(st[3]) == 0.0
+
+
+def test_f16x3_saturates_instead_of_overflowing(ops, bf16x6):
+    """A tensor that grew beyond the head-room of its previous-step scale: the largest elements saturate at 65504 / scale -- the
+    result stays finite (no inf - inf) and is exact again once the scale has followed (one roll later); a NaN operand element
+    stays visible."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    a = torch.randn(1024, 256, device='cuda', generator=gen) * 1e-4
+    b = torch.randn(256, 256, device='cuda', generator=gen) * 0.05
+    ref = a.double() @ b.double().t()
+    for stale in (1 / 64, 1 / 4096, 0.0):
+        st = _grad_state(a, b, stale)
+        out = _nt_grad(a, b, st)
+        assert bool(torch.isfinite(out).all()), stale
+        hip.call('vqcpc_grad_scale_roll', st, 1)                    # the kernel saw the true amax
+        assert _rms(_nt_grad(a, b, st), ref) < 1e-6
+    a2 = a.clone()
+    a2[5, 7] = float('nan')
+    out = _nt_grad(a2, b, _grad_state(a, b))
+    assert bool(torch.isnan(out[5]).all()) and bool(torch.isfinite(out[6]).all())
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 1024, 256), (2048, 256, 512)])
+def test_f16x3_input_gradient_epilogues(ops, bf16x6, M, N, K):
+    """The epilogue forms of the input-gradient GEMMs -- + residual, + two residuals, relu / dropout gate as a bit mask --
+    against the six-product kernels' (both fp32-class: they differ by rounding noise only; the gate's zero pattern is equal)."""
+    gen = torch.Generator(device='cuda').manual_seed(M + K)
+    a = torch.randn(M, K, device='cuda', generator=gen) * 1e-3
+    b = torch.randn(N, K, device='cuda', generator=gen) * 0.05
+    add = torch.randn(M, N, device='cuda', generator=gen) * 1e-4
+    add2 = torch.randn(M, N, device='cuda', generator=gen) * 1e-4
+    st = _grad_state(a, b)
+    for kw in ({}, dict(add=add), dict(add=add, add2=add2)):
+        six = ops.gemm_nt(a, b, **kw)
+        assert float((six - _nt_grad(a, b, st, **kw)).abs().max() / six.abs().max()) < 3e-6, list(kw)
+    h, mask = ops.gemm_nt_relu_mask(torch.randn(M, K, device='cuda', generator=gen), torch.randn(N, K, device='cuda', generator=gen),
+                                    torch.zeros(N, device='cuda'))
+    six = ops.gemm_nt_gatebits(a, b, mask, gate_scale=1.25)
+    g3 = _nt_grad(a, b, st, mask=mask, gate_scale=1.25)
+    assert torch.equal(six == 0, g3 == 0) and float((six - g3).abs().max() / six.abs().max()) < 3e-6
+    assert bool(((h > 0) == (g3 != 0)).float().mean() > 0.999)
+
+
+@pytest.mark.parametrize('M,N,K,scale_a', [(4096, 256, 256, 1.0), (131072, 256, 256, 1e-6), (65536, 1024, 256, 1e-4), (1056, 256, 512, 1.0)])
+def test_f16x3_weight_gradient_gemm_vs_fp64(ops, bf16x6, M, N, K, scale_a):
+    """vqcpc_gemm_tn_grad: dW = A^T B within the fp32 class of an fp64 product (the contraction over 10^5 rows carries fp32
+    accumulation noise, as the fp32 MFMA kernel's does), db = column sums of A in exact fp32 arithmetic, accumulation into an
+    existing gradient (accumulate = 1), amax of both operands reported."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M + N)
+    a = torch.randn(M, N, device='cuda', generator=gen) * scale_a
+    b = torch.randn(M, K, device='cuda', generator=gen)
+    ref, ref_b = a.double().t() @ b.double(), a.double().sum(0)
+    st = _grad_state(a, b)
+    nb = hip.query('vqcpc_gemm_tn_grad_workspace', M, N, K)
+    ws = hip.workspace(nb, a.device)
+    dw, db = torch.empty(N, K, device='cuda'), torch.empty(N, device='cuda')
+    hip.call('vqcpc_gemm_tn_grad', a, N, b, K, dw, db, M, N, K, 0, ws, nb, st)
+    torch.cuda.synchronize()
+    assert float(st[2]) == float(a.abs().max()) and float(st[3]) == float(b.abs().max())
+    hip.set_gemm_mode(0)
+    try:
+        e32 = _rms(ops.gemm_tn(a, b, want_bias=False)[0], ref)
+    finally:
+        hip.set_gemm_mode(1)
+    e = _rms(dw, ref)
+    assert e < 1.5e-6 and e < 2.0 * e32 + 1e-7, (e, e32)
+    assert _rms(db, ref_b) < 1e-6
+    base_w, base_b = torch.randn(N, K, device='cuda', generator=gen) * scale_a, torch.randn(N, device='cuda', generator=gen) * scale_a
+    acc_w, acc_b = base_w.clone(), base_b.clone()
+    hip.call('vqcpc_gemm_tn_grad', a, N, b, K, acc_w, acc_b, M, N, K, 1, ws, nb, st)
+    assert float((acc_w - (base_w + dw)).abs().max()) <= 1e-6 * float(dw.abs().max())
+    assert float((acc_b - (base_b + db)).abs().max()) <= 1e-6 * float(db.abs().max())
+
+
+def test_f16x3_arithmetic_is_taken_inside_a_backward_scope_only(ops, bf16x6):
+    """ops.set_gradient_arithmetic('f16x3'): gemm_nt / gemm_nt_gatebits / gemm_tn(into=...) inside ops.direct_weight_gradients(flat)
+    go through vqcpc_gemm_nt_grad / _tn_grad with one scale site each (in call order, primed on first use, rolled when the scope
+    closes); outside a scope, and for the forward's epilogues, nothing changes; a ragged last round of tiles is cut by rows."""
+    from vqcpc_bach_amd import hip
+
+    class Flat:                                    # stands in for parallel.FlatParameters
+        flat = torch.zeros(4, device='cuda')
+
+    gen = torch.Generator(device='cuda').manual_seed(9)
+    M, N, K = 2048 + 128, 256, 512
+    a, b = torch.randn(M, K, device='cuda', generator=gen) * 1e-3, torch.randn(N, K, device='cuda', generator=gen) * 0.1
+    ga, xb = torch.randn(4096, 256, device='cuda', generator=gen) * 1e-3, torch.randn(4096, 512, device='cuda', generator=gen)
+    six = ops.gemm_nt(a, b)
+    six_w = ops.gemm_tn(ga, xb)
+    calls, raw = [], hip.call
+    prev = ops.set_gradient_arithmetic('f16x3')
+    saved = ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS
+    ops.GRAD_MIN_TILES = ops.GRAD_TN_MIN_ROWS = 0
+    try:
+        assert torch.equal(ops.gemm_nt(a, b), six), 'outside a backward scope: the six-product kernels'
+        owner = Flat()
+        hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+        for step in range(2):
+            calls.clear()
+            with ops.direct_weight_gradients(owner):
+                g3 = ops.gemm_nt(a, b)
+                fwd_like = ops.gemm_nt(a, b, bias=torch.zeros(N, device='cuda'))        # a bias epilogue is not a gradient GEMM
+                dw = torch.zeros(256, 512, device='cuda')
+                dbias = torch.zeros(256, device='cuda')
+                ops.gemm_tn(ga, xb, into=(dw, dbias))
+            tab = owner._grad_scales[None]
+            assert tab.keys == [('nt', M, N, K), ('tn', 4096, 256, 512)]
+            assert calls.count('vqcpc_gemm_nt_grad') == 1 and calls.count('vqcpc_gemm_tn_grad') == 1
+            assert calls.count('vqcpc_grad_amax') == (4 if step == 0 else 0), 'primed once'
+            assert calls.count('vqcpc_grad_scale_roll') == 1
+            assert calls.count('vqcpc_gemm_nt') == 2, 'the 128 ragged rows + the bias GEMM'
+            assert torch.equal(fwd_like, six)
+            assert not torch.equal(g3, six) and float((g3 - six).abs().max() / six.abs().max()) < 3e-6
+            assert float((dw - six_w[0]).abs().max() / six_w[0].abs().max()) < 3e-6
+            assert float((dbias - six_w[1]).abs().max() / six_w[1].abs().max()) < 3e-6
+            torch.cuda.synchronize()
+            assert float(tab.state[0]) == float(a[:2048].abs().max()) and float(tab.state[2]) == 0.0
+    finally:
+        hip.call = raw
+        ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS = saved
+        ops.set_gradient_arithmetic(prev)
+
+
 def test_gru_fused_steps_equal_the_gemm_plus_gate_launches(ops):
     """vqcpc_gru_step_fwd / _bwd (one launch per time step) against the same layer run as GEMM + gate launches: same values
     up to the summation order of the fp32 recurrent product (both are exact-fp32 MFMA chains, split differently)."""

@@ -5,6 +5,12 @@ from vqcpc_bach_amd import hip, ops
 hip.load(); hip.set_gemm_mode(int(os.environ.get('VQCPC_ONE_GEMM_MODE', '1')))
 M, N, K = 557056, int(sys.argv[1]), int(sys.argv[2])
 a = torch.randn(M, K, device='cuda'); b = torch.randn(N, K, device='cuda'); bias = torch.randn(N, device='cuda'); out = torch.empty(M, N, device='cuda')
+grad = int(os.environ.get('VQCPC_ONE_GEMM_GRAD', '0'))     # 3: the opt-in three-product gradient arithmetic (no bias epilogue)
+if grad:
+    hip.set_gradient_products(grad); hip.gradient_scope(True)
 for _ in range(6):
-    ops.gemm_nt(a, b, bias=bias, out=out)
+    if grad:
+        ops.gemm_nt(a, b, out=out)
+    else:
+        ops.gemm_nt(a, b, bias=None if os.environ.get('VQCPC_ONE_GEMM_NOBIAS') else bias, out=out)
 torch.cuda.synchronize()

@@ -5,6 +5,9 @@ from vqcpc_bach_amd import hip, ops
 hip.load(); hip.set_gemm_mode(int(os.environ.get('VQCPC_TN_MODE', '1')))
 M, N, K = 557056, int(sys.argv[1]), int(sys.argv[2])
 a = torch.randn(M, N, device='cuda'); b = torch.randn(M, K, device='cuda')
+grad = int(os.environ.get('VQCPC_ONE_GEMM_GRAD', '0'))
+if grad:
+    hip.set_gradient_products(grad); hip.gradient_scope(True)
 for _ in range(6):
     ops.gemm_tn(a, b)
 torch.cuda.synchronize()

@@ -20,7 +20,15 @@ def run(script, args, env_extra, match, counters):
         for row in csv.DictReader(open(f)):
             if any(m in row['Kernel_Name'] for m in match):
                 tot[row['Counter_Name']] += float(row['Counter_Value']); n[row['Counter_Name']] += 1
-    return {k: tot[k] / n[k] for k in tot}
+    dur = []
+    for f in glob.glob(d + '/**/*kernel_trace.csv', recursive=True):
+        for row in csv.DictReader(open(f)):
+            if any(m in row['Kernel_Name'] for m in match):
+                dur.append((float(row['End_Timestamp']) - float(row['Start_Timestamp'])) / 1e3)
+    res = {k: tot[k] / n[k] for k in tot}
+    if dur:
+        res['kernel_us(profiled pass)'] = sum(dur) / len(dur)
+    return res
 
 
 def main():
@@ -32,13 +40,28 @@ def main():
         cases = [('NT 557056 x 256 x 1024', 'one_gemm.py', [256, 1024], {'VQCPC_ONE_GEMM_MODE': '1'}, ['gemm_nt_x6_'], 544.0),
                  ('NT 557056 x 1024 x 256', 'one_gemm.py', [1024, 256], {'VQCPC_ONE_GEMM_MODE': '1'}, ['gemm_nt_x6_'], 544.0),
                  ('NT 1024 x 256, no stores (ABL 32)', 'one_gemm.py', [1024, 256], {'VQCPC_ONE_GEMM_MODE': '1', 'VQCPC_PP_ABL': '32'}, ['gemm_nt_x6_'], 544.0)]
+    if os.environ.get('PMC_COMPARE') == 'grad':     # six-product against three-product (gradient arithmetic) kernels, round 5
+        g3 = {'VQCPC_ONE_GEMM_MODE': '1', 'VQCPC_ONE_GEMM_GRAD': '3'}
+        g6 = {'VQCPC_ONE_GEMM_MODE': '1', 'VQCPC_ONE_GEMM_NOBIAS': '1'}
+        cases = [('NT 256x1024 six', 'one_gemm.py', [256, 1024], g6, ['gemm_nt_x6_'], 544.0),
+                 ('NT 256x1024 three', 'one_gemm.py', [256, 1024], g3, ['gemm_nt_x6_'], 544.0),
+                 ('NT 1024x256 six', 'one_gemm.py', [1024, 256], g6, ['gemm_nt_x6_'], 544.0),
+                 ('NT 1024x256 three', 'one_gemm.py', [1024, 256], g3, ['gemm_nt_x6_'], 544.0),
+                 ('TN 1024x256 six', 'one_gemm_tn.py', [1024, 256], {'VQCPC_TN_MODE': '1'}, ['gemm_tn_x6_p'], M / 16.0 * 4 / 256.0),
+                 ('TN 1024x256 three', 'one_gemm_tn.py', [1024, 256], {'VQCPC_TN_MODE': '1', 'VQCPC_ONE_GEMM_GRAD': '3'}, ['gemm_tn_x6_p'], M / 16.0 * 4 / 256.0)]
+    if os.environ.get('PMC_COMPARE') == 'g3':       # the software-pipelined fp16 three-product kernels (csrc/gemm_grad.hip), round 5
+        g3 = {'VQCPC_ONE_GEMM_MODE': '1', 'VQCPC_ONE_GEMM_GRAD': '3'}
+        cases = [('NT 256x1024 bf16x3 pp', 'one_gemm.py', [256, 1024], g3, ['gemm_nt_x6_'], 544.0),
+                 ('NT 256x1024 f16x3 g3', 'one_gemm_g3.py', ['nt', 256, 1024], {}, ['gemm_nt_g3'], 544.0),
+                 ('NT 1024x256 f16x3 g3', 'one_gemm_g3.py', ['nt', 1024, 256], {}, ['gemm_nt_g3'], 544.0),
+                 ('TN 1024x256 f16x3 g3', 'one_gemm_g3.py', ['tn', 1024, 256], {}, ['gemm_tn_g3'], M / 16.0 * 4 / 256.0)]
     res = {}
     for label, script, args, env, match, steps_per_wg in cases:
         r = {}
         for g in GROUPS:
             r.update(run(script, args, env, match, g))
         res[label] = (r, steps_per_wg)
-    names = [c for g in GROUPS for c in g]
+    names = [c for g in GROUPS for c in g] + ['kernel_us(profiled pass)']
     out.write(f'{"counter (per launch)":32s}' + ''.join(f'{l:>28s}' for l in res) + '   | per wave and K step (2048 waves):' + '\n')
     for c in names:
         line = f'{c:32s}'

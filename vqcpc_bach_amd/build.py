@@ -21,7 +21,7 @@ OBJ = os.path.join(CSRC, '_obj')
 LIB = os.path.join(HERE, 'libvqcpc_hip.so')
 LAB_OBJ = os.path.join(CSRC, '_obj_lab')
 LAB_LIB = os.path.join(HERE, 'libvqcpc_hip_lab.so')
-SOURCES = ['util.hip', 'vq.hip', 'nce.hip', 'embed_ln.hip', 'relattn.hip', 'relattn_sub.hip', 'relattn16.hip', 'relattn_x.hip', 'gemm.hip', 'gemm_bf16.hip', 'student.hip', 'gru.hip']
+SOURCES = ['util.hip', 'vq.hip', 'nce.hip', 'embed_ln.hip', 'relattn.hip', 'relattn_sub.hip', 'relattn16.hip', 'relattn_x.hip', 'gemm.hip', 'gemm_bf16.hip', 'gemm_grad.hip', 'student.hip', 'gru.hip']
 LAB_SOURCES = ['gemm_dma.hip', 'gemm_planes.hip', 'gemm_sw.hip']      # measurement-only translation units
 # the VQ argmin must reproduce separately-rounded sub/mul/add: no FMA contraction in that file
 EXTRA = {'vq.hip': ['-ffp-contract=off']}

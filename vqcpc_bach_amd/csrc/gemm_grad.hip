@@ -1,0 +1,737 @@
+// Gradient GEMMs of the backward pass on THREE fp16 MFMAs per product (round 5): dgrad (NT) and wgrad (TN) of every large
+// linear layer -- vqcpc_encoder_trainer.py:311-313 (`loss.backward()`) through transformer_custom.py:279-289 and
+// multihead_attention_custom.py:171,346 -- at fp32-class accuracy with half the matrix instructions of the six-product
+// bf16 split the forward pass uses (gemm.hip).
+//
+// Arithmetic.  Each fp32 operand element x of a tensor with scale s = 2^e is carried as two fp16 planes
+//      h = rtz_f16(x s)             (v_cvt_pkrtz_f16_f32: 11 significant bits, saturating at +-65504, never inf)
+//      m = rn_f16(x s - h)          (v_fma_mixlo/hi_f16: the fp32 FMA x s - h is exact, one rounding to fp16)
+// so |x s - h - m| <= 2^-21 |x s| (fp16 subnormals are honoured by the converts and by the matrix pipe:
+// tools/micro/f16_probe.hip) and a product is  hh + hm + mh  on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped mm
+// term is < 2^-20 |ab| with mean 2^-22 |ab| (a relative bias of the RESULT, not of sum |ab|).  Measured against fp64:
+// rms 3-5e-7 of the result's rms, i.e. the class of an fp32 GEMM (fp32-MFMA kernel: 3-8e-7; bf16 pair planes: 4.4e-6).
+// The forward pass (losses, code assignment) never uses this arithmetic.
+//
+// Scales.  e is chosen per operand TENSOR so that its largest magnitude of the PREVIOUS step lands in [2^11, 2^12): four
+// binades of head-room (a tensor may grow 16 x from one step to the next and stay exact; beyond that its largest elements
+// saturate at 65504 / s, finite), 22-bit operands down to 2^-14 of the largest element, an absolute floor of 2^-36 of it below.  The kernels compute the operand's amax of THIS
+// step while they stage it (v_max3 on the raw registers, one atomic max per wave) and leave it for the next step: the caller
+// owns a 4-float state per GEMM call site {amax A, amax B (read), amax A, amax B (written)} and rolls it once per step
+// (vqcpc_grad_scale_roll); vqcpc_grad_amax primes a site on its first use.  Power-of-two scales are exact; the result is
+// multiplied by 2^-(eA + eB) in the epilogue.
+//
+// Schedule (both kernels): 256 x 256 output tile, 8 waves of 128 x 64, K steps of 16, 24 MFMAs per wave and step.  No phases:
+// every wave runs the same software pipeline -- MFMAs of step j, fragment reads of step j+1 (a ring of THREE 32 KB LDS slots),
+// split + LDS write of step j+2 from raw registers requested two steps earlier, request of step j+4 -- with ONE workgroup
+// barrier per step placed between the last writes of step j+2 and their first read.  The six-product kernels' ping-pong of a
+// "memory phase" and an "MFMA phase" is latency-bound once the MFMA phase is 768 cycles (profiles/r05_pmc_grad3_vs_six.txt:
+// a K step takes 2 990 cycles per wave for 768 of matrix work, 980 of them parked in s_waitcnt / s_barrier).
+#include <algorithm>
+#include <atomic>
+
+#include "gemm_common.h"
+
+namespace vq {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef __fp16 fp16x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int kG = 256;                      // tile edge
+constexpr int kGBK = 16;                     // contraction elements per step
+constexpr int kGThreads = 512;
+constexpr int kGPlane = kG * 32;             // NT: 256 rows x 16 fp16 = 8 KB per plane
+constexpr int kGSlot = 4 * kGPlane;          // A.h | A.m | B.h | B.m
+constexpr int kGSlots = 3;
+constexpr int kGTarget = 11;                 // amax of the previous step -> [2^11, 2^12): saturation 16-32 x above it
+
+// scale exponent of a tensor whose previous-step amax is `amax` (0 / denormal: the clamp; inf / nan: the other clamp)
+__device__ __forceinline__ int g3_scale_exp(float amax) {
+    const int E = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    return max(-60, min(60, (kGTarget + 127) - E));
+}
+__device__ __forceinline__ float g3_pow2(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
+
+// two fp32 -> (h, m) fp16 pairs, element 0 in the low half.  h = rtz_f16(x s) saturates at +-65504 by itself; the residual is
+// taken from x s clamped to the fp16 range (v_med3_f32), so an element beyond the head-room of a stale scale becomes +-65504
+// (h) + 0 (m) instead of an infinite m -- bounded, finite, and gone one step later when the scale has followed.  A NaN input
+// stays a NaN (through h: the clamp only feeds m).
+__device__ __forceinline__ void g3_split_pair(float a, float b, float s, uint32_t& h, uint32_t& m) {
+    const float xa = a * s, xb = b * s;
+    h = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_pkrtz(xa, xb));
+    const float ta = __builtin_amdgcn_fmed3f(xa, -65504.0f, 65504.0f), tb = __builtin_amdgcn_fmed3f(xb, -65504.0f, 65504.0f);
+    asm("v_fma_mixlo_f16 %0, %1, 1.0, -%2 op_sel:[0,0,0] op_sel_hi:[0,0,1]" : "=v"(m) : "v"(ta), "v"(h));
+    asm("v_fma_mixhi_f16 %0, %1, 1.0, -%2 op_sel:[0,0,1] op_sel_hi:[0,0,1]" : "+v"(m) : "v"(tb), "v"(h));
+}
+__device__ __forceinline__ void g3_amax4(const float4& v, float& amax) {
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.x), "v"(v.y));
+    asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(amax) : "v"(v.z), "v"(v.w));
+}
+__device__ __forceinline__ void g3_split4(const float4& v, float s, uint2& h, uint2& m) {
+    g3_split_pair(v.x, v.y, s, h.x, m.x);
+    g3_split_pair(v.z, v.w, s, h.y, m.y);
+}
+// amax of a wave -> one atomic max on the non-negative float's bit pattern (order independent: deterministic)
+__device__ __forceinline__ void g3_amax_publish(float amax, float* slot) {
+    amax = wave_max(amax);
+    if ((threadIdx.x & 63) == 0 && amax > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(amax));
+}
+
+// =====================================================================================================================
+// dgrad: C[M, N] = epilogue(A[M, K] . B[N, K]^T), A = output gradient rows, B = W^T rows (ops.transpose)
+// EPI in {0, E_ADD, E_ADD | E_ADD2, E_GATEBITS}
+// =====================================================================================================================
+// ABL (lab builds, VQCPC_G3_ABL; results are wrong by construction): 1 = no operand requests after the prologue, 2 = no split /
+// LDS stores after the prologue, 4 = no MFMAs, 8 = no output stores, 16 = no fragment reads after the prologue
+template <int EPI, int ABL = 0>
+__global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* __restrict__ A, int64_t lda,
+                                                                  const float* __restrict__ B, int64_t ldb,
+                                                                  float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
+                                                                  int tiles_n, int tiles, EpiParams ep,
+                                                                  float* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemg[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    const int T = K / kGBK;                              // steps per output tile (even: K % 32 == 0)
+    const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int S = my_tiles * T;                          // this workgroup's stream of steps (even)
+
+    const int ea = g3_scale_exp(state[0]), eb = g3_scale_exp(state[1]);
+    const float sa = g3_pow2(ea), sb = g3_pow2(eb), inv = g3_pow2(-(ea + eb));
+    float amax_a = 0.0f, amax_b = 0.0f;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+
+    // ---- load cursor: one call = the four 16-byte pieces of the NEXT step of the stream, in stream order ----
+    const int ld_row = (tid >> 8) * 128 + ((tid & 255) >> 2), ld_c4 = (tid & 3) * 4;
+    int ld_tile = blockIdx.x, ld_k = 0;
+    const float* a_src;
+    const float* b_src;
+#define G_SET_SRC()                                                         \
+    {                                                                       \
+        const int t_ = xcd_swizzle(min(ld_tile, tiles - 1), tiles);         \
+        a_src = A + ((int64_t)(t_ / tiles_n) * kG + ld_row) * lda + ld_c4;  \
+        b_src = B + ((int64_t)(t_ % tiles_n) * kG + ld_row) * ldb + ld_c4;  \
+        if (ABL & 32) {     /* timing only: whole 128-byte lines per request (8 lanes per row), same bytes per two steps */ \
+            a_src = A + ((int64_t)(t_ / tiles_n) * kG + (tid >> 3)) * lda + (tid & 7) * 4;  \
+            b_src = B + ((int64_t)(t_ % tiles_n) * kG + (tid >> 3)) * ldb + (tid & 7) * 4;  \
+        }                                                                   \
+    }
+    G_SET_SRC()
+    // the four pieces of a step are re-requested one by one (each right after it has been split), the cursor moves after the last
+#define G_LDK ((ABL & 32) ? (ld_k & ~16) : ld_k)
+#define G_OPAQUE(V) asm volatile("" : "+v"(V.x), "+v"(V.y), "+v"(V.z), "+v"(V.w));
+#define G_LD_A0(S_) if (!(ABL & 1) || !in_loop) { S_##a0 = *reinterpret_cast<const float4*>(a_src + G_LDK); } else { G_OPAQUE(S_##a0) }
+#define G_LD_A1(S_) if (!(ABL & 1) || !in_loop) { S_##a1 = *reinterpret_cast<const float4*>(a_src + (int64_t)64 * lda + G_LDK); } else { G_OPAQUE(S_##a1) }
+#define G_LD_B0(S_) if (!(ABL & 1) || !in_loop) { S_##b0 = *reinterpret_cast<const float4*>(b_src + G_LDK); } else { G_OPAQUE(S_##b0) }
+#define G_LD_B1(S_) if (!(ABL & 1) || !in_loop) { S_##b1 = *reinterpret_cast<const float4*>(b_src + (int64_t)64 * ldb + G_LDK); } else { G_OPAQUE(S_##b1) }
+#define G_ADVANCE()                                                         \
+    if (ABL & 32) {                                                         \
+        if (ld_k & 16) { a_src -= 128 * lda; b_src -= 128 * ldb; } else { a_src += 128 * lda; b_src += 128 * ldb; } \
+    }                                                                       \
+    ld_k += kGBK;                                                           \
+    if (ld_k == K) {                                                        \
+        ld_k = 0;                                                           \
+        ld_tile += gridDim.x;            /* past the end: re-reads the last tile, never used */ \
+        G_SET_SRC()                                                         \
+    }
+    float4 xa0, xa1, xb0, xb1, ya0, ya1, yb0, yb1;      // two raw sets: steps j+2 (being split) and j+3
+
+    // LDS image of a plane: unpadded 32-byte rows, the two 16-byte chunks of a row XOR-swizzled by bit 3 of the row (the image of
+    // gemm_nt_x6_pp_kernel: fragment reads and the staging stores are conflict free)
+#define G_ST(R, PLANE0, ROW, SC, AM, WB)                                                                     \
+    if (!(ABL & 2) || !in_loop) {                                                                            \
+        uint2 h_, m_;                                                                                        \
+        g3_amax4(R, AM);                                                                                     \
+        g3_split4(R, SC, h_, m_);                                                                            \
+        const int o_ = (ROW) * 32 + ((((ld_c4 >> 3) ^ ((ROW) >> 3)) & 1) << 4) + (ld_c4 & 7) * 2;            \
+        *reinterpret_cast<uint2*>((WB) + ((PLANE0) + 0) * kGPlane + o_) = h_;                                \
+        *reinterpret_cast<uint2*>((WB) + ((PLANE0) + 1) * kGPlane + o_) = m_;                                \
+    }
+    const int swz = ((kh ^ (li >> 3)) & 1) << 4;
+    const int a_off = (wm * 128 + li) * 32 + swz;
+    const int b_off = 2 * kGPlane + (wn * 64 + li) * 32 + swz;
+    half8 fa[2][2];                                      // [buffer][h | m]: row tile g of the step lives in buffer g & 1
+    half8 fb[2][2];                                      // [h | m][column tile]
+#define G_MFMA1(MT, NT, PA, PB) \
+    if (!(ABL & 4)) acc[MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[(MT) & 1][PA], fb[PB][NT], acc[MT][NT], 0, 0, 0); \
+    else { asm volatile("" : "+v"(fa[(MT) & 1][PA]), "+v"(fb[PB][NT])); }
+#define G_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define G_BARRIER()                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- epilogue of the output tile with linear index `ep_tile` (buffer addressing; the add operand one 32 x 32 tile ahead) ----
+    int ep_tile = blockIdx.x;
+    constexpr bool HAS_AUX = (EPI & E_ADD) != 0;
+    const int ldci = (int)ldc;
+    const int ldxi = (int)ep.ldadd;
+#define G_EPILOGUE()                                                                                                   \
+    {                                                                                                                  \
+        const int t_ = xcd_swizzle(ep_tile, tiles);                                                                    \
+        const int64_t m0 = (int64_t)(t_ / tiles_n) * kG;                                                               \
+        const int n0 = (t_ % tiles_n) * kG;                                                                            \
+        const __amdgpu_buffer_rsrc_t rc =                                                                              \
+            __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ldc + n0), 0, 0x7FFFFFFF, 0x00020000);                  \
+        const int voff_c = ((wm * 128 + 4 * kh) * ldci + wn * 64 + li) * 4;                                            \
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)(HAS_AUX ? ep.add + m0 * (int64_t)ldxi + n0 : C), 0, 0x7FFFFFFF, 0x00020000);                       \
+        const int voff_x = ((wm * 128 + 4 * kh) * ldxi + wn * 64 + li) * 4;                                            \
+        const int ldx2i = (int)ep.ldadd2;                                                                              \
+        const __amdgpu_buffer_rsrc_t rx2 = __builtin_amdgcn_make_buffer_rsrc(                                          \
+            (void*)((EPI & E_ADD2) ? ep.add2 + m0 * (int64_t)ldx2i + n0 : C), 0, 0x7FFFFFFF, 0x00020000);              \
+        const int voff_x2 = ((wm * 128 + 4 * kh) * ldx2i + wn * 64 + li) * 4;                                          \
+        float aux[2][16];                                                                                              \
+        if (HAS_AUX) {                                                                                                 \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) aux[0][r] = __builtin_bit_cast(                             \
+                float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff_x, (((r & 3) + 8 * (r >> 2)) * ldxi) * 4, 0));    \
+        }                                                                                                              \
+        const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(                                           \
+            (void*)((EPI & E_GATEBITS) ? (void*)ep.mask : (void*)C), 0, 0x7FFFFFFF, 0x00020000);                       \
+        const int nw16 = (N >> 5) * 16;                                   /* bytes of one 4-row group of mask words */  \
+        const int mrow4 = (int)((m0 + wm * 128) >> 2), mcb = (n0 >> 5) + wn * 2;                                       \
+        u32x4 gb[2][4];                                                                                                \
+        if (EPI & E_GATEBITS) {                                                                                        \
+            _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) gb[0][jj] = __builtin_bit_cast(u32x4,                     \
+                __builtin_amdgcn_raw_buffer_load_b128(rm, kh * nw16, ((mrow4 + 2 * jj) * (N >> 5) + mcb) * 16, 0));    \
+        }                                                                                                              \
+        const float gsc = (EPI & E_GATEBITS) ? inv * ep.gate_scale : inv;                                              \
+        _Pragma("unroll") for (int tile = 0; tile < 8; ++tile) {                                                       \
+            const int mt = tile >> 1, nt = tile & 1;                                                                   \
+            if ((EPI & E_GATEBITS) && tile + 1 < 8) {                                                                  \
+                const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;                                                 \
+                _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) gb[(tile + 1) & 1][jj] = __builtin_bit_cast(u32x4,    \
+                    __builtin_amdgcn_raw_buffer_load_b128(rm, kh * nw16,                                               \
+                        ((mrow4 + mt2 * 8 + 2 * jj) * (N >> 5) + mcb + nt2) * 16, 0));                                 \
+            }                                                                                                          \
+            if (HAS_AUX && tile + 1 < 8) {                                                                             \
+                const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;                                                 \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) aux[(tile + 1) & 1][r] = __builtin_bit_cast(            \
+                    float, __builtin_amdgcn_raw_buffer_load_b32(                                                       \
+                               rx, voff_x, ((mt2 * 32 + (r & 3) + 8 * (r >> 2)) * ldxi + nt2 * 32) * 4, 0));           \
+            }                                                                                                          \
+            float a2[16];                                                                                              \
+            if (EPI & E_ADD2) {                                                                                        \
+                _Pragma("unroll") for (int r = 0; r < 16; ++r) a2[r] = __builtin_bit_cast(                             \
+                    float, __builtin_amdgcn_raw_buffer_load_b32(                                                       \
+                               rx2, voff_x2, ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldx2i + nt * 32) * 4, 0));          \
+            }                                                                                                          \
+            _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
+                float v = acc[mt][nt][r] * gsc;              /* exact: a power of two (times the gate's 1 / (1 - p)) */ \
+                if (EPI & E_GATEBITS) v = ((gb[tile & 1][r >> 2][r & 3] >> li) & 1u) ? v : 0.0f;                      \
+                if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
+                if (EPI & E_ADD2) v += a2[r];                                                                          \
+                if (ABL & 8) { asm volatile("" :: "v"(v)); } else                                                      \
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
+                                                      ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
+                acc[mt][nt][r] = 0.0f;                                                                                 \
+            }                                                                                                          \
+        }                                                                                                              \
+        ep_tile += gridDim.x;                                                                                          \
+    }
+
+    // ---- one step j of the stream (RS = raw set holding step j+2) ----
+    // LDS ring of three slots: `cur` holds step j, `rd` step j+1, `wr` receives step j+2.  Registers: ONE set of B fragments
+    // and TWO A-fragment buffers (row tile g of the step in buffer g & 1) -- 32 fragment registers instead of the 72 of the
+    // six-product kernel -- refilled just in time: A tile g+1 while tile g multiplies (tile 0 of step j+1 during tile 3), the B
+    // column-tile-0 fragments of step j+1 after the step's last column-0 MFMA (the 21st), column tile 1 after the last MFMA.
+    // The two waves of a SIMD run this stream in near lockstep, so matrix work and everything else only overlap if they
+    // alternate INSIDE a wave (with whole 6-MFMA groups followed by the group's staging work the kernel took the SUM of its
+    // matrix time and its memory-side time, profiles/r05_g3_ablation_v1.log): every MFMA is followed by ONE small chunk of the
+    // step's other work, fenced so that hipcc keeps the placement:
+    //   behind MFMAs 0 1 | 3 4 | 6 7 | 9 10: split of elements 0-1 | 2-3 of the four 16-byte pieces of step j+2; behind 2 | 5 | 8 |
+    //   11: the piece's two ds_write_b64 and its re-request (step j+4);
+    //   behind 0 1 | 6 7 | 12 13: the A fragments of row tiles 1, 2, 3 of step j (plane m first: the next tile's first MFMA reads
+    //   it), four to six MFMAs before their first use; behind 18 19: row tile 0 of step j+1; behind 20 / 23 (the last MFMA of
+    //   column tile 0 / 1): the B fragments of step j+1;
+    //   behind MFMA 16: THE barrier of the step -- after the last store of step j+2 (11) and the last read of step j (13), before
+    //   the first read of step j+1 (18; it was stored during step j-1) and before the next step's first store, which lands in the
+    //   slot step j occupied.
+    uint2 ph, pm;
+#define G_P_XY(R, SC, AM)                                                                                    \
+    if (!(ABL & 2) || !in_loop) {                                                                            \
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(AM) : "v"(R.x), "v"(R.y));                                \
+        g3_split_pair(R.x, R.y, SC, ph.x, pm.x);                                                             \
+    }
+#define G_P_ZW(R, SC, AM)                                                                                    \
+    if (!(ABL & 2) || !in_loop) {                                                                            \
+        asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(AM) : "v"(R.z), "v"(R.w));                                \
+        g3_split_pair(R.z, R.w, SC, ph.y, pm.y);                                                             \
+    }
+#define G_P_WR(PLANE0, ROW, WB)                                                                              \
+    if (!(ABL & 2) || !in_loop) {                                                                            \
+        const int o_ = (ROW) * 32 + ((((ld_c4 >> 3) ^ ((ROW) >> 3)) & 1) << 4) + (ld_c4 & 7) * 2;            \
+        *reinterpret_cast<uint2*>((WB) + ((PLANE0) + 0) * kGPlane + o_) = ph;                                \
+        *reinterpret_cast<uint2*>((WB) + ((PLANE0) + 1) * kGPlane + o_) = pm;                                \
+    }
+    // A fragment (plane PC) of row tile MT -> buffer MT & 1
+#define G_RA(MT, PC, RB)                                                                                     \
+    if (!(ABL & 16) || !in_loop) fa[(MT) & 1][PC] = *reinterpret_cast<const half8*>((RB) + a_off + (PC) * kGPlane + (MT) * 32 * 32);
+    // both planes of the B fragment of column tile NT
+#define G_RB(NT, RB)                                                                                         \
+    if (!(ABL & 16) || !in_loop) {                                                                           \
+        fb[0][NT] = *reinterpret_cast<const half8*>((RB) + b_off + (NT) * 32 * 32);                          \
+        fb[1][NT] = *reinterpret_cast<const half8*>((RB) + b_off + kGPlane + (NT) * 32 * 32);                \
+    }
+#define G_S(MT, NT, PA, PB, ...) G_MFMA1(MT, NT, PA, PB) G_FENCE() __VA_ARGS__ G_FENCE()
+#define G_STEP(RS)                                                                                \
+    {                                                                                             \
+        unsigned char* const cur = smemg + sc * kGSlot;                                           \
+        unsigned char* const rd = smemg + sr * kGSlot;                                            \
+        unsigned char* const wr = smemg + sw * kGSlot;                                            \
+        G_S(0, 0, 1, 0, G_P_XY(RS##a0, sa, amax_a) G_RA(1, 1, cur))                               \
+        G_S(0, 0, 0, 1, G_P_ZW(RS##a0, sa, amax_a) G_RA(1, 0, cur))                               \
+        G_S(0, 0, 0, 0, G_P_WR(0, ld_row, wr) G_LD_A0(RS))                                        \
+        G_S(0, 1, 1, 0, G_P_XY(RS##a1, sa, amax_a))                                               \
+        G_S(0, 1, 0, 1, G_P_ZW(RS##a1, sa, amax_a))                                               \
+        G_S(0, 1, 0, 0, G_P_WR(0, ld_row + 64, wr) G_LD_A1(RS))                                   \
+        G_S(1, 0, 1, 0, G_P_XY(RS##b0, sb, amax_b) G_RA(2, 1, cur))                               \
+        G_S(1, 0, 0, 1, G_P_ZW(RS##b0, sb, amax_b) G_RA(2, 0, cur))                               \
+        G_S(1, 0, 0, 0, G_P_WR(2, ld_row, wr) G_LD_B0(RS))                                        \
+        G_S(1, 1, 1, 0, G_P_XY(RS##b1, sb, amax_b))                                               \
+        G_S(1, 1, 0, 1, G_P_ZW(RS##b1, sb, amax_b))                                               \
+        G_S(1, 1, 0, 0, G_P_WR(2, ld_row + 64, wr) G_LD_B1(RS) G_ADVANCE())                       \
+        G_S(2, 0, 1, 0, G_RA(3, 1, cur))                                                          \
+        G_S(2, 0, 0, 1, G_RA(3, 0, cur))                                                          \
+        G_S(2, 0, 0, 0, )                                                                         \
+        G_S(2, 1, 1, 0, )                                                                         \
+        G_MFMA1(2, 1, 0, 1)                                                                       \
+        G_BARRIER()                                                                               \
+        G_S(2, 1, 0, 0, )                                                                         \
+        G_S(3, 0, 1, 0, G_RA(0, 1, rd))                                                           \
+        G_S(3, 0, 0, 1, G_RA(0, 0, rd))                                                           \
+        G_S(3, 0, 0, 0, G_RB(0, rd))                                                              \
+        G_S(3, 1, 1, 0, )                                                                         \
+        G_S(3, 1, 0, 1, )                                                                         \
+        G_S(3, 1, 0, 0, G_RB(1, rd))                                                              \
+        sc = sr;                                                                                  \
+        sr = sw;                                                                                  \
+        sw = (sw == kGSlots - 1) ? 0 : sw + 1;                                                    \
+        if (++kt == T) {                     /* the output tile is complete */                    \
+            kt = 0;                                                                               \
+            G_EPILOGUE()                                                                          \
+            G_FENCE()                                                                             \
+        }                                                                                         \
+    }
+
+    // prologue: steps 0 and 1 split into slots 0 and 1, steps 2 and 3 requested, first fragments of step 0 read
+    int kt = 0, sc = 0, sr = 1, sw = 2;
+    bool in_loop = false;
+    G_LD_A0(x) G_LD_A1(x) G_LD_B0(x) G_LD_B1(x) G_ADVANCE()
+    G_LD_A0(y) G_LD_A1(y) G_LD_B0(y) G_LD_B1(y) G_ADVANCE()
+    {
+        unsigned char* const w0 = smemg;
+        unsigned char* const w1 = smemg + kGSlot;
+        G_ST(xa0, 0, ld_row, sa, amax_a, w0) G_ST(xa1, 0, ld_row + 64, sa, amax_a, w0)
+        G_ST(xb0, 2, ld_row, sb, amax_b, w0) G_ST(xb1, 2, ld_row + 64, sb, amax_b, w0)
+        G_LD_A0(x) G_LD_A1(x) G_LD_B0(x) G_LD_B1(x) G_ADVANCE()
+        G_ST(ya0, 0, ld_row, sa, amax_a, w1) G_ST(ya1, 0, ld_row + 64, sa, amax_a, w1)
+        G_ST(yb0, 2, ld_row, sb, amax_b, w1) G_ST(yb1, 2, ld_row + 64, sb, amax_b, w1)
+        G_LD_A0(y) G_LD_A1(y) G_LD_B0(y) G_LD_B1(y) G_ADVANCE()
+        G_BARRIER()
+        G_RA(0, 0, w0) G_RA(0, 1, w0) G_RB(0, w0) G_RB(1, w0)
+    }
+    in_loop = true;
+#pragma unroll 1
+    for (int s = 0; s < S; s += 2) {
+        G_STEP(x)
+        G_STEP(y)
+    }
+    // the clamped run-ahead requests re-read the last tile: amax of real data only
+    g3_amax_publish(amax_a, state + 2);
+    g3_amax_publish(amax_b, state + 3);
+#undef G_STEP
+#undef G_S
+#undef G_RB
+#undef G_RA
+#undef G_P_WR
+#undef G_P_ZW
+#undef G_P_XY
+#undef G_EPILOGUE
+#undef G_BARRIER
+#undef G_FENCE
+#undef G_MFMA1
+#undef G_ST
+#undef G_ADVANCE
+#undef G_LD_B1
+#undef G_LD_B0
+#undef G_LD_A1
+#undef G_LD_A0
+#undef G_OPAQUE
+#undef G_LDK
+#undef G_SET_SRC
+}
+
+// =====================================================================================================================
+// wgrad: dW[N, K] = A[M, N]^T . B[M, K] (+ column sums of A), contraction over the M rows split across blockIdx.y
+// LDS image of gemm_tn_x6_pq_kernel (a staging thread owns four consecutive rows of four columns of one operand; a fragment
+// is two conflict-free ds_read_b64), partial sums into the workspace, deterministic reduction by the caller.
+// =====================================================================================================================
+constexpr int kQES = 2048 + 64;                      // bytes per (col & 3) block: [m >> 3][(m >> 2) & 1][64 slots] x 8 B, + 64 B
+constexpr int kQPlane = 4 * kQES;                    // 8448 B
+constexpr int kQSlot = 4 * kQPlane;                  // A.h | A.m | B.h | B.m
+constexpr int kQTM = 16;                             // rows of the contraction per step
+
+__global__ __launch_bounds__(kGThreads, 2) void gemm_tn_g3_kernel(const float* __restrict__ A, int64_t lda,
+                                                                  const float* __restrict__ B, int64_t ldb, int64_t M, int N,
+                                                                  int K, int tiles_k, int64_t rows_per_split,
+                                                                  float* __restrict__ ws, float* __restrict__ ws_bias,
+                                                                  float* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemq[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    // (tile, split) of this workgroup: the tiles of ONE split are neighbours on one XCD (see gemm_tn_x6_pq_kernel)
+    int bx = blockIdx.x, by = blockIdx.y;
+    if (gridDim.x > 1 && gridDim.y % 8 == 0) {
+        const int L = by * (int)gridDim.x + bx;
+        const int j = L >> 3;
+        bx = j % (int)gridDim.x;
+        by = (j / (int)gridDim.x) * 8 + (L & 7);
+    }
+    const int tn = bx / tiles_k, tk = bx % tiles_k;
+    const int n0 = tn * kG, k0 = tk * kG;
+    const int64_t m_begin = (int64_t)by * rows_per_split;
+    const int64_t m_end = min(m_begin + rows_per_split, M);          // (m_end - m_begin) % 32 == 0 (host)
+    const bool want_bias = (ws_bias != nullptr) && tk == 0;
+
+    const int ea = g3_scale_exp(state[0]), eb = g3_scale_exp(state[1]);
+    const float inv = g3_pow2(-(ea + eb));
+    float amax = 0.0f;
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // staging: thread = (operand, row quad rq of 4, column quad c4 of 64): rows 4 rq .. 4 rq + 3 of the 16-row step
+    const int c4 = (tid & 63) * 4, rq = (tid >> 6) & 3, opnd = tid >> 8;          // opnd is uniform per wave
+    const float sc = g3_pow2(opnd ? eb : ea);
+    const int64_t ld_s = opnd ? ldb : lda;
+    const float* s_src = (opnd ? B + k0 : A + n0) + (m_begin + 4 * rq) * ld_s + c4;
+    const int st_off = opnd * 2 * kQPlane + (rq >> 1) * 1024 + (rq & 1) * 512 + (c4 >> 2) * 8;
+    const int64_t nsteps = (m_end - m_begin) / kQTM;                              // even
+    float4 x0, x1, x2, x3, y0, y1, y2, y3;                                        // raw sets: steps j+2 and j+3
+    int64_t ld_step = 0;                                                          // next step to request (clamped to the last)
+#define Q_LD(S_, R)                                                                                          \
+    S_##R = *reinterpret_cast<const float4*>(s_src + (min(ld_step, nsteps - 1) * kQTM + (R)) * ld_s);
+    // amax and the bias sums read the raw registers; `counts_` is false for the clamped run-ahead steps past the end
+#define Q_STATS(S_, counts_)                                                                                 \
+    if (counts_) {                                                                                           \
+        g3_amax4(S_##0, amax); g3_amax4(S_##1, amax); g3_amax4(S_##2, amax); g3_amax4(S_##3, amax);          \
+        if (want_bias && opnd == 0) {                                                                        \
+            bsum.x += ((S_##0).x + (S_##1).x) + ((S_##2).x + (S_##3).x);                                     \
+            bsum.y += ((S_##0).y + (S_##1).y) + ((S_##2).y + (S_##3).y);                                     \
+            bsum.z += ((S_##0).z + (S_##1).z) + ((S_##2).z + (S_##3).z);                                     \
+            bsum.w += ((S_##0).w + (S_##1).w) + ((S_##2).w + (S_##3).w);                                     \
+        }                                                                                                    \
+    }
+    half8 fa[2][2], fb[2][2];                            // as in gemm_nt_g3_kernel: two A buffers, one B set
+    const int fr_off = (li & 3) * kQES + kh * 1024 + (li >> 2) * 8;
+#define Q_FRAG(DST, P)                                                                                       \
+    {                                                                                                        \
+        const uint2 p0_ = *reinterpret_cast<const uint2*>(P);                                                \
+        const uint2 p1_ = *reinterpret_cast<const uint2*>((P) + 512);                                        \
+        const u32x4 u_ = {p0_.x, p0_.y, p1_.x, p1_.y};                                                       \
+        DST = __builtin_bit_cast(half8, u_);                                                                 \
+    }
+#define Q_RA(MT, PC, RB) Q_FRAG(fa[(MT) & 1][PC], (RB) + fr_off + (PC) * kQPlane + wm * 256 + (MT) * 64)
+#define Q_RB(NT, RB)                                                                                         \
+    Q_FRAG(fb[0][NT], (RB) + fr_off + 2 * kQPlane + wn * 128 + (NT) * 64)                                    \
+    Q_FRAG(fb[1][NT], (RB) + fr_off + 3 * kQPlane + wn * 128 + (NT) * 64)
+#define Q_MFMA1(MT, NT, PA, PB) \
+    acc[MT][NT] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[(MT) & 1][PA], fb[PB][NT], acc[MT][NT], 0, 0, 0);
+#define Q_FENCE() __builtin_amdgcn_sched_barrier(0);
+#define Q_BARRIER()                                                   \
+    __builtin_amdgcn_sched_barrier(0);                                \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");   \
+    __builtin_amdgcn_sched_barrier(0);
+    // column E of the raw set: rows 0-1 | rows 2-3 | the two stores
+    uint2 ph, pm;
+#define Q_C01(S_, E) g3_split_pair((S_##0).E, (S_##1).E, sc, ph.x, pm.x);
+#define Q_C23(S_, E) g3_split_pair((S_##2).E, (S_##3).E, sc, ph.y, pm.y);
+#define Q_CWR(EI, WB)                                                                                        \
+    {                                                                                                        \
+        unsigned char* d_ = (WB) + st_off + (EI) * kQES;                                                     \
+        *reinterpret_cast<uint2*>(d_) = ph;                                                                  \
+        *reinterpret_cast<uint2*>(d_ + kQPlane) = pm;                                                        \
+    }
+#define Q_COL(S_, E, EI, WB) Q_C01(S_, E) Q_C23(S_, E) Q_CWR(EI, WB)
+#define Q_S(MT, NT, PA, PB, ...) Q_MFMA1(MT, NT, PA, PB) Q_FENCE() __VA_ARGS__ Q_FENCE()
+    // step j: the pipeline and chunk placement of gemm_nt_g3_kernel (`cur` / `rd` / `wr` = slots of steps j / j+1 / j+2); the four
+    // rows of the raw set are re-requested together once its fourth column has been split
+#define Q_STEP(RS)                                                                                \
+    {                                                                                             \
+        unsigned char* const cur = smemq + sc_ * kQSlot;                                          \
+        unsigned char* const rd = smemq + sr * kQSlot;                                            \
+        unsigned char* const wr = smemq + sw * kQSlot;                                            \
+        const bool counts_ = st + 2 < nsteps;                                                     \
+        Q_S(0, 0, 1, 0, Q_C01(RS, x) Q_RA(1, 1, cur))                                             \
+        Q_S(0, 0, 0, 1, Q_C23(RS, x) Q_RA(1, 0, cur))                                             \
+        Q_S(0, 0, 0, 0, Q_CWR(0, wr))                                                             \
+        Q_S(0, 1, 1, 0, Q_C01(RS, y))                                                             \
+        Q_S(0, 1, 0, 1, Q_C23(RS, y))                                                             \
+        Q_S(0, 1, 0, 0, Q_CWR(1, wr))                                                             \
+        Q_S(1, 0, 1, 0, Q_C01(RS, z) Q_RA(2, 1, cur))                                             \
+        Q_S(1, 0, 0, 1, Q_C23(RS, z) Q_RA(2, 0, cur))                                             \
+        Q_S(1, 0, 0, 0, Q_CWR(2, wr))                                                             \
+        Q_S(1, 1, 1, 0, Q_C01(RS, w))                                                             \
+        Q_S(1, 1, 0, 1, Q_C23(RS, w))                                                             \
+        Q_S(1, 1, 0, 0, Q_CWR(3, wr))                                                             \
+        Q_S(2, 0, 1, 0, Q_STATS(RS, counts_) Q_RA(3, 1, cur))                                     \
+        Q_S(2, 0, 0, 1, Q_LD(RS, 0) Q_LD(RS, 1) Q_LD(RS, 2) Q_LD(RS, 3) ++ld_step; Q_RA(3, 0, cur)) \
+        Q_S(2, 0, 0, 0, )                                                                         \
+        Q_S(2, 1, 1, 0, )                                                                         \
+        Q_MFMA1(2, 1, 0, 1)                                                                       \
+        Q_BARRIER()                                                                               \
+        Q_S(2, 1, 0, 0, )                                                                         \
+        Q_S(3, 0, 1, 0, Q_RA(0, 1, rd))                                                           \
+        Q_S(3, 0, 0, 1, Q_RA(0, 0, rd))                                                           \
+        Q_S(3, 0, 0, 0, Q_RB(0, rd))                                                              \
+        Q_S(3, 1, 1, 0, )                                                                         \
+        Q_S(3, 1, 0, 1, )                                                                         \
+        Q_S(3, 1, 0, 0, Q_RB(1, rd))                                                              \
+        sc_ = sr;                                                                                 \
+        sr = sw;                                                                                  \
+        sw = (sw == kGSlots - 1) ? 0 : sw + 1;                                                    \
+        ++st;                                                                                     \
+    }
+
+    if (nsteps > 0) {
+        int sc_ = 0, sr = 1, sw = 2;
+        int64_t st = 0;
+        Q_LD(x, 0) Q_LD(x, 1) Q_LD(x, 2) Q_LD(x, 3) ++ld_step;
+        Q_LD(y, 0) Q_LD(y, 1) Q_LD(y, 2) Q_LD(y, 3) ++ld_step;
+        {
+            unsigned char* const w0 = smemq;
+            unsigned char* const w1 = smemq + kQSlot;
+            Q_STATS(x, true)
+            Q_COL(x, x, 0, w0) Q_COL(x, y, 1, w0) Q_COL(x, z, 2, w0) Q_COL(x, w, 3, w0)
+            Q_LD(x, 0) Q_LD(x, 1) Q_LD(x, 2) Q_LD(x, 3) ++ld_step;
+            Q_STATS(y, true)                                   /* nsteps >= 2 (even) */
+            Q_COL(y, x, 0, w1) Q_COL(y, y, 1, w1) Q_COL(y, z, 2, w1) Q_COL(y, w, 3, w1)
+            Q_LD(y, 0) Q_LD(y, 1) Q_LD(y, 2) Q_LD(y, 3) ++ld_step;
+            Q_BARRIER()
+            Q_RA(0, 0, w0) Q_RA(0, 1, w0) Q_RB(0, w0) Q_RB(1, w0)
+        }
+#pragma unroll 1
+        while (st < nsteps) {
+            Q_STEP(x)
+            Q_STEP(y)
+        }
+    }
+#undef Q_STEP
+#undef Q_S
+#undef Q_COL
+#undef Q_CWR
+#undef Q_C23
+#undef Q_C01
+#undef Q_BARRIER
+#undef Q_FENCE
+#undef Q_MFMA1
+#undef Q_RB
+#undef Q_RA
+#undef Q_FRAG
+#undef Q_STATS
+#undef Q_LD
+
+    float* out = ws + (int64_t)by * N * K;
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const int col = k0 + wn * 64 + nt * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = n0 + wm * 128 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                out[(int64_t)row * K + col] = acc[mt][nt][r] * inv;
+            }
+        }
+    }
+    // each operand's amax goes to its own slot (the waves of one operand are uniform)
+    g3_amax_publish(amax, state + 2 + opnd);
+    if (want_bias) {
+        __syncthreads();
+        float* red = reinterpret_cast<float*>(smemq);          // [4 row quads][256]
+        if (opnd == 0) *reinterpret_cast<float4*>(red + rq * kG + c4) = bsum;
+        __syncthreads();
+        if (tid < kG) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) tot += red[g * kG + tid];
+            ws_bias[(int64_t)by * N + n0 + tid] = tot;
+        }
+    }
+}
+
+// amax of a (rows, cols) fp32 matrix with row stride ld -> atomic max into *slot (priming of a call site's state)
+__global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int cols,
+                                                        float* __restrict__ slot) {
+    const int c4n = cols >> 2;
+    const int64_t total = rows * c4n;
+    float amax = 0.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / c4n;
+        const int c = (int)(i - r * c4n) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(x + r * ld + c);
+        g3_amax4(v, amax);
+    }
+    g3_amax_publish(amax, slot);
+}
+
+// per call site: {read A, read B, written A, written B}: read <- written (a site that did not run keeps its value), written <- 0
+__global__ __launch_bounds__(256) void grad_scale_roll_kernel(float* __restrict__ state, int nsites) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nsites * 2) return;
+    float* s = state + (i >> 1) * 4 + (i & 1);
+    const float w = s[2];
+    if (w > 0.0f) s[0] = w;
+    s[2] = 0.0f;
+}
+
+static int tn_g3_splits(int64_t M, int N, int K) {
+    const int64_t tiles = (int64_t)(N / kG) * (K / kG);
+    int64_t s = std::max<int64_t>(1, kNumCU / tiles);
+    s = std::min<int64_t>(s, std::max<int64_t>(1, M / 256));
+    return (int)s;
+}
+
+}  // namespace vq
+
+using namespace vq;
+
+extern "C" {
+
+// dgrad shapes the three-product kernel takes: whole 256 x 256 tiles, K a multiple of 32.  (Whether the tiles fill the 256
+// persistent workgroups well enough is the caller's policy: ops.py cuts ragged launches by rows.)
+int vqcpc_gemm_nt_grad_supported(int64_t M, int N, int K) {
+    return (M >= kG && (M % kG) == 0 && N >= kG && (N % kG) == 0 && K >= 32 && (K % 32) == 0 && (M / kG) * (N / kG) < (1ll << 30)) ? 1 : 0;
+}
+
+int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                       const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, const void* gate_mask,
+                       float gate_scale, float* scale_state, void* stream) {
+    VQ_REQUIRE(A && B && C && scale_state, "gemm_nt_grad: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_nt_grad_supported(M, N, K), "gemm_nt_grad: M, N multiples of 256 and K of 32, got M=%lld N=%d K=%d",
+               (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B),
+               "gemm_nt_grad: bad leading dimensions / alignment");
+    VQ_REQUIRE(!(add2 && !add) && !(gate_mask && add), "gemm_nt_grad: epilogue is one of none / add / add + add2 / gate mask");
+    VQ_REQUIRE(!gate_mask || aligned16(gate_mask), "gemm_nt_grad: gate mask must be 16-byte aligned");
+    EpiParams ep{};
+    ep.add = add;
+    ep.ldadd = ldadd;
+    ep.add2 = add2;
+    ep.ldadd2 = ldadd2;
+    ep.mask = (uint32_t*)const_cast<void*>(gate_mask);
+    ep.gate_scale = gate_scale;
+    const int tn = N / kG;
+    const int tiles = (int)((M / kG) * tn);
+    const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kGThreads);
+    const size_t lds = (size_t)kGSlots * kGSlot;
+    hipStream_t st = (hipStream_t)stream;
+#define G3_LAUNCH(EPIV)                                                                                                  \
+    {                                                                                                                    \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_g3_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      (int)lds);                                                                         \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_g3_kernel<EPIV>), grid, block, lds, st, A, lda, B, ldb, C, ldc, M, N, K, tn, tiles,  \
+                           ep, scale_state);                                                                             \
+    }
+#if VQCPC_LAB
+    {
+        static const int abl = lab_env_int("VQCPC_G3_ABL", 0);
+        if (abl && !gate_mask && !add) {
+#define G3_ABL_CASE(V)                                                                                                   \
+    if (abl == V) {                                                                                                      \
+        (void)hipFuncSetAttribute((const void*)gemm_nt_g3_kernel<0, V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm_nt_g3_kernel<0, V>), grid, block, lds, st, A, lda, B, ldb, C, ldc, M, N, K, tn, tiles, ep, \
+                           scale_state);                                                                                 \
+    }
+            G3_ABL_CASE(1) G3_ABL_CASE(2) G3_ABL_CASE(4) G3_ABL_CASE(8) G3_ABL_CASE(16) G3_ABL_CASE(19) G3_ABL_CASE(32)
+#undef G3_ABL_CASE
+            VQ_CHECK_LAUNCH("gemm_nt_g3 (ablation)");
+            return VQCPC_OK;
+        }
+    }
+#endif
+    if (gate_mask) G3_LAUNCH(E_GATEBITS)
+    else if (add2) G3_LAUNCH(E_ADD | E_ADD2)
+    else if (add) G3_LAUNCH(E_ADD)
+    else G3_LAUNCH(0)
+#undef G3_LAUNCH
+    VQ_CHECK_LAUNCH("gemm_nt_g3");
+    return VQCPC_OK;
+}
+
+// wgrad shapes: whole 256 x 256 output tiles, M a multiple of 32 (an even number of 16-row steps per split)
+int vqcpc_gemm_tn_grad_supported(int64_t M, int N, int K) {
+    return (N >= kG && (N % kG) == 0 && K >= kG && (K % kG) == 0 && M >= 32 && (M % 32) == 0) ? 1 : 0;
+}
+
+int64_t vqcpc_gemm_tn_grad_workspace(int64_t M, int N, int K) {
+    return (int64_t)tn_g3_splits(std::max<int64_t>(M, 1), N, K) * ((int64_t)N * K + N) * (int64_t)sizeof(float);
+}
+
+int vqcpc_gemm_tn_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
+                       int accumulate, void* workspace, int64_t workspace_bytes, float* scale_state, void* stream) {
+    VQ_REQUIRE(A && B && dW && workspace && scale_state, "gemm_tn_grad: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_tn_grad_supported(M, N, K), "gemm_tn_grad: shape M=%lld N=%d K=%d not supported", (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= N && ldb >= K && aligned16(A) && aligned16(B),
+               "gemm_tn_grad: bad leading dimensions / alignment");
+    if (workspace_bytes < vqcpc_gemm_tn_grad_workspace(M, N, K)) {
+        set_error("gemm_tn_grad: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    const int splits = tn_g3_splits(M, N, K);
+    const int64_t rows_per_split = round_up(ceil_div(M, splits), 32);
+    float* ws = (float*)workspace;
+    float* ws_bias = db ? ws + (int64_t)splits * N * K : nullptr;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)kGSlots * kQSlot;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_tn_g3_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    const int tk = K / kG;
+    hipLaunchKernelGGL(gemm_tn_g3_kernel, dim3((N / kG) * tk, splits), dim3(kGThreads), lds, s, A, lda, B, ldb, M, N, K, tk,
+                       rows_per_split, ws, ws_bias, scale_state);
+    VQ_CHECK_LAUNCH("gemm_tn_g3");
+    return launch_reduce_splits2(ws, (int64_t)N * K, splits, dW, (int64_t)N * K, ws_bias, N, db, db ? N : 0, accumulate, s);
+}
+
+int vqcpc_grad_amax(const float* x, int64_t ld, int64_t rows, int cols, float* amax_slot, void* stream) {
+    VQ_REQUIRE(x && amax_slot && rows >= 1 && cols >= 4 && cols % 4 == 0 && ld % 4 == 0 && ld >= cols && aligned16(x),
+               "grad_amax: bad arguments");
+    const int64_t total = rows * (cols / 4);
+    const unsigned blocks = (unsigned)std::min<int64_t>(ceil_div(total, 256), 4 * kNumCU);
+    hipLaunchKernelGGL(grad_amax_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, ld, rows, cols, amax_slot);
+    VQ_CHECK_LAUNCH("grad_amax");
+    return VQCPC_OK;
+}
+
+int vqcpc_grad_scale_roll(float* state, int nsites, void* stream) {
+    VQ_REQUIRE(state && nsites >= 0, "grad_scale_roll: bad arguments");
+    if (nsites == 0) return VQCPC_OK;
+    hipLaunchKernelGGL(grad_scale_roll_kernel, dim3((unsigned)ceil_div(2 * nsites, 256)), dim3(256), 0, (hipStream_t)stream,
+                       state, nsites);
+    VQ_CHECK_LAUNCH("grad_scale_roll");
+    return VQCPC_OK;
+}
+
+}  // extern "C"

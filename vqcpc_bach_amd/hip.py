@@ -58,6 +58,15 @@ SIGNATURES = {
     'vqcpc_gemm_get_gradient_products': (c_int, []),
     'vqcpc_gemm_gradient_scope': (c_int, [c_int]),
     'vqcpc_gemm_tn_workspace': (c_i64, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_nt_grad_supported': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_nt_grad': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_i64, c_ptr, c_i64,
+                                   c_ptr, c_f32, c_ptr, c_ptr]),
+    'vqcpc_gemm_tn_grad_supported': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_tn_grad_workspace': (c_i64, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_tn_grad': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr,
+                                   c_ptr]),
+    'vqcpc_grad_amax': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
+    'vqcpc_grad_scale_roll': (c_int, [c_ptr, c_int, c_ptr]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_tn_groupable': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_grouped_workspace': (c_i64, [c_int, c_ptr, c_ptr, c_ptr]),

@@ -30,6 +30,111 @@ def dropout_mask(n, p, seed, device):
 
 
 # ------------------------------------------------------------------------------------------------------------------
+# gradient arithmetic of the backward pass (round 5): three fp16 MFMAs per product at fp32-class accuracy, csrc/gemm_grad.hip
+# ------------------------------------------------------------------------------------------------------------------
+# 'six'    the forward's exact six-product bf16 split everywhere (what every forward GEMM uses, always)
+# 'f16x3'  dgrad / wgrad of the 256-tile shapes inside a trainer's backward on vqcpc_gemm_nt_grad / vqcpc_gemm_tn_grad: each
+#          operand as two fp16 planes (11 + 11 bits) under a per-tensor power-of-two scale that follows the tensor's amax of the
+#          previous step; rms error vs fp64 3-5e-7 (fp32 MFMA kernel: 3-8e-7), x 1.4 the six-product kernels
+# 'bf16x3' the round-3 two-bf16-plane form (hip.set_gradient_products(3)): 18-bit operands, rms 4.4e-6 -- kept for comparison
+GRAD_ARITH = os.environ.get('VQCPC_GRAD_ARITH', 'six')
+GRAD_MIN_TILES = 256           # dgrad: fewer 256 x 256 tiles than CUs -> the six-product path (its 128-tile kernels fill the chip)
+GRAD_TN_MIN_ROWS = 8192        # wgrad: as the 256-tile six-product kernel (tests set both to 0 to reach the kernels with small shapes)
+_GRAD_SCALES = None            # the open gradient scope's GradScales (None: outside a trainer's backward, or another arithmetic)
+
+
+def set_gradient_arithmetic(name):
+    """Selects the arithmetic of the gradient GEMMs launched inside a trainer's backward pass (see above); returns the previous
+    name.  Forward GEMMs -- losses, code assignment -- are never affected."""
+    global GRAD_ARITH
+    assert name in ('six', 'f16x3', 'bf16x3'), name
+    prev, GRAD_ARITH = GRAD_ARITH, name
+    hip.set_gradient_products(3 if name == 'bf16x3' else 6)
+    return prev
+
+
+class GradScales:
+    """Scale state of the f16x3 gradient GEMMs of ONE backward pass shape (owned by a trainer's flat parameter buffer): 4 floats
+    per call site -- amax |A|, |B| of the previous step (read), of this step (written by the kernels) -- in call order.  The
+    backward of a trainer issues the same GEMMs in the same order every step; a site whose (kind, M, N, K) changes is primed
+    again.  `roll()` once per step: this step's amax becomes the next step's scale."""
+
+    CAPACITY = 512
+
+    def __init__(self, device):
+        self.state = torch.zeros(4 * self.CAPACITY, dtype=torch.float32, device=device)
+        self.keys = []
+        self.cursor = 0
+
+    def begin(self):
+        self.cursor = 0
+
+    def site(self, key, a, lda, rows_a, cols_a, b, ldb, rows_b, cols_b):
+        i = self.cursor
+        self.cursor += 1
+        assert i < self.CAPACITY, 'GradScales: more gradient GEMM call sites than the table holds'
+        st = self.state[4 * i:4 * i + 4]
+        if i == len(self.keys) or self.keys[i] != key:
+            # first use of the site (or another product took its place): prime the scale with the operands' own amax
+            if i == len(self.keys):
+                self.keys.append(key)
+            else:
+                self.keys[i] = key
+                st.zero_()
+            hip.call('vqcpc_grad_amax', a, lda, rows_a, cols_a, st[0:1])
+            hip.call('vqcpc_grad_amax', b, ldb, rows_b, cols_b, st[1:2])
+        return st
+
+    def roll(self):
+        if self.keys:
+            hip.call('vqcpc_grad_scale_roll', self.state, len(self.keys))
+
+
+def _grad_scales_of(owner, tag):
+    tabs = getattr(owner, '_grad_scales', None)
+    if tabs is None:
+        tabs = owner._grad_scales = {}
+    t = tabs.get(tag)
+    if t is None:
+        flat = getattr(owner, 'flat', owner)
+        t = tabs[tag] = GradScales(flat.device)
+    return t
+
+
+_grad_cut = {}                 # (M, N) -> rows of the dgrad launch that go through the three-product kernel (0: none)
+
+
+def _grad_rows(M, N, K):
+    """Rows of an (M, K) x (N, K)^T input-gradient product for vqcpc_gemm_nt_grad: all of them when the 256-tiles fill whole
+    rounds of the 256 persistent workgroups well (>= 80 %), the whole rounds otherwise (139 264 x 256: 2.125 rounds -> 2), the
+    rest goes the six-product way."""
+    hit = _grad_cut.get((M, N, K, GRAD_MIN_TILES))
+    if hit is not None:
+        return hit
+    rows = 0
+    if M >= 256 and hip.query('vqcpc_gemm_nt_grad_supported', M - M % 256, N, K):
+        tn = N // 256
+        tiles = (M // 256) * tn
+        if tiles >= max(GRAD_MIN_TILES, 1):
+            rounds = tiles / 256.0
+            if GRAD_MIN_TILES == 0 or (M % 256 == 0 and rounds / -(-tiles // 256) >= 0.8):
+                rows = M - M % 256
+            else:
+                rows = ((tiles // 256) * 256 // tn) * 256
+    _grad_cut[(M, N, K, GRAD_MIN_TILES)] = rows
+    return rows
+
+
+def _tn_grad_ok(M, N, K):
+    if not hip.query('vqcpc_gemm_tn_grad_supported', M, N, K):
+        return False
+    if GRAD_TN_MIN_ROWS == 0:
+        return True
+    tiles = (N // 256) * (K // 256)
+    return M >= GRAD_TN_MIN_ROWS and tiles * min(max(1, 256 // tiles), max(1, M // 256)) >= 128
+
+
+# ------------------------------------------------------------------------------------------------------------------
 # raw kernel wrappers (no autograd)
 # ------------------------------------------------------------------------------------------------------------------
 def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, add=None, add2=None, out=None):
@@ -49,6 +154,17 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         add, lda_ = _rows(add)
     if add2 is not None:
         add2, lda2_ = _rows(add2)
+    if (_GRAD_SCALES is not None and bias is None and not act and not drop_p and gate is None and (add2 is None or add is not None)
+            and hip.get_gemm_mode() == 1):
+        # inside a trainer's backward pass: the input-gradient product on three fp16 MFMAs (whole rounds of 256-tiles)
+        m_g = _grad_rows(M, N, K)
+        if m_g and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
+            st = _GRAD_SCALES.site(('nt', M, N, K), a, lda, M, K, b, ldb, N, K)
+            hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, ldc, m_g, N, K, add, lda_, add2, lda2_, None, 1.0, st)
+            if m_g < M:            # the ragged last round: six products (same epilogue)
+                hip.call('vqcpc_gemm_nt', a[m_g:], lda, b, ldb, out[m_g:], ldc, M - m_g, N, K, None, 0, 0.0, 0, None, 0, 1.0,
+                         None if add is None else add[m_g:], lda_, None if add2 is None else add2[m_g:], lda2_)
+            return out
     if (SPLIT_K and M <= _SPLITK_MAX_ROWS and K >= 512 and not act and not drop_p and gate is None and add2 is None
             and hip.get_gemm_mode() == 1):
         # few output tiles, long K (student / decoder steps): K cut over partial planes, see include/vqcpc.h
@@ -124,6 +240,10 @@ def gemm_nt_gatebits(a, b, mask, gate_scale=1.0):
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if _GRAD_SCALES is not None and _grad_rows(M, N, K) == M:
+        st = _GRAD_SCALES.site(('ntg', M, N, K), a, lda, M, K, b, ldb, N, K)
+        hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, N, M, N, K, None, 0, None, 0, mask, float(gate_scale), st)
+        return out
     hip.call('vqcpc_gemm_nt_gatebits', a, lda, b, ldb, out, N, M, N, K, mask, float(gate_scale))
     return out
 
@@ -143,6 +263,13 @@ def gemm_tn(a, b, want_bias=True, into=None):
         db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
     global LAST_TN_DEFERRED
     LAST_TN_DEFERRED = False
+    if _GRAD_SCALES is not None and hip.get_gemm_mode() == 1 and _tn_grad_ok(M, N, K):
+        # inside a trainer's backward pass: the weight gradient on three fp16 MFMAs per product
+        st = _GRAD_SCALES.site(('tn', M, N, K), a, lda, M, N, b, ldb, M, K)
+        nbytes = hip.query('vqcpc_gemm_tn_grad_workspace', M, N, K)
+        ws = hip.workspace(nbytes, a.device)
+        hip.call('vqcpc_gemm_tn_grad', a, lda, b, ldb, dw, db, M, N, K, 0 if into is None else 1, ws, nbytes, st)
+        return dw, db
     if into is not None and _DIRECT_WGRAD and GROUP_WGRADS and hip.query('vqcpc_gemm_tn_groupable', M, N, K):
         # inside a trainer's backward pass: small weight gradients are collected and issued together when the pass ends
         # (flush_wgrads, called by direct_weight_gradients.__exit__): a few grouped launches instead of two per weight
@@ -373,24 +500,29 @@ class direct_weight_gradients:
     straight into the parameters' existing `.grad` buffers (the flat all-reduce bucket) and hand `None` to autograd.
     Outside it (plain `backward()`, `torch.autograd.grad`) gradients are returned to autograd as usual."""
 
-    def __init__(self, flat_parameters=None):
+    def __init__(self, flat_parameters=None, tag=None):
         """flat_parameters: the trainer's parallel.FlatParameters (or its flat fp32 buffer) -- the transposed dgrad operands
         of its weights are then prepared by one launch (ops.WEIGHT_T, a cache owned by that object) instead of one per
-        weight."""
+        weight, and the scale states of the f16x3 gradient arithmetic (ops.GradScales) live on it.  tag: distinguishes several
+        backward passes per step over the same buffer (the student step's bucketed form: teacher | encoder + decoder)."""
         self.flat = flat_parameters
+        self.tag = tag
 
     def __enter__(self):
-        global _DIRECT_WGRAD
+        global _DIRECT_WGRAD, _GRAD_SCALES
         self.prev, _DIRECT_WGRAD = _DIRECT_WGRAD, True
         if self.prev:                      # nested scope: the outermost one owns the deferred work and the transposed weights
             return self
         hip.gradient_scope(True)           # the GEMMs launched from here on are gradient GEMMs (hip.set_gradient_products)
+        if self.flat is not None and GRAD_ARITH == 'f16x3' and hip.get_gemm_mode() == 1:
+            _GRAD_SCALES = _grad_scales_of(self.flat, self.tag)
+            _GRAD_SCALES.begin()
         if self.flat is not None and BATCHED_TRANSPOSES:
             WEIGHT_T.begin(self.flat)
         return self
 
     def __exit__(self, *exc):
-        global _DIRECT_WGRAD
+        global _DIRECT_WGRAD, _GRAD_SCALES
         _DIRECT_WGRAD = self.prev
         if self.prev:                      # an inner scope neither flushes nor discards what the outer scope deferred
             return False
@@ -398,11 +530,14 @@ class direct_weight_gradients:
             if exc[0] is None:
                 flush_wgrads()                  # the deferred small weight gradients, still inside the gradient scope
                 flush_reductions()              # ... and the LayerNorm weight / bias partial sums
+                if _GRAD_SCALES is not None:
+                    _GRAD_SCALES.roll()         # this step's operand amax becomes the next step's scale
             else:
                 _PENDING_WGRADS.clear()
                 _PENDING_REDUCTIONS.clear()
                 _PENDING_VEC_REDUCTIONS.clear()
         finally:
+            _GRAD_SCALES = None
             hip.gradient_scope(False)
             WEIGHT_T.end()
         return False

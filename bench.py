@@ -62,6 +62,9 @@ def parse():
                     help='replay the training step from HIP graphs (vqcpc_bach_amd/graphs.py): one graph per step on one rank, '
                          'two around the eager RCCL all-reduce on several (VQCPC_DP_GRAPH=capture|off changes that)')
     ap.add_argument('--no-graph', dest='graph', action='store_false')
+    ap.add_argument('--grad-arith', default=None, choices=['six', 'f16x3', 'bf16x3'],
+                    help='arithmetic of the gradient GEMMs inside backward (ops.set_gradient_arithmetic); default: what '
+                         'train_model() selects (ops.TRAINING_GRAD_ARITH)')
     ap.add_argument('--grad-products', type=int, default=6, choices=[3, 6],
                     help='opt-in gradient arithmetic of the bf16x6 mode (include/vqcpc.h): 3 = two rounded bf16 planes and three '
                          'MFMAs per product in the input- / weight-gradient GEMMs (~2^-17 per product); the forward, the losses '
@@ -97,6 +100,8 @@ class GemmTimer:
             e1.record()
             epi = '+'.join(k for k in ('bias', 'act', 'drop_p', 'gate', 'add', 'add2')
                            if kw.get(k) is not None and (torch.is_tensor(kw[k]) or kw[k] != 0)) or 'none'
+            if getattr(ops, 'LAST_GEMM_F16X3', False):
+                epi = 'f16x3:' + epi
             timer.records['gemm_nt'].append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
                                              4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[0]),
                                              (a.shape[0], b.shape[0], a.shape[1], epi)))
@@ -113,7 +118,8 @@ class GemmTimer:
                 return out
             timer.records['gemm_tn'].append((e0, e1, 2.0 * a.shape[0] * a.shape[1] * b.shape[1],
                                              4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[1] * b.shape[1]),
-                                             (a.shape[0], a.shape[1], b.shape[1], 'wgrad')))
+                                             (a.shape[0], a.shape[1], b.shape[1],
+                                              'f16x3:wgrad' if getattr(ops, 'LAST_GEMM_F16X3', False) else 'wgrad')))
             return out
 
         raw_flush = ops.flush_wgrads
@@ -184,7 +190,7 @@ class GemmTimer:
                 e1.record()
                 M, N, K = a.shape[0], b.shape[0], a.shape[1]
                 timer.records['gemm_nt'].append((e0, e1, 2.0 * M * N * K, 4.0 * (M * K + N * K + M * N) + extra_bytes * M * N,
-                                                 (M, N, K, epi)))
+                                                 (M, N, K, ('f16x3:' if getattr(ops, 'LAST_GEMM_F16X3', False) else '') + epi)))
                 return out
             return f
 
@@ -210,10 +216,19 @@ class GemmTimer:
         recs = self.records[name]
         if not recs:
             return None
-        ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+        times = [r[0].elapsed_time(r[1]) for r in recs]
+        ms = sum(times)
         flops = sum(r[2] for r in recs)
-        return dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), tflops=flops / (ms * 1e-3) / 1e12,
-                    flops_per_launch=flops / len(recs), bytes_per_launch=sum(r[3] for r in recs) / len(recs))
+        out = dict(launches=len(recs), total_ms=ms, avg_us=1e3 * ms / len(recs), tflops=flops / (ms * 1e-3) / 1e12,
+                   flops_per_launch=flops / len(recs), bytes_per_launch=sum(r[3] for r in recs) / len(recs))
+        # launches by arithmetic: the f16x3 gradient GEMMs (three MFMAs per product) against everything else
+        g3 = [(t, r[2]) for t, r in zip(times, recs) if str(r[4][3]).startswith('f16x3:')]
+        if g3:
+            g_ms, g_fl = sum(t for t, _ in g3), sum(f for _, f in g3)
+            out['f16x3'] = dict(launches=len(g3), total_ms=g_ms, flops=g_fl, tflops=g_fl / (g_ms * 1e-3) / 1e12)
+            out['rest'] = dict(launches=len(recs) - len(g3), total_ms=ms - g_ms, flops=flops - g_fl,
+                               tflops=((flops - g_fl) / ((ms - g_ms) * 1e-3) / 1e12) if ms > g_ms else 0.0)
+        return out
 
 
 def hbm_traffic_from_file(kernel, calls_per_step):
@@ -242,8 +257,8 @@ def live_pmc(args, B, timeout_s=100):
     steps, warm = 2, 2
     n_steps = warm + 2 * steps                   # warm-up epoch + the bare-step loop + the timed epoch of the inner run
     inner = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(steps), '--warmup', str(warm),
-             '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-products',
-             str(args.grad_products), '--no-graph',
+             '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-arith',
+             str(args.grad_arith), '--no-graph',
              '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc', '--no-extras', '--no-secondary']
     out = {'steps': n_steps}
     tmp = tempfile.mkdtemp(prefix='vqcpc_pmc_', dir='/tmp')
@@ -542,7 +557,9 @@ def main():
     hip.load()
     gemm_mode = 2 if args.gemm_mode in ('bf16', '8') else (1 if args.gemm_mode in ('bf16x6', '1') else 0)
     hip.set_gemm_mode(8 if gemm_mode == 2 else gemm_mode)
-    hip.set_gradient_products(args.grad_products)
+    if args.grad_arith is None:
+        args.grad_arith = 'bf16x3' if args.grad_products == 3 else (ops.TRAINING_GRAD_ARITH if gemm_mode == 1 else 'six')
+    ops.set_gradient_arithmetic(args.grad_arith)
     share = os.environ.get('VQCPC_DP_SHARE_GPU', '0') == '1'
     # (a launcher may mask visibility to ONE device per rank: then the check is the PCI-id census below, after the group exists)
     if args.gpus > 1 and not share and 1 < torch.cuda.device_count() < args.gpus:
@@ -692,15 +709,14 @@ def main():
                      'note': f'{n_ar} back-to-back all-reduces of the flat fp32 gradient bucket after the timed region (max over '
                              'ranks); inside the step the same call sits between the two graph replays'}
         del bucket
-    # Extra, NOT the headline: the same steps with the opt-in three-product gradient arithmetic (include/vqcpc.h), measured
-    # after the timed region so that it cannot touch `value`.  Forward (losses, code assignment) identical; gradients carry
-    # ~2^-17 per product instead of ~2^-24.  Under the socket's power cap the MFMA count is what the GEMM rate follows
-    # (profiles/r03_gemm_power_limit.txt), so this is the measured price of the exact split in the backward pass.
-    extra_g3 = None
-    if (gemm_mode == 1 and args.grad_products == 6 and not args.no_extras and args.config == 'C1' and dp.world_size == 1
+    # Extra, NOT the headline: the same steps with the forward's six-product split in the backward pass as well (what every
+    # round before the fifth measured), after the timed region so that it cannot touch `value`: the price of carrying 24-bit
+    # operand mantissas through six MFMAs where 22 bits through three give the same fp32-class gradients.
+    extra_six = None
+    if (gemm_mode == 1 and args.grad_arith == 'f16x3' and not args.no_extras and args.config == 'C1' and dp.world_size == 1
             and not args.host_inputs):
         try:
-            hip.set_gradient_products(3)
+            ops.set_gradient_arithmetic('six')
             if use_graph:
                 trainer.enable_step_graph(True)
                 trainer._graph_eager_steps = 0
@@ -712,15 +728,14 @@ def main():
             m3 = run_epoch(n3, False)
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t0
-            extra_g3 = {'value': round(B * n3 / dt3, 2), 'unit': 'windows/s', 'ms_per_step': round(1e3 * dt3 / n3, 3), 'steps': n3,
-                        'final_loss': round(float(m3['loss']), 5),
-                        'note': 'NOT the headline: input- and weight-gradient GEMMs with two rounded bf16 planes and three MFMAs '
-                                'per product (hip.set_gradient_products(3) / bench.py --grad-products 3); forward, losses and code '
-                                'assignment unchanged, gradient rms error 4.4e-6 instead of 5e-7 (tools/bench_grad3.py)'}
+            extra_six = {'value': round(B * n3 / dt3, 2), 'unit': 'windows/s', 'ms_per_step': round(1e3 * dt3 / n3, 3), 'steps': n3,
+                         'final_loss': round(float(m3['loss']), 5),
+                         'note': 'NOT the headline: the same steps with six-product (bf16x6) gradient GEMMs as well '
+                                 '(ops.set_gradient_arithmetic(\'six\') / bench.py --grad-arith six), i.e. the configuration rounds 1-4 reported'}
         except Exception as e:                        # never lose the headline line to the extra
-            extra_g3 = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+            extra_six = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
         finally:
-            hip.set_gradient_products(args.grad_products)
+            ops.set_gradient_arithmetic(args.grad_arith)
             if use_graph:
                 trainer.enable_step_graph(False)
     pmc = None
@@ -755,6 +770,24 @@ def main():
                                'gemm_nt_skinny_kernel in fp32); one v_mfma_f32_32x32x16_bf16 per product, fp32 accumulate')
             else:
                 peak, kname = PEAK_F32_MFMA_TFLOPS, 'gemm_nt = every NT GEMM launch (gemm_nt_kernel<MODE=0>, gemm_nt_skinny_kernel; fp32 v_mfma_f32_32x32x2_f32)'
+            by_arith = None
+            if gemm_mode == 1 and 'f16x3' in nt:
+                # mixed arithmetic: forward launches on six MFMAs per product (ceiling 2500 / 6), the backward's 256-tile input
+                # gradients on three (2500 / 3).  The fraction is time-weighted: (sum of flops_i / peak_i) / measured time, i.e.
+                # `peak` below is the ceiling of THIS mix of launches
+                p6, p3 = PEAK_BF16_MFMA_TFLOPS / 6.0, PEAK_BF16_MFMA_TFLOPS / 3.0
+                g3_, r6_ = nt['f16x3'], nt['rest']
+                ideal_ms = (g3_['flops'] / p3 + r6_['flops'] / p6) / 1e9
+                peak = (g3_['flops'] + r6_['flops']) / ideal_ms / 1e9
+                by_arith = {'six_products': {'achieved': round(r6_['tflops'], 2), 'peak': round(p6, 1), 'frac': round(r6_['tflops'] / p6, 4),
+                                             'launches_per_step': r6_['launches'] // timed_steps,
+                                             'ms_per_step': round(r6_['total_ms'] / timed_steps, 3)},
+                            'f16x3': {'achieved': round(g3_['tflops'], 2), 'peak': round(p3, 1), 'frac': round(g3_['tflops'] / p3, 4),
+                                      'launches_per_step': g3_['launches'] // timed_steps,
+                                      'ms_per_step': round(g3_['total_ms'] / timed_steps, 3),
+                                      'kernel': 'gemm_nt_g3_kernel (csrc/gemm_grad.hip): two fp16 planes per operand under a '
+                                                'per-tensor power-of-two scale, 3x v_mfma_f32_32x32x16_f16 per product'}}
+                kname += '; inside backward the input-gradient GEMMs of the 256-tile shapes run on gemm_nt_g3_kernel (f16x3: three fp16 MFMAs per product)'
             calls_per_step = max(1, nt['launches'] // timed_steps)
             traffic = traffic_src = eff_mhz = pipe_busy = None
             if pmc and 'gemm_nt' in pmc:
@@ -769,7 +802,7 @@ def main():
             if traffic is None and args.config == 'C1' and gemm_mode == 1:
                 traffic, traffic_src = hbm_traffic_from_file('gemm_nt', calls_per_step)
             roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
-                            frac=round(nt['tflops'] / peak, 4),
+                            frac=round(nt['tflops'] / peak, 4), by_arithmetic=by_arith,
                             traffic=traffic, traffic_unit='HBM bytes per ops.gemm_nt call', traffic_source=traffic_src,
                             algorithmic_bytes_per_launch=round(nt['bytes_per_launch']),
                             launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),
@@ -806,15 +839,29 @@ def main():
                                     f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}'),
                        'global_batch': B * dp.world_size, 'seq_len': seq_len,
                        'parallelism': f'dp{dp.world_size}', 'params': n_params,
-                       'path': ('what train_model() selects by default: bf16x6 GEMM arithmetic + step-graph replay'
-                                if (gemm_mode == 1 and use_graph and args.grad_products == 6) else
-                                'non-default switches (see gemm / gradient_products / step_graph)'),
-                       'gradient_products': args.grad_products,
-                       'gemm': ('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy)' if gemm_mode == 1 else
+                       'path': ('what train_model() selects by default: bf16x6 GEMM arithmetic, f16x3 gradient GEMMs, step-graph replay'
+                                if (gemm_mode == 1 and use_graph and args.grad_arith == ops.TRAINING_GRAD_ARITH) else
+                                'non-default switches (see gemm / gradient_arithmetic / step_graph)'),
+                       'gradient_arithmetic': args.grad_arith if gemm_mode == 1 else 'as the forward',
+                       'gemm': (('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy: exact 3-way bf16 split, 6 MFMAs per product)'
+                                 + ('; backward dgrad / wgrad of the 256-tile shapes: f16x3 (two fp16 planes per operand, 11 + 11 bits '
+                                    'under a per-tensor power-of-two scale, 3 MFMAs per product, rms error vs fp64 3-5e-7 = the class '
+                                    'of the fp32-MFMA kernel; forward, losses and code assignment untouched)'
+                                    if args.grad_arith == 'f16x3' else
+                                    '; backward: two bf16 planes, 3 MFMAs per product (18-bit operands)' if args.grad_arith == 'bf16x3'
+                                    else '')) if gemm_mode == 1 else
                                 'bf16 operands, fp32 accumulate (reduced precision)' if gemm_mode == 2 else 'fp32 MFMA')},
             'roofline': roofline,
             'allreduce': allreduce,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
+                         'by_arithmetic': ({'f16x3': {'achieved': round(tn['f16x3']['tflops'], 2), 'peak': round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1),
+                                                      'frac': round(tn['f16x3']['tflops'] / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
+                                                      'launches_per_step': tn['f16x3']['launches'] // timed_steps,
+                                                      'ms_per_step': round(tn['f16x3']['total_ms'] / timed_steps, 3)},
+                                            'six_products': {'achieved': round(tn['rest']['tflops'], 2),
+                                                             'launches_per_step': tn['rest']['launches'] // timed_steps,
+                                                             'ms_per_step': round(tn['rest']['total_ms'] / timed_steps, 3)}}
+                                           if 'f16x3' in tn else None),
                          'share_of_step': round(tn['total_ms'] / (dt * 1e3 * timed_steps / args.steps), 3),
                          'effective_clock_mhz': (pmc or {}).get('gemm_tn', {}).get('effective_clock_mhz'),
                          'mfma_pipe_busy_at_effective_clock': (pmc or {}).get('gemm_tn', {}).get('mfma_pipe_busy')} if tn else None),
@@ -834,8 +881,8 @@ def main():
                                 'host_enqueue_ms_per_step': round(1e3 * t_enqueued / n_host, 3),
                                 'note': 'same steps without epoch()\'s metric bookkeeping; not the metric'},
         }
-        if extra_g3 is not None:
-            line['extra_gradient_products_3'] = extra_g3
+        if extra_six is not None:
+            line['extra_six_product_gradients'] = extra_six
         if student:     # BASELINE configs[3]: an extra measurement, not the headline metric
             line['metric'], line['unit'] = 'student-train sequences/sec (Bach 4-voice, 24 beats = 384 tokens)', 'sequences/s'
             tk, dk = config['auxiliary_networks_kwargs']['teacher_kwargs'], config['downscaler_kwargs']

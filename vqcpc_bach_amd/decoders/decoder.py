@@ -316,14 +316,15 @@ class Decoder(GraphedTraining, nn.Module):
         return means
 
     def train_model(self, batch_size, num_batches, num_epochs, lr, schedule_lr, plot=False, num_workers=0, **kwargs):
-        from .. import hip
-        mode_before = hip.gemm_mode_state()
+        from .. import hip, ops
+        mode_before, arith_before = hip.gemm_mode_state(), ops.gradient_arithmetic_state()
         self.use_training_defaults()               # bf16x6 GEMMs + step-graph replay unless the caller chose otherwise
         self.trained_gemm_mode = hip.get_gemm_mode()
         try:
             return self._train_epochs(batch_size, num_batches, num_epochs, lr, schedule_lr, num_workers)
         finally:
-            hip.restore_gemm_mode_state(mode_before)      # process-wide setting: put back what the caller had (encoder.py)
+            hip.restore_gemm_mode_state(mode_before)      # process-wide settings: put back what the caller had (encoder.py)
+            ops.restore_gradient_arithmetic_state(arith_before)
 
     def _train_epochs(self, batch_size, num_batches, num_epochs, lr, schedule_lr, num_workers):
         best_val = 1e8

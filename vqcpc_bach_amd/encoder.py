@@ -150,7 +150,8 @@ class EncoderTrainer(nn.Module):
                 self.writer = None
         best_val = 1e8
         from . import hip
-        mode_before = hip.gemm_mode_state()
+        from . import ops
+        mode_before, arith_before = hip.gemm_mode_state(), ops.gradient_arithmetic_state()
         if hasattr(self, 'use_training_defaults'):
             self.use_training_defaults()           # bf16x6 GEMMs + step-graph replay unless the caller chose otherwise
         self.trained_gemm_mode = hip.get_gemm_mode()        # what the epochs below run in (0 fp32 MFMA / 1 bf16x6 / 2 bf16)
@@ -161,6 +162,7 @@ class EncoderTrainer(nn.Module):
             # the GEMM arithmetic is a process-wide setting: a caller who chose nothing gets back what was there before
             # (evaluation / generation code that runs after training sees the mode it would have seen without it)
             hip.restore_gemm_mode_state(mode_before)
+            ops.restore_gradient_arithmetic_state(arith_before)
 
     def _train_epochs(self, batch_size, num_batches, num_epochs, lr, corrupt_labels, schedule_lr, plot, num_workers, best_val):
         self.init_optimizers(lr=lr, schedule_lr=schedule_lr)

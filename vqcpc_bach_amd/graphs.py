@@ -178,9 +178,12 @@ class GraphedTraining:
 
     def use_training_defaults(self):
         """Called by `train_model()` (the reference's entry point, encoder.py:244): a caller who chose nothing gets the
-        configuration bench.py measures -- bf16x6 GEMM arithmetic and step-graph replay (`VQCPC_STEP_GRAPH=0`,
-        `VQCPC_GEMM_MODE=...`, `enable_step_graph(False)` or `hip.set_gemm_mode()` beforehand override it)."""
+        configuration bench.py measures -- bf16x6 GEMM arithmetic, f16x3 gradient GEMMs inside backward, step-graph replay
+        (`VQCPC_STEP_GRAPH=0`, `VQCPC_GEMM_MODE=...`, `VQCPC_GRAD_ARITH=six`, `enable_step_graph(False)`, `hip.set_gemm_mode()` or
+        `ops.set_gradient_arithmetic()` beforehand override it)."""
         hip.use_training_default_gemm_mode()
+        from . import ops
+        ops.use_training_default_gradient_arithmetic()      # f16x3 gradient GEMMs (active in the bf16x6 mode only)
         if not self._graph_explicit and os.environ.get('VQCPC_STEP_GRAPH', '1') != '0':
             self.enable_step_graph(True)
             self._graph_explicit = False

@@ -38,19 +38,42 @@ def dropout_mask(n, p, seed, device):
 #          previous step; rms error vs fp64 3-5e-7 (fp32 MFMA kernel: 3-8e-7), x 1.4 the six-product kernels
 # 'bf16x3' the round-3 two-bf16-plane form (hip.set_gradient_products(3)): 18-bit operands, rms 4.4e-6 -- kept for comparison
 GRAD_ARITH = os.environ.get('VQCPC_GRAD_ARITH', 'six')
+TRAINING_GRAD_ARITH = 'f16x3'  # what train_model() / bench.py select in the bf16x6 mode (GraphedTraining.use_training_defaults)
+_grad_arith_explicit = 'VQCPC_GRAD_ARITH' in os.environ
 GRAD_MIN_TILES = 256           # dgrad: fewer 256 x 256 tiles than CUs -> the six-product path (its 128-tile kernels fill the chip)
 GRAD_TN_MIN_ROWS = 8192        # wgrad: as the 256-tile six-product kernel (tests set both to 0 to reach the kernels with small shapes)
+LAST_GEMM_F16X3 = False       # set by gemm_nt / gemm_nt_gatebits / gemm_tn: did the last call go through the f16x3 kernels (bench.py reads it)
 _GRAD_SCALES = None            # the open gradient scope's GradScales (None: outside a trainer's backward, or another arithmetic)
 
 
 def set_gradient_arithmetic(name):
     """Selects the arithmetic of the gradient GEMMs launched inside a trainer's backward pass (see above); returns the previous
     name.  Forward GEMMs -- losses, code assignment -- are never affected."""
-    global GRAD_ARITH
+    global GRAD_ARITH, _grad_arith_explicit
     assert name in ('six', 'f16x3', 'bf16x3'), name
     prev, GRAD_ARITH = GRAD_ARITH, name
+    _grad_arith_explicit = True
     hip.set_gradient_products(3 if name == 'bf16x3' else 6)
     return prev
+
+
+def gradient_arithmetic_state():
+    return (GRAD_ARITH, _grad_arith_explicit)
+
+
+def restore_gradient_arithmetic_state(state):
+    global GRAD_ARITH, _grad_arith_explicit
+    GRAD_ARITH, _grad_arith_explicit = state
+    hip.set_gradient_products(3 if GRAD_ARITH == 'bf16x3' else 6)
+
+
+def use_training_default_gradient_arithmetic():
+    """What `train_model()` selects when the caller chose nothing (neither set_gradient_arithmetic() nor VQCPC_GRAD_ARITH): the
+    f16x3 gradient GEMMs -- fp32-class (rms 3-5e-7 vs fp64, tools/bench_grad_f16.py; every parity suite passes in it at unchanged
+    tolerances), forward untouched -- i.e. the configuration bench.py measures.  The bare library default stays 'six'."""
+    global GRAD_ARITH
+    if not _grad_arith_explicit:
+        GRAD_ARITH = TRAINING_GRAD_ARITH
 
 
 class GradScales:
@@ -105,22 +128,20 @@ _grad_cut = {}                 # (M, N) -> rows of the dgrad launch that go thro
 
 
 def _grad_rows(M, N, K):
-    """Rows of an (M, K) x (N, K)^T input-gradient product for vqcpc_gemm_nt_grad: all of them when the 256-tiles fill whole
-    rounds of the 256 persistent workgroups well (>= 80 %), the whole rounds otherwise (139 264 x 256: 2.125 rounds -> 2), the
-    rest goes the six-product way."""
+    """Rows of an (M, K) x (N, K)^T input-gradient product that go through vqcpc_gemm_nt_grad: all of them (minus a remainder below
+    one tile) when its 256 x 256 tiles fill whole rounds of the 256 persistent workgroups to >= 80 %, none otherwise -- measured
+    at C1 (profiles/r05_perf_log.md): 139 264 x 256 is 2.125 rounds; cut into 2 rounds + a six-product remainder it was SLOWER
+    than the six-product path's own cut (0.228 -> 0.251 ms), so ragged shapes keep the six-product kernels."""
     hit = _grad_cut.get((M, N, K, GRAD_MIN_TILES))
     if hit is not None:
         return hit
     rows = 0
     if M >= 256 and hip.query('vqcpc_gemm_nt_grad_supported', M - M % 256, N, K):
-        tn = N // 256
-        tiles = (M // 256) * tn
-        if tiles >= max(GRAD_MIN_TILES, 1):
-            rounds = tiles / 256.0
-            if GRAD_MIN_TILES == 0 or (M % 256 == 0 and rounds / -(-tiles // 256) >= 0.8):
-                rows = M - M % 256
-            else:
-                rows = ((tiles // 256) * 256 // tn) * 256
+        tiles = (M // 256) * (N // 256)
+        if GRAD_MIN_TILES == 0:
+            rows = M - M % 256
+        elif tiles >= GRAD_MIN_TILES and M % 256 == 0 and (tiles / 256.0) / -(-tiles // 256) >= 0.8:
+            rows = M
     _grad_cut[(M, N, K, GRAD_MIN_TILES)] = rows
     return rows
 
@@ -139,6 +160,8 @@ def _tn_grad_ok(M, N, K):
 # ------------------------------------------------------------------------------------------------------------------
 def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.0, add=None, add2=None, out=None):
     """out[M,N] = epilogue(a[M,K] @ b[N,K]^T); see include/vqcpc.h."""
+    global LAST_GEMM_F16X3
+    LAST_GEMM_F16X3 = False
     a, lda = _rows(_f32(a))
     b, ldb = _rows(_f32(b))
     M, K = a.shape
@@ -160,6 +183,7 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         m_g = _grad_rows(M, N, K)
         if m_g and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
             st = _GRAD_SCALES.site(('nt', M, N, K), a, lda, M, K, b, ldb, N, K)
+            LAST_GEMM_F16X3 = True
             hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, ldc, m_g, N, K, add, lda_, add2, lda2_, None, 1.0, st)
             if m_g < M:            # the ragged last round: six products (same epilogue)
                 hip.call('vqcpc_gemm_nt', a[m_g:], lda, b, ldb, out[m_g:], ldc, M - m_g, N, K, None, 0, 0.0, 0, None, 0, 1.0,
@@ -240,8 +264,11 @@ def gemm_nt_gatebits(a, b, mask, gate_scale=1.0):
     M, K = a.shape
     N = b.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    global LAST_GEMM_F16X3
+    LAST_GEMM_F16X3 = False
     if _GRAD_SCALES is not None and _grad_rows(M, N, K) == M:
         st = _GRAD_SCALES.site(('ntg', M, N, K), a, lda, M, K, b, ldb, N, K)
+        LAST_GEMM_F16X3 = True
         hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, N, M, N, K, None, 0, None, 0, mask, float(gate_scale), st)
         return out
     hip.call('vqcpc_gemm_nt_gatebits', a, lda, b, ldb, out, N, M, N, K, mask, float(gate_scale))
@@ -261,9 +288,11 @@ def gemm_tn(a, b, want_bias=True, into=None):
     else:
         dw = torch.empty(N, K, dtype=torch.float32, device=a.device)
         db = torch.empty(N, dtype=torch.float32, device=a.device) if want_bias else None
-    global LAST_TN_DEFERRED
+    global LAST_TN_DEFERRED, LAST_GEMM_F16X3
     LAST_TN_DEFERRED = False
+    LAST_GEMM_F16X3 = False
     if _GRAD_SCALES is not None and hip.get_gemm_mode() == 1 and _tn_grad_ok(M, N, K):
+        LAST_GEMM_F16X3 = True
         # inside a trainer's backward pass: the weight gradient on three fp16 MFMAs per product
         st = _GRAD_SCALES.site(('tn', M, N, K), a, lda, M, N, b, ldb, M, K)
         nbytes = hip.query('vqcpc_gemm_tn_grad_workspace', M, N, K)

@@ -9,7 +9,7 @@ class DropoutSeeds:
     def __init__(self, base=0x5EED):
         self.base = int(base) & 0xFFFFFFFF
         self.counter = 0
-        self.generation = 0         # bumped by manual_seed(): invalidates every trainer's forked stream
+        self.generation = 0         # bumped by manual_seed(): a trainer whose stream was forked earlier warns once (see stream_of)
         self.rank_salt = 0          # set once per process by the trainers' init_optimizers (data-parallel rank)
 
     def set_rank(self, rank):
@@ -18,10 +18,10 @@ class DropoutSeeds:
         self.rank_salt = (int(rank) * 0x9E3779B1) & 0xFFFFFFFF
 
     def manual_seed(self, base):
-        """Re-seeds the process-wide source AND every trainer: a trainer that has already stepped re-forks its stream from
-        the new (base, counter) at its next step (as if it were taking its first), so `SEEDS.manual_seed(s)` between two
-        runs of one trainer object reproduces the masks of the first run.  (`trainer.seed_dropout(base)` re-seeds one
-        trainer only.)"""
+        """Re-seeds the process-wide source, i.e. every trainer that has NOT taken a step yet.  A trainer that has stepped owns
+        its stream (two trainers seeded one after the other in one process must not reach into each other: tests/test_graphs_gpu.py
+        ::test_two_trainers_interleaved_...) and keeps it: `trainer.seed_dropout(base)` re-seeds that trainer; its next step
+        warns once that this call did not."""
         self.base = int(base) & 0xFFFFFFFF
         self.counter = 0
         self.generation += 1
@@ -45,8 +45,12 @@ class _OwnedStream:
     def __enter__(self):
         s, st = self.seeds, getattr(self.owner, '_dropout_stream', None)
         self.outer = (s.base, s.counter)
-        if st is not None and len(st) > 2 and st[2] != s.generation:
-            st = None                                # SEEDS.manual_seed() since this stream was forked: fork again
+        if st is not None and len(st) > 2 and st[2] != s.generation and not getattr(self.owner, '_dropout_reseed_warned', False):
+            import warnings
+            self.owner._dropout_reseed_warned = True
+            warnings.warn('SEEDS.manual_seed() was called after this trainer took its first step: the trainer keeps its own '
+                          'dropout-seed stream (call trainer.seed_dropout(base) to re-seed it)', stacklevel=3)
+        self._gen = st[2] if (st is not None and len(st) > 2) else s.generation     # the generation this stream belongs to
         if st is None:
             st = (s.base, s.counter)
         s.base, s.counter = st[0], st[1]
@@ -54,7 +58,7 @@ class _OwnedStream:
 
     def __exit__(self, *exc):
         s = self.seeds
-        self.owner._dropout_stream = (s.base, s.counter, s.generation)
+        self.owner._dropout_stream = (s.base, s.counter, self._gen)
         s.base, s.counter = self.outer
         return False
 

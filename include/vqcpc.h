@@ -37,19 +37,26 @@ extern "C" {
  * enqueued on the `stream` argument, nothing is synchronised), EXCEPT for the following settings, which are plain
  * process-wide values read at launch time.  They are configuration, not data: set them before the work they apply to is
  * enqueued and do not change them from a second thread while another one launches.
- *   vqcpc_gemm_set_mode / vqcpc_gemm_bf16_set_variant   which GEMM arithmetic / kernel vqcpc_gemm_* launch (read by vqcpc_gemm_nt,
- *                              _tn, _tn_grouped, _nt_splitk, _nt_relu_mask, _nt_gatebits, _nt_bf16 and by the *_workspace /
- *                              *_supported / *_groupable queries, whose answers belong to the mode they were asked in)
- *   vqcpc_gemm_set_gradient_products / vqcpc_gemm_gradient_scope   the opt-in gradient arithmetic of the bf16x6 mode: the scope
- *                              is a counter, opened and closed by ONE thread around its backward pass
+ *   vqcpc_gemm_set_mode        which GEMM ARITHMETIC vqcpc_gemm_* launch: 0 fp32 MFMA / 1 bf16x6 / 8 bf16 (read by vqcpc_gemm_nt,
+ *                              _tn, _tn_grouped, _nt_splitk, _nt_relu_mask, _nt_gatebits and by the *_workspace / *_supported /
+ *                              *_groupable queries, whose answers belong to the mode they were asked in).  The product library
+ *                              has NO kernel-selection switch (round 5: the A/B bits +2 / +4 of this call and
+ *                              vqcpc_gemm_bf16_set_variant exist in lab builds only)
+ *   vqcpc_gemm_set_gradient_products / vqcpc_gemm_gradient_scope   the bf16-pair gradient arithmetic of round 3 (kept for
+ *                              comparison): the scope is a counter, opened and closed by ONE thread around its backward pass.
+ *                              The f16x3 gradient GEMMs that training uses (vqcpc_gemm_nt_grad / _tn_grad) are explicit entry
+ *                              points whose only state -- the per-call-site scale floats -- is caller-owned device memory
  *   vqcpc_relattn_force_general                         A/B switch of the attention dispatch (tests)
  *   vqcpc_rng_salt_set / vqcpc_rng_salt_advance         a DEVICE-side value (one copy per translation unit) XOR-ed into every
  *                              dropout seed: 0 outside a replayed step graph; a captured step sets it in its first node and
  *                              puts it back to 0 in its last, so work enqueued after a replay on the same stream sees 0
  *   vqcpc_last_error                                    thread-local message of the last failing call of the calling thread
- * Several trainers in one process may therefore interleave their steps at STEP granularity on one thread (tested:
- * tests/test_graphs_gpu.py::test_two_trainers_interleaved_in_one_process_equal_each_run_apart); concurrent steps from two
- * threads must agree on the settings above.
+ * Several trainers in one process may therefore interleave their steps at STEP granularity, on one thread or on several
+ * (tested: tests/test_graphs_gpu.py::test_two_trainers_interleaved_in_one_process_equal_each_run_apart and
+ * ::test_two_trainers_stepping_from_two_threads_equal_each_run_apart): the Python host layer serialises training steps with one
+ * process-wide lock (vqcpc_bach_amd/graphs.py STEP_LOCK -- torch.autograd runs every backward node of a device on ONE engine
+ * thread, so two concurrent backward passes would interleave there whatever the caller's threads do); callers of the C ABI that
+ * step from several threads must agree on the settings above.
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_abi_version(void);
 const char* vqcpc_last_error(void);
@@ -468,12 +475,10 @@ int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_cast_bf16(const float* in, int64_t ld_in, void* out, int64_t rows, int cols, void* stream);
 int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K);
-/* Kernel selection of vqcpc_gemm_nt_bf16 / vqcpc_gemm_tn_bf16 (process-wide; A/B measurements): 1 (default) = operands delivered
- * global -> LDS by DMA in whole 128-byte lines -- NT: K tiles of 64, one barrier per K tile (K % 128 == 0, otherwise kernel 0);
- * TN: 64-row slots in their row-major form, fragments by ds_read_b64_tr_b16 -- 0 = the register-staged kernels (NT: ping-pong,
- * K tiles of 32; TN: row pairs interleaved with v_perm, ds_read_b32 fragments).  NT results are identical bit for bit; TN results
- * agree to fp32 rounding of the partial sums (the split boundaries differ: multiples of 128 instead of 64 rows). */
-int vqcpc_gemm_bf16_set_variant(int variant);
+/* vqcpc_gemm_nt_bf16 / vqcpc_gemm_tn_bf16 deliver their operands global -> LDS by DMA in whole 128-byte lines -- NT: K tiles of
+ * 64, one barrier per K tile (K % 128 == 0, otherwise the register-staged ping-pong kernel with K tiles of 32: bit-identical
+ * results); TN: 64-row slots in their row-major form, fragments by ds_read_b64_tr_b16.  (The A/B switch between the DMA and
+ * the register-staged kernels, vqcpc_gemm_bf16_set_variant, is a lab-build entry point.) */
 int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, void* Cb, int64_t ldcb,
                        int64_t M, int N, int K, const float* bias, int act, float drop_p, uint64_t seed, const float* gate,
                        int64_t ldgate, const void* gate_bf16, int64_t ldgate_bf16, float gate_scale, const float* add,
@@ -562,6 +567,8 @@ int vqcpc_adam_step_dev(float* p, float* g, float* m, float* v, int64_t n, const
  *   vqcpc_gemm_nt_planes C[M,N] = epi(A . B^T) with A = P3 of [M][K], B = P3 of [N][K]; epilogue arguments as vqcpc_gemm_nt.
  *                        M, N multiples of 256, K of 32, each operand's planes below 4 GB (vqcpc_gemm_nt_planes_supported).
  * ------------------------------------------------------------------------------------------------------------------ */
+/* A/B switch of vqcpc_gemm_nt_bf16 / _tn_bf16: 1 (default) = the LDS-DMA kernels, 0 = the register-staged ones. */
+int vqcpc_gemm_bf16_set_variant(int variant);
 int64_t vqcpc_planes_bytes(int64_t rows, int cols);
 int vqcpc_split3_planes(const float* x, int64_t ld, int64_t rows, int cols, void* planes, void* stream);
 int vqcpc_join3_planes(const void* planes, int64_t rows, int cols, float* x, int64_t ld, void* stream);

@@ -51,8 +51,16 @@ def test_product_library_is_not_the_lab_bench(lib):
         assert not hasattr(lib, s), f'{s} is a lab entry point'
     blob = open(hip.LIB_PATH, 'rb').read()
     for needle in (b'gemm_nt_x6_dma_kernel', b'gemm_nt_x6_sw', b'planes_kernel', b'VQCPC_PP_ABL', b'VQCPC_TN_PQ', b'VQCPC_PP_GRID',
-                   b'VQCPC_S64_MAX_TILES', b'VQCPC_BF16_STAGGER', b'VQCPC_GEMM_ABL'):
+                   b'VQCPC_S64_MAX_TILES', b'VQCPC_BF16_STAGGER', b'VQCPC_GEMM_ABL', b'VQCPC_G3_ABL'):
         assert needle not in blob, needle
+    # ... and it has no kernel-selection switch: the A/B bits of vqcpc_gemm_set_mode are refused, the arithmetic modes are not
+    before = lib.vqcpc_gemm_get_mode()
+    try:
+        for m in (3, 5, 17, 33):
+            assert lib.vqcpc_gemm_set_mode(m) != 0, m
+        assert lib.vqcpc_gemm_set_mode(1) == 0 and lib.vqcpc_gemm_get_mode() == 1
+    finally:
+        lib.vqcpc_gemm_set_mode({0: 0, 1: 1, 2: 8}[before])
 
 
 def test_abi_version_and_error_string(lib):

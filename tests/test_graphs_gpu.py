@@ -215,3 +215,74 @@ def test_two_trainers_interleaved_in_one_process_equal_each_run_apart(graph_a, g
         tb.enable_step_graph(False)
     finally:
         hip.set_gemm_mode(0)
+
+
+@pytest.mark.parametrize('graph_a,graph_b', [(True, False), (True, True)])
+def test_two_trainers_stepping_from_two_threads_equal_each_run_apart(graph_a, graph_b):
+    """SURVEY.md section 8(b) "re-entrant", the part the round-4 review found untested: two trainers of different shapes driven from
+    TWO Python threads, each on its own HIP stream, started together -- with dropout, eager and replayed steps, and
+    torch.autograd's single engine thread running both backward passes.  utils.STEP_LOCK serialises their steps on the host and
+    chains them on the device (the next step's stream waits for the previous step's last kernel: the device-side RNG salt and
+    the gradient scope are never shared): losses and parameters bit-identical to each trainer running alone."""
+    import threading
+    from vqcpc_bach_amd import hip
+    from vqcpc_bach_amd.utils import SEEDS
+    hip.load()
+    cfg_a, sd_a, batches_a = _cpc_setup(0.2)
+    cfg_b = O.make_cfg(emb=32, vocab=[56] * 4, d=128, H=4, layers=[1, 1], ff=256, D=32, K=16, ncb=1, zdim=32, up_hidden=64,
+                       cdim=32, gru_hidden=64, B=4, N=5, Kl=2, Kr=2)
+    sd_b = O.init_state(cfg_b, seed=33)
+    batches_b = [O.synthetic_batch(cfg_b, seed=90 + i) for i in range(6)]
+    st = {}
+    O.encoder_forward(batches_b[0]['negative_samples'].reshape(-1, 4, 4), sd_b, cfg_b, stages=st)
+    sd_b['encoder.quantizer.embeddings.0'] = st['z'].reshape(-1, cfg_b['D'])[:cfg_b['K']].clone() + 0.01
+
+    def make(cfg, sd, seed, dropout, graph):
+        SEEDS.manual_seed(seed)
+        tr = build_trainer(cfg, sd, lr=2e-3, dropout=dropout)
+        tr.train()
+        tr.seed_dropout(seed)                       # each trainer's own stream, whatever the other thread seeds meanwhile
+        tr.enable_step_graph(graph)
+        return tr
+
+    def run(tr, batches, losses, stream=None, gate=None):
+        ctx = torch.cuda.stream(stream) if stream is not None else torch.cuda.stream(torch.cuda.current_stream())
+        with ctx:
+            if gate is not None:
+                gate.wait()
+            for b in batches:
+                losses.append(float(tr.train_step({k: v.cuda() for k, v in b.items()}, train=True)['loss']))
+            torch.cuda.current_stream().synchronize()
+
+    hip.set_gemm_mode(1)
+    try:
+        apart = []
+        for cfg, sd, batches, seed, p, graph in ((cfg_a, sd_a, batches_a, 7, 0.2, graph_a), (cfg_b, sd_b, batches_b, 8, 0.1, graph_b)):
+            tr = make(cfg, sd, seed, p, graph)
+            losses = []
+            run(tr, batches, losses)
+            apart.append((losses, tr.flat.flat.detach().clone()))
+            tr.enable_step_graph(False)
+        ta, tb = make(cfg_a, sd_a, 7, 0.2, graph_a), make(cfg_b, sd_b, 8, 0.1, graph_b)
+        la, lb, errors = [], [], []
+        gate = threading.Barrier(2)
+
+        def worker(tr, batches, losses):
+            try:
+                run(tr, batches, losses, stream=torch.cuda.Stream(), gate=gate)
+            except BaseException as e:              # surfaced by the main thread
+                errors.append(e)
+
+        threads = [threading.Thread(target=worker, args=(ta, batches_a, la)), threading.Thread(target=worker, args=(tb, batches_b, lb))]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join(timeout=600)
+        assert not errors, errors
+        torch.cuda.synchronize()
+        assert la == apart[0][0] and lb == apart[1][0], (la, apart[0][0], lb, apart[1][0])
+        assert torch.equal(ta.flat.flat, apart[0][1]) and torch.equal(tb.flat.flat, apart[1][1])
+        ta.enable_step_graph(False)
+        tb.enable_step_graph(False)
+    finally:
+        hip.set_gemm_mode(0)

@@ -294,6 +294,11 @@ def bf16_nt_variant(request):
     """Both kernels behind vqcpc_gemm_nt_bf16: 1 = K tiles of 64 by LDS-DMA (default, K % 128 == 0), 0 = ping-pong, K tiles of 32."""
     from vqcpc_bach_amd import hip
     hip.load()
+    if not hip.is_lab():
+        if request.param == 0:
+            pytest.skip('the A/B switch between the bf16 kernels is a lab-build entry point (VQCPC_LAB=1)')
+        yield request.param                       # the product library always prefers the DMA kernels
+        return
     hip.call('vqcpc_gemm_bf16_set_variant', request.param)
     yield request.param
     hip.call('vqcpc_gemm_bf16_set_variant', 1)
@@ -338,6 +343,7 @@ def test_gemm_nt_bf16_native_kernel(ops, bf16_nt_variant, M, N, K):
     assert torch.equal(ops.gemm_nt_bf16(dev(eye), dev(bb2)).cpu(), bb2.t().contiguous())
 
 
+@lab_only
 @pytest.mark.parametrize('M,N,K', [(512, 256, 128), (256 * 260, 256, 256), (2048, 512, 2048), (256 * 300, 512, 512)])
 def test_gemm_nt_bf16_kernels_are_bit_identical(ops, M, N, K):
     """The LDS-DMA kernel (K tiles of 64) sums every output element over k in the order of the ping-pong kernel (K tiles of
@@ -363,6 +369,45 @@ def test_gemm_nt_bf16_kernels_are_bit_identical(ops, M, N, K):
             assert all(torch.equal(x, y) for x, y in zip(*outs)), sorted(kw)
     finally:
         hip.call('vqcpc_gemm_bf16_set_variant', 1)
+
+
+@pytest.mark.parametrize('M,N,K', [(256 * 300, 512, 512), (128 * 1024, 256, 1024)])
+def test_dma_gemm_kernels_under_memory_contention(ops, M, N, K):
+    """Race screen of the two kernels that order their LDS-DMA deliveries with COUNTED `s_waitcnt vmcnt(n)` instead of barriers
+    around every transfer (gemm_nt_bf16_k64_kernel, gemm_tn_bf16_tr_kernel; SURVEY.md section 5 "race detection"): 200 launches
+    each while a second stream streams 1 GB copies through HBM / L2 (which stretches and reorders the latency of every DMA), bit
+    for bit against the result of a quiet launch -- and, on a lab build, against the register-staged kernels, which have no
+    counted waits.  A counted wait that is one transfer short shows up as a stale fragment under exactly this load."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + K)
+    a, b = ops.cast_bf16(dev(torch.randn(M, K, generator=gen))), ops.cast_bf16(dev(torch.randn(N, K, generator=gen)))
+    bias = dev(torch.randn(N, generator=gen))
+    g, x = ops.cast_bf16(dev(torch.randn(M, N, generator=gen))), a
+    quiet_nt = ops.gemm_nt_bf16(a, b, bias=bias).clone()
+    quiet_tn = [t.clone() for t in ops.gemm_tn_bf16(g, x)]
+    if hip.is_lab():
+        hip.call('vqcpc_gemm_bf16_set_variant', 0)
+        try:
+            assert torch.equal(ops.gemm_nt_bf16(a, b, bias=bias), quiet_nt), 'DMA vs register-staged NT kernel'
+        finally:
+            hip.call('vqcpc_gemm_bf16_set_variant', 1)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    src, dst = torch.empty(1 << 28, dtype=torch.float32, device='cuda'), torch.empty(1 << 28, dtype=torch.float32, device='cuda')
+    stop = torch.zeros(1, device='cuda')
+    bad_nt = bad_tn = 0
+    with torch.cuda.stream(side):
+        for _ in range(400):                       # ~1.6 TB of copy / add traffic queued beside the GEMMs
+            dst.copy_(src, non_blocking=True)
+            src.add_(stop)
+    for i in range(200):
+        if not torch.equal(ops.gemm_nt_bf16(a, b, bias=bias), quiet_nt):
+            bad_nt += 1
+        dw, db = ops.gemm_tn_bf16(g, x)
+        if not (torch.equal(dw, quiet_tn[0]) and torch.equal(db, quiet_tn[1])):
+            bad_tn += 1
+    torch.cuda.synchronize()
+    assert bad_nt == 0 and bad_tn == 0, (bad_nt, bad_tn)
 
 
 @pytest.mark.parametrize('M,N,K', [(512, 256, 256), (4096, 512, 256), (128 * 700, 256, 768), (33280, 1024, 512), (128, 256, 256),

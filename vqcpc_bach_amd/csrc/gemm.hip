@@ -1841,12 +1841,19 @@ static std::atomic<int> g_grad_scope{0};
 static int gradient_products_now() {
     return g_grad_scope.load(std::memory_order_relaxed) > 0 ? g_grad_products.load(std::memory_order_relaxed) : 6;
 }
-static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups (A/B switch)
+// A/B switches of the kernel selection exist in LAB builds only (round 5: the product library keeps no such process-wide value;
+// what is left there is the arithmetic mode and the bf16-pair gradient scope, include/vqcpc.h "PROCESS-WIDE STATE")
 #if VQCPC_LAB
-static std::atomic<int> g_use_sw{0};   // bf16x6 NT 256-tile: software-pipelined one-wave-per-SIMD kernel (gemm_sw.hip), A/B switch
+static std::atomic<int> g_use_pp{1};   // bf16x6 NT 256-tile: ping-pong wave groups
+static std::atomic<int> g_use_sw{0};   // bf16x6 NT 256-tile: software-pipelined one-wave-per-SIMD kernel (gemm_sw.hip)
 static std::atomic<int> g_use_dma{0};  // bf16x6 NT 256-tile: LDS-DMA operand delivery (gemm_dma.hip) instead of register staging
+static std::atomic<int> g_use_t2{1};   // bf16x6 NT: use the 256x256 tile kernel where shapes allow
+static inline bool pp_enabled() { return g_use_pp.load(std::memory_order_relaxed) != 0; }
+static inline bool t2_enabled() { return g_use_t2.load(std::memory_order_relaxed) != 0; }
+#else
+static constexpr bool pp_enabled() { return true; }
+static constexpr bool t2_enabled() { return true; }
 #endif
-static std::atomic<int> g_use_t2{1};   // bf16x6 NT: use the 256x256 tile kernel where shapes allow (A/B switch)
 static int gemm_mode() {
     int m = g_gemm_mode.load(std::memory_order_relaxed);
     if (m < 0) {
@@ -2026,8 +2033,8 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
     // bf16x6, full 256 x 256 tiles: the high-arithmetic-intensity kernel (one workgroup of 8 waves per CU)
     // the 256-tile kernel runs ONE workgroup per CU: pick it only when its last (partial) round of tiles does not waste
     // more than the ~8 % it gains per tile over the 128-tile kernel (2 workgroups per CU, 4x more tiles)
-    bool t2_ok = mode == 1 && g_use_t2.load(std::memory_order_relaxed) && (M % kT2 == 0) && (N % kT2 == 0) &&
-                 (K % (2 * kT2BK) == 0) && (!add2 || (flags == (E_ADD | E_ADD2) && g_use_pp.load(std::memory_order_relaxed)));
+    bool t2_ok = mode == 1 && t2_enabled() && (M % kT2 == 0) && (N % kT2 == 0) &&
+                 (K % (2 * kT2BK) == 0) && (!add2 || (flags == (E_ADD | E_ADD2) && pp_enabled()));
     if (t2_ok && may_split) {
         // cost model in units of one round of 256-tiles (256 workgroups): a round of the 128-tile kernel (512 workgroups)
         // does half the work ~8 % less efficiently.  A partial last round wastes whole CUs, so a GEMM of 2.1 rounds is cut by
@@ -2072,7 +2079,7 @@ static int gemm_nt_launch(const float* A, int64_t lda, const float* B, int64_t l
         const dim3 grid2((unsigned)std::min(tiles2, grid_cap)), block2(kT2Threads);
         // the gate epilogue (relu / dropout backward: reads an M x N operand, N = 4 K) is HBM-bound; all eight waves storing
         // together (lockstep kernel) keep more bytes in flight than one wave group at a time: 0.92 vs 1.21 ms at C1
-        const bool use_pp = g_use_pp.load(std::memory_order_relaxed) != 0 && flags != E_GATE;
+        const bool use_pp = pp_enabled() && flags != E_GATE;
         const size_t lds2 = 2 * kT2Buf;
         const size_t lds_pp = 2 * 6 * kT2 * 32;          // ping-pong kernel: unpadded swizzled planes (96 KB)
         const size_t lds_pp2 = 2 * 4 * kT2 * 32;         // its two-plane gradient variant (64 KB)
@@ -2226,8 +2233,12 @@ int vqcpc_gemm_set_mode(int mode) {
         g_gemm_mode.store(2, std::memory_order_relaxed);
         return VQCPC_OK;
     }
+#if VQCPC_LAB
     g_use_t2.store((mode & 2) ? 0 : 1, std::memory_order_relaxed);
     g_use_pp.store((mode & 4) ? 0 : 1, std::memory_order_relaxed);
+#else
+    VQ_REQUIRE((mode & 6) == 0, "gemm_set_mode: the kernel-selection switches (+2, +4, +16, +32) exist in lab builds only");
+#endif
     mode &= 1;
     g_gemm_mode.store(mode, std::memory_order_relaxed);
     return VQCPC_OK;
@@ -2318,7 +2329,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const float* __res
 // rows (M when it does not cut): a caller with a workspace can run the remaining rows through vqcpc_gemm_nt_splitk instead
 // of the single under-filled 128-tile launch (bias / residual epilogues, K >= 1024).
 int64_t vqcpc_gemm_nt_main_rows(int64_t M, int N, int K) {
-    if (gemm_mode() != 1 || !g_use_t2.load(std::memory_order_relaxed) || M % kT2 || N % kT2 || K % (2 * kT2BK)) return M;
+    if (gemm_mode() != 1 || !t2_enabled() || M % kT2 || N % kT2 || K % (2 * kT2BK)) return M;
     const int64_t mt = M / kT2, tn = N / kT2, t256 = mt * tn;
     const int64_t tiles = ceil_div(M, BM) * ceil_div(N, BN);
     const double c256 = ceil((double)t256 / kNumCU);
@@ -2381,7 +2392,7 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
         set_error("gemm_tn: workspace too small");
         return VQCPC_EWORKSPACE;
     }
-    const bool use256 = gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && tn_can_use_256(M, N, K);
+    const bool use256 = gemm_mode() == 1 && t2_enabled() && tn_can_use_256(M, N, K);
     const int splits = use256 ? tn_splits_256(M, N, K) : tn_splits(M, N, K);
     const int64_t rows_per_split = round_up(ceil_div(M, splits), TM);
     const int tiles_k = (int)ceil_div(K, BN);
@@ -2398,7 +2409,7 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
             attr_done = true;
         }
         const int tk2 = K / kT2;
-        if (g_use_pp.load(std::memory_order_relaxed)) {
+        if (pp_enabled()) {
             static bool attr_pp = false;
             constexpr int kPQBuf3 = 2 * 6 * 4 * (2048 + 64), kPQBuf2 = 2 * 4 * 4 * (2048 + 64);       // gemm_tn_x6_pq_kernel images
             if (!attr_pp) {
@@ -2468,7 +2479,7 @@ int vqcpc_gemm_tn(const float* A, int64_t lda, const float* B, int64_t ldb, floa
 // (small products): only then is the deferred result bit-identical to the immediate one.
 int vqcpc_gemm_tn_deferred_splits(int64_t M, int N, int K) {
     if (M < 1 || N < 4 || K < 4 || (N % 4) || (K % 4)) return 0;
-    const bool use256 = gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && tn_can_use_256(M, N, K);
+    const bool use256 = gemm_mode() == 1 && t2_enabled() && tn_can_use_256(M, N, K);
     const int splits = use256 ? tn_splits_256(M, N, K) : tn_splits(M, N, K);
     return ((int64_t)N * K >= (1 << 16) && splits <= 64) ? splits : 0;
 }
@@ -2481,7 +2492,7 @@ int vqcpc_gemm_tn_groupable(int64_t M, int N, int K) {
     const int mode = gemm_mode();
     if (mode != 1 && mode != 2) return 0;
     if (M < 1 || N < 4 || K < 4 || (N % 4) || (K % 4)) return 0;
-    if (mode == 1 && g_use_t2.load(std::memory_order_relaxed) && tn_can_use_256(M, N, K)) return 0;
+    if (mode == 1 && t2_enabled() && tn_can_use_256(M, N, K)) return 0;
     // deferred problems keep both operands alive until the gradient scope closes and run on ~64 workgroups each: only the
     // genuinely small ones (student / decoder steps, narrow projections) are worth grouping -- at most 64 MB of operands
     return (M <= (1 << 20) && M * ((int64_t)N + K) * 4 <= (64ll << 20)) ? 1 : 0;
@@ -2609,7 +2620,7 @@ int vqcpc_gemm_tn_grouped(int n, const void* const* A, const int64_t* lda, const
 // element "output > 0"; the backward's epilogue d_h = (d_y . W2) * [h > 0] / (1 - p) reads the bits instead of the
 // M x 4d fp32 activation (2.3 GB per layer at C1).  256-tile ping-pong kernel only: M, N multiples of 256, K of 32, bf16x6.
 int vqcpc_gemm_gatebits_supported(int64_t M, int N, int K) {
-    return (gemm_mode() == 1 && g_use_t2.load(std::memory_order_relaxed) && g_use_pp.load(std::memory_order_relaxed) &&
+    return (gemm_mode() == 1 && t2_enabled() && pp_enabled() &&
             M >= kT2 && M % kT2 == 0 && N % kT2 == 0 && K % 32 == 0 && K >= 32)
                ? 1 : 0;
 }

@@ -913,13 +913,20 @@ int vqcpc_cast_bf16(const float* in, int64_t ld_in, void* out, int64_t rows, int
     return VQCPC_OK;
 }
 
-static std::atomic<int> g_bf16_nt_variant{1};      // 1: K tiles of 64 by LDS-DMA (gemm_nt_bf16_k64_kernel, K % 128 == 0); 0: ping-pong kernel, K tiles of 32
-
+// 1: K tiles of 64 by LDS-DMA (gemm_nt_bf16_k64_kernel, K % 128 == 0; the transposed-read weight-gradient kernel); 0: the
+// ping-pong kernels, K tiles of 32 (what shapes the DMA kernels do not take still run on).  The A/B SWITCH between them is a
+// lab-build facility (round 5): the product library always prefers variant 1.
+#if VQCPC_LAB
+static std::atomic<int> g_bf16_nt_variant{1};
+static inline int bf16_variant() { return g_bf16_nt_variant.load(std::memory_order_relaxed); }
 int vqcpc_gemm_bf16_set_variant(int variant) {
     VQ_REQUIRE(variant == 0 || variant == 1, "gemm_bf16_set_variant: 0 (ping-pong kernel, K tiles of 32) or 1 (K tiles of 64 by LDS-DMA)");
     g_bf16_nt_variant.store(variant, std::memory_order_relaxed);
     return VQCPC_OK;
 }
+#else
+static constexpr int bf16_variant() { return 1; }
+#endif
 
 int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K) { return (M % kB == 0 && N % kB == 0 && K % (2 * kBBK) == 0) ? 1 : 0; }
 
@@ -951,7 +958,7 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     const int tiles = (int)((M / kB) * tn);
     const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kBThreads);
     hipStream_t st = (hipStream_t)stream;
-    const bool k64 = g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && K % (2 * kKBK) == 0;
+    const bool k64 = bf16_variant() == 1 && K % (2 * kKBK) == 0;
 #define BL(EPIV, OUTV)                                                                                                 \
     if (flags == (EPIV) && out == (OUTV) && k64) {                                                                     \
         static bool attr_k64 = false;                                                                                  \
@@ -1030,7 +1037,7 @@ int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     // transposed-read kernel: splits of whole 128-row pairs of slots.  Its DMA offsets (row within the split) * ld * 2 are
     // 32-bit against a 2 GB buffer resource based at the split's first row: taken only when a split's rows fit that range
     const int64_t rps = round_up(ceil_div(M, splits), 2 * kTRRows);
-    if (g_bf16_nt_variant.load(std::memory_order_relaxed) == 1 && lda < (1 << 20) && ldb < (1 << 20) &&
+    if (bf16_variant() == 1 && lda < (1 << 20) && ldb < (1 << 20) &&
         (rps + 2 * kTRRows) * std::max(lda, ldb) * 2 < ((int64_t)1 << 31)) {
         static bool attr_tr = false;
         if (!attr_tr) {

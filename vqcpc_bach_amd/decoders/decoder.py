@@ -31,7 +31,7 @@ from ..graphs import GraphedTraining
 from ..parallel import DataParallelContext, FlatParameters
 from ..transformer.transformer_custom import (TransformerCustom, TransformerDecoderCustom, TransformerDecoderLayerCustom,
                                               TransformerEncoderCustom, TransformerEncoderLayerCustom, mask_code)
-from ..utils import dict_pretty_print, flatten, SEEDS
+from ..utils import dict_pretty_print, flatten, SEEDS, STEP_LOCK
 
 
 class HeadsFn(torch.autograd.Function):
@@ -287,10 +287,11 @@ class Decoder(GraphedTraining, nn.Module):
 
     def train_step(self, tensor_dict, train=True):
         if not train:
-            x = self.data_processor.checked(self.data_processor.preprocess(tensor_dict['x']))
-            codes = self.encode(tensor_dict['x'])
-            with torch.no_grad():
-                return self.compute_loss(codes, x)[0].detach()
+            with STEP_LOCK:
+                x = self.data_processor.checked(self.data_processor.preprocess(tensor_dict['x']))
+                codes = self.encode(tensor_dict['x'])
+                with torch.no_grad():
+                    return self.compute_loss(codes, x)[0].detach()
         with SEEDS.stream_of(self):            # this trainer's own dropout-seed stream (utils.DropoutSeeds.stream_of)
             out = self._graphed_step(tensor_dict, self._train_step_body, parts=(self._step_compute, self._step_apply))
             if out is None:

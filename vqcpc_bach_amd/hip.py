@@ -34,7 +34,6 @@ SIGNATURES = {
                               c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'vqcpc_cast_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr]),
     'vqcpc_gemm_nt_bf16_supported': (c_int, [c_i64, c_int, c_int]),
-    'vqcpc_gemm_bf16_set_variant': (c_int, [c_int]),
     'vqcpc_gemm_nt_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int,
                                    c_f32, c_u64, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_tn_bf16_supported': (c_int, [c_i64, c_int, c_int]),
@@ -168,6 +167,7 @@ SIGNATURES = {
 # Entry points of LAB builds only (`VQCPC_LAB=1 python -m vqcpc_bach_amd.build` -> libvqcpc_hip_lab.so, the `#ifdef VQCPC_LAB`
 # section of include/vqcpc.h): rejected kernel designs kept for A/B measurements by the tools under tools/
 LAB_SIGNATURES = {
+    'vqcpc_gemm_bf16_set_variant': (c_int, [c_int]),
     'vqcpc_planes_bytes': (c_i64, [c_i64, c_int]),
     'vqcpc_split3_planes': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     'vqcpc_join3_planes': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_i64, c_ptr]),

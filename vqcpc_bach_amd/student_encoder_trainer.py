@@ -24,7 +24,7 @@ import torch
 from . import ops
 from .encoder import EncoderTrainer
 from .graphs import GraphedTraining
-from .utils import SEEDS
+from .utils import SEEDS, STEP_LOCK
 from .parallel import DataParallelContext, FlatParameters
 from .vqcpc_encoder_trainer import VQCPCEncoderTrainer
 
@@ -344,7 +344,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
 
     def train_step(self, tensor_dict, train=True, masked_event_index=None):
         if not train:
-            with torch.no_grad():
+            with STEP_LOCK, torch.no_grad():
                 return self.compute_losses(tensor_dict, masked_event_index)[2]
         # the masked event is drawn on the host exactly as the reference does (student_encoder_trainer.py:159-160)
         x = tensor_dict['x']

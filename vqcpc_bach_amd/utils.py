@@ -2,6 +2,44 @@
 import torch
 
 
+class _StepLock:
+    """ONE training / evaluation step of ONE trainer at a time, process-wide (SURVEY.md section 8(b) "re-entrant").  The host layer
+    keeps per-step state in module globals (ops: the open gradient scope, its deferred weight gradients, transposed weights and
+    f16x3 scale table; this module: the dropout-seed source) and torch.autograd executes every backward node of a device on one
+    engine thread, so two trainers stepping from two Python threads would interleave there whatever the callers do; the device
+    side has one RNG salt per translation unit that a replayed step graph sets and clears.  The lock serialises the steps on the
+    host, and the event it hands from one holder to the next orders them on the device as well (the next holder's stream waits
+    for the previous holder's last kernel), so threads with their own HIP streams are safe too.  Re-entrant; a few microseconds
+    per step."""
+
+    def __init__(self):
+        import threading
+        self._lock = threading.RLock()
+        self._depth = 0
+        self._event = None
+
+    def __enter__(self):
+        self._lock.acquire()
+        self._depth += 1
+        if self._depth == 1 and self._event is not None:
+            torch.cuda.current_stream().wait_event(self._event)
+        return self
+
+    def __exit__(self, *exc):
+        try:
+            if self._depth == 1 and torch.cuda.is_available() and torch.cuda.is_initialized():
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream())
+                self._event = ev
+        finally:
+            self._depth -= 1
+            self._lock.release()
+        return False
+
+
+STEP_LOCK = _StepLock()
+
+
 class DropoutSeeds:
     """Counter-based seed source for the in-kernel dropout RNG: every dropout site draws a fresh 64-bit seed, so masks
     are reproducible from (base seed, call order) and never stored."""
@@ -43,6 +81,7 @@ class _OwnedStream:
         self.seeds, self.owner = seeds, owner
 
     def __enter__(self):
+        STEP_LOCK.__enter__()                    # one training step at a time, process-wide (see _StepLock)
         s, st = self.seeds, getattr(self.owner, '_dropout_stream', None)
         self.outer = (s.base, s.counter)
         if st is not None and len(st) > 2 and st[2] != s.generation and not getattr(self.owner, '_dropout_reseed_warned', False):
@@ -60,6 +99,7 @@ class _OwnedStream:
         s = self.seeds
         self.owner._dropout_stream = (s.base, s.counter, self._gen)
         s.base, s.counter = self.outer
+        STEP_LOCK.__exit__(*exc)
         return False
 
 

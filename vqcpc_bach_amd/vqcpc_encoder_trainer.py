@@ -17,7 +17,7 @@ import torch
 from . import hip, ops, vqcpc_helper
 from .encoder import EncoderTrainer
 from .graphs import GraphedTraining
-from .utils import SEEDS
+from .utils import SEEDS, STEP_LOCK
 from .parallel import DataParallelContext, FlatParameters
 from .vqcpc_helper import cpc_scores_and_loss
 
@@ -254,7 +254,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         """One iteration.  Returns device-side metrics.  With `enable_step_graph()` a training step is a HIP-graph replay
         (graphs.py) once the first eager steps have done the lazy initialisations."""
         if not train:
-            with torch.no_grad():
+            with STEP_LOCK, torch.no_grad():
                 out = self.compute_losses(tensor_dict, corrupt_labels)[1]
                 out['metrics'] = self._step_metrics(out)
                 return out

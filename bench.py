@@ -71,6 +71,8 @@ def parse():
                          'and the code assignment are unaffected.  Default 6 = the exact split everywhere (the headline)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra (non-headline) measurement of the opt-in three-product gradient arithmetic')
+    ap.add_argument('--no-n1-leg', action='store_true',
+                    help='multi-rank runs: skip the single-rank leg on rank 0\'s GPU that follows the timed region (n1_same_node)')
     ap.add_argument('--no-secondary', action='store_true',
                     help='skip the short runs of the other configurations (C3 student step, DEC decoder step, C4 in bf16) that '
                          'the default N = 1 / C1 run reports under "secondary" after -- and outside -- the headline measurement')
@@ -504,6 +506,36 @@ def secondary_runs(timeout_s=240):
     return out
 
 
+def n1_same_node_leg(args, B, device_index, timeout_s=300):
+    """Multi-rank runs: the SAME command on ONE rank, on rank 0's GPU of THIS node, right after the timed region (a child process;
+    the other ranks wait at a barrier) -- so that scaling efficiency = value / (N x n1 value) is computed on one node's clocks and
+    one lease instead of against another run's BENCH line.  The benefit of the multi-GPU path stays UNMEASURED until the driver's
+    8-GPU run; this leg only makes that run self-explaining."""
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ('RANK', 'LOCAL_RANK', 'WORLD_SIZE', 'MASTER_ADDR', 'MASTER_PORT',
+                                                            'GROUP_RANK', 'LOCAL_WORLD_SIZE', 'ROLE_RANK', 'ROLE_WORLD_SIZE',
+                                                            'TORCHELASTIC_RUN_ID', 'VQCPC_DP_SHARE_GPU', 'VQCPC_DP_BACKEND',
+                                                            'VQCPC_FORCE_DIST')}
+    vis = env.get('HIP_VISIBLE_DEVICES') or env.get('ROCR_VISIBLE_DEVICES') or env.get('CUDA_VISIBLE_DEVICES')
+    ids = [x for x in vis.split(',') if x != ''] if vis else None
+    env['HIP_VISIBLE_DEVICES'] = ids[device_index] if ids and device_index < len(ids) else str(device_index)
+    cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--config', args.config, '--steps', str(args.steps), '--warmup',
+           str(args.warmup), '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-arith',
+           str(args.grad_arith), '--no-cpu-baseline', '--no-live-pmc', '--no-extras', '--no-secondary', '--no-kernel-timing']
+    if not args.graph:
+        cmd.append('--no-graph')
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, env=env)
+        line = json.loads([l for l in r.stdout.splitlines() if l.startswith('{')][-1])
+        return {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': line['steps'],
+                'wall_s': round(time.perf_counter() - t0, 1),
+                'note': 'the same command with --gpus 1 on rank 0\'s GPU of this node, run right after the timed region while '
+                        'the other ranks idle at a barrier'}
+    except Exception as e:
+        return {'error': f'{type(e).__name__}: {str(e)[:200]}', 'wall_s': round(time.perf_counter() - t0, 1)}
+
+
 def flush_c_stdio():
     """RCCL prints its version banner with printf; on a pipe that text sits in libc's buffer until exit and would land
     AFTER the JSON line.  Flushing libc's streams on every rank before rank 0 prints keeps the JSON line last."""
@@ -671,12 +703,14 @@ def main():
     t0 = time.perf_counter()
     means = run_epoch(args.steps, not use_graph)
     torch.cuda.synchronize()
+    dt_local = time.perf_counter() - t0                 # this rank's own time (before it waits for the others)
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     clock_info = clock.finish() if clock is not None else None
     timer.enabled = False
     dt = dp.max_over_ranks(dt)
+    per_rank_ms = dp.gather_floats(1e3 * dt_local / args.steps) if dp.distributed else None
     timed_steps = max(1, len(range(0, args.steps, 4)))
     graph_replays, graphs_per_step = None, None
     if use_graph:
@@ -709,6 +743,12 @@ def main():
                      'note': f'{n_ar} back-to-back all-reduces of the flat fp32 gradient bucket after the timed region (max over '
                              'ranks); inside the step the same call sits between the two graph replays'}
         del bucket
+    n1_leg = None
+    if dp.distributed and not args.no_n1_leg:
+        torch.cuda.synchronize()
+        if dp.rank == 0:
+            n1_leg = n1_same_node_leg(args, B, dev.index if dev.index is not None else 0)
+        dp.barrier()                                  # the other ranks idle here meanwhile
     # Extra, NOT the headline: the same steps with the forward's six-product split in the backward pass as well (what every
     # round before the fifth measured), after the timed region so that it cannot touch `value`: the price of carrying 24-bit
     # operand mantissas through six MFMAs where 22 bits through three give the same fp32-class gradients.
@@ -853,6 +893,11 @@ def main():
                                 'bf16 operands, fp32 accumulate (reduced precision)' if gemm_mode == 2 else 'fp32 MFMA')},
             'roofline': roofline,
             'allreduce': allreduce,
+            'per_rank': ({'ms_per_step_min': round(min(per_rank_ms), 3), 'ms_per_step_max': round(max(per_rank_ms), 3),
+                          'ms_per_step': [round(x, 3) for x in per_rank_ms],
+                          'note': 'each rank\'s own time over the timed region, taken before it waits for the others; '
+                                  '`ms_per_step` above is the barrier-to-barrier maximum'} if per_rank_ms else None),
+            'n1_same_node': n1_leg,
             'gemm_tn': ({'achieved': round(tn['tflops'], 2), 'unit': 'TFLOP/s', 'avg_launch_us': round(tn['avg_us'], 1),
                          'by_arithmetic': ({'f16x3': {'achieved': round(tn['f16x3']['tflops'], 2), 'peak': round(PEAK_BF16_MFMA_TFLOPS / 3.0, 1),
                                                       'frac': round(tn['f16x3']['tflops'] / (PEAK_BF16_MFMA_TFLOPS / 3.0), 4),
@@ -883,6 +928,18 @@ def main():
         }
         if extra_six is not None:
             line['extra_six_product_gradients'] = extra_six
+        if n1_leg and n1_leg.get('value'):
+            # what the multi-rank step costs beyond the single-rank step of the same node: the all-reduce (and its launch
+            # gaps) that is NOT hidden.  The driver computes scaling efficiency itself from its own per-N runs; this is the
+            # same quantity on one lease, for reading the first multi-GPU run.
+            step_n, step_1 = line['ms_per_step'], n1_leg['ms_per_step']
+            line['scaling_same_node'] = {'efficiency': round(value / (dp.world_size * n1_leg['value']), 4),
+                                         'exposed_ms_per_step': round(step_n - step_1, 3),
+                                         'exposed_share_of_step': round((step_n - step_1) / step_n, 4),
+                                         'allreduce_alone_ms': (allreduce or {}).get('ms_per_step'),
+                                         'note': 'ms_per_step(N ranks) - ms_per_step(1 rank, same node, same command): '
+                                                 'the part of the gradient all-reduce (+ the two-graph step\'s launch gap) '
+                                                 'that the step does not hide; compare with allreduce_alone_ms'}
         if student:     # BASELINE configs[3]: an extra measurement, not the headline metric
             line['metric'], line['unit'] = 'student-train sequences/sec (Bach 4-voice, 24 beats = 384 tokens)', 'sequences/s'
             tk, dk = config['auxiliary_networks_kwargs']['teacher_kwargs'], config['downscaler_kwargs']

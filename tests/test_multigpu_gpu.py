@@ -180,6 +180,15 @@ def test_bench_contract_with_two_ranks_sharing_this_gpu():
     assert line['config']['global_batch'] == 64 and line['config']['parallelism'] == 'dp2'
     assert abs(line['value'] - 64 * 4 / (line['ms_per_step'] * 4e-3)) < 0.01 * line['value']
     assert line['roofline'] is not None and line['roofline']['achieved'] > 0
+    # round 5: what makes the first real multi-GPU run self-explaining -- every rank's own time, and a single-rank leg of the same
+    # command on rank 0's GPU in the same job (here: the same GPU both ranks share), from which the same-node efficiency follows
+    pr = line['per_rank']
+    assert len(pr['ms_per_step']) == 2 and 0 < pr['ms_per_step_min'] <= pr['ms_per_step_max'] <= line['ms_per_step'] * 1.001
+    n1 = line['n1_same_node']
+    assert n1 and n1.get('value', 0) > 0 and n1['steps'] == 4, n1
+    ss = line['scaling_same_node']
+    assert abs(ss['efficiency'] - line['value'] / (2 * n1['value'])) < 1e-3
+    assert abs(ss['exposed_ms_per_step'] - (line['ms_per_step'] - n1['ms_per_step'])) < 2e-3
 
 
 def test_bench_refuses_a_rank_count_that_differs_from_gpus():

@@ -77,6 +77,15 @@ class DataParallelContext:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
+    def gather_floats(self, value):
+        """One float per rank, in rank order, on every rank."""
+        if not self.distributed:
+            return [float(value)]
+        t = torch.zeros(self.world_size, dtype=torch.float64, device=self.device)
+        t[self.rank] = float(value)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return [float(x) for x in t.tolist()]
+
     def distinct_devices(self):
         """Number of DIFFERENT physical GPUs behind the ranks of the group (by PCI domain / bus / device id), or None when it
         cannot be told.  bench.py refuses a multi-rank measurement whose ranks share a GPU."""

@@ -158,6 +158,8 @@ int vqcpc_gemm_gradient_scope(int open);
  * consecutive sites: once per step; vqcpc_grad_amax primes [0] / [1] of a site on its first use (atomic max of |x| into *slot).
  * vqcpc_gemm_nt_grad: C = epilogue(A . B^T) with epilogue none | + add | + add + add2 | gate-bit mask * gate_scale (the forms
  *   of the input-gradient GEMMs); M, N multiples of 256, K of 32 (persistent over the tiles: the caller cuts ragged rounds).
+ *   add == C (same pointer and leading dimension, add2 == NULL): C += A . B^T in place, by fp32 atomic adds at the L2 (one add
+ *   per element: the value load-add-store gives, without the epilogue's operand loads).
  * vqcpc_gemm_tn_grad: dW = A^T . B (+ db = column sums of A, fp32 exact), as vqcpc_gemm_tn (accumulate 0 | 1); N, K multiples
  *   of 256, M of 32. */
 int vqcpc_gemm_nt_grad_supported(int64_t M, int N, int K);

@@ -1832,6 +1832,12 @@ def test_f16x3_input_gradient_epilogues(ops, bf16x6, M, N, K):
     for kw in ({}, dict(add=add), dict(add=add, add2=add2)):
         six = ops.gemm_nt(a, b, **kw)
         assert float((six - _nt_grad(a, b, st, **kw)).abs().max() / six.abs().max()) < 3e-6, list(kw)
+    # the residual already in C (add == C): accumulated in place by fp32 atomic adds -- one add per element, the same bits as
+    # the out-of-place form
+    from vqcpc_bach_amd import hip
+    acc = add.clone()
+    hip.call('vqcpc_gemm_nt_grad', a, K, b, K, acc, N, M, N, K, acc, N, None, 0, None, 1.0, st)
+    assert torch.equal(acc, _nt_grad(a, b, st, add=add))
     h, mask = ops.gemm_nt_relu_mask(torch.randn(M, K, device='cuda', generator=gen), torch.randn(N, K, device='cuda', generator=gen),
                                     torch.zeros(N, device='cuda'))
     six = ops.gemm_nt_gatebits(a, b, mask, gate_scale=1.25)

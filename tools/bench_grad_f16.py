@@ -121,6 +121,21 @@ print(f'  gate bits: {float((six - g3).abs().max() / six.abs().max()):.2e}   zer
 del a, b, add, add2, six, g3, h, mask
 
 M = 557056
+print('== + residual epilogue: out-of-place (add operand loaded) vs in place (atomic accumulate), M = 557056', flush=True)
+for N, K in ((256, 1024), (256, 768), (256, 256)):
+    a = torch.randn(M, K, device='cuda'); b = torch.randn(N, K, device='cuda'); add = torch.randn(M, N, device='cuda'); out = torch.empty(M, N, device='cuda')
+    st = state_for(a, b)
+    t_none = timed(lambda: nt_grad(a, b, st, out=out))
+    t_add = timed(lambda: nt_grad(a, b, st, add=add, out=out))
+    ref = nt_grad(a, b, st, add=add).clone()
+    acc = add.clone()
+    nt_grad(a, b, st, add=acc, out=acc)
+    same = float((acc - ref).abs().max() / ref.abs().max())
+    t_acc = timed(lambda: nt_grad(a, b, st, add=acc, out=acc))
+    fl = 2.0 * M * N * K / 1e9
+    print(f'  {N} x {K}: none {fl / t_none:6.1f}   + add {fl / t_add:6.1f}   in place {fl / t_acc:6.1f} TFLOP/s   (in place vs out of place: max rel diff {same:.1e})', flush=True)
+    del a, b, add, out, acc, ref
+
 print('== speed (C1 backward shapes, M = 557056; TFLOP/s = 2 M N K / t)', flush=True)
 shapes = (('nt', 1024, 256), ('nt', 256, 1024), ('nt', 256, 256), ('nt', 256, 768), ('tn', 1024, 256), ('tn', 256, 1024), ('tn', 256, 256), ('tn', 768, 256))
 for kind, N, K in (shapes[:2] + shapes[4:5] if QUICK else shapes):

@@ -78,7 +78,11 @@ __device__ __forceinline__ void g3_amax_publish(float amax, float* slot) {
 
 // =====================================================================================================================
 // dgrad: C[M, N] = epilogue(A[M, K] . B[N, K]^T), A = output gradient rows, B = W^T rows (ops.transpose)
-// EPI in {0, E_ADD, E_ADD | E_ADD2, E_GATEBITS}
+// EPI in {0, E_ADD, E_ADD | E_ADD2, E_GATEBITS, G_ACCUM}
+// G_ACCUM: C += A . B^T by buffer_atomic_add_f32 (no return): the "+ residual" form when the residual already sits in C.  One
+// fp32 add per element at the L2, the same value load-add-store gives, and no operand load for the epilogue to wait for (with
+// E_ADD all eight waves stall on those loads together at every tile boundary: the slowest epilogue of this kernel).
+constexpr int G_ACCUM = 512;
 // =====================================================================================================================
 // ABL (lab builds, VQCPC_G3_ABL; results are wrong by construction): 1 = no operand requests after the prologue, 2 = no split /
 // LDS stores after the prologue, 4 = no MFMAs, 8 = no output stores, 16 = no fragment reads after the prologue
@@ -228,7 +232,10 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
                 if (EPI & E_GATEBITS) v = ((gb[tile & 1][r >> 2][r & 3] >> li) & 1u) ? v : 0.0f;                      \
                 if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
                 if (EPI & E_ADD2) v += a2[r];                                                                          \
-                if (ABL & 8) { asm volatile("" :: "v"(v)); } else                                                      \
+                if (ABL & 8) { asm volatile("" :: "v"(v)); } else if (EPI & G_ACCUM)                                   \
+                (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rc, voff_c,                                   \
+                                                      ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
+                else                                                                                                   \
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
                                                       ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
                 acc[mt][nt][r] = 0.0f;                                                                                 \
@@ -670,6 +677,7 @@ int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb,
     }
 #endif
     if (gate_mask) G3_LAUNCH(E_GATEBITS)
+    else if (add && !add2 && add == C && ldadd == ldc) G3_LAUNCH(G_ACCUM)        // the residual already sits in C: accumulate in place
     else if (add2) G3_LAUNCH(E_ADD | E_ADD2)
     else if (add) G3_LAUNCH(E_ADD)
     else G3_LAUNCH(0)

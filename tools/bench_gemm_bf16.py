@@ -1,6 +1,7 @@
 """bf16 NT GEMM (configs[4] path) per epilogue / output form at the C4 layer shapes (a quarter of the rows).
     python tools/bench_gemm_bf16.py [rows]"""
 import os, sys, statistics, torch
+os.environ.setdefault('VQCPC_LAB', '1')        # the A/B switch between the bf16 kernels is a lab-build entry point
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 from vqcpc_bach_amd import hip, ops
 hip.load()

@@ -488,24 +488,64 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_k64_kernel(const bf
     constexpr int kTileRows = kB;
     B_EPI_DECLS(4 * kKOperand)
 
-    // stream position s (K tile kt of the current output tile): RB_ = its slot, WB_ = the other one
+    // stream position s (K tile kt of the current output tile): RB_ = its slot, WB_ = the other one.
+    // Round 5: the 12 fragment reads of a half and the 8 DMA requests of a K tile are issued BETWEEN the MFMAs (one or two per
+    // MFMA pair, fenced), not in a block in front of them.  The two waves of a SIMD leave every barrier together and run the same
+    // stream: a block of 8 LDS-DMA requests + 12 reads in front of 16 MFMAs is a block in front of BOTH waves' MFMAs -- the matrix
+    // pipe idled for its issue time (60-180 cycles per DMA piece) once per K tile (the lesson of csrc/gemm_grad.hip, where the
+    // grouped schedule took the sum of matrix and memory-side time).  Same products in the same order: bit-identical results.
+#define K_PAIR(S_, KS, MT)                                                                                              \
+    acc[MT][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##a[KS][MT]),                     \
+                                                         __builtin_bit_cast(bf16x8, S_##b[KS][0]), acc[MT][0], 0, 0, 0); \
+    acc[MT][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, S_##a[KS][MT]),                     \
+                                                         __builtin_bit_cast(bf16x8, S_##b[KS][1]), acc[MT][1], 0, 0, 0);
+#define K_F() __builtin_amdgcn_sched_barrier(0);
+    // MFMAs of the X half with the reads of the Y half (k16 steps 2, 3 of slot SLOT) between them
+#define K_MFMA_X_READ_Y(SLOT)                                                                                           \
+    K_PAIR(x, 0, 0) K_F() K_RD(yb[0][0], b_ad2, (SLOT) * kKOperand); K_RD(yb[0][1], b_ad2, (SLOT) * kKOperand + 32 * kKRowB); K_F() \
+    K_PAIR(x, 0, 1) K_F() K_RD(ya[0][0], a_ad2, (SLOT) * kKOperand); K_RD(ya[0][1], a_ad2, (SLOT) * kKOperand + 32 * kKRowB); K_F() \
+    K_PAIR(x, 0, 2) K_F() K_RD(ya[0][2], a_ad2, (SLOT) * kKOperand + 64 * kKRowB); K_RD(ya[0][3], a_ad2, (SLOT) * kKOperand + 96 * kKRowB); K_F() \
+    K_PAIR(x, 0, 3) K_F() K_RD(yb[1][0], b_ad3, (SLOT) * kKOperand); K_RD(yb[1][1], b_ad3, (SLOT) * kKOperand + 32 * kKRowB); K_F() \
+    K_PAIR(x, 1, 0) K_F() K_RD(ya[1][0], a_ad3, (SLOT) * kKOperand); K_F()                                              \
+    K_PAIR(x, 1, 1) K_F() K_RD(ya[1][1], a_ad3, (SLOT) * kKOperand + 32 * kKRowB); K_F()                                \
+    K_PAIR(x, 1, 2) K_F() K_RD(ya[1][2], a_ad3, (SLOT) * kKOperand + 64 * kKRowB); K_F()                                \
+    K_PAIR(x, 1, 3) K_F() K_RD(ya[1][3], a_ad3, (SLOT) * kKOperand + 96 * kKRowB); K_F()
+    // one DMA piece (8 rows x 128 bytes) of operand OP (a | b), piece J of the K tile at the load cursor, into slot DSLOT
+#define K_DMA(OP, J, DSLOT, OPBASE)                                                                                     \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_##OP, (lds_ptr_t)(smem + ((OPBASE) + (DSLOT)) * kKOperand + wave * 4096 + (J) * 1024), \
+                                             16, ((J) & 1) ? voff_##OP##o : voff_##OP##e, ((J) * 8 * ld##OP##i + ld_k) * 2, 0, 0);
+#define K_ADVANCE()                                                                                                     \
+    ld_k += kKBK;                                                                                                       \
+    if (ld_k == K) {                                                                                                    \
+        ld_k = 0;                                                                                                       \
+        ld_tile += gridDim.x;            /* past the end: re-reads the last tile, never used */                         \
+        K_SET_SRC()                                                                                                     \
+    }
+    // MFMAs of the Y half with the DMA requests of the next K tile for slot DSLOT and (RD) the reads of the X half (k16 steps 0, 1)
+    // of slot RSLOT between them
+#define K_MFMA_Y_ISSUE_READ_X(DSLOT, RSLOT, RD)                                                                         \
+    K_PAIR(y, 0, 0) K_F() K_DMA(a, 0, DSLOT, 0) if (RD) { K_RD(xb[0][0], b_ad0, (RSLOT) * kKOperand); K_RD(xb[0][1], b_ad0, (RSLOT) * kKOperand + 32 * kKRowB); } K_F() \
+    K_PAIR(y, 0, 1) K_F() K_DMA(a, 1, DSLOT, 0) if (RD) { K_RD(xa[0][0], a_ad0, (RSLOT) * kKOperand); K_RD(xa[0][1], a_ad0, (RSLOT) * kKOperand + 32 * kKRowB); } K_F() \
+    K_PAIR(y, 0, 2) K_F() K_DMA(a, 2, DSLOT, 0) if (RD) { K_RD(xa[0][2], a_ad0, (RSLOT) * kKOperand + 64 * kKRowB); K_RD(xa[0][3], a_ad0, (RSLOT) * kKOperand + 96 * kKRowB); } K_F() \
+    K_PAIR(y, 0, 3) K_F() K_DMA(a, 3, DSLOT, 0) if (RD) { K_RD(xb[1][0], b_ad1, (RSLOT) * kKOperand); K_RD(xb[1][1], b_ad1, (RSLOT) * kKOperand + 32 * kKRowB); } K_F() \
+    K_PAIR(y, 1, 0) K_F() K_DMA(b, 0, DSLOT, 2) if (RD) { K_RD(xa[1][0], a_ad1, (RSLOT) * kKOperand); } K_F()           \
+    K_PAIR(y, 1, 1) K_F() K_DMA(b, 1, DSLOT, 2) if (RD) { K_RD(xa[1][1], a_ad1, (RSLOT) * kKOperand + 32 * kKRowB); } K_F() \
+    K_PAIR(y, 1, 2) K_F() K_DMA(b, 2, DSLOT, 2) if (RD) { K_RD(xa[1][2], a_ad1, (RSLOT) * kKOperand + 64 * kKRowB); } K_F() \
+    K_PAIR(y, 1, 3) K_F() K_DMA(b, 3, DSLOT, 2) if (RD) { K_RD(xa[1][3], a_ad1, (RSLOT) * kKOperand + 96 * kKRowB); } K_ADVANCE() K_F()
 #define K_TILE(RB_, WB_)                                                                                                \
     {                                                                                                                   \
         const bool boundary = (kt == 0 && s > 0);                                                                       \
         if (boundary) {                                                                                                 \
             B_EPILOGUE_P(false)                                                                                         \
             K_READ_X(RB_)                                                                                               \
+            K_LGKM_WAIT(x)                                                                                              \
         }                                                                                                               \
-        K_READ_Y(RB_)                                                                                                   \
-        if (boundary) { K_LGKM_WAIT(x) }                                                                                \
-        K_MFMA(x)                                                                                                       \
+        K_MFMA_X_READ_Y(RB_)                                                                                            \
         K_LGKM_WAIT(y)                                                                                                  \
         K_SYNC(boundary)                                                                                                \
-        K_ISSUE(RB_)                                                                                                    \
         ++s;                                                                                                            \
         kt = (kt + 1 == T) ? 0 : kt + 1;                                                                                \
-        if (kt != 0) { K_READ_X(WB_) }                                                                                  \
-        K_MFMA(y)                                                                                                       \
+        K_MFMA_Y_ISSUE_READ_X(RB_, WB_, kt != 0)                                                                        \
         if (kt != 0) { K_LGKM_WAIT(x) }                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     }
@@ -527,6 +567,12 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_nt_bf16_k64_kernel(const bf
     B_EPILOGUE_P(false)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the run-ahead DMAs must not outlive the workgroup's LDS
 #undef K_TILE
+#undef K_MFMA_Y_ISSUE_READ_X
+#undef K_ADVANCE
+#undef K_DMA
+#undef K_MFMA_X_READ_Y
+#undef K_F
+#undef K_PAIR
 #undef K_SYNC
 #undef K_MFMA
 #undef K_LGKM_WAIT
@@ -832,16 +878,52 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_tn_bf16_tr_kernel(const bf1
     __builtin_amdgcn_sched_barrier(0);                                                                                  \
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                                       \
     __builtin_amdgcn_sched_barrier(0);
+    // Round 5 (as gemm_nt_bf16_k64_kernel above): the 24 transposing reads of a half and the 8 DMA requests of a slot are issued
+    // BETWEEN the MFMAs (three reads, one request per MFMA pair, fenced) instead of in a block in front of both waves' MFMAs.
+    // Same products in the same order: bit-identical partial sums.
+#define R_PAIR(S_, H, MT)                                                                                               \
+    acc[MT][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R_FRAG(S_##a[H][MT]), R_FRAG(S_##b[H][0]), acc[MT][0], 0, 0, 0); \
+    acc[MT][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(R_FRAG(S_##a[H][MT]), R_FRAG(S_##b[H][1]), acc[MT][1], 0, 0, 0);
+#define R_F() __builtin_amdgcn_sched_barrier(0);
+#define R_DMA(OP, J, DSLOT, OPBASE)                                                                                     \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_##OP, (lds_ptr_t)(smem + ((OPBASE) + (DSLOT)) * kTROperand + wave * 4096 + (J) * 1024), \
+                                             16, ((J) & 1) ? voff_##OP##o : voff_##OP##e,                              \
+                                             (min(ld_slot, S - 1) * kTRRows + 2 * (J)) * ld##OP##i * 2, 0, 0);
+#define R_BIAS(S_)                                                                                                      \
+    if (want_bias) {                                                                                                    \
+        _Pragma("unroll") for (int h = 0; h < 2; ++h)                                                                   \
+            _Pragma("unroll") for (int mt = 0; mt < 4; ++mt)                                                            \
+                bsum[mt] += (R_BSUM1(S_##a[h][mt][0].x) + R_BSUM1(S_##a[h][mt][0].y)) +                                 \
+                            (R_BSUM1(S_##a[h][mt][1].x) + R_BSUM1(S_##a[h][mt][1].y));                                  \
+    }
+#define R_MFMA_X_READ_Y(SLOT)                                                                                           \
+    R_PAIR(x, 0, 0) R_F() R_RD(yb[0][0][0], b_ad[0], (SLOT) * kTROperand + (16 * (2)) * kTRRowB); R_RD(yb[0][0][1], b_ad[0], (SLOT) * kTROperand + (16 * (2) + 4) * kTRRowB); R_RD(yb[0][1][0], b_ad[1], (SLOT) * kTROperand + (16 * (2)) * kTRRowB); R_F() \
+    R_PAIR(x, 0, 1) R_F() R_RD(yb[0][1][1], b_ad[1], (SLOT) * kTROperand + (16 * (2) + 4) * kTRRowB); R_RD(ya[0][0][0], a_ad[0], (SLOT) * kTROperand + (16 * (2)) * kTRRowB); R_RD(ya[0][0][1], a_ad[0], (SLOT) * kTROperand + (16 * (2) + 4) * kTRRowB); R_F() \
+    R_PAIR(x, 0, 2) R_F() R_RD(ya[0][1][0], a_ad[1], (SLOT) * kTROperand + (16 * (2)) * kTRRowB); R_RD(ya[0][1][1], a_ad[1], (SLOT) * kTROperand + (16 * (2) + 4) * kTRRowB); R_RD(ya[0][2][0], a_ad[2], (SLOT) * kTROperand + (16 * (2)) * kTRRowB); R_F() \
+    R_PAIR(x, 0, 3) R_F() R_RD(ya[0][2][1], a_ad[2], (SLOT) * kTROperand + (16 * (2) + 4) * kTRRowB); R_RD(ya[0][3][0], a_ad[3], (SLOT) * kTROperand + (16 * (2)) * kTRRowB); R_RD(ya[0][3][1], a_ad[3], (SLOT) * kTROperand + (16 * (2) + 4) * kTRRowB); R_F() \
+    R_PAIR(x, 1, 0) R_F() R_RD(yb[1][0][0], b_ad[0], (SLOT) * kTROperand + (16 * (3)) * kTRRowB); R_RD(yb[1][0][1], b_ad[0], (SLOT) * kTROperand + (16 * (3) + 4) * kTRRowB); R_RD(yb[1][1][0], b_ad[1], (SLOT) * kTROperand + (16 * (3)) * kTRRowB); R_F() \
+    R_PAIR(x, 1, 1) R_F() R_RD(yb[1][1][1], b_ad[1], (SLOT) * kTROperand + (16 * (3) + 4) * kTRRowB); R_RD(ya[1][0][0], a_ad[0], (SLOT) * kTROperand + (16 * (3)) * kTRRowB); R_RD(ya[1][0][1], a_ad[0], (SLOT) * kTROperand + (16 * (3) + 4) * kTRRowB); R_F() \
+    R_PAIR(x, 1, 2) R_F() R_RD(ya[1][1][0], a_ad[1], (SLOT) * kTROperand + (16 * (3)) * kTRRowB); R_RD(ya[1][1][1], a_ad[1], (SLOT) * kTROperand + (16 * (3) + 4) * kTRRowB); R_RD(ya[1][2][0], a_ad[2], (SLOT) * kTROperand + (16 * (3)) * kTRRowB); R_F() \
+    R_PAIR(x, 1, 3) R_F() R_RD(ya[1][2][1], a_ad[2], (SLOT) * kTROperand + (16 * (3) + 4) * kTRRowB); R_RD(ya[1][3][0], a_ad[3], (SLOT) * kTROperand + (16 * (3)) * kTRRowB); R_RD(ya[1][3][1], a_ad[3], (SLOT) * kTROperand + (16 * (3) + 4) * kTRRowB); R_F() \
+    R_BIAS(x)
+#define R_MFMA_Y_ISSUE_READ_X(DSLOT, RSLOT)                                                                             \
+    R_PAIR(y, 0, 0) R_F() R_DMA(a, 0, DSLOT, 0) R_RD(xb[0][0][0], b_ad[0], (RSLOT) * kTROperand + (16 * (0)) * kTRRowB); R_RD(xb[0][0][1], b_ad[0], (RSLOT) * kTROperand + (16 * (0) + 4) * kTRRowB); R_RD(xb[0][1][0], b_ad[1], (RSLOT) * kTROperand + (16 * (0)) * kTRRowB); R_F() \
+    R_PAIR(y, 0, 1) R_F() R_DMA(a, 1, DSLOT, 0) R_RD(xb[0][1][1], b_ad[1], (RSLOT) * kTROperand + (16 * (0) + 4) * kTRRowB); R_RD(xa[0][0][0], a_ad[0], (RSLOT) * kTROperand + (16 * (0)) * kTRRowB); R_RD(xa[0][0][1], a_ad[0], (RSLOT) * kTROperand + (16 * (0) + 4) * kTRRowB); R_F() \
+    R_PAIR(y, 0, 2) R_F() R_DMA(a, 2, DSLOT, 0) R_RD(xa[0][1][0], a_ad[1], (RSLOT) * kTROperand + (16 * (0)) * kTRRowB); R_RD(xa[0][1][1], a_ad[1], (RSLOT) * kTROperand + (16 * (0) + 4) * kTRRowB); R_RD(xa[0][2][0], a_ad[2], (RSLOT) * kTROperand + (16 * (0)) * kTRRowB); R_F() \
+    R_PAIR(y, 0, 3) R_F() R_DMA(a, 3, DSLOT, 0) R_RD(xa[0][2][1], a_ad[2], (RSLOT) * kTROperand + (16 * (0) + 4) * kTRRowB); R_RD(xa[0][3][0], a_ad[3], (RSLOT) * kTROperand + (16 * (0)) * kTRRowB); R_RD(xa[0][3][1], a_ad[3], (RSLOT) * kTROperand + (16 * (0) + 4) * kTRRowB); R_F() \
+    R_PAIR(y, 1, 0) R_F() R_DMA(b, 0, DSLOT, 2) R_RD(xb[1][0][0], b_ad[0], (RSLOT) * kTROperand + (16 * (1)) * kTRRowB); R_RD(xb[1][0][1], b_ad[0], (RSLOT) * kTROperand + (16 * (1) + 4) * kTRRowB); R_RD(xb[1][1][0], b_ad[1], (RSLOT) * kTROperand + (16 * (1)) * kTRRowB); R_F() \
+    R_PAIR(y, 1, 1) R_F() R_DMA(b, 1, DSLOT, 2) R_RD(xb[1][1][1], b_ad[1], (RSLOT) * kTROperand + (16 * (1) + 4) * kTRRowB); R_RD(xa[1][0][0], a_ad[0], (RSLOT) * kTROperand + (16 * (1)) * kTRRowB); R_RD(xa[1][0][1], a_ad[0], (RSLOT) * kTROperand + (16 * (1) + 4) * kTRRowB); R_F() \
+    R_PAIR(y, 1, 2) R_F() R_DMA(b, 2, DSLOT, 2) R_RD(xa[1][1][0], a_ad[1], (RSLOT) * kTROperand + (16 * (1)) * kTRRowB); R_RD(xa[1][1][1], a_ad[1], (RSLOT) * kTROperand + (16 * (1) + 4) * kTRRowB); R_RD(xa[1][2][0], a_ad[2], (RSLOT) * kTROperand + (16 * (1)) * kTRRowB); R_F() \
+    R_PAIR(y, 1, 3) R_F() R_DMA(b, 3, DSLOT, 2) R_RD(xa[1][2][1], a_ad[2], (RSLOT) * kTROperand + (16 * (1) + 4) * kTRRowB); R_RD(xa[1][3][0], a_ad[3], (RSLOT) * kTROperand + (16 * (1)) * kTRRowB); R_RD(xa[1][3][1], a_ad[3], (RSLOT) * kTROperand + (16 * (1) + 4) * kTRRowB); R_F() \
+    ++ld_slot;                                                                                                          \
+    R_BIAS(y)
     // slot s (RB_ = its buffer, WB_ = the other one)
 #define R_SLOT(RB_, WB_)                                                                                                \
     {                                                                                                                   \
-        R_READ_Y(RB_)                                                                                                   \
-        R_MFMA(x)                                                                                                       \
+        R_MFMA_X_READ_Y(RB_)                                                                                            \
         R_LGKM_WAIT(y)                                                                                                  \
         R_SYNC()                        /* own DMA of slot s+1 landed, everybody's after the barrier; slot s fully read */ \
-        R_ISSUE(RB_)                    /* slot s+2 */                                                                  \
-        R_READ_X(WB_)                                                                                                   \
-        R_MFMA(y)                                                                                                       \
+        R_MFMA_Y_ISSUE_READ_X(RB_, WB_) /* slot s+2 requested, first half of slot s+1 read */                           \
         R_LGKM_WAIT(x)                                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
     }
@@ -862,6 +944,12 @@ __global__ __launch_bounds__(kBThreads, 2) void gemm_tn_bf16_tr_kernel(const bf1
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the clamped run-ahead DMAs must not outlive the workgroup's LDS
     }
 #undef R_SLOT
+#undef R_MFMA_Y_ISSUE_READ_X
+#undef R_MFMA_X_READ_Y
+#undef R_BIAS
+#undef R_DMA
+#undef R_F
+#undef R_PAIR
 #undef R_SYNC
 #undef R_MFMA
 #undef R_BSUM1

@@ -127,21 +127,29 @@ def _grad_scales_of(owner, tag):
 _grad_cut = {}                 # (M, N) -> rows of the dgrad launch that go through the three-product kernel (0: none)
 
 
+GRAD_CUT_MIN_K = 1 << 30       # ragged dgrad launches cut into whole rounds + a six-product remainder from this K on: OFF (measured slower)
+
+
 def _grad_rows(M, N, K):
-    """Rows of an (M, K) x (N, K)^T input-gradient product that go through vqcpc_gemm_nt_grad: all of them (minus a remainder below
-    one tile) when its 256 x 256 tiles fill whole rounds of the 256 persistent workgroups to >= 80 %, none otherwise -- measured
-    at C1 (profiles/r05_perf_log.md): 139 264 x 256 is 2.125 rounds; cut into 2 rounds + a six-product remainder it was SLOWER
-    than the six-product path's own cut (0.228 -> 0.251 ms), so ragged shapes keep the six-product kernels."""
+    """Rows of an (M, K) x (N, K)^T input-gradient product that go through vqcpc_gemm_nt_grad: all of them when its 256 x 256 tiles
+    fill whole rounds of the 256 persistent workgroups to >= 80 %, none otherwise.  Ragged launches (139 264 x 256: 2.125 rounds)
+    cut into whole rounds + a six-product remainder (GRAD_CUT_MIN_K) were measured twice at C1 (profiles/r05_perf_log.md) and
+    were slower both times -- K = 256 alone: 0.228 -> 0.251 ms per call; every K >= 512 launch with the remainder through the
+    split-K path: the step went from 24.5 to 24.8 ms -- so they stay on the six-product path, which cuts such launches itself."""
     hit = _grad_cut.get((M, N, K, GRAD_MIN_TILES))
     if hit is not None:
         return hit
     rows = 0
     if M >= 256 and hip.query('vqcpc_gemm_nt_grad_supported', M - M % 256, N, K):
-        tiles = (M // 256) * (N // 256)
+        tn = N // 256
+        tiles = (M // 256) * tn
         if GRAD_MIN_TILES == 0:
             rows = M - M % 256
-        elif tiles >= GRAD_MIN_TILES and M % 256 == 0 and (tiles / 256.0) / -(-tiles // 256) >= 0.8:
-            rows = M
+        elif tiles >= GRAD_MIN_TILES and M % 256 == 0:
+            if (tiles / 256.0) / -(-tiles // 256) >= 0.8:
+                rows = M
+            elif K >= GRAD_CUT_MIN_K:
+                rows = ((tiles // 256) * 256 // tn) * 256
     _grad_cut[(M, N, K, GRAD_MIN_TILES)] = rows
     return rows
 
@@ -185,9 +193,9 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
             st = _GRAD_SCALES.site(('nt', M, N, K), a, lda, M, K, b, ldb, N, K)
             LAST_GEMM_F16X3 = True
             hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, ldc, m_g, N, K, add, lda_, add2, lda2_, None, 1.0, st)
-            if m_g < M:            # the ragged last round: six products (same epilogue)
-                hip.call('vqcpc_gemm_nt', a[m_g:], lda, b, ldb, out[m_g:], ldc, M - m_g, N, K, None, 0, 0.0, 0, None, 0, 1.0,
-                         None if add is None else add[m_g:], lda_, None if add2 is None else add2[m_g:], lda2_)
+            if m_g < M:            # the ragged last round: six products, through this function's own dispatch (split-K for long K)
+                gemm_nt(a[m_g:], b, add=None if add is None else add[m_g:], add2=None if add2 is None else add2[m_g:], out=out[m_g:])
+                LAST_GEMM_F16X3 = True
             return out
     if (SPLIT_K and M <= _SPLITK_MAX_ROWS and K >= 512 and not act and not drop_p and gate is None and add2 is None
             and hip.get_gemm_mode() == 1):
@@ -231,7 +239,7 @@ def gemm_nt_residual(a, b, res, res_may_alias=None):
     M, K = a.shape
     N = b.shape[0]
     if (_GRAD_SCALES is not None and res.dtype == torch.float32 and res.is_contiguous() and res.shape == (M, N)
-            and hip.get_gemm_mode() == 1 and _grad_rows(M, N, K) == M
+            and hip.get_gemm_mode() == 1 and _grad_rows(M, N, K) > 0
             and (res_may_alias is None or res_may_alias.data_ptr() != res.data_ptr())):
         return gemm_nt(a, b, add=res, out=res)
     return gemm_nt(a, b, add=res)

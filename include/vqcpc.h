@@ -63,7 +63,9 @@ const char* vqcpc_last_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Dropout RNG shared by all kernels: keep(seed, i) = (u24(mix32((uint32)i * 0x9E3779B1 + lo(seed) ^ hi(seed))) >= p * 2^24)
- * with mix32 = the 'lowbias32' integer finaliser (8 VALU ops per element).
+ * with mix32(x): x ^= x >> 16; y = mul24(x, 0x6B43A9); y ^= y >> 15; y = mul24(y, 0x52DCE7) + x; y ^= y >> 14 (mul24 = the low 32 bits of
+ * the product of the operands' low 24 bits: the full-rate v_mul_u32_u24; round 5 -- rounds 1-4 used the 'lowbias32' finaliser, two
+ * quarter-rate 32-bit multiplies per element).
  * vqcpc_dropout_mask writes that keep-mask (1.0f / 0.0f) for i in [0, n) so that tests can reproduce every
  * in-kernel mask (element index conventions are documented per kernel).
  * ------------------------------------------------------------------------------------------------------------------ */

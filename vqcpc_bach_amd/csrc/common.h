@@ -82,14 +82,20 @@ __device__ __forceinline__ uint64_t rng_seed_eff(uint64_t seed) { return seed ^ 
 __device__ __forceinline__ uint32_t rng_x0(uint64_t seed_eff, uint32_t idx_lo) {
     return idx_lo * kRngMul + static_cast<uint32_t>(seed_eff);
 }
+// Round 5: the mixer runs on the FULL-RATE 24-bit multiplier (v_mul_u32_u24 / v_mad_u32_u24) -- the 'lowbias32' finaliser of rounds
+// 1-4 needs two v_mul_lo_u32, quarter-rate instructions, ~16 issue slots per element against ~10 here, and a GEMM epilogue with
+// dropout evaluates it 128 times per lane and output tile (bias + relu + dropout was 17 % slower than bias + relu on the bf16
+// GEMMs of configs[4]).  x ^= x >> 16 first, so that the 24 bits the multiplier sees depend on all 32 (no period of 2^24
+// elements); keep rate, lag-1 / lag-2 / lag-N autocorrelation of the masks, chi^2 of the 24-bit values and the correlation
+// between consecutive seeds were checked against the old mixer on 4 M indices (tools/micro/rng_quality.py): equal within noise.
 __device__ __forceinline__ uint32_t rng_u24_from_x0(uint32_t x, uint32_t seed_hi) {
     x ^= seed_hi;
     x ^= x >> 16;
-    x *= 0x7FEB352Du;
-    x ^= x >> 15;
-    x *= 0x846CA68Bu;
-    x ^= x >> 16;
-    return x >> 8;   // top 24 bits
+    uint32_t y = __umul24(x, 0x6B43A9u);
+    y ^= y >> 15;
+    y = __umul24(y, 0x52DCE7u) + x;
+    y ^= y >> 14;
+    return y >> 8;   // top 24 bits
 }
 __device__ __forceinline__ uint32_t rng_u24(uint64_t seed, uint64_t idx) {
     const uint64_t se = rng_seed_eff(seed);

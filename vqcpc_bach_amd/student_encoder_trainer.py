@@ -278,7 +278,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         self.flat.zero_grad()
         with torch.enable_grad():
             t = self.forward_teacher(x, m)
-        with ops.direct_weight_gradients(self.flat):
+        with ops.direct_weight_gradients(self.flat, tag='teacher'):       # own f16x3 scale table: two backward passes per step
             t['loss'].backward()
         return dict(x=x, m=m, teacher_logits=[lg.detach() for lg in t['weights_per_category']],
                     monitored=dict(t['monitored_quantities']))
@@ -286,7 +286,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
     def _step_compute_encdec(self, st):
         with torch.enable_grad():
             e = self._encdec_losses(*self._encode_decode(st['x'], st['m']), st['teacher_logits'])
-        with ops.direct_weight_gradients(self.flat):
+        with ops.direct_weight_gradients(self.flat, tag='encdec'):
             e['loss'].backward()
         out = dict(st['monitored'], **e['monitored_quantities'])
         out.update(masked_event_index=st['m'], encoding_indices=e['encoding_indices'], teacher_logits=st['teacher_logits'],

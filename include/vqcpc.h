@@ -334,7 +334,8 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
                             int64_t M, int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes,
                             void* stream);
 /* the same two kernels with an extra bf16 copy of the output that feeds GEMMs in the bf16 path (configs[4]):
- * y_bf16 [M][d] = bf16(y); d_r_bf16 [M][d] = bf16(d_r) (bf16(d_s) when drop_p == 0, where d_r == d_s).  NULL = no copy. */
+ * y_bf16 [M][d] = bf16(y); d_r_bf16 [M][d] = bf16(d_r) (bf16(d_s) when drop_p == 0, where d_r == d_s).  NULL = no copy.
+ * forward: y may be NULL when y_bf16 is given (the bf16 copy is the only consumer: 6 instead of 10 bytes per element). */
 int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
                                 void* y_bf16, float* mean, float* rstd, int64_t M, int d, float eps, float drop_p,
                                 uint64_t seed, void* stream);
@@ -471,8 +472,10 @@ int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int
  *                        (transformer_custom.py:282-289 FFN, multihead_attention_custom.py:171-196,338 projections).
  *                        C (fp32) and / or Cb (bf16) receive the result; epilogue as vqcpc_gemm_nt (bias, act = 1 relu,
  *                        dropout, gate: out *= gate > 0 ? gate_scale : 0 with an fp32 `gate` or a bf16 `gate_bf16` operand,
- *                        add).  M, N multiples of 256, K of 64 (vqcpc_gemm_nt_bf16_supported); lda / ldb / ldcb / ldgate_bf16
- *                        in bf16 elements.
+ *                        add: an fp32 `add` or -- round 5, the residual stream of the bf16 path kept in bf16: the LayerNorm's
+ *                        bf16 output is then its ONLY output -- a bf16 `add_bf16` operand, bias / bias + dropout epilogues).
+ *                        M, N multiples of 256, K of 64 (vqcpc_gemm_nt_bf16_supported); lda / ldb / ldcb / ldgate_bf16 /
+ *                        ldadd_bf16 in bf16 elements.
  *   vqcpc_gemm_tn_bf16   dW[N,K] (+)= A[M,N]^T . B[M,K], db[N] (+)= column sums of A: the weight / bias gradient of F.linear
  *                        on bf16 operands (what autograd derives for the calls above); as vqcpc_gemm_tn.  M multiple of 128,
  *                        N and K of 256 (vqcpc_gemm_tn_bf16_supported).
@@ -486,7 +489,7 @@ int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K);
 int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, void* Cb, int64_t ldcb,
                        int64_t M, int N, int K, const float* bias, int act, float drop_p, uint64_t seed, const float* gate,
                        int64_t ldgate, const void* gate_bf16, int64_t ldgate_bf16, float gate_scale, const float* add,
-                       int64_t ldadd, void* stream);
+                       int64_t ldadd, const void* add_bf16, int64_t ldadd_bf16, void* stream);
 int vqcpc_gemm_tn_bf16_supported(int64_t M, int N, int K);
 int64_t vqcpc_gemm_tn_bf16_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,

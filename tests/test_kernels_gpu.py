@@ -371,6 +371,31 @@ def test_gemm_nt_bf16_kernels_are_bit_identical(ops, M, N, K):
         hip.call('vqcpc_gemm_bf16_set_variant', 1)
 
 
+@pytest.mark.parametrize('M,N,K', [(512, 512, 256), (256 * 260, 512, 2048)])
+def test_gemm_nt_bf16_residual_operand_in_bf16(ops, M, N, K):
+    """Round 5: the residual of the feed-forward block on the bf16 path is read from the LayerNorm's bf16 output (`add_bf16`; that
+    output is then the LayerNorm's ONLY output: vqcpc_add_layernorm_fwd_b16 with y == NULL).  bf16 -> fp32 is exact, so the result
+    equals the fp32-residual form on the same values bit for bit; the LayerNorm's bf16 output does not depend on whether the fp32
+    one is written."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + K)
+    a, b = ops.cast_bf16(dev(torch.randn(M, K, generator=gen))), ops.cast_bf16(dev(torch.randn(N, K, generator=gen)))
+    bias = dev(torch.randn(N, generator=gen))
+    res_b = dev(torch.randn(M, N, generator=gen)).bfloat16()
+    for kw in (dict(bias=bias), dict(bias=bias, drop_p=0.1, seed=3)):
+        assert torch.equal(ops.gemm_nt_bf16(a, b, add_b=res_b, **kw), ops.gemm_nt_bf16(a, b, add=res_b.float(), **kw)), sorted(kw)
+    s_in = dev(torch.randn(M, N, generator=gen))
+    g, be = dev(torch.randn(N, generator=gen)), dev(torch.randn(N, generator=gen))
+    outs = []
+    for with_f32 in (True, False):
+        y = torch.empty(M, N, device='cuda') if with_f32 else None
+        yb = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        mean, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+        hip.call('vqcpc_add_layernorm_fwd_b16', s_in, N, None, g, be, y, yb, mean, rstd, M, N, 1e-5, 0.0, 0)
+        outs.append((yb, mean, rstd))
+    assert all(torch.equal(x, y) for x, y in zip(*outs))
+
+
 @pytest.mark.parametrize('M,N,K', [(256 * 300, 512, 512), (128 * 1024, 256, 1024)])
 def test_dma_gemm_kernels_under_memory_contention(ops, M, N, K):
     """Race screen of the two kernels that order their LDS-DMA deliveries with COUNTED `s_waitcnt vmcnt(n)` instead of barriers
@@ -515,14 +540,16 @@ def test_encoder_layer_bf16_native_path_matches_the_rounded_operand_path(ops):
     x = torch.randn(nblk * L, d, device='cuda', requires_grad=True)
     g = torch.randn(nblk * L, d, device='cuda')
     res = {}
-    real, real_in = ops.bf16_native, ops.ATT_B16_IN
+    real, real_in, real_res = ops.bf16_native, ops.ATT_B16_IN, ops.BF16_RESIDUAL
     try:
         hip.set_gemm_mode(8)
-        # 'io': the product's native path (q | k | v and d ctx bf16 into the attention kernels as well); True: native GEMMs with
-        # fp32 attention inputs; False: rounded-operand path
+        # 'io': the product's native path (q | k | v and d ctx bf16 into the attention kernels as well, and -- round 5 -- the first
+        # LayerNorm's output in bf16 only, residual of the feed-forward block included); True: native GEMMs with fp32 attention
+        # inputs and an fp32 residual stream; False: rounded-operand path
         for native in ('io', True, False):
             ops.bf16_native = real if native else (lambda *shapes: False)
             ops.ATT_B16_IN = native == 'io'
+            ops.BF16_RESIDUAL = native == 'io'
             assert ops.bf16_native((1024, 512, 256)) == bool(native)
             for p_ in layer.parameters():
                 p_.grad = None
@@ -531,7 +558,7 @@ def test_encoder_layer_bf16_native_path_matches_the_rounded_operand_path(ops):
             (y * g).sum().backward()
             res[native] = [y.detach().clone(), x.grad.clone()] + [p_.grad.clone() for p_ in layer.parameters()]
     finally:
-        ops.bf16_native, ops.ATT_B16_IN = real, real_in
+        ops.bf16_native, ops.ATT_B16_IN, ops.BF16_RESIDUAL = real, real_in, real_res
         hip.set_gemm_mode(0)
     for a_, b_ in zip(res[True], res[False]):
         assert rel_err(a_, b_) < 5e-3, rel_err(a_, b_)          # bf16 roundings of near-identical fp32 values may flip

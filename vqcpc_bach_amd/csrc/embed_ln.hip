@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
                 o.y = (s[it].y - mu) * rs * gm[it].y + bt[it].y;
                 o.z = (s[it].z - mu) * rs * gm[it].z + bt[it].z;
                 o.w = (s[it].w - mu) * rs * gm[it].w + bt[it].w;
-                nt_store4(y + row * d + col, o);
+                if (y) nt_store4(y + row * d + col, o);       // NULL: the bf16 copy is the only consumer (bf16 path, round 5)
                 if (y_b16) *reinterpret_cast<uint2*>(y_b16 + row * d + col) = round4_bf16(o);   // GEMM operand copy
             }
         }
@@ -599,7 +599,7 @@ int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, con
                                 void* y_bf16, float* mean, float* rstd, int64_t M, int d, float eps, float drop_p,
                                 uint64_t seed, void* stream) {
     if (M == 0) return VQCPC_OK;
-    VQ_REQUIRE(x && gamma && beta && y && mean && rstd, "add_layernorm_fwd: null pointer");
+    VQ_REQUIRE(x && gamma && beta && (y || y_bf16) && mean && rstd, "add_layernorm_fwd: null pointer");
     VQ_REQUIRE(M >= 0 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_fwd: bad shape");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "add_layernorm_fwd: bad dropout probability");
     hipStream_t s = (hipStream_t)stream;

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void cast_bf16_kernel(const float* __restrict_
 }
 
 // extra epilogue features of the bf16 kernel (on top of gemm_common.h's E_*)
-enum { B_OUT_F32 = 1, B_OUT_BF16 = 2, B_GATE_BF16 = 4 };
+enum { B_OUT_F32 = 1, B_OUT_BF16 = 2, B_GATE_BF16 = 4, B_ADD_BF16 = 8 };   // B_ADD_BF16: the residual operand (E_ADD) is bf16, in `gate_b`
 // cache policy of the output stores (" nt", " sc1", ..: measurement builds, tools/build_lab_variants.sh)
 #ifndef VQ_BF16_STORE_POL
 #define VQ_BF16_STORE_POL ""
@@ -61,7 +61,7 @@ struct Bf16Out {
     int64_t ldc;
     bf16_t* cb;          // bf16 output (B_OUT_BF16), dense or strided
     int64_t ldcb;
-    const bf16_t* gate_b;   // bf16 gate operand (B_GATE_BF16): only its sign is used
+    const bf16_t* gate_b;   // bf16 gate operand (B_GATE_BF16): only its sign is used; or the bf16 residual operand (B_ADD_BF16)
     int64_t ldgate_b;
     int stagger;            // start delay of workgroup b: ((b >> 3) & 3) * stagger * 64 clocks (see the kernel); -1 = measurement
                             // variant without the epilogue's global stores (VQCPC_BF16_STAGGER=-1, tools/bench_gemm_bf16.py)
@@ -82,7 +82,7 @@ struct Bf16Out {
 #define B_EPI_DECLS(SCR_OFF)                                                                                           \
     int ep_tile = blockIdx.x;                                                                                          \
     constexpr bool HAS_AUX = (EPI & (E_GATE | E_ADD)) != 0;                                                            \
-    constexpr bool AUX_B16 = (OUT & B_GATE_BF16) != 0;             /* gate operand is bf16 (sign only) */              \
+    constexpr bool AUX_B16 = (OUT & (B_GATE_BF16 | B_ADD_BF16)) != 0;  /* gate (sign only) / residual operand is bf16 */     \
     const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned char*)smem;                 \
     const unsigned scr = lds0 + (SCR_OFF) + wave * 4096;                                                               \
     const unsigned scr_w = scr + ((4 * kh) * 32 + li) * 4;                                                             \
@@ -138,7 +138,7 @@ struct Bf16Out {
                     }                                                                                                  \
                     v *= pos ? ep.gate_scale : 0.0f;                                                                   \
                 }                                                                                                      \
-                if (EPI & E_ADD) v += AUX.f[j][c];                                                                     \
+                if (EPI & E_ADD) v += AUX_B16 ? __uint_as_float(((AUX.h[j][c >> 1] >> (16 * (c & 1))) & 0xFFFFu) << 16) : AUX.f[j][c]; \
                 ov[c] = v;                                                                                             \
             }                                                                                                          \
             if ((OUT & B_OUT_F32) && o.stagger != -1)                                                                  \
@@ -1021,7 +1021,7 @@ int vqcpc_gemm_nt_bf16_supported(int64_t M, int N, int K) { return (M % kB == 0 
 int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, float* C, int64_t ldc, void* Cb, int64_t ldcb,
                        int64_t M, int N, int K, const float* bias, int act, float drop_p, uint64_t seed, const float* gate,
                        int64_t ldgate, const void* gate_bf16, int64_t ldgate_bf16, float gate_scale, const float* add,
-                       int64_t ldadd, void* stream) {
+                       int64_t ldadd, const void* add_bf16, int64_t ldadd_bf16, void* stream) {
     if (M == 0) return VQCPC_OK;
     VQ_REQUIRE(A && B && (C || Cb), "gemm_nt_bf16: null pointer");
     VQ_REQUIRE(vqcpc_gemm_nt_bf16_supported(M, N, K), "gemm_nt_bf16: M, N must be multiples of 256 and K of 64 (M=%lld N=%d K=%d)",
@@ -1031,17 +1031,20 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     VQ_REQUIRE(aligned16(A) && aligned16(B) && (!C || aligned16(C)) && (reinterpret_cast<uintptr_t>(Cb) & 7u) == 0,
                "gemm_nt_bf16: alignment");
     VQ_REQUIRE(!(gate && gate_bf16), "gemm_nt_bf16: one gate operand only");
+    VQ_REQUIRE(!(add && add_bf16) && !(add_bf16 && (gate || gate_bf16)), "gemm_nt_bf16: one residual operand, and no gate beside a bf16 one");
+    VQ_REQUIRE(!add_bf16 || (ldadd_bf16 >= N && ldadd_bf16 % 4 == 0 && (reinterpret_cast<uintptr_t>(add_bf16) & 7u) == 0),
+               "gemm_nt_bf16: bf16 residual operand: alignment / leading dimension");
     VQ_REQUIRE(act == 0 || act == 1, "gemm_nt_bf16: act must be 0 or 1");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt_bf16: bad dropout probability");
     EpiParams ep{bias, act, drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed, gate, ldgate, gate_scale, add, ldadd, nullptr, 0, 0};
     static const int stagger_per_ktile = lab_env_int("VQCPC_BF16_STAGGER", 0);
     const int tiles_total = (int)((M / kB) * (N / kB));
-    Bf16Out o{C, ldc, (bf16_t*)Cb, ldcb, (const bf16_t*)gate_bf16, ldgate_bf16,
+    Bf16Out o{C, ldc, (bf16_t*)Cb, ldcb, (const bf16_t*)(add_bf16 ? add_bf16 : gate_bf16), add_bf16 ? ldadd_bf16 : ldgate_bf16,
               stagger_per_ktile < 0 ? stagger_per_ktile : (tiles_total >= 4 * kNumCU ? stagger_per_ktile * (K / kBBK) : 0)};
     const bool has_gate = gate || gate_bf16;
     const int flags = (bias ? E_BIAS : 0) | (act == 1 ? E_RELU : 0) | (ep.thr ? E_DROP : 0) | (has_gate ? E_GATE : 0) |
-                      (add ? E_ADD : 0);
-    const int out = (C ? B_OUT_F32 : 0) | (Cb ? B_OUT_BF16 : 0) | (gate_bf16 ? B_GATE_BF16 : 0);
+                      ((add || add_bf16) ? E_ADD : 0);
+    const int out = (C ? B_OUT_F32 : 0) | (Cb ? B_OUT_BF16 : 0) | (gate_bf16 ? B_GATE_BF16 : 0) | (add_bf16 ? B_ADD_BF16 : 0);
     const int tn = N / kB;
     const int tiles = (int)((M / kB) * tn);
     const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kBThreads);
@@ -1091,6 +1094,8 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     BL(E_BIAS, B_OUT_BF16)                           // in_proj output for the all-bf16 attention kernels
     BL(E_BIAS | E_ADD, B_OUT_F32)                    // residual sums for LayerNorm (see gemm.hip)
     BL(E_BIAS | E_DROP | E_ADD, B_OUT_F32)
+    BL(E_BIAS | E_ADD, B_OUT_F32 | B_ADD_BF16)       // the same with the residual read from the LayerNorm's bf16 output (round 5)
+    BL(E_BIAS | E_DROP | E_ADD, B_OUT_F32 | B_ADD_BF16)
 #undef BL
     set_error("gemm_nt_bf16: unsupported epilogue / output combination (flags %d, out %d)", flags, out);
     return VQCPC_EINVAL;

@@ -35,7 +35,7 @@ SIGNATURES = {
     'vqcpc_cast_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr]),
     'vqcpc_gemm_nt_bf16_supported': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_nt_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int,
-                                   c_f32, c_u64, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr]),
+                                   c_f32, c_u64, c_ptr, c_i64, c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_tn_bf16_supported': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_bf16_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),

@@ -492,7 +492,7 @@ def bf16_native(*shapes):
 
 
 def gemm_nt_bf16(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_b=None, gate_scale=1.0, add=None, out=None,
-                 out_f32=True, out_bf16=False):
+                 out_f32=True, out_bf16=False, add_b=None):
     """epilogue(a[M,K] @ b[N,K]^T) on bf16 operands (fp32 tensors are cast first).  Returns the fp32 result, the bf16
     result, or (fp32, bf16) when both are requested."""
     a, b = cast_bf16(a), cast_bf16(b)
@@ -514,8 +514,12 @@ def gemm_nt_bf16(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_b=N
         ldgb = gate_b.shape[1]
     if add is not None:
         add, lda_ = _rows(add)
+    ldab = 0
+    if add_b is not None:                 # residual operand in bf16 (the LayerNorm's bf16 output)
+        assert add_b.dtype == torch.bfloat16 and add_b.is_contiguous() and add is None
+        ldab = add_b.shape[1]
     hip.call('vqcpc_gemm_nt_bf16', a, K, b, K, c, ldc, cb, ldcb, M, N, K, bias, int(act), float(drop_p), int(seed), gate, ldg,
-             gate_b, ldgb, float(gate_scale), add, lda_)
+             gate_b, ldgb, float(gate_scale), add, lda_, add_b, ldab)
     return (c, cb) if (out_f32 and out_bf16) else (c if out_f32 else cb)
 
 
@@ -991,7 +995,10 @@ class EncoderLayerFn(torch.autograd.Function):
         # s1 = x + dropout(att Wo^T + bo): the residual sum is formed by the out-proj epilogue (bias -> dropout -> + x), so the
         # LayerNorm kernels read ONE input stream and the backward needs neither x nor the projection output again
         sform1 = _residual_sum_in_epilogue(Mq, d, d, nat)
-        x1 = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+        # bf16 path: x1 = LN1(...) feeds the two feed-forward GEMMs (bf16 operand) and the residual of s2 = x1 + dropout(FFN): with
+        # the residual read from the bf16 copy as well (round 5) the LayerNorm writes 2 instead of 6 bytes per element and the
+        # FFN2 epilogue reads 2 instead of 4 -- the residual stream between LN1 and LN2 is bf16, as the GEMM operands already are
+        x1 = None if (nat and BF16_RESIDUAL) else torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         x1b = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
@@ -1004,7 +1011,8 @@ class EncoderLayerFn(torch.autograd.Function):
         h2b = None
         if nat:     # the FFN hidden activation exists in bf16 only: FFN2, the backward gate and the weight gradient read it
             h2b = gemm_nt_bf16(x1b, w1, bias=b1, act=1, drop_p=p, seed=s[2], out_f32=False, out_bf16=True)
-            s2 = gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add=x1)
+            s2 = (gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add_b=x1b) if x1 is None else
+                  gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add=x1))
             sform2 = True
             h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
         else:
@@ -1044,7 +1052,7 @@ class EncoderLayerFn(torch.autograd.Function):
         (x, qkv, qproj, probs, att, s1, x1, mean1, rstd1, h2, s2, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
          g2) = ctx.saved_tensors
         if dy is None:
-            dy = torch.zeros_like(x1)
+            dy = torch.zeros_like(s2)
         L, H, p, s, f, ext_qkv = ctx.meta
         bqkv, bo, b1, b2 = ctx.biases
         be1, be2 = ctx.ln_betas
@@ -1457,6 +1465,7 @@ class DropoutSeluFn(torch.autograd.Function):
 # A15: GRU layer of the context network (time-major rows: row = t * B + b)
 # ------------------------------------------------------------------------------------------------------------------
 ATT_B16_IN = os.environ.get('VQCPC_ATT_B16_IN', '1') != '0'          # A/B switch: bf16 q | k | v and d ctx INTO the L = 16 attention kernels
+BF16_RESIDUAL = os.environ.get('VQCPC_BF16_RESIDUAL', '1') != '0'      # A/B switch: LN1's output in bf16 only on the bf16 path
 ATT_B16_OUT = os.environ.get('VQCPC_ATT_B16_OUT', '1') != '0'        # A/B switch: bf16 outputs straight from the L = 16 attention
 GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)
 

@@ -343,6 +343,15 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
                                 const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
                                 float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
                                 int64_t workspace_bytes, void* stream);
+/* the s-form (r == NULL) with the residual sum itself in bf16: x_bf16 [M][ldx] bf16, written by the producing GEMM's epilogue
+ * (vqcpc_gemm_nt_bf16 with bias, drop_p, seed, a residual operand and a bf16 output only).  Same arithmetic on the upcast values
+ * (bit-identical to the fp32-input kernels given the same values); 2 instead of 4 bytes per element in.  configs[4] bf16 path
+ * (transformer_custom.py:279-289: norm1 / norm2 of a layer); x_bf16 8-byte aligned, ldx % 4 == 0. */
+int vqcpc_layernorm_fwd_xb16(const void* x_bf16, int64_t ldx, const float* gamma, const float* beta, float* y, void* y_bf16,
+                             float* mean, float* rstd, int64_t M, int d, float eps, void* stream);
+int vqcpc_layernorm_bwd_xb16(const float* dy, const void* x_bf16, int64_t ldx, const float* gamma, const float* mean,
+                             const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma, float* d_beta, int64_t M,
+                             int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream);
 /* d_gamma == d_beta == NULL in either backward form: the [vqcpc_add_layernorm_bwd_partials(M, d, r != NULL)][2 d] column partials (d gamma | d beta)
  * stay in `workspace` for a later vqcpc_reduce_grouped.  vqcpc_reduce_grouped: n independent reductions out_i[c] (+)= sum over
  * s < nsplit_i of ws_i[s * stride_i + c], c < count_i, 32 per launch (host arrays of device pointers; a repeated output is
@@ -473,7 +482,8 @@ int vqcpc_upscale_bwd(const float* g, float* dx, float* d_emb, int64_t rows, int
  *                        C (fp32) and / or Cb (bf16) receive the result; epilogue as vqcpc_gemm_nt (bias, act = 1 relu,
  *                        dropout, gate: out *= gate > 0 ? gate_scale : 0 with an fp32 `gate` or a bf16 `gate_bf16` operand,
  *                        add: an fp32 `add` or -- round 5, the residual stream of the bf16 path kept in bf16: the LayerNorm's
- *                        bf16 output is then its ONLY output -- a bf16 `add_bf16` operand, bias / bias + dropout epilogues).
+ *                        bf16 output is then its ONLY output -- a bf16 `add_bf16` operand, bias / bias + dropout epilogues; the
+ *                        residual sum may itself leave as Cb only: vqcpc_layernorm_fwd_xb16 / _bwd_xb16 read it so).
  *                        M, N multiples of 256, K of 64 (vqcpc_gemm_nt_bf16_supported); lda / ldb / ldcb / ldgate_bf16 /
  *                        ldadd_bf16 in bf16 elements.
  *   vqcpc_gemm_tn_bf16   dW[N,K] (+)= A[M,N]^T . B[M,K], db[N] (+)= column sums of A: the weight / bias gradient of F.linear

@@ -396,6 +396,63 @@ def test_gemm_nt_bf16_residual_operand_in_bf16(ops, M, N, K):
     assert all(torch.equal(x, y) for x, y in zip(*outs))
 
 
+@pytest.mark.parametrize('M,N,K', [(1024, 512, 512), (4352, 256, 256), (2560, 1024, 128)])
+def test_residual_sum_in_bf16_and_layernorm_on_it(ops, M, N, K):
+    """Round 5: on the bf16 path the residual sum s = x + dropout(a W^T + b) leaves the GEMM epilogue in bf16 ONLY and the LayerNorm
+    kernels read it so (vqcpc_layernorm_fwd_xb16 / _bwd_xb16).  The bf16 output is the rounding of the fp32 output of the same
+    epilogue, and the LayerNorm kernels on the bf16 sum equal the fp32-input kernels on the upcast values bit for bit (forward:
+    y, bf16 copy, mean, rstd; backward: d_s, the bf16 d_r with the regenerated mask, d_gamma, d_beta)."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator().manual_seed(M + K)
+    a, b = ops.cast_bf16(dev(torch.randn(M, K, generator=gen))), ops.cast_bf16(dev(torch.randn(N, K, generator=gen)))
+    bias = dev(torch.randn(N, generator=gen))
+    res = dev(torch.randn(M, N, generator=gen))
+    res_b = res.bfloat16()
+    for kw in (dict(bias=bias), dict(bias=bias, drop_p=0.1, seed=3)):
+        for r in (dict(add=res), dict(add_b=res_b)):
+            f32 = ops.gemm_nt_bf16(a, b, **kw, **r)
+            b16 = ops.gemm_nt_bf16(a, b, out_f32=False, out_bf16=True, **kw, **r)
+            assert b16.dtype == torch.bfloat16 and torch.equal(b16, f32.bfloat16()), (sorted(kw), sorted(r))
+    sb = b16
+    sf = sb.float()
+    g, be = dev(torch.randn(N, generator=gen)), dev(torch.randn(N, generator=gen))
+
+    def fwd(xb16):
+        y, yb = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        mean, rstd = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+        if xb16:
+            hip.call('vqcpc_layernorm_fwd_xb16', sb, N, g, be, y, yb, mean, rstd, M, N, 1e-5)
+        else:
+            hip.call('vqcpc_add_layernorm_fwd_b16', sf, N, None, g, be, y, yb, mean, rstd, M, N, 1e-5, 0.0, 0)
+        return y, yb, mean, rstd
+
+    ref, got = fwd(False), fwd(True)
+    assert all(torch.equal(x, y) for x, y in zip(ref, got))
+    yb_only = torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+    m2, r2 = torch.empty(M, device='cuda'), torch.empty(M, device='cuda')
+    hip.call('vqcpc_layernorm_fwd_xb16', sb, N, g, be, None, yb_only, m2, r2, M, N, 1e-5)       # the norm1 form: no fp32 output
+    assert torch.equal(yb_only, ref[1]) and torch.equal(m2, ref[2])
+    _, _, mean, rstd = ref
+    dy = dev(torch.randn(M, N, generator=gen))
+    nbytes = hip.query('vqcpc_add_layernorm_bwd_workspace', M, N)
+
+    def bwd(xb16, p):
+        ds, drb = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        dg, db = torch.empty(N, device='cuda'), torch.empty(N, device='cuda')
+        ws = torch.empty(nbytes // 4, device='cuda')
+        if xb16:
+            hip.call('vqcpc_layernorm_bwd_xb16', dy, sb, N, g, mean, rstd, ds, None, drb, dg, db, M, N, p, 5, ws, nbytes)
+        else:
+            hip.call('vqcpc_add_layernorm_bwd_b16', dy, sf, N, None, g, mean, rstd, ds, None, drb, dg, db, M, N, p, 5, ws, nbytes)
+        return ds, drb, dg, db
+
+    for p in (0.0, 0.1):
+        assert all(torch.equal(x, y) for x, y in zip(bwd(False, p), bwd(True, p))), p
+    with pytest.raises(hip.VqcpcHipError):           # an unaligned bf16 stream is refused, not read
+        hip.call('vqcpc_layernorm_fwd_xb16', sb.view(-1)[1:1 + (M - 1) * N].view(M - 1, N), N, g, be, None, yb_only, m2, r2, M - 1, N,
+                 1e-5)
+
+
 @pytest.mark.parametrize('M,N,K', [(256 * 300, 512, 512), (128 * 1024, 256, 1024)])
 def test_dma_gemm_kernels_under_memory_contention(ops, M, N, K):
     """Race screen of the two kernels that order their LDS-DMA deliveries with COUNTED `s_waitcnt vmcnt(n)` instead of barriers

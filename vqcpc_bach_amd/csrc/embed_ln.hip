@@ -138,10 +138,19 @@ __device__ __forceinline__ void nt_store4(float* p, const float4& v) {
     __builtin_nontemporal_store(t, reinterpret_cast<nt_f4*>(p));
 }
 
+// four bf16 values (8 bytes) of a streamed row -> fp32 (exact)
+__device__ __forceinline__ float4 nt_load4_bf16(const unsigned short* p) {
+    typedef unsigned nt_u2 __attribute__((ext_vector_type(2)));
+    const nt_u2 v = __builtin_nontemporal_load(reinterpret_cast<const nt_u2*>(p));
+    return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xFFFF0000u), __uint_as_float(v.y << 16),
+                       __uint_as_float(v.y & 0xFFFF0000u));
+}
+
 // NIT = 256-column groups per row (as in the backward): gamma / beta stay in registers for the whole row loop, and the NEXT row of
 // the wave is requested before the current one is reduced and written (a row is two dependent wave reductions: without the
 // prefetch a wave has one 1 KB load in flight)
-template <bool HAS_R, int NIT = kLnMaxIt>
+// XB16 (round 5, bf16 path, !HAS_R): the residual sum `x` was written in bf16 by the producing GEMM epilogue (2 bytes per element in)
+template <bool HAS_R, int NIT = kLnMaxIt, bool XB16 = false>
 __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict__ x, int64_t ldx,
                                                          const float* __restrict__ r, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, float* __restrict__ y,
@@ -165,7 +174,8 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
     _Pragma("unroll") for (int it = 0; it < NIT; ++it) {                                 \
         const int col = lane * 4 + it * 256;                                             \
         const bool ok = (ROW) < M && col < d;                                            \
-        xn[it] = ok ? nt_load4(x + (ROW) * ldx + col) : zero4;                           \
+        xn[it] = !ok ? zero4 : XB16 ? nt_load4_bf16(reinterpret_cast<const unsigned short*>(x) + (ROW) * ldx + col) \
+                                    : nt_load4(x + (ROW) * ldx + col);                   \
         if (HAS_R) rn[it] = ok ? nt_load4(r + (ROW) * d + col) : zero4;                  \
     }
     LNF_FETCH(row)
@@ -227,7 +237,7 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // for d_r = d_s . mask -- one input stream fewer.
 // NIT = 256-column groups per row (d <= 256 NIT): with the generic 4 the kernel holds 152 registers (3 waves per SIMD); NIT = 1
 // (d <= 256) and 2 (d <= 512) keep the per-row arrays small enough for 8 / 5 waves -- more rows in flight per CU
-template <bool HAS_R, bool MASKED = HAS_R, int NIT = kLnMaxIt>
+template <bool HAS_R, bool MASKED = HAS_R, int NIT = kLnMaxIt, bool XB16 = false>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          int64_t ldx, const float* __restrict__ r,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -256,7 +266,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
         for (int it = 0; it < NIT; ++it) {
             const int col = lane * 4 + it * 256;
             if (it < nit && col < d) {
-                float4 xv = nt_load4(x + row * ldx + col);
+                float4 xv = XB16 ? nt_load4_bf16(reinterpret_cast<const unsigned short*>(x) + row * ldx + col)
+                                 : nt_load4(x + row * ldx + col);
                 msk[it] = make_float4(1.f, 1.f, 1.f, 1.f);
                 if (MASKED) {
                     const uint64_t e = (uint64_t)row * d + col;
@@ -595,32 +606,47 @@ int vqcpc_add_layernorm_fwd(const float* x, int64_t ldx, const float* r, const f
     return vqcpc_add_layernorm_fwd_b16(x, ldx, r, gamma, beta, y, nullptr, mean, rstd, M, d, eps, drop_p, seed, stream);
 }
 
-int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
-                                void* y_bf16, float* mean, float* rstd, int64_t M, int d, float eps, float drop_p,
-                                uint64_t seed, void* stream) {
+static int ln_fwd_launch(const void* xv, bool xb16, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
+                         void* y_bf16, float* mean, float* rstd, int64_t M, int d, float eps, float drop_p, uint64_t seed,
+                         void* stream) {
     if (M == 0) return VQCPC_OK;
+    const float* x = (const float*)xv;              // XB16 kernels reinterpret it
     VQ_REQUIRE(x && gamma && beta && (y || y_bf16) && mean && rstd, "add_layernorm_fwd: null pointer");
     VQ_REQUIRE(M >= 0 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_fwd: bad shape");
     VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "add_layernorm_fwd: bad dropout probability");
+    VQ_REQUIRE(!xb16 || (!r && (reinterpret_cast<uintptr_t>(xv) & 7u) == 0), "layernorm_fwd_xb16: one bf16 input stream, 8-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     const uint32_t thr = drop_threshold(drop_p);
     const float ik = 1.0f / (1.0f - drop_p);
-#define LN_FWD(HR, NITV)                                                                                                  \
-    hipLaunchKernelGGL((add_ln_fwd_kernel<HR, NITV>), dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean, rstd, \
-                       M, d, eps, thr, ik, seed, (unsigned short*)y_bf16)
-#define LN_FWD_D(HR)                    \
-    if (d <= 256) LN_FWD(HR, 1);        \
-    else if (d <= 512) LN_FWD(HR, 2);   \
-    else LN_FWD(HR, 4)
-    if (r) {
-        LN_FWD_D(true);
+#define LN_FWD(HR, NITV, XB)                                                                                              \
+    hipLaunchKernelGGL((add_ln_fwd_kernel<HR, NITV, XB>), dim3(ln_blocks(M)), dim3(256), 0, s, x, ldx, r, gamma, beta, y, mean, \
+                       rstd, M, d, eps, thr, ik, seed, (unsigned short*)y_bf16)
+#define LN_FWD_D(HR, XB)                    \
+    if (d <= 256) LN_FWD(HR, 1, XB);        \
+    else if (d <= 512) LN_FWD(HR, 2, XB);   \
+    else LN_FWD(HR, 4, XB)
+    if (xb16) {
+        LN_FWD_D(false, true);
+    } else if (r) {
+        LN_FWD_D(true, false);
     } else {
-        LN_FWD_D(false);
+        LN_FWD_D(false, false);
     }
 #undef LN_FWD_D
 #undef LN_FWD
     VQ_CHECK_LAUNCH("add_layernorm_fwd");
     return VQCPC_OK;
+}
+
+int vqcpc_add_layernorm_fwd_b16(const float* x, int64_t ldx, const float* r, const float* gamma, const float* beta, float* y,
+                                void* y_bf16, float* mean, float* rstd, int64_t M, int d, float eps, float drop_p,
+                                uint64_t seed, void* stream) {
+    return ln_fwd_launch(x, false, ldx, r, gamma, beta, y, y_bf16, mean, rstd, M, d, eps, drop_p, seed, stream);
+}
+
+int vqcpc_layernorm_fwd_xb16(const void* x_bf16, int64_t ldx, const float* gamma, const float* beta, float* y, void* y_bf16,
+                             float* mean, float* rstd, int64_t M, int d, float eps, void* stream) {
+    return ln_fwd_launch(x_bf16, true, ldx, nullptr, gamma, beta, y, y_bf16, mean, rstd, M, d, eps, 0.0f, 0, stream);
 }
 
 int64_t vqcpc_add_layernorm_bwd_workspace(int64_t M, int d) {
@@ -635,16 +661,18 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
                                        workspace, workspace_bytes, stream);
 }
 
-int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
-                                const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
-                                float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
-                                int64_t workspace_bytes, void* stream) {
+static int ln_bwd_launch(const float* dy, const void* xv, bool xb16, int64_t ldx, const float* r, const float* gamma,
+                         const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
+                         float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
     // d_gamma == d_beta == NULL: the column partials stay in `workspace` ([vqcpc_add_layernorm_bwd_partials(M, d, r != NULL)][2 d]: d gamma | d beta)
     // for the caller to reduce later (vqcpc_reduce_grouped: the trainers sum the partials of every LayerNorm of a backward pass
     // in one launch)
+    const float* x = (const float*)xv;              // XB16 kernels reinterpret it
     VQ_REQUIRE(dy && x && gamma && mean && rstd && d_s && workspace && ((d_gamma != nullptr) == (d_beta != nullptr)),
                "add_layernorm_bwd: null pointer");
     VQ_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_bwd: bad shape");
+    VQ_REQUIRE(!xb16 || (!r && (reinterpret_cast<uintptr_t>(xv) & 7u) == 0), "layernorm_bwd_xb16: one bf16 input stream, 8-byte aligned");
     if (workspace_bytes < vqcpc_add_layernorm_bwd_workspace(M, d)) {
         set_error("add_layernorm_bwd: workspace too small");
         return VQCPC_EWORKSPACE;
@@ -653,19 +681,22 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
     const uint32_t thr = drop_threshold(drop_p);
     const float ik = 1.0f / (1.0f - drop_p);
     const int blocks = ln_bwd_blocks(M, r != nullptr, d);
-#define LN_BWD(HR, MK, NITV)                                                                                              \
-    hipLaunchKernelGGL((add_ln_bwd_kernel<HR, MK, NITV>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, d_s, \
-                       d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16)
-#define LN_BWD_D(HR, MK)                     \
-    if (d <= 256) LN_BWD(HR, MK, 1);         \
-    else if (d <= 512) LN_BWD(HR, MK, 2);    \
-    else LN_BWD(HR, MK, 4)
-    if (r) {
-        LN_BWD_D(true, true);
-    } else if (thr && (d_r || d_r_bf16)) {   // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
-        LN_BWD_D(false, true);
+#define LN_BWD(HR, MK, NITV, XB)                                                                                          \
+    hipLaunchKernelGGL((add_ln_bwd_kernel<HR, MK, NITV, XB>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, \
+                       d_s, d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16)
+#define LN_BWD_D(HR, MK, XB)                     \
+    if (d <= 256) LN_BWD(HR, MK, 1, XB);         \
+    else if (d <= 512) LN_BWD(HR, MK, 2, XB);    \
+    else LN_BWD(HR, MK, 4, XB)
+    const bool masked = thr && (d_r || d_r_bf16);   // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
+    if (xb16) {
+        if (masked) { LN_BWD_D(false, true, true); } else { LN_BWD_D(false, false, true); }
+    } else if (r) {
+        LN_BWD_D(true, true, false);
+    } else if (masked) {
+        LN_BWD_D(false, true, false);
     } else {
-        LN_BWD_D(false, false);
+        LN_BWD_D(false, false, false);
     }
 #undef LN_BWD_D
 #undef LN_BWD
@@ -673,6 +704,21 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
     if (!d_gamma) return VQCPC_OK;
     return launch_reduce_splits2((const float*)workspace, (int64_t)2 * d, blocks, d_gamma, d, (const float*)workspace + d,
                                  (int64_t)2 * d, d_beta, d, 0, s);
+}
+
+int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, const float* r, const float* gamma,
+                                const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
+                                float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
+                                int64_t workspace_bytes, void* stream) {
+    return ln_bwd_launch(dy, x, false, ldx, r, gamma, mean, rstd, d_s, d_r, d_r_bf16, d_gamma, d_beta, M, d, drop_p, seed, workspace,
+                         workspace_bytes, stream);
+}
+
+int vqcpc_layernorm_bwd_xb16(const float* dy, const void* x_bf16, int64_t ldx, const float* gamma, const float* mean,
+                             const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma, float* d_beta, int64_t M,
+                             int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+    return ln_bwd_launch(dy, x_bf16, true, ldx, nullptr, gamma, mean, rstd, d_s, d_r, d_r_bf16, d_gamma, d_beta, M, d, drop_p, seed,
+                         workspace, workspace_bytes, stream);
 }
 
 int vqcpc_add_layernorm_bwd_partials(int64_t M, int d, int has_r) { return ln_bwd_blocks(std::max<int64_t>(M, 1), has_r != 0, d); }

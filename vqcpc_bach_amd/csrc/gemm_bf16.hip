@@ -1096,6 +1096,10 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     BL(E_BIAS | E_DROP | E_ADD, B_OUT_F32)
     BL(E_BIAS | E_ADD, B_OUT_F32 | B_ADD_BF16)       // the same with the residual read from the LayerNorm's bf16 output (round 5)
     BL(E_BIAS | E_DROP | E_ADD, B_OUT_F32 | B_ADD_BF16)
+    BL(E_BIAS | E_ADD, B_OUT_BF16)                   // ... and the residual sum itself written in bf16 (the LayerNorm kernels read
+    BL(E_BIAS | E_DROP | E_ADD, B_OUT_BF16)          //     it so: vqcpc_layernorm_fwd_xb16 / _bwd_xb16)
+    BL(E_BIAS | E_ADD, B_OUT_BF16 | B_ADD_BF16)
+    BL(E_BIAS | E_DROP | E_ADD, B_OUT_BF16 | B_ADD_BF16)
 #undef BL
     set_error("gemm_nt_bf16: unsupported epilogue / output combination (flags %d, out %d)", flags, out);
     return VQCPC_EINVAL;

@@ -1002,7 +1002,13 @@ class EncoderLayerFn(torch.autograd.Function):
         mean1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd1 = torch.empty(Mq, dtype=torch.float32, device=dev)
         x1b = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
-        if sform1:
+        # ... and the residual sums s1, s2 themselves leave their GEMM epilogues in bf16: 2 instead of 4 bytes out of the epilogue,
+        # into the LayerNorm forward and into its backward (include/vqcpc.h: vqcpc_layernorm_fwd_xb16)
+        s16 = nat and BF16_RESIDUAL and BF16_SUMS
+        if s16:
+            s1 = gemm_nt_bf16(attb, wo, bias=bo, drop_p=p, seed=s[1], add=xs, out_f32=False, out_bf16=True)
+            hip.call('vqcpc_layernorm_fwd_xb16', s1, d, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5)
+        elif sform1:
             s1 = lin(attb if nat else att, wo, bias=bo, drop_p=p, seed=s[1], add=xs)
             hip.call('vqcpc_add_layernorm_fwd_b16', s1, d, None, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5, 0.0, 0)
         else:           # s1 holds the projection output a; LayerNorm adds x and the dropout itself
@@ -1011,7 +1017,7 @@ class EncoderLayerFn(torch.autograd.Function):
         h2b = None
         if nat:     # the FFN hidden activation exists in bf16 only: FFN2, the backward gate and the weight gradient read it
             h2b = gemm_nt_bf16(x1b, w1, bias=b1, act=1, drop_p=p, seed=s[2], out_f32=False, out_bf16=True)
-            s2 = (gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add_b=x1b) if x1 is None else
+            s2 = (gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add_b=x1b, out_f32=not s16, out_bf16=s16) if x1 is None else
                   gemm_nt_bf16(h2b, w2, bias=b2, drop_p=p, seed=s[3], add=x1))
             sform2 = True
             h2 = att = x1b[:0]                       # placeholders in the saved list (never read on this path)
@@ -1029,7 +1035,9 @@ class EncoderLayerFn(torch.autograd.Function):
         mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         yb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
-        if sform2:
+        if s16:
+            hip.call('vqcpc_layernorm_fwd_xb16', s2, d, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5)
+        elif sform2:
             hip.call('vqcpc_add_layernorm_fwd_b16', s2, d, None, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, 0.0, 0)
         else:
             hip.call('vqcpc_add_layernorm_fwd_b16', x1, d, s2, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, p, s[3])
@@ -1052,7 +1060,7 @@ class EncoderLayerFn(torch.autograd.Function):
         (x, qkv, qproj, probs, att, s1, x1, mean1, rstd1, h2, s2, mean2, rstd2, wqkv, wo, e1, e2, w1, w2, g1,
          g2) = ctx.saved_tensors
         if dy is None:
-            dy = torch.zeros_like(s2)
+            dy = torch.zeros(s2.shape, dtype=torch.float32, device=s2.device)
         L, H, p, s, f, ext_qkv = ctx.meta
         bqkv, bo, b1, b2 = ctx.biases
         be1, be2 = ctx.ln_betas
@@ -1078,8 +1086,13 @@ class EncoderLayerFn(torch.autograd.Function):
             else:
                 dg = torch.empty(d, dtype=torch.float32, device=dev)
                 db = torch.empty(d, dtype=torch.float32, device=dev)
-            hip.call('vqcpc_add_layernorm_bwd_b16', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed,
-                     ws, nbytes)
+            if xin.dtype == torch.bfloat16:              # the residual sum was written in bf16 (s-form only)
+                assert r is None
+                hip.call('vqcpc_layernorm_bwd_xb16', dyv, xin, ldxin, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed, ws,
+                         nbytes)
+            else:
+                hip.call('vqcpc_add_layernorm_bwd_b16', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed,
+                         ws, nbytes)
             return ds, (dr if dr is not None else (None if (nat and p > 0) else ds)), dg, db, drb
 
         sform1, sform2 = ctx.sform
@@ -1466,6 +1479,7 @@ class DropoutSeluFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------------
 ATT_B16_IN = os.environ.get('VQCPC_ATT_B16_IN', '1') != '0'          # A/B switch: bf16 q | k | v and d ctx INTO the L = 16 attention kernels
 BF16_RESIDUAL = os.environ.get('VQCPC_BF16_RESIDUAL', '1') != '0'      # A/B switch: LN1's output in bf16 only on the bf16 path
+BF16_SUMS = os.environ.get('VQCPC_BF16_SUMS', '1') != '0'              # A/B switch: ... and the residual sums s1 / s2 (LayerNorm inputs)
 ATT_B16_OUT = os.environ.get('VQCPC_ATT_B16_OUT', '1') != '0'        # A/B switch: bf16 outputs straight from the L = 16 attention
 GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)
 

@@ -65,6 +65,9 @@ def parse():
     ap.add_argument('--grad-arith', default=None, choices=['six', 'f16x3', 'bf16x3'],
                     help='arithmetic of the gradient GEMMs inside backward (ops.set_gradient_arithmetic); default: what '
                          'train_model() selects (ops.TRAINING_GRAD_ARITH)')
+    ap.add_argument('--fwd-arith', default=None, choices=['six', 'f16x3'],
+                    help='arithmetic of the forward GEMMs of the training step (ops.set_forward_arithmetic); default: what '
+                         'train_model() selects (ops.TRAINING_FWD_ARITH with the f16x3 gradient arithmetic, six otherwise)')
     ap.add_argument('--grad-products', type=int, default=6, choices=[3, 6],
                     help='opt-in gradient arithmetic of the bf16x6 mode (include/vqcpc.h): 3 = two rounded bf16 planes and three '
                          'MFMAs per product in the input- / weight-gradient GEMMs (~2^-17 per product); the forward, the losses '
@@ -260,7 +263,7 @@ def live_pmc(args, B, timeout_s=100):
     n_steps = warm + 2 * steps                   # warm-up epoch + the bare-step loop + the timed epoch of the inner run
     inner = [sys.executable, os.path.abspath(__file__), '--config', args.config, '--steps', str(steps), '--warmup', str(warm),
              '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-arith',
-             str(args.grad_arith), '--no-graph',
+             str(args.grad_arith), '--fwd-arith', str(args.fwd_arith), '--no-graph',
              '--no-cpu-baseline', '--no-kernel-timing', '--no-live-pmc', '--no-extras', '--no-secondary']
     out = {'steps': n_steps}
     tmp = tempfile.mkdtemp(prefix='vqcpc_pmc_', dir='/tmp')
@@ -521,7 +524,7 @@ def n1_same_node_leg(args, B, device_index, timeout_s=300):
     env['HIP_VISIBLE_DEVICES'] = ids[device_index] if ids and device_index < len(ids) else str(device_index)
     cmd = [sys.executable, os.path.abspath(__file__), '--gpus', '1', '--config', args.config, '--steps', str(args.steps), '--warmup',
            str(args.warmup), '--batch', str(B), '--dropout', str(args.dropout), '--gemm-mode', str(args.gemm_mode), '--grad-arith',
-           str(args.grad_arith), '--no-cpu-baseline', '--no-live-pmc', '--no-extras', '--no-secondary', '--no-kernel-timing']
+           str(args.grad_arith), '--fwd-arith', str(args.fwd_arith), '--no-cpu-baseline', '--no-live-pmc', '--no-extras', '--no-secondary', '--no-kernel-timing']
     if not args.graph:
         cmd.append('--no-graph')
     t0 = time.perf_counter()
@@ -592,6 +595,9 @@ def main():
     if args.grad_arith is None:
         args.grad_arith = 'bf16x3' if args.grad_products == 3 else (ops.TRAINING_GRAD_ARITH if gemm_mode == 1 else 'six')
     ops.set_gradient_arithmetic(args.grad_arith)
+    if args.fwd_arith is None:
+        args.fwd_arith = ops.TRAINING_FWD_ARITH if (gemm_mode == 1 and args.grad_arith == ops.TRAINING_GRAD_ARITH) else 'six'
+    ops.set_forward_arithmetic(args.fwd_arith)
     share = os.environ.get('VQCPC_DP_SHARE_GPU', '0') == '1'
     # (a launcher may mask visibility to ONE device per rank: then the check is the PCI-id census below, after the group exists)
     if args.gpus > 1 and not share and 1 < torch.cuda.device_count() < args.gpus:
@@ -752,11 +758,12 @@ def main():
     # Extra, NOT the headline: the same steps with the forward's six-product split in the backward pass as well (what every
     # round before the fifth measured), after the timed region so that it cannot touch `value`: the price of carrying 24-bit
     # operand mantissas through six MFMAs where 22 bits through three give the same fp32-class gradients.
-    extra_six = None
-    if (gemm_mode == 1 and args.grad_arith == 'f16x3' and not args.no_extras and args.config == 'C1' and dp.world_size == 1
-            and not args.host_inputs):
+    extra_six, extra_fwd_six = None, None
+
+    def extra_leg(grad_arith, fwd_arith, note):
         try:
-            ops.set_gradient_arithmetic('six')
+            ops.set_gradient_arithmetic(grad_arith)
+            ops.set_forward_arithmetic(fwd_arith)
             if use_graph:
                 trainer.enable_step_graph(True)
                 trainer._graph_eager_steps = 0
@@ -768,16 +775,25 @@ def main():
             m3 = run_epoch(n3, False)
             torch.cuda.synchronize()
             dt3 = time.perf_counter() - t0
-            extra_six = {'value': round(B * n3 / dt3, 2), 'unit': 'windows/s', 'ms_per_step': round(1e3 * dt3 / n3, 3), 'steps': n3,
-                         'final_loss': round(float(m3['loss']), 5),
-                         'note': 'NOT the headline: the same steps with six-product (bf16x6) gradient GEMMs as well '
-                                 '(ops.set_gradient_arithmetic(\'six\') / bench.py --grad-arith six), i.e. the configuration rounds 1-4 reported'}
+            return {'value': round(B * n3 / dt3, 2), 'unit': 'windows/s', 'ms_per_step': round(1e3 * dt3 / n3, 3), 'steps': n3,
+                    'final_loss': round(float(m3['loss']), 5), 'note': note}
         except Exception as e:                        # never lose the headline line to the extra
-            extra_six = {'error': f'{type(e).__name__}: {str(e)[:200]}'}
+            return {'error': f'{type(e).__name__}: {str(e)[:200]}'}
         finally:
             ops.set_gradient_arithmetic(args.grad_arith)
+            ops.set_forward_arithmetic(args.fwd_arith)
             if use_graph:
                 trainer.enable_step_graph(False)
+
+    if (gemm_mode == 1 and args.grad_arith == 'f16x3' and not args.no_extras and args.config == 'C1' and dp.world_size == 1
+            and not args.host_inputs):
+        if args.fwd_arith == 'f16x3':
+            extra_fwd_six = extra_leg('f16x3', 'six',
+                                      'NOT the headline: the same steps with the six-product (bf16x6) split in every FORWARD product '
+                                      '(ops.set_forward_arithmetic(\'six\') / bench.py --fwd-arith six), f16x3 gradient GEMMs')
+        extra_six = extra_leg('six', 'six',
+                              'NOT the headline: the same steps with six-product (bf16x6) GEMMs everywhere, forward and backward '
+                              '(bench.py --grad-arith six --fwd-arith six), i.e. the configuration rounds 1-4 reported')
     pmc = None
     want_pmc = args.live_pmc if args.live_pmc is not None else (dp.world_size == 1 and args.config == 'C1' and not args.host_inputs)
     if want_pmc and dp.rank == 0 and dp.world_size == 1:
@@ -879,14 +895,23 @@ def main():
                                     f'd_model={config["downscaler_kwargs"]["d_model"]}, dropout={args.dropout}'),
                        'global_batch': B * dp.world_size, 'seq_len': seq_len,
                        'parallelism': f'dp{dp.world_size}', 'params': n_params,
-                       'path': ('what train_model() selects by default: bf16x6 GEMM arithmetic, f16x3 gradient GEMMs, step-graph replay'
-                                if (gemm_mode == 1 and use_graph and args.grad_arith == ops.TRAINING_GRAD_ARITH) else
-                                'non-default switches (see gemm / gradient_arithmetic / step_graph)'),
+                       'path': ('what train_model() selects by default: bf16x6 GEMM mode with the f16x3 kernels for the whole-round '
+                                '256-tile products of the training step (forward and backward), step-graph replay'
+                                if (gemm_mode == 1 and use_graph and args.grad_arith == ops.TRAINING_GRAD_ARITH
+                                    and args.fwd_arith == ops.TRAINING_FWD_ARITH) else
+                                'non-default switches (see gemm / gradient_arithmetic / forward_arithmetic / step_graph)'),
                        'gradient_arithmetic': args.grad_arith if gemm_mode == 1 else 'as the forward',
+                       'forward_arithmetic': args.fwd_arith if gemm_mode == 1 else 'the GEMM mode',
                        'gemm': (('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy: exact 3-way bf16 split, 6 MFMAs per product)'
-                                 + ('; backward dgrad / wgrad of the 256-tile shapes: f16x3 (two fp16 planes per operand, 11 + 11 bits '
-                                    'under a per-tensor power-of-two scale, 3 MFMAs per product, rms error vs fp64 3-5e-7 = the class '
-                                    'of the fp32-MFMA kernel; forward, losses and code assignment untouched)'
+                                 + ('; the whole-round 256-tile products of the training step -- dgrad / wgrad'
+                                    + (' AND the forward launches' if args.fwd_arith == 'f16x3' else '') +
+                                    ' -- on f16x3 (two fp16 planes per operand, 11 + 11 bits under a per-tensor power-of-two '
+                                    'scale, 3 MFMAs per product; rms error vs fp64 2.7e-7 / 4.1e-7 at K = 256 / 1024 against '
+                                    '2.4e-7 / 4.9e-7 for the six-product split and 2.9e-7 / 5.7e-7 for the exact fp32-MFMA kernel; '
+                                    'oracle parity suites green at unchanged tolerances, indices bit-exact; '
+                                    + ('full-size C1 code assignments: 1 of 69 632 differs from the six-product forward, 0 from the '
+                                       'exact fp32-MFMA forward; evaluation / inference stay on six products)'
+                                       if args.fwd_arith == 'f16x3' else 'forward, losses and code assignment untouched)')
                                     if args.grad_arith == 'f16x3' else
                                     '; backward: two bf16 planes, 3 MFMAs per product (18-bit operands)' if args.grad_arith == 'bf16x3'
                                     else '')) if gemm_mode == 1 else
@@ -926,6 +951,8 @@ def main():
                                 'host_enqueue_ms_per_step': round(1e3 * t_enqueued / n_host, 3),
                                 'note': 'same steps without epoch()\'s metric bookkeeping; not the metric'},
         }
+        if extra_fwd_six is not None:
+            line['extra_six_product_forward'] = extra_fwd_six
         if extra_six is not None:
             line['extra_six_product_gradients'] = extra_six
         if n1_leg and n1_leg.get('value'):

@@ -172,8 +172,21 @@ int vqcpc_gemm_tn_grad_supported(int64_t M, int N, int K);
 int64_t vqcpc_gemm_tn_grad_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,
                        int accumulate, void* workspace, int64_t workspace_bytes, float* scale_state, void* stream);
+/* The same kernel for the FORWARD products of a training step (opt-in: ops.FWD_ARITH / VQCPC_FWD_ARITH=f16x3; the library default and
+ * every evaluation / inference call stay on vqcpc_gemm_nt): C = epilogue(A . B^T + bias) with the forward epilogues of vqcpc_gemm_nt
+ * that the 256-tile launches use -- act 0: bias | bias + add | bias + dropout + add (F.linear + dropout + residual,
+ * transformer_custom.py:279-289); act 1 with mask_out: bias + relu (+ dropout) and the bit mask of the positive outputs
+ * (vqcpc_gemm_nt_relu_mask).  Same dropout element index and mask layout as vqcpc_gemm_nt; shapes and scale_state as
+ * vqcpc_gemm_nt_grad. */
+int vqcpc_gemm_nt_f16x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                        const float* bias, int act, float drop_p, uint64_t seed, const float* add, int64_t ldadd, void* mask_out,
+                        float* scale_state, void* stream);
 int vqcpc_grad_amax(const float* x, int64_t ld, int64_t rows, int cols, float* amax_slot, void* stream);
 int vqcpc_grad_scale_roll(float* state, int nsites, void* stream);
+/* the same, and *saturated_count (uint32, device) += the number of (site, operand) pairs whose amax of this step lay beyond the fp16
+ * range under the scale the step used -- elements above 65504 / scale were clamped there: the monitor of a scale that lagged by more
+ * than its 16-32 x head-room (the trainers warn at the end of an epoch when it is non-zero) */
+int vqcpc_grad_scale_roll_counted(float* state, int nsites, void* saturated_count, void* stream);
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                   float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream);

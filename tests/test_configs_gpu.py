@@ -86,11 +86,16 @@ def _oracle_step(cfg, seed):
     return _ORACLE_CACHE[key]
 
 
-def _step_vs_oracle(cfg, seed, trainer_backward=False):
+def _step_vs_oracle(cfg, seed, trainer_backward=False, forward_scope=False):
     sd, batch, otr, ref = _oracle_step(cfg, seed)
     tr = build_trainer(cfg, sd, lr=1e-4)
     tr.train()
-    loss, out = tr.compute_losses(batch)
+    if forward_scope:                          # as the trainers' step does it: the forward inside ops.forward_arithmetic
+        from vqcpc_bach_amd import ops
+        with ops.forward_arithmetic(tr.flat):
+            loss, out = tr.compute_losses(batch)
+    else:
+        loss, out = tr.compute_losses(batch)
     tr.flat.zero_grad()
     if trainer_backward:                       # as the trainers' step does it: weight gradients straight into the bucket,
         from vqcpc_bach_amd import ops         # batched transposes, and the gradient scope of the GEMM library open
@@ -133,6 +138,31 @@ def test_c1_model_dimensions_with_the_products_own_gate_selection(gemm_mode):
     rows = 8 * (8 + 8 + 15 * 8) * 16
     assert ops.gatebits_worthwhile(rows, 1024, 256) and not ops.gatebits_worthwhile(rows // 4, 1024, 256)
     _step_vs_oracle(cfg, seed=31)
+
+
+@pytest.mark.parametrize('cfg_name,B', [('C1', 8), ('C4', 4)])
+def test_model_dimensions_with_f16x3_forward_arithmetic(gemm_mode, cfg_name, B):
+    """Opt-in ops.FWD_ARITH = 'f16x3': the forward products of the training step on the three-product fp16 kernel as well (every
+    eligible launch forced through it), gradients likewise -- against the oracle at the UNCHANGED tolerances: indices bit-exact,
+    losses within 5e-5, every gradient within 5e-4."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('an arithmetic of the bf16x6 mode')
+    from vqcpc_bach_amd import hip, ops
+    calls, raw = [], hip.call
+    prev = ops.set_gradient_arithmetic('f16x3')
+    saved = ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS, ops.FWD_ARITH
+    ops.GRAD_MIN_TILES = ops.GRAD_TN_MIN_ROWS = 0
+    ops.FWD_ARITH = 'f16x3'
+    hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+    try:
+        _step_vs_oracle(O.make_cfg(cfg_name, B=B), seed=31, trainer_backward=True, forward_scope=True)
+    finally:
+        hip.call = raw
+        ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS, ops.FWD_ARITH = saved
+        ops.set_gradient_arithmetic(prev)
+    n_fwd = calls.count('vqcpc_gemm_nt_f16x3')
+    print(f'{n_fwd} forward launches on the three-product kernel')
+    assert n_fwd >= 8, n_fwd
 
 
 def _full_size_c4_properties(bf16):

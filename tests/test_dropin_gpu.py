@@ -172,17 +172,20 @@ from test_dropin_gpu import make_reference_style_config, run_main_encoder
 vqcpc_bach_amd.install_as_vqcpcb()
 hip.load()
 assert hip.get_gemm_mode() == 0                       # bare library default: exact fp32 MFMA
-assert ops.GRAD_ARITH == 'six'                        # ... and the forward's six-product split in backward too
-seen = []
+assert ops.GRAD_ARITH == 'six' and ops.FWD_ARITH == 'six'   # ... and the six-product split in backward and in every forward too
+seen, seen_fwd = [], []
 raw_enter = ops.direct_weight_gradients.__enter__
 ops.direct_weight_gradients.__enter__ = lambda self: (seen.append(ops.GRAD_ARITH), raw_enter(self))[1]
+raw_fenter = ops.forward_arithmetic.__enter__
+ops.forward_arithmetic.__enter__ = lambda self: (seen_fwd.append(ops.FWD_ARITH), raw_fenter(self))[1]
 cfg = make_reference_style_config()
 cfg.update(num_batches=6, num_epochs=1)
 tr, _, hist = run_main_encoder(cfg, train=True, load=False, model_root=sys.argv[1])
 assert tr.trained_gemm_mode == 1, tr.trained_gemm_mode    # train_model chose bf16x6 for its epochs ...
 assert hip.get_gemm_mode() == 0                       # ... and put the process-wide setting back
 assert seen and set(seen) == {'f16x3'}, seen          # backward passes ran under the f16x3 gradient arithmetic (round 5) ...
-assert ops.GRAD_ARITH == 'six'                        # ... which train_model() put back as well
+assert seen_fwd and set(seen_fwd) == {'f16x3'}, seen_fwd      # ... and the training forwards under the f16x3 forward arithmetic
+assert ops.GRAD_ARITH == 'six' and ops.FWD_ARITH == 'six'     # ... which train_model() put back as well
 assert tr._graph is not None and tr._graph.replays >= 3, 'training steps are graph replays by default'
 print('REPLAYS', tr._graph.replays)
 # explicit choices win
@@ -200,6 +203,6 @@ print('OK')
 ''' % (ROOT, ROOT)
     import tempfile
     with tempfile.TemporaryDirectory() as d:
-        env = {k: v for k, v in os.environ.items() if k not in ('VQCPC_GEMM_MODE', 'VQCPC_STEP_GRAPH', 'VQCPC_GRAD_ARITH')}
+        env = {k: v for k, v in os.environ.items() if k not in ('VQCPC_GEMM_MODE', 'VQCPC_STEP_GRAPH', 'VQCPC_GRAD_ARITH', 'VQCPC_FWD_ARITH')}
         r = subprocess.run([sys.executable, '-c', code, d], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and 'OK' in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

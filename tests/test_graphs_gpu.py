@@ -59,6 +59,36 @@ def test_graph_replay_is_the_eager_step():
     assert abs(tr.current_lr() - 2e-3 * O.lr_lambda(len(batches))) < 1e-12
 
 
+def test_graph_replay_is_the_eager_step_under_the_f16x3_arithmetic():
+    """The training defaults of round 5 inside a captured step: the f16x3 kernels for the forward and the gradient products, their
+    scale tables (primed in the eager warm-up steps, rolled by graph nodes) -- replayed steps == eager steps at the model
+    dimensions of configs[1] (every eligible product forced through the kernels)."""
+    from vqcpc_bach_amd import ops
+    cfg = O.make_cfg('C1', B=4)
+    sd = O.init_state(cfg, seed=23)
+    batches = [O.synthetic_batch(cfg, seed=70 + i) for i in range(5)]
+    prev = ops.set_gradient_arithmetic('f16x3')
+    saved = ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS, ops.FWD_ARITH
+    ops.GRAD_MIN_TILES = ops.GRAD_TN_MIN_ROWS = 0
+    ops.FWD_ARITH = 'f16x3'
+    from vqcpc_bach_amd import hip
+    calls, raw = [], hip.call
+    hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+    try:
+        l_e, p_e, r_e, tr_e = _run(cfg, sd, batches, graph=False)
+        n_eager = calls.count('vqcpc_gemm_nt_f16x3')
+        l_g, p_g, r_g, tr = _run(cfg, sd, batches, graph=True)
+    finally:
+        hip.call = raw
+        ops.GRAD_MIN_TILES, ops.GRAD_TN_MIN_ROWS, ops.FWD_ARITH = saved
+        ops.set_gradient_arithmetic(prev)
+    assert n_eager >= 2 * len(batches), n_eager                   # the forward did run on the three-product kernel
+    assert r_e == 0 and r_g == len(batches) - tr.graph_warmup_steps, (r_e, r_g)
+    assert np.allclose(l_e, l_g, rtol=1e-6, atol=0), (l_e, l_g)
+    assert float((p_e - p_g).abs().max()) < 1e-6 * float(p_e.abs().max())
+    assert ops.scale_saturations(tr.flat) == 0 and ops.scale_saturations(tr_e.flat) == 0
+
+
 def test_graph_replays_draw_fresh_dropout_masks_and_training_still_works():
     cfg, sd, batches = _cpc_setup(0.2)
     same = [batches[0]] * 8

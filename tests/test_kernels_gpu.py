@@ -1891,12 +1891,16 @@ def test_f16x3_saturates_instead_of_overflowing(ops, bf16x6):
     a = torch.randn(1024, 256, device='cuda', generator=gen) * 1e-4
     b = torch.randn(256, 256, device='cuda', generator=gen) * 0.05
     ref = a.double() @ b.double().t()
+    count = torch.zeros(1, dtype=torch.int32, device='cuda')
     for stale in (1 / 64, 1 / 4096, 0.0):
         st = _grad_state(a, b, stale)
         out = _nt_grad(a, b, st)
         assert bool(torch.isfinite(out).all()), stale
-        hip.call('vqcpc_grad_scale_roll', st, 1)                    # the kernel saw the true amax
+        hip.call('vqcpc_grad_scale_roll_counted', st, 1, count)     # the kernel saw the true amax; the roll counts the clamped operand
         assert _rms(_nt_grad(a, b, st), ref) < 1e-6
+    assert int(count) == 3                                          # one operand (A) of one site, three times
+    hip.call('vqcpc_grad_scale_roll_counted', st, 1, count)         # a step within the head-room adds nothing
+    assert int(count) == 3
     a2 = a.clone()
     a2[5, 7] = float('nan')
     out = _nt_grad(a2, b, _grad_state(a, b))
@@ -1928,6 +1932,61 @@ def test_f16x3_input_gradient_epilogues(ops, bf16x6, M, N, K):
     g3 = _nt_grad(a, b, st, mask=mask, gate_scale=1.25)
     assert torch.equal(six == 0, g3 == 0) and float((six - g3).abs().max() / six.abs().max()) < 3e-6
     assert bool(((h > 0) == (g3 != 0)).float().mean() > 0.999)
+
+
+def _nt_f16x3(a, b, st, bias, act=0, drop_p=0.0, seed=0, add=None, want_mask=False):
+    from vqcpc_bach_amd import hip
+    M, K = a.shape
+    N = b.shape[0]
+    out = torch.empty(M, N, device='cuda')
+    mask = torch.empty(M * (N // 32), dtype=torch.int32, device='cuda') if want_mask else None
+    hip.call('vqcpc_gemm_nt_f16x3', a, a.stride(0), b, b.stride(0), out, N, M, N, K, bias, int(act), float(drop_p), int(seed), add,
+             0 if add is None else add.stride(0), mask, st)
+    return (out, mask) if want_mask else out
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 1024, 256), (2048, 256, 1024), (1024, 768, 256)])
+def test_f16x3_forward_epilogues(ops, bf16x6, M, N, K):
+    """vqcpc_gemm_nt_f16x3, the forward forms of the three-product kernel (opt-in FWD_ARITH = 'f16x3'): bias, bias + residual, bias +
+    dropout + residual, bias + relu (+ dropout) with the bit mask -- against fp64 (rms in the class of the six-product and the
+    exact fp32-MFMA kernels) and against vqcpc_gemm_nt: the SAME dropout pattern (same element index), the same mask bits wherever
+    the pre-activation is not within rounding noise of zero, and the mask the backward reads equals `out > 0` exactly."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M + K)
+    a = torch.randn(M, K, device='cuda', generator=gen)
+    b = torch.randn(N, K, device='cuda', generator=gen) * K ** -0.5
+    bias = torch.randn(N, device='cuda', generator=gen) * 0.1
+    add = torch.randn(M, N, device='cuda', generator=gen)
+    st = _grad_state(a, b)
+    pre = a.double() @ b.double().t() + bias.double()
+    hip.set_gemm_mode(0)
+    try:
+        e32 = _rms(ops.gemm_nt(a, b, bias=bias), pre)
+    finally:
+        hip.set_gemm_mode(1)
+    e6 = _rms(ops.gemm_nt(a, b, bias=bias), pre)
+    e3 = _rms(_nt_f16x3(a, b, st, bias), pre)
+    print(f'rms error vs fp64: fp32 MFMA {e32:.2e}  bf16x6 {e6:.2e}  f16x3 {e3:.2e}')
+    assert e3 < 1e-6 and e3 < 1.5 * max(e32, e6) + 5e-8, (e3, e6, e32)
+    assert _rms(_nt_f16x3(a, b, st, bias, add=add), pre + add.double()) < 1e-6
+    for p in (0.1,):
+        six = ops.gemm_nt(a, b, bias=bias, drop_p=p, seed=11, add=add)
+        g3 = _nt_f16x3(a, b, st, bias, drop_p=p, seed=11, add=add)
+        assert torch.equal((six - add) == 0, (g3 - add) == 0), 'dropout pattern'
+        assert float((six - g3).abs().max() / six.abs().max()) < 3e-6
+    for p in (0.0, 0.1):
+        h6, m6 = ops.gemm_nt_relu_mask(a, b, bias, drop_p=p, seed=5)
+        h3, m3 = _nt_f16x3(a, b, st, bias, act=1, drop_p=p, seed=5, want_mask=True)
+        assert float((h6 - h3).abs().max() / h6.abs().max()) < 3e-6, p
+        # the mask is the bit pattern of out > 0, in the layout vqcpc_gemm_nt_gatebits reads
+        g = torch.ones(M, 256, device='cuda')
+        eye = torch.zeros(N, 256, device='cuda')          # (g @ eye^T) is irrelevant: only the zero pattern of the gated product counts
+        eye[:, 0] = 1.0
+        gated = ops.gemm_nt_gatebits(g, eye, m3)
+        assert torch.equal(gated != 0, h3 > 0), p
+        # against the six-product kernel's mask: differs only where the pre-activation is within rounding noise of zero
+        diff = (h6 > 0) != (h3 > 0)
+        assert float(diff.float().mean()) < 1e-5 and bool((pre[diff].abs() < 1e-5).all()), (p, int(diff.sum()))
 
 
 @pytest.mark.parametrize('M,N,K,scale_a', [(4096, 256, 256, 1.0), (131072, 256, 256, 1e-6), (65536, 1024, 256, 1e-4), (1056, 256, 512, 1.0)])
@@ -1997,7 +2056,7 @@ def test_f16x3_arithmetic_is_taken_inside_a_backward_scope_only(ops, bf16x6):
             assert tab.keys == [('nt', M, N, K), ('tn', 4096, 256, 512)]
             assert calls.count('vqcpc_gemm_nt_grad') == 1 and calls.count('vqcpc_gemm_tn_grad') == 1
             assert calls.count('vqcpc_grad_amax') == (4 if step == 0 else 0), 'primed once'
-            assert calls.count('vqcpc_grad_scale_roll') == 1
+            assert calls.count('vqcpc_grad_scale_roll_counted') == 1
             assert calls.count('vqcpc_gemm_nt') == 2, 'the 128 ragged rows + the bias GEMM'
             assert torch.equal(fwd_like, six)
             assert not torch.equal(g3, six) and float((g3 - six).abs().max() / six.abs().max()) < 3e-6

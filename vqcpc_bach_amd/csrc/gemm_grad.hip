@@ -78,7 +78,8 @@ __device__ __forceinline__ void g3_amax_publish(float amax, float* slot) {
 
 // =====================================================================================================================
 // dgrad: C[M, N] = epilogue(A[M, K] . B[N, K]^T), A = output gradient rows, B = W^T rows (ops.transpose)
-// EPI in {0, E_ADD, E_ADD | E_ADD2, E_GATEBITS, G_ACCUM}
+// EPI in {0, E_ADD, E_ADD | E_ADD2, E_GATEBITS, G_ACCUM} (gradient products) and the forward forms of vqcpc_gemm_nt_f16x3:
+// E_BIAS, E_BIAS | E_ADD, E_BIAS | E_DROP | E_ADD, E_BIAS | E_RELU | E_MASKOUT, E_BIAS | E_RELU | E_DROP | E_MASKOUT
 // G_ACCUM: C += A . B^T by buffer_atomic_add_f32 (no return): the "+ residual" form when the residual already sits in C.  One
 // fp32 add per element at the L2, the same value load-add-store gives, and no operand load for the epilogue to wait for (with
 // E_ADD all eight waves stall on those loads together at every tile boundary: the slowest epilogue of this kernel).
@@ -177,11 +178,28 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
     constexpr bool HAS_AUX = (EPI & E_ADD) != 0;
     const int ldci = (int)ldc;
     const int ldxi = (int)ep.ldadd;
+    // forward epilogues (round 5: vqcpc_gemm_nt_f16x3): bias, relu, dropout and the bit mask of the positive outputs, exactly as in
+    // gemm_nt_x6_pp_kernel (same dropout element index, same mask layout); the tile's two bias values are requested one output tile ahead
+    float bias_nx0 = 0.0f, bias_nx1 = 0.0f;
+    const uint64_t drop_se = rng_seed_eff(ep.seed);
+    const uint32_t drop_sh = (uint32_t)(drop_se >> 32), nc1 = (uint32_t)N * kRngMul;
+#define G_BIAS_REQUEST(TILE)                                                                                           \
+    if (EPI & E_BIAS) {                                                                                                \
+        const int tb_ = xcd_swizzle(min((TILE), tiles - 1), tiles);                                                    \
+        const float* bp_ = ep.bias + (tb_ % tiles_n) * kG + wn * 64 + li;                                              \
+        bias_nx0 = bp_[0];                                                                                             \
+        bias_nx1 = bp_[32];                                                                                            \
+    }
+    G_BIAS_REQUEST(ep_tile)
 #define G_EPILOGUE()                                                                                                   \
     {                                                                                                                  \
         const int t_ = xcd_swizzle(ep_tile, tiles);                                                                    \
         const int64_t m0 = (int64_t)(t_ / tiles_n) * kG;                                                               \
         const int n0 = (t_ % tiles_n) * kG;                                                                            \
+        const int64_t row_base = m0 + wm * 128 + 4 * kh;                                                               \
+        const int col_base = n0 + wn * 64 + li;                                                                        \
+        const float bv_cur0 = bias_nx0, bv_cur1 = bias_nx1;                                                            \
+        G_BIAS_REQUEST(ep_tile + (int)gridDim.x)                                                                       \
         const __amdgpu_buffer_rsrc_t rc =                                                                              \
             __builtin_amdgcn_make_buffer_rsrc((void*)(C + m0 * ldc + n0), 0, 0x7FFFFFFF, 0x00020000);                  \
         const int voff_c = ((wm * 128 + 4 * kh) * ldci + wn * 64 + li) * 4;                                            \
@@ -198,7 +216,7 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
                 float, __builtin_amdgcn_raw_buffer_load_b32(rx, voff_x, (((r & 3) + 8 * (r >> 2)) * ldxi) * 4, 0));    \
         }                                                                                                              \
         const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(                                           \
-            (void*)((EPI & E_GATEBITS) ? (void*)ep.mask : (void*)C), 0, 0x7FFFFFFF, 0x00020000);                       \
+            (void*)((EPI & (E_GATEBITS | E_MASKOUT)) ? (void*)ep.mask : (void*)C), 0, 0x7FFFFFFF, 0x00020000);         \
         const int nw16 = (N >> 5) * 16;                                   /* bytes of one 4-row group of mask words */  \
         const int mrow4 = (int)((m0 + wm * 128) >> 2), mcb = (n0 >> 5) + wn * 2;                                       \
         u32x4 gb[2][4];                                                                                                \
@@ -209,6 +227,11 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
         const float gsc = (EPI & E_GATEBITS) ? inv * ep.gate_scale : inv;                                              \
         _Pragma("unroll") for (int tile = 0; tile < 8; ++tile) {                                                       \
             const int mt = tile >> 1, nt = tile & 1;                                                                   \
+            /* dropout hash input of this lane's first row of the tile; the other 15 rows are multiples of nc1 away */ \
+            const uint32_t x0t = (EPI & E_DROP) ? rng_x0(drop_se, (uint32_t)(row_base + mt * 32 + ep.row0) * (uint32_t)N + \
+                                                                      (uint32_t)(col_base + nt * 32)) : 0u;            \
+            const float bv = nt ? bv_cur1 : bv_cur0;                                                                   \
+            uint32_t mword = 0;                                                                                        \
             if ((EPI & E_GATEBITS) && tile + 1 < 8) {                                                                  \
                 const int mt2 = (tile + 1) >> 1, nt2 = (tile + 1) & 1;                                                 \
                 _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) gb[(tile + 1) & 1][jj] = __builtin_bit_cast(u32x4,    \
@@ -229,9 +252,18 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
             }                                                                                                          \
             _Pragma("unroll") for (int r = 0; r < 16; ++r) {                                                           \
                 float v = acc[mt][nt][r] * gsc;              /* exact: a power of two (times the gate's 1 / (1 - p)) */ \
+                if (EPI & E_BIAS) v += bv;                                                                             \
+                if (EPI & E_RELU) v = fmaxf(v, 0.0f);                                                                  \
+                if (EPI & E_DROP)   /* == drop_scale(ep.seed, (row + ep.row0) * N + col, ..): thr > 0 on this path */   \
+                    v *= rng_u24_from_x0(x0t + (uint32_t)((r & 3) + 8 * (r >> 2)) * nc1, drop_sh) >= ep.thr ? ep.inv_keep : 0.0f; \
                 if (EPI & E_GATEBITS) v = ((gb[tile & 1][r >> 2][r & 3] >> li) & 1u) ? v : 0.0f;                      \
                 if (EPI & E_ADD) v += aux[tile & 1][r];                                                                \
                 if (EPI & E_ADD2) v += a2[r];                                                                          \
+                if (EPI & E_MASKOUT) {                                                                                 \
+                    const uint64_t bal = __ballot(v > 0.0f);      /* low word: this row for kh = 0, high word: kh = 1 */ \
+                    asm volatile("s_nop 4\n\tv_writelane_b32 %0, %1, %2\n\tv_writelane_b32 %0, %3, %4"                 \
+                                 : "+v"(mword) : "s"((uint32_t)bal), "n"(r), "s"((uint32_t)(bal >> 32)), "n"(16 + r));   \
+                }                                                                                                      \
                 if (ABL & 8) { asm volatile("" :: "v"(v)); } else if (EPI & G_ACCUM)                                   \
                 (void)__builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(v, rc, voff_c,                                   \
                                                       ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
@@ -239,6 +271,11 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rc, voff_c,                     \
                                                       ((mt * 32 + (r & 3) + 8 * (r >> 2)) * ldci + nt * 32) * 4, 0);   \
                 acc[mt][nt][r] = 0.0f;                                                                                 \
+            }                                                                                                          \
+            if ((EPI & E_MASKOUT) && lane < 32) {    /* lane = r + 16 kh holds the word of row (r & 3) + 8 (r >> 2) + 4 kh */ \
+                const int jj = (lane >> 2) & 3, khh = lane >> 4;                                                       \
+                __builtin_amdgcn_raw_buffer_store_b32(mword, rm, (2 * jj + khh) * nw16 + (lane & 3) * 4,               \
+                                                      ((mrow4 + mt * 8) * (N >> 5) + mcb + nt) * 16, 0);               \
             }                                                                                                          \
         }                                                                                                              \
         ep_tile += gridDim.x;                                                                                          \
@@ -362,6 +399,7 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
 #undef G_P_ZW
 #undef G_P_XY
 #undef G_EPILOGUE
+#undef G_BIAS_REQUEST
 #undef G_BARRIER
 #undef G_FENCE
 #undef G_MFMA1
@@ -598,11 +636,15 @@ __global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict_
 }
 
 // per call site: {read A, read B, written A, written B}: read <- written (a site that did not run keeps its value), written <- 0
-__global__ __launch_bounds__(256) void grad_scale_roll_kernel(float* __restrict__ state, int nsites) {
+// `saturated` (may be NULL): counts the (site, operand) pairs whose amax of THIS step lay beyond the fp16 range under the scale the
+// step used (the elements above 65504 / scale were clamped there): the caller's monitor of a scale that lagged too far
+__global__ __launch_bounds__(256) void grad_scale_roll_kernel(float* __restrict__ state, int nsites,
+                                                              unsigned int* __restrict__ saturated) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nsites * 2) return;
     float* s = state + (i >> 1) * 4 + (i & 1);
     const float w = s[2];
+    if (saturated && w * g3_pow2(g3_scale_exp(s[0])) > 65504.0f) atomicAdd(saturated, 1u);
     if (w > 0.0f) s[0] = w;
     s[2] = 0.0f;
 }
@@ -686,6 +728,65 @@ int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb,
     return VQCPC_OK;
 }
 
+// The forward products of a TRAINING step on the same kernel (round 5): C = epilogue(A . B^T) with the epilogues of vqcpc_gemm_nt that
+// the 256-tile forward launches use -- bias; bias + residual; bias + dropout + residual (the residual sums of LayerNorm); bias +
+// relu (+ dropout) with the bit mask of the positive outputs (vqcpc_gemm_nt_relu_mask).  Same dropout element index and mask layout
+// as vqcpc_gemm_nt, so the backward is unchanged.  Scale state as for vqcpc_gemm_nt_grad.
+int vqcpc_gemm_nt_f16x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                        const float* bias, int act, float drop_p, uint64_t seed, const float* add, int64_t ldadd, void* mask_out,
+                        float* scale_state, void* stream) {
+    VQ_REQUIRE(A && B && C && scale_state && bias, "gemm_nt_f16x3: null pointer (a bias is part of every forward form)");
+    VQ_REQUIRE(vqcpc_gemm_nt_grad_supported(M, N, K), "gemm_nt_f16x3: M, N multiples of 256 and K of 32, got M=%lld N=%d K=%d",
+               (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B),
+               "gemm_nt_f16x3: bad leading dimensions / alignment");
+    VQ_REQUIRE(act == 0 || act == 1, "gemm_nt_f16x3: act must be 0 or 1");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f, "gemm_nt_f16x3: bad dropout probability");
+    VQ_REQUIRE((act == 1) == (mask_out != nullptr) && !(act == 1 && add) && !(add && ldadd < N),
+               "gemm_nt_f16x3: epilogue is one of bias / bias + add / bias + dropout + add / bias + relu (+ dropout) + mask_out");
+    VQ_REQUIRE(!mask_out || aligned16(mask_out), "gemm_nt_f16x3: mask must be 16-byte aligned");
+    EpiParams ep{};
+    ep.bias = bias;
+    ep.act = act;
+    ep.thr = drop_threshold(drop_p);
+    ep.inv_keep = 1.0f / (1.0f - drop_p);
+    ep.seed = seed;
+    ep.add = add;
+    ep.ldadd = ldadd;
+    ep.mask = (uint32_t*)mask_out;
+    ep.gate_scale = 1.0f;
+    const int tn = N / kG;
+    const int tiles = (int)((M / kG) * tn);
+    const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kGThreads);
+    const size_t lds = (size_t)kGSlots * kGSlot;
+    hipStream_t st = (hipStream_t)stream;
+#define G3_LAUNCH(EPIV)                                                                                                  \
+    {                                                                                                                    \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_g3_kernel<EPIV>, hipFuncAttributeMaxDynamicSharedMemorySize,  \
+                                      (int)lds);                                                                         \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_g3_kernel<EPIV>), grid, block, lds, st, A, lda, B, ldb, C, ldc, M, N, K, tn, tiles,  \
+                           ep, scale_state);                                                                             \
+    }
+    const bool drop = ep.thr != 0;
+    if (act == 1) {
+        if (drop) G3_LAUNCH(E_BIAS | E_RELU | E_DROP | E_MASKOUT)
+        else G3_LAUNCH(E_BIAS | E_RELU | E_MASKOUT)
+    } else if (add) {
+        if (drop) G3_LAUNCH(E_BIAS | E_DROP | E_ADD)
+        else G3_LAUNCH(E_BIAS | E_ADD)
+    } else {
+        VQ_REQUIRE(!drop, "gemm_nt_f16x3: dropout without a residual or relu is not a forward form of the step");
+        G3_LAUNCH(E_BIAS)
+    }
+#undef G3_LAUNCH
+    VQ_CHECK_LAUNCH("gemm_nt_g3 (forward)");
+    return VQCPC_OK;
+}
+
 // wgrad shapes: whole 256 x 256 output tiles, M a multiple of 32 (an even number of 16-row steps per split)
 int vqcpc_gemm_tn_grad_supported(int64_t M, int N, int K) {
     return (N >= kG && (N % kG) == 0 && K >= kG && (K % kG) == 0 && M >= 32 && (M % 32) == 0) ? 1 : 0;
@@ -737,8 +838,17 @@ int vqcpc_grad_scale_roll(float* state, int nsites, void* stream) {
     VQ_REQUIRE(state && nsites >= 0, "grad_scale_roll: bad arguments");
     if (nsites == 0) return VQCPC_OK;
     hipLaunchKernelGGL(grad_scale_roll_kernel, dim3((unsigned)ceil_div(2 * nsites, 256)), dim3(256), 0, (hipStream_t)stream,
-                       state, nsites);
+                       state, nsites, (unsigned int*)nullptr);
     VQ_CHECK_LAUNCH("grad_scale_roll");
+    return VQCPC_OK;
+}
+
+int vqcpc_grad_scale_roll_counted(float* state, int nsites, void* saturated_count, void* stream) {
+    VQ_REQUIRE(state && nsites >= 0 && saturated_count, "grad_scale_roll_counted: bad arguments");
+    if (nsites == 0) return VQCPC_OK;
+    hipLaunchKernelGGL(grad_scale_roll_kernel, dim3((unsigned)ceil_div(2 * nsites, 256)), dim3(256), 0, (hipStream_t)stream,
+                       state, nsites, (unsigned int*)saturated_count);
+    VQ_CHECK_LAUNCH("grad_scale_roll_counted");
     return VQCPC_OK;
 }
 

@@ -64,8 +64,11 @@ SIGNATURES = {
     'vqcpc_gemm_tn_grad_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_grad': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr,
                                    c_ptr]),
+    'vqcpc_gemm_nt_f16x3': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr,
+                                    c_i64, c_ptr, c_ptr, c_ptr]),
     'vqcpc_grad_amax': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     'vqcpc_grad_scale_roll': (c_int, [c_ptr, c_int, c_ptr]),
+    'vqcpc_grad_scale_roll_counted': (c_int, [c_ptr, c_int, c_ptr, c_ptr]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_tn_groupable': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_grouped_workspace': (c_i64, [c_int, c_ptr, c_ptr, c_ptr]),

@@ -44,6 +44,24 @@ GRAD_MIN_TILES = 256           # dgrad: fewer 256 x 256 tiles than CUs -> the si
 GRAD_TN_MIN_ROWS = 8192        # wgrad: as the 256-tile six-product kernel (tests set both to 0 to reach the kernels with small shapes)
 LAST_GEMM_F16X3 = False       # set by gemm_nt / gemm_nt_gatebits / gemm_tn: did the last call go through the f16x3 kernels (bench.py reads it)
 _GRAD_SCALES = None            # the open gradient scope's GradScales (None: outside a trainer's backward, or another arithmetic)
+# arithmetic of the FORWARD products of a training step (ops.forward_arithmetic scope, the trainers' compute_losses): 'six' = the
+# bf16x6 split everywhere; 'f16x3' = the whole-round 256-tile launches on three fp16 MFMAs per product with per-tensor scales, the
+# kernel of the gradient GEMMs (rms error vs fp64 at the forward's shapes: 2.7e-7 against 2.4e-7 for the six-product split and
+# 2.9e-7 for the exact fp32-MFMA kernel, profiles/r05_bench_grad_f16.log).  Evaluation / encode-only calls never use it.
+FWD_ARITH = os.environ.get('VQCPC_FWD_ARITH', 'six')
+TRAINING_FWD_ARITH = 'f16x3'   # what train_model() / bench.py select in the bf16x6 mode, with TRAINING_GRAD_ARITH
+_fwd_arith_explicit = 'VQCPC_FWD_ARITH' in os.environ
+_FWD_SCALES = None             # the open forward scope's GradScales
+
+
+def set_forward_arithmetic(name):
+    """Selects the arithmetic of the forward products of a TRAINING step (see above); returns the previous name.  Evaluation and
+    inference are never affected."""
+    global FWD_ARITH, _fwd_arith_explicit
+    assert name in ('six', 'f16x3'), name
+    prev, FWD_ARITH = FWD_ARITH, name
+    _fwd_arith_explicit = True
+    return prev
 
 
 def set_gradient_arithmetic(name):
@@ -58,12 +76,12 @@ def set_gradient_arithmetic(name):
 
 
 def gradient_arithmetic_state():
-    return (GRAD_ARITH, _grad_arith_explicit)
+    return (GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit)
 
 
 def restore_gradient_arithmetic_state(state):
-    global GRAD_ARITH, _grad_arith_explicit
-    GRAD_ARITH, _grad_arith_explicit = state
+    global GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit
+    GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit = state
     hip.set_gradient_products(3 if GRAD_ARITH == 'bf16x3' else 6)
 
 
@@ -71,9 +89,15 @@ def use_training_default_gradient_arithmetic():
     """What `train_model()` selects when the caller chose nothing (neither set_gradient_arithmetic() nor VQCPC_GRAD_ARITH): the
     f16x3 gradient GEMMs -- fp32-class (rms 3-5e-7 vs fp64, tools/bench_grad_f16.py; every parity suite passes in it at unchanged
     tolerances), forward untouched -- i.e. the configuration bench.py measures.  The bare library default stays 'six'."""
-    global GRAD_ARITH
+    global GRAD_ARITH, FWD_ARITH
     if not _grad_arith_explicit:
         GRAD_ARITH = TRAINING_GRAD_ARITH
+    # ... and the forward products of the training step on the same kernel (ops.forward_arithmetic): the same error class again
+    # (2.7e-7 vs 2.4e-7 six products vs 2.9e-7 exact fp32 MFMA at the forward's shapes), the oracle parity suites green at unchanged
+    # tolerances with it, code assignments as close to the exact fp32-MFMA arithmetic's as the six-product split's are
+    # (tools/fwd_f16x3_flips.py); evaluation / inference stay on six products
+    if not _fwd_arith_explicit:
+        FWD_ARITH = TRAINING_FWD_ARITH
 
 
 class GradScales:
@@ -86,6 +110,7 @@ class GradScales:
 
     def __init__(self, device):
         self.state = torch.zeros(4 * self.CAPACITY, dtype=torch.float32, device=device)
+        self.saturated = torch.zeros(1, dtype=torch.int32, device=device)      # (site, operand) pairs clamped by a lagging scale, ever
         self.keys = []
         self.cursor = 0
 
@@ -110,7 +135,15 @@ class GradScales:
 
     def roll(self):
         if self.keys:
-            hip.call('vqcpc_grad_scale_roll', self.state, len(self.keys))
+            hip.call('vqcpc_grad_scale_roll_counted', self.state, len(self.keys), self.saturated)
+
+
+def scale_saturations(owner):
+    """Number of (call site, operand) pairs, over every step so far, whose tensor outgrew the fp16 range under its previous-step
+    scale (its largest elements were clamped for that one step) in the f16x3 scale tables that live on `owner` (a trainer's flat
+    parameters).  Reads the device: call it where the host waits anyway (the trainers: end of an epoch)."""
+    tabs = getattr(owner, '_grad_scales', None) or {}
+    return sum(int(t.saturated.item()) for t in tabs.values())
 
 
 def _grad_scales_of(owner, tag):
@@ -185,6 +218,18 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         add, lda_ = _rows(add)
     if add2 is not None:
         add2, lda2_ = _rows(add2)
+    if (_FWD_SCALES is not None and _GRAD_SCALES is None and not act and gate is None and add2 is None and hip.get_gemm_mode() == 1
+            and (not drop_p or (bias is not None and add is not None)) and (bias is not None or add is None)
+            and _grad_rows(M, N, K) == M and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        # forward product of a training step on three fp16 MFMAs (FWD_ARITH = 'f16x3'): bias / bias + residual / bias + dropout +
+        # residual epilogues, or none
+        st = _FWD_SCALES.site(('fnt', M, N, K), a, lda, M, K, b, ldb, N, K)
+        LAST_GEMM_F16X3 = True
+        if bias is None:
+            hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, ldc, M, N, K, None, 0, None, 0, None, 1.0, st)
+        else:
+            hip.call('vqcpc_gemm_nt_f16x3', a, lda, b, ldb, out, ldc, M, N, K, bias, 0, float(drop_p), int(seed), add, lda_, None, st)
+        return out
     if (_GRAD_SCALES is not None and bias is None and not act and not drop_p and gate is None and (add2 is None or add is not None)
             and hip.get_gemm_mode() == 1):
         # inside a trainer's backward pass: the input-gradient product on three fp16 MFMAs (whole rounds of 256-tiles)
@@ -276,6 +321,14 @@ def gemm_nt_relu_mask(a, b, bias, drop_p=0.0, seed=0):
     N = b.shape[0]
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     mask = torch.empty(M * (N // 32), dtype=torch.int32, device=a.device)
+    global LAST_GEMM_F16X3
+    LAST_GEMM_F16X3 = False
+    if (_FWD_SCALES is not None and _GRAD_SCALES is None and hip.get_gemm_mode() == 1 and _grad_rows(M, N, K) == M
+            and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        st = _FWD_SCALES.site(('fntm', M, N, K), a, lda, M, K, b, ldb, N, K)
+        LAST_GEMM_F16X3 = True
+        hip.call('vqcpc_gemm_nt_f16x3', a, lda, b, ldb, out, N, M, N, K, bias, 1, float(drop_p), int(seed), None, 0, mask, st)
+        return out, mask
     hip.call('vqcpc_gemm_nt_relu_mask', a, lda, b, ldb, out, N, M, N, K, bias, float(drop_p), int(seed), mask)
     return out, mask
 
@@ -549,6 +602,35 @@ def gemm_tn_bf16(a, b, want_bias=True, into=None):
 
 _DIRECT_WGRAD = False
 BATCHED_TRANSPOSES = os.environ.get('VQCPC_BATCHED_TRANSPOSES', '1') != '0'      # A/B switch
+
+
+class forward_arithmetic:
+    """Context manager used by the trainers around the FORWARD pass of a training step (compute_losses): with
+    `FWD_ARITH == 'f16x3'` (and the bf16x6 GEMM mode) the whole-round 256-tile products inside it run on the three-product fp16
+    kernel with their own scale table on `flat_parameters` (call order, as the gradient scope's), rolled when the scope closes.
+    Nothing else changes: outside the scope -- evaluation, encode_indices, inference -- every product stays on six MFMAs."""
+
+    def __init__(self, flat_parameters, tag=None):
+        self.flat = flat_parameters
+        self.tag = tag
+
+    def __enter__(self):
+        global _FWD_SCALES
+        self.prev = _FWD_SCALES
+        self.mine = None
+        if (self.prev is None and self.flat is not None and FWD_ARITH == 'f16x3' and hip.get_gemm_mode() == 1
+                and torch.is_grad_enabled()):
+            self.mine = _FWD_SCALES = _grad_scales_of(self.flat, ('fwd', self.tag))
+            self.mine.begin()
+        return self
+
+    def __exit__(self, *exc):
+        global _FWD_SCALES
+        if self.mine is not None:
+            _FWD_SCALES = self.prev
+            if exc[0] is None:
+                self.mine.roll()
+        return False
 
 
 class direct_weight_gradients:

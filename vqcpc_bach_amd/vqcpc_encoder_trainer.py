@@ -228,7 +228,7 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
 
     def _step_compute(self, tensor_dict, corrupt_labels=False):
         """zero_grad / forward / backward (:310-312) + the step's metric vector: everything before the gradient all-reduce."""
-        with torch.enable_grad():              # whatever the caller's ambient grad mode: this IS the training step
+        with torch.enable_grad(), ops.forward_arithmetic(self.flat):     # whatever the caller's ambient grad mode: this IS the training step
             loss, out = self.compute_losses(tensor_dict, corrupt_labels)
         self.flat.zero_grad()
         with ops.direct_weight_gradients(self.flat):
@@ -294,4 +294,17 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
         means = dict(loss=host[0], accuracy=host[5:], loss_quantize=host[1], loss_contrastive=host[2],
                      num_codewords=host[3], num_codewords_negative=host[4])
         means['loss_monitor'] = -sum(means['accuracy']) / len(means['accuracy'])
+        if train:
+            self._warn_on_scale_saturation()
         return means
+
+    def _warn_on_scale_saturation(self):
+        """f16x3 arithmetic: a tensor that grew by more than the 16-32 x head-room of its previous-step scale had its largest elements
+        clamped for one step (csrc/gemm_grad.hip).  That never happened in the runs of this repository; if it does, say so."""
+        n = ops.scale_saturations(self.flat)
+        if n > getattr(self, '_scale_saturations_seen', 0):
+            import warnings
+            warnings.warn(f'f16x3 GEMM arithmetic: {n - getattr(self, "_scale_saturations_seen", 0)} operand tensors outgrew the fp16 range '
+                          'under their previous-step scale during this epoch (clamped for one step each); '
+                          'ops.set_gradient_arithmetic("six") / ops.FWD_ARITH = "six" select the scale-free arithmetic')
+            self._scale_saturations_seen = n

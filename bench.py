@@ -951,6 +951,9 @@ def main():
                                 'host_enqueue_ms_per_step': round(1e3 * t_enqueued / n_host, 3),
                                 'note': 'same steps without epoch()\'s metric bookkeeping; not the metric'},
         }
+        if gemm_mode == 1 and 'f16x3' in (args.grad_arith, args.fwd_arith) and hasattr(trainer, 'flat'):
+            # operands that outgrew the head-room of their previous-step scale (clamped for one step), over the whole run
+            line['f16x3_scale_saturations'] = ops.scale_saturations(trainer.flat)
         if extra_fwd_six is not None:
             line['extra_six_product_forward'] = extra_fwd_six
         if extra_six is not None:

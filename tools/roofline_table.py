@@ -6,8 +6,10 @@ import csv, sys
 
 ROWS_LN = 2 * (557056 + 139264 + 139264 + 34816)           # LayerNorm rows per step (8 instances), d = 256
 FAMILIES = [   # (label, match substrings, algorithmic work per step, unit, peak, note)
-    ('NT GEMMs (`gemm_nt_x6_pp` incl. mask-out / gate-bits / residual-sum epilogues, 128-tile + split-K planes, skinny / narrow)', ('gemm_nt', 'splitk'), 2.59e12, 'TFLOP/s', 416.7e12, 'forward + input gradients after dead-row elimination and the first-layer table'),
-    ('TN GEMMs (`gemm_tn_x6_pq`: ping-pong wave groups, quad-row LDS image; `gemm_tn_x6_grouped`: the small products of the step in grouped launches)', ('gemm_tn',), 1.30e12, 'TFLOP/s', 416.7e12, 'weight / bias gradients'),
+    ('NT GEMMs on three fp16 MFMAs per product (`gemm_nt_g3_kernel`, round 5: the whole-round 256-tile launches of the step, forward and input gradients)', ('gemm_nt_g3',), 1.99e12, 'TFLOP/s', 833.3e12, 'peak = 2500 / 3'),
+    ('NT GEMMs on six bf16 MFMAs per product (`gemm_nt_x6_pp` ragged / under-filled launches, 128-tile + split-K planes, skinny / narrow)', ('gemm_nt', 'splitk'), 0.60e12, 'TFLOP/s', 416.7e12, 'peak = 2500 / 6; the 2.125-round N = 256 launches of the 139 264-row stack and everything below 256 tiles'),
+    ('TN GEMMs on three fp16 MFMAs per product (`gemm_tn_g3_kernel`)', ('gemm_tn_g3',), 1.28e12, 'TFLOP/s', 833.3e12, 'weight / bias gradients of the 256-tile shapes'),
+    ('TN GEMMs on six products (`gemm_tn_x6*`: the small products of the step, grouped launches)', ('gemm_tn',), 0.02e12, 'TFLOP/s', 416.7e12, ''),
     ('`add_ln_bwd` (reads dy, s; writes d_s, d_r; mask regenerated)', ('add_ln_bwd',), 4.0 * ROWS_LN * 1024, 'TB/s', 8e12, '4 streams of rows x 1 KB'),
     ('`add_ln_fwd` (reads the residual sum s, writes y)', ('add_ln_fwd',), 2.0 * ROWS_LN * 1024, 'TB/s', 8e12, '2 streams'),
     ('`relattn16_bwd`', ('relattn16_bwd',), 2.57e9, 'TB/s', 8e12, ''),
@@ -51,12 +53,13 @@ def main(path):
     rest_ms = sum(float(r[2]) for i, r in enumerate(rows) if i not in used and not r[0].startswith(('TOTAL', 'trace')))
     out.append(('everything else (upscaler activation, Adam / clip, transposes, dropout masks, codeword counts, token check, ...)', rest_n / steps, rest_ms / steps, 'latency', '-', ''))
     tot_n = sum(o[1] for o in out); tot_ms = sum(o[2] for o in out)
-    print(f'# Per-kernel time per step at C1 (1 x MI355X, B = 256, bf16x6 GEMMs, graph replay) -- from `{path}` ({steps} steps)\n')
+    print(f'# Per-kernel time per step at C1 (1 x MI355X, B = 256, training defaults: bf16x6 mode with the f16x3 kernels for the whole-round products, graph replay) -- from `{path}` ({steps} steps)\n')
     print('| kernel family | launches / step | ms / step | achieved | of peak | note |')
     print('|---|---|---|---|---|---|')
     for label, n, per, ach, frac, note in out:
         print(f'| {label} | {n:.0f} | {per:.3f} | {ach} | {frac} | {note} |')
-    print(f'\nTotal: {tot_n:.0f} launches and {tot_ms:.2f} ms of kernel time per step (GEMMs {out[0][2] + out[1][2]:.2f} ms = {100 * (out[0][2] + out[1][2]) / tot_ms:.0f} %).')
+    gemm_ms = sum(o[2] for o in out if 'GEMMs' in o[0])
+    print(f'\nTotal: {tot_n:.0f} launches and {tot_ms:.2f} ms of kernel time per step (GEMMs {gemm_ms:.2f} ms = {100 * gemm_ms / tot_ms:.0f} %).')
 
 
 if __name__ == '__main__':

@@ -13,6 +13,7 @@ from vqcpc_bach_amd import configs, getters, hip, ops  # noqa: E402
 
 def main():
     name = sys.argv[1] if len(sys.argv) > 1 else 'C1'
+    torch.manual_seed(int(sys.argv[2]) if len(sys.argv) > 2 else 0)          # parameters; the batch is seeded by the generator
     config = configs.make_config(name, dropout=0.0)
     dlg = getters.get_dataloader_generator('bach', 'vqcpc', dict(config['dataloader_generator_kwargs'], device='cuda', seed=7))
     enc = getters.get_encoder('/tmp/vqcpc_fwd_flips', dlg, config)

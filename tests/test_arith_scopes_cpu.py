@@ -1,0 +1,110 @@
+"""Host logic of the f16x3 arithmetic scopes (vqcpc_bach_amd/ops.py: GradScales, forward_arithmetic, the dispatch inside gemm_nt /
+gemm_nt_relu_mask, the training defaults) with the kernel library replaced by a recorder: which entry point a product takes, in
+which order the scale sites are used, when they are primed and rolled.  No GPU, no library."""
+import pytest
+import torch
+
+
+def Z(*shape):
+    return torch.empty(*shape, device='meta')            # shapes and strides only: nothing is computed in these tests
+
+
+class _Owner:
+    def __init__(self):
+        self.flat = torch.zeros(4)
+
+
+@pytest.fixture
+def rec(monkeypatch):
+    from vqcpc_bach_amd import hip, ops
+    calls = []
+    monkeypatch.setattr(hip, 'call', lambda name, *args: calls.append((name, args)) or 0)
+    monkeypatch.setattr(hip, 'query', lambda name, *args: 1)
+    monkeypatch.setattr(hip, 'get_gemm_mode', lambda: 1)
+    monkeypatch.setattr(hip, 'gradient_scope', lambda on: None, raising=False)
+    monkeypatch.setattr(hip, 'set_gradient_products', lambda n: None, raising=False)
+    monkeypatch.setattr(ops, '_grad_cut', {})
+    monkeypatch.setattr(ops, '_f32', lambda t: t)        # the device check of the product path: operands here are `meta` tensors
+    state = ops.gradient_arithmetic_state()
+    yield calls
+    ops.restore_gradient_arithmetic_state(state)
+
+
+def _names(calls):
+    return [c[0] for c in calls]
+
+
+def test_forward_scope_routes_whole_round_products_to_the_three_product_kernel(rec):
+    from vqcpc_bach_amd import ops
+    ops.set_forward_arithmetic('f16x3')
+    owner = _Owner()
+    M, N, K = 256 * 256, 256, 1024                       # 256 tiles: one whole round
+    a, w, bias, res = Z(M, K), Z(N, K), Z(N), Z(M, N)
+    ragged = Z(256 * 544, K)                   # 544 tiles = 2.125 rounds: the last round is 12.5 % full -> six products
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        ops.gemm_nt(a, w, bias=bias)
+        ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=3, add=res)
+        ops.gemm_nt(a, w)                                # no epilogue: the gradient entry point serves it
+        ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=3) # dropout without a residual is not a forward form of the kernel
+        ops.gemm_nt(ragged, w, bias=bias)
+        ops.gemm_nt_relu_mask(a, Z(1024, K), Z(1024), drop_p=0.1, seed=5)
+    names = _names(rec)
+    assert names.count('vqcpc_grad_amax') == 8           # four sites, two operands each, primed on first use
+    kernels = [n for n in names if n.startswith('vqcpc_gemm')]
+    assert kernels[:4] == ['vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt'], kernels
+    assert kernels[-1] == 'vqcpc_gemm_nt_f16x3' and kernels.count('vqcpc_gemm_nt_f16x3') == 3      # the ragged launch took neither
+    assert all(k in ('vqcpc_gemm_nt', 'vqcpc_gemm_nt_splitk') for k in kernels[4:-1]), kernels     # (its row cut is the six-product path's)
+    assert names[-1] == 'vqcpc_grad_scale_roll_counted'  # rolled when the scope closes
+    tab = owner._grad_scales[('fwd', None)]
+    assert tab.keys == [('fnt', M, N, K), ('fnt', M, N, K), ('fnt', M, N, K), ('fntm', M, 1024, K)]
+    # the same step again: same sites in the same order, nothing primed
+    del rec[:]
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        ops.gemm_nt(a, w, bias=bias)
+        st_first = rec[-1][1][-1]
+    assert 'vqcpc_grad_amax' not in _names(rec)
+    assert st_first.data_ptr() == tab.state.data_ptr() and st_first.numel() == 4
+    # another product at a site: primed again, the stale state cleared
+    del rec[:]
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        ops.gemm_nt(Z(M, 512), Z(N, 512), bias=bias)
+    assert _names(rec).count('vqcpc_grad_amax') == 2 and tab.keys[0] == ('fnt', M, N, 512)
+
+
+def test_forward_scope_is_inert_outside_training_and_by_default(rec):
+    from vqcpc_bach_amd import ops
+    owner = _Owner()
+    a, w, bias = Z(256 * 256, 256), Z(256, 256), Z(256)
+    assert ops.FWD_ARITH == 'six'                        # bare library default
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        ops.gemm_nt(a, w, bias=bias)
+    ops.set_forward_arithmetic('f16x3')
+    with torch.no_grad(), ops.forward_arithmetic(owner):        # evaluation / inference: never
+        ops.gemm_nt(a, w, bias=bias)
+    ops.gemm_nt(a, w, bias=bias)                         # outside any scope
+    assert _names(rec) == ['vqcpc_gemm_nt'] * 3
+    with pytest.raises(RuntimeError):                    # an exception inside the scope: closed, not rolled
+        with torch.enable_grad(), ops.forward_arithmetic(owner):
+            ops.gemm_nt(a, w, bias=bias)
+            raise RuntimeError('step failed')
+    assert ops._FWD_SCALES is None and 'vqcpc_grad_scale_roll_counted' not in _names(rec)
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        with ops.forward_arithmetic(owner):              # nested: the outer scope owns the table
+            ops.gemm_nt(a, w, bias=bias)
+        assert ops._FWD_SCALES is not None
+    assert _names(rec).count('vqcpc_grad_scale_roll_counted') == 1
+
+
+def test_training_defaults_select_both_arithmetics_unless_the_caller_chose(rec):
+    from vqcpc_bach_amd import ops
+    ops.restore_gradient_arithmetic_state(('six', False, 'six', False))
+    ops.use_training_default_gradient_arithmetic()
+    assert (ops.GRAD_ARITH, ops.FWD_ARITH) == (ops.TRAINING_GRAD_ARITH, ops.TRAINING_FWD_ARITH) == ('f16x3', 'f16x3')
+    ops.restore_gradient_arithmetic_state(('six', False, 'six', False))
+    ops.set_forward_arithmetic('six')                    # an explicit choice wins over train_model()'s default
+    ops.use_training_default_gradient_arithmetic()
+    assert (ops.GRAD_ARITH, ops.FWD_ARITH) == ('f16x3', 'six')
+    ops.restore_gradient_arithmetic_state(('six', False, 'six', False))
+    ops.set_gradient_arithmetic('six')
+    ops.use_training_default_gradient_arithmetic()
+    assert (ops.GRAD_ARITH, ops.FWD_ARITH) == ('six', 'f16x3')

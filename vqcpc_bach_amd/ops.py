@@ -41,7 +41,7 @@ GRAD_ARITH = os.environ.get('VQCPC_GRAD_ARITH', 'six')
 TRAINING_GRAD_ARITH = 'f16x3'  # what train_model() / bench.py select in the bf16x6 mode (GraphedTraining.use_training_defaults)
 _grad_arith_explicit = 'VQCPC_GRAD_ARITH' in os.environ
 GRAD_ROUND_FILL = float(os.environ.get('VQCPC_GRAD_ROUND_FILL', '0.8'))    # least fill of the last round of 256-tiles (A/B switch)
-GRAD_MIN_TILES = 256           # dgrad: fewer 256 x 256 tiles than CUs -> the six-product path (its 128-tile kernels fill the chip)
+GRAD_MIN_TILES = int(os.environ.get('VQCPC_GRAD_MIN_TILES', '256'))           # dgrad: fewer 256 x 256 tiles than CUs -> the six-product path (its 128-tile kernels fill the chip)
 GRAD_TN_MIN_ROWS = 8192        # wgrad: as the 256-tile six-product kernel (tests set both to 0 to reach the kernels with small shapes)
 LAST_GEMM_F16X3 = False       # set by gemm_nt / gemm_nt_gatebits / gemm_tn: did the last call go through the f16x3 kernels (bench.py reads it)
 _GRAD_SCALES = None            # the open gradient scope's GradScales (None: outside a trainer's backward, or another arithmetic)

@@ -322,8 +322,18 @@ def test_c4_bf16_mode_vs_bf16_cast_oracle(gemm_mode):
     # feed-forward block alike): the oracle's cast point moves with it (rounding = identity for the gradient)
     ln_calls = [0]
 
+    class _Bf16Grad(torch.autograd.Function):                        # ... and the gradient that comes back through a LayerNorm's input
+        @staticmethod                                                # (residual branch: LayerNorm backward -> dgrad epilogue in bf16)
+        def forward(ctx, x):
+            return x.view_as(x)
+
+        @staticmethod
+        def backward(ctx, g):
+            return g.bfloat16().float()
+
     def ln_bf16_after_norm1(x, w, b):
         ln_calls[0] += 1
+        x = _Bf16Grad.apply(x)
         x = x + (x.bfloat16().float() - x).detach()              # ... and so do the residual sums the LayerNorms read (bf16 out of
         y = real_ln(x, w, b)                                     # the out-proj / FFN2 epilogues)
         return y + (y.bfloat16().float() - y).detach() if ln_calls[0] % 2 == 1 else y

@@ -441,13 +441,22 @@ def test_residual_sum_in_bf16_and_layernorm_on_it(ops, M, N, K):
         dg, db = torch.empty(N, device='cuda'), torch.empty(N, device='cuda')
         ws = torch.empty(nbytes // 4, device='cuda')
         if xb16:
-            hip.call('vqcpc_layernorm_bwd_xb16', dy, sb, N, g, mean, rstd, ds, None, drb, dg, db, M, N, p, 5, ws, nbytes)
+            hip.call('vqcpc_layernorm_bwd_xb16', dy, sb, N, g, mean, rstd, ds, None, None, drb, dg, db, M, N, p, 5, ws, nbytes)
         else:
             hip.call('vqcpc_add_layernorm_bwd_b16', dy, sf, N, None, g, mean, rstd, ds, None, drb, dg, db, M, N, p, 5, ws, nbytes)
         return ds, drb, dg, db
 
     for p in (0.0, 0.1):
-        assert all(torch.equal(x, y) for x, y in zip(bwd(False, p), bwd(True, p))), p
+        ref_b = bwd(False, p)
+        assert all(torch.equal(x, y) for x, y in zip(ref_b, bwd(True, p))), p
+        # the gradient of the residual branch in bf16 only (d_s == NULL): the rounding of the fp32 one, everything else unchanged
+        dsb, drb = (torch.empty(M, N, device='cuda', dtype=torch.bfloat16) for _ in range(2))
+        dg, db = torch.empty(N, device='cuda'), torch.empty(N, device='cuda')
+        ws = torch.empty(nbytes // 4, device='cuda')
+        hip.call('vqcpc_layernorm_bwd_xb16', dy, sb, N, g, mean, rstd, None, dsb, None, drb, dg, db, M, N, p, 5, ws, nbytes)
+        assert torch.equal(dsb, ref_b[0].bfloat16()) and torch.equal(drb, ref_b[1]) and torch.equal(dg, ref_b[2]), p
+    a2 = ops.cast_bf16(dev(torch.randn(M, K, generator=gen)))                 # ... and its consumer: dgrad + bf16 residual
+    assert torch.equal(ops.gemm_nt_bf16(a2, b, add_b=dsb), ops.gemm_nt_bf16(a2, b, add=dsb.float()))
     with pytest.raises(hip.VqcpcHipError):           # an unaligned bf16 stream is refused, not read
         hip.call('vqcpc_layernorm_fwd_xb16', sb.view(-1)[1:1 + (M - 1) * N].view(M - 1, N), N, g, be, None, yb_only, m2, r2, M - 1, N,
                  1e-5)

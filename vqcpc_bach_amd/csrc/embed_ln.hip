@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ rstd, float* __restrict__ d_s,
                                                          float* __restrict__ d_r, float* __restrict__ ws, int64_t M, int d,
                                                          uint32_t thr, float inv_keep, uint64_t seed,
-                                                         unsigned short* __restrict__ dr_b16) {
+                                                         unsigned short* __restrict__ dr_b16,
+                                                         unsigned short* __restrict__ ds_b16) {
     constexpr int kRedW = NIT * 256;                    // columns a wave's partials span
     __shared__ float red[4 * 2 * kRedW];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -308,7 +309,10 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                 o.y = rs * (gy[it].y - m1 - xh[it].y * m2);
                 o.z = rs * (gy[it].z - m1 - xh[it].z * m2);
                 o.w = rs * (gy[it].w - m1 - xh[it].w * m2);
-                nt_store4(d_s + row * d + col, o);
+                if (d_s) nt_store4(d_s + row * d + col, o);
+                // bf16 path (round 5): the gradient of the residual branch may leave in bf16 only -- its one consumer is the
+                // residual operand of the next input-gradient GEMM's epilogue (vqcpc_gemm_nt_bf16, add_bf16)
+                if (ds_b16) *reinterpret_cast<uint2*>(ds_b16 + row * d + col) = round4_bf16(o);
                 if (MASKED && (d_r != nullptr || dr_b16 != nullptr)) {
                     o.x *= msk[it].x;
                     o.y *= msk[it].y;
@@ -664,14 +668,15 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
 static int ln_bwd_launch(const float* dy, const void* xv, bool xb16, int64_t ldx, const float* r, const float* gamma,
                          const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
                          float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
-                         int64_t workspace_bytes, void* stream) {
+                         int64_t workspace_bytes, void* stream, void* d_s_bf16 = nullptr) {
     // d_gamma == d_beta == NULL: the column partials stay in `workspace` ([vqcpc_add_layernorm_bwd_partials(M, d, r != NULL)][2 d]: d gamma | d beta)
     // for the caller to reduce later (vqcpc_reduce_grouped: the trainers sum the partials of every LayerNorm of a backward pass
     // in one launch)
     const float* x = (const float*)xv;              // XB16 kernels reinterpret it
-    VQ_REQUIRE(dy && x && gamma && mean && rstd && d_s && workspace && ((d_gamma != nullptr) == (d_beta != nullptr)),
+    VQ_REQUIRE(dy && x && gamma && mean && rstd && (d_s || d_s_bf16) && workspace && ((d_gamma != nullptr) == (d_beta != nullptr)),
                "add_layernorm_bwd: null pointer");
     VQ_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_bwd: bad shape");
+    VQ_REQUIRE(!d_s_bf16 || (reinterpret_cast<uintptr_t>(d_s_bf16) & 7u) == 0, "layernorm_bwd: bf16 d_s must be 8-byte aligned");
     VQ_REQUIRE(!xb16 || (!r && (reinterpret_cast<uintptr_t>(xv) & 7u) == 0), "layernorm_bwd_xb16: one bf16 input stream, 8-byte aligned");
     if (workspace_bytes < vqcpc_add_layernorm_bwd_workspace(M, d)) {
         set_error("add_layernorm_bwd: workspace too small");
@@ -683,7 +688,7 @@ static int ln_bwd_launch(const float* dy, const void* xv, bool xb16, int64_t ldx
     const int blocks = ln_bwd_blocks(M, r != nullptr, d);
 #define LN_BWD(HR, MK, NITV, XB)                                                                                          \
     hipLaunchKernelGGL((add_ln_bwd_kernel<HR, MK, NITV, XB>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, \
-                       d_s, d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16)
+                       d_s, d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16, (unsigned short*)d_s_bf16)
 #define LN_BWD_D(HR, MK, XB)                     \
     if (d <= 256) LN_BWD(HR, MK, 1, XB);         \
     else if (d <= 512) LN_BWD(HR, MK, 2, XB);    \
@@ -715,10 +720,11 @@ int vqcpc_add_layernorm_bwd_b16(const float* dy, const float* x, int64_t ldx, co
 }
 
 int vqcpc_layernorm_bwd_xb16(const float* dy, const void* x_bf16, int64_t ldx, const float* gamma, const float* mean,
-                             const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma, float* d_beta, int64_t M,
-                             int d, float drop_p, uint64_t seed, void* workspace, int64_t workspace_bytes, void* stream) {
+                             const float* rstd, float* d_s, void* d_s_bf16, float* d_r, void* d_r_bf16, float* d_gamma,
+                             float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
     return ln_bwd_launch(dy, x_bf16, true, ldx, nullptr, gamma, mean, rstd, d_s, d_r, d_r_bf16, d_gamma, d_beta, M, d, drop_p, seed,
-                         workspace, workspace_bytes, stream);
+                         workspace, workspace_bytes, stream, d_s_bf16);
 }
 
 int vqcpc_add_layernorm_bwd_partials(int64_t M, int d, int has_r) { return ln_bwd_blocks(std::max<int64_t>(M, 1), has_r != 0, d); }

@@ -988,6 +988,11 @@ def _residual_sum_in_epilogue(M, N, K, nat):
     return (M // 256) * (N // 256) >= SFORM_MIN_TILES and M % 256 == 0 and N % 256 == 0 or SFORM_MIN_TILES == 0
 
 
+def _dgrad_plus_residual_bf16(g, wt, res):
+    """g @ wt^T + res on the bf16 path; `res` fp32 or -- the gradient of a residual branch kept in bf16 -- bf16."""
+    return gemm_nt_bf16(g, wt, add_b=res) if res.dtype == torch.bfloat16 else gemm_nt_bf16(g, wt, add=res)
+
+
 class EncoderLayerFn(torch.autograd.Function):
     """y = LN2(x1 + drop(W2 drop(relu(W1 x1 + b1)) + b2)),  x1 = LN1(x + drop(Wo attn(x) + bo)).
     Parameter order: in_proj_weight, in_proj_bias, out_proj.weight, out_proj.bias, e1, e2, linear1.weight,
@@ -1156,9 +1161,12 @@ class EncoderLayerFn(torch.autograd.Function):
 
         nat = ctx.bf16 is not None
 
-        def ln_bwd(dyv, xin, ldxin, r, gamma, beta, mean, rstd, seed):
+        def ln_bwd(dyv, xin, ldxin, r, gamma, beta, mean, rstd, seed, ds_bf16=False):
             # r None: xin is the residual sum itself (s-form, include/vqcpc.h); the mask of d_r is regenerated from `seed`
-            ds = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+            # ds_bf16 (bf16 path, xin in bf16): the gradient of the residual branch leaves in bf16 only (returned in place of ds)
+            ds_bf16 = ds_bf16 and xin.dtype == torch.bfloat16
+            ds = None if ds_bf16 else torch.empty(Mq, d, dtype=torch.float32, device=dev)
+            dsb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if ds_bf16 else None
             # bf16 path: the gradient of the sub-layer output only feeds GEMMs, which read its bf16 copy -> no fp32 d_r stream
             dr = torch.empty(Mq, d, dtype=torch.float32, device=dev) if (p > 0 and not nat) else None
             drb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None    # GEMM-operand copy of dr
@@ -1171,16 +1179,19 @@ class EncoderLayerFn(torch.autograd.Function):
                 db = torch.empty(d, dtype=torch.float32, device=dev)
             if xin.dtype == torch.bfloat16:              # the residual sum was written in bf16 (s-form only)
                 assert r is None
-                hip.call('vqcpc_layernorm_bwd_xb16', dyv, xin, ldxin, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed, ws,
+                hip.call('vqcpc_layernorm_bwd_xb16', dyv, xin, ldxin, gamma, mean, rstd, ds, dsb, dr, drb, dg, db, Mq, d, p, seed, ws,
                          nbytes)
+                if ds_bf16:
+                    ds = dsb
             else:
                 hip.call('vqcpc_add_layernorm_bwd_b16', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed,
                          ws, nbytes)
             return ds, (dr if dr is not None else (None if (nat and p > 0) else ds)), dg, db, drb
 
         sform1, sform2 = ctx.sform
+        g16 = nat and BF16_GRAD_SUMS            # bf16 path: d s2 / d s1 only feed the residual operand of a dgrad epilogue -> bf16
         if sform2:
-            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, be2, mean2, rstd2, s[3])
+            ds2, df, dg2, dbe2, dfb = ln_bwd(dy, s2, d, None, g2, be2, mean2, rstd2, s[3], ds_bf16=g16)
         else:
             ds2, df, dg2, dbe2, dfb = ln_bwd(dy, x1, d, s2, g2, be2, mean2, rstd2, s[3])
         lin = gemm_nt_bf16 if nat else gemm_nt
@@ -1190,7 +1201,8 @@ class EncoderLayerFn(torch.autograd.Function):
             da = gemm_nt_bf16(dfb, transpose(w2), gate_b=h2b, gate_scale=1.0 / (1.0 - p), out_f32=False, out_bf16=True)
             dw2, db2 = wgrad(dfb, h2b, w2, b2)
             dw1, db1 = wgrad(da, x1b, w1, b1)
-            dx1 = gemm_nt_bf16(da, transpose(w1), add=ds2)
+            dx1 = (gemm_nt_bf16(da, transpose(w1), add_b=ds2) if ds2.dtype == torch.bfloat16 else
+                   gemm_nt_bf16(da, transpose(w1), add=ds2))
         else:
             # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
             if ctx.gate_mask is not None:
@@ -1201,8 +1213,11 @@ class EncoderLayerFn(torch.autograd.Function):
             dw1, db1 = wgrad(da, x1, w1, b1)
             dx1 = gemm_nt_residual(da, transpose(w1), ds2, res_may_alias=df)     # ds2 is dead afterwards
         del da, df, ds2
+        # d s1 is bf16 only where the dgrad of the in_proj consumes it here (the all-bf16 attention paths below)
+        g16_1 = (g16 and f == 1 and not ext_qkv and ctx.qkv_tokens is None and ATT_B16_OUT and ctx.needs_input_grad[0]
+                 and bool(hip.query('vqcpc_relattn16_b16_supported', L, H, hd) or hip.query('vqcpc_relattn_b16_supported', L, H, hd)))
         if sform1:
-            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, be1, mean1, rstd1, s[1])
+            ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, s1, d, None, g1, be1, mean1, rstd1, s[1], ds_bf16=g16_1)
         else:
             ds1, dA, dg1, dbe1, dAb = ln_bwd(dx1, xs, ldxs, s1, g1, be1, mean1, rstd1, s[1])
         b16_io = nat and f == 1 and qkv.dtype == torch.bfloat16       # the all-bf16 attention backward reads d ctx as bf16
@@ -1230,7 +1245,7 @@ class EncoderLayerFn(torch.autograd.Function):
                     hip.call('vqcpc_relattn16_bwd_b16', datt, d, qkv, 3 * d, None, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk,
                              H, hd, p, s[0], ws, nbytes)
                 dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
-                dx = gemm_nt_bf16(dqkvb, transpose(wqkv), add=ds1) if need_dx else None
+                dx = _dgrad_plus_residual_bf16(dqkvb, transpose(wqkv), ds1) if need_dx else None
                 de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
                 return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
                         dbe1, dg2, dbe2)
@@ -1239,7 +1254,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 hip.call('vqcpc_relattn_bwd_b16', datt, d, qkv, 3 * d, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk, L, H, hd, p,
                          s[0], ws, nbytes)
                 dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
-                dx = gemm_nt_bf16(dqkvb, transpose(wqkv), add=ds1) if need_dx else None
+                dx = _dgrad_plus_residual_bf16(dqkvb, transpose(wqkv), ds1) if need_dx else None
                 de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
                 return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
                         dbe1, dg2, dbe2)
@@ -1562,6 +1577,7 @@ class DropoutSeluFn(torch.autograd.Function):
 # ------------------------------------------------------------------------------------------------------------------
 ATT_B16_IN = os.environ.get('VQCPC_ATT_B16_IN', '1') != '0'          # A/B switch: bf16 q | k | v and d ctx INTO the L = 16 attention kernels
 BF16_RESIDUAL = os.environ.get('VQCPC_BF16_RESIDUAL', '1') != '0'      # A/B switch: LN1's output in bf16 only on the bf16 path
+BF16_GRAD_SUMS = os.environ.get('VQCPC_BF16_GRAD_SUMS', '1') != '0'    # A/B switch: ... and the gradients of the residual branches (LayerNorm backward -> dgrad epilogue)
 BF16_SUMS = os.environ.get('VQCPC_BF16_SUMS', '1') != '0'              # A/B switch: ... and the residual sums s1 / s2 (LayerNorm inputs)
 ATT_B16_OUT = os.environ.get('VQCPC_ATT_B16_OUT', '1') != '0'        # A/B switch: bf16 outputs straight from the L = 16 attention
 GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)

@@ -153,7 +153,8 @@ int vqcpc_gemm_gradient_scope(int open);
  * multihead_attention_custom.py:171,346) for the 256 x 256-tile shapes.  Each operand element x of a tensor with the
  * power-of-two scale s is carried as h = rtz_f16(x s) (saturating) and m = rn_f16(x s - h): |x s - h - m| <= 2^-21 |x s|, a
  * product is hh + hm + mh on v_mfma_f32_32x32x16_f16 with fp32 accumulation, the result is multiplied by 2^-(eA + eB).
- * Explicit entry points, no process-wide switch: the caller chooses them for its backward pass; the forward pass never does.
+ * Explicit entry points, no process-wide switch: the caller chooses them for its backward pass (and, with vqcpc_gemm_nt_f16x3 below,
+ * for the forward products of a training step; evaluation / inference callers use vqcpc_gemm_nt).
  * `scale_state`: 4 floats per CALL SITE, caller-owned device memory: [0] / [1] = amax |A| / |B| of the PREVIOUS step (read:
  * the scale maps it into [2^12, 2^13)), [2] / [3] = amax of THIS call's operands (atomic max by the kernel; zero them before).
  * vqcpc_grad_scale_roll(state, nsites) moves [2], [3] -> [0], [1] (sites that ran) and zeroes [2], [3] for `nsites`

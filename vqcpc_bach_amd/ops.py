@@ -67,7 +67,7 @@ def set_forward_arithmetic(name):
 
 def set_gradient_arithmetic(name):
     """Selects the arithmetic of the gradient GEMMs launched inside a trainer's backward pass (see above); returns the previous
-    name.  Forward GEMMs -- losses, code assignment -- are never affected."""
+    name.  Forward GEMMs are chosen separately (set_forward_arithmetic)."""
     global GRAD_ARITH, _grad_arith_explicit
     assert name in ('six', 'f16x3', 'bf16x3'), name
     prev, GRAD_ARITH = GRAD_ARITH, name
@@ -89,7 +89,7 @@ def restore_gradient_arithmetic_state(state):
 def use_training_default_gradient_arithmetic():
     """What `train_model()` selects when the caller chose nothing (neither set_gradient_arithmetic() nor VQCPC_GRAD_ARITH): the
     f16x3 gradient GEMMs -- fp32-class (rms 3-5e-7 vs fp64, tools/bench_grad_f16.py; every parity suite passes in it at unchanged
-    tolerances), forward untouched -- i.e. the configuration bench.py measures.  The bare library default stays 'six'."""
+    tolerances) -- i.e. the configuration bench.py measures.  The bare library default stays 'six'."""
     global GRAD_ARITH, FWD_ARITH
     if not _grad_arith_explicit:
         GRAD_ARITH = TRAINING_GRAD_ARITH

@@ -169,6 +169,16 @@ int vqcpc_gemm_nt_grad_supported(int64_t M, int N, int K);
 int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                        const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, const void* gate_mask,
                        float gate_scale, float* scale_state, void* stream);
+/* vqcpc_gemm_nt_grad_splitk: the same product for FEW output tiles and a long K -- the remainder rows of a launch whose 256-tiles
+ * do not fill whole rounds of the persistent kernel (139 264 x 256: two rounds + 32 tiles).  `splits` K slices run as one launch
+ * (grid = tiles x splits, partial products into `workspace` planes), one pass sums the planes in ascending order and applies the
+ * epilogue: + bias, dropout (row0 = global row of the first row of this call, for the element index (row0 + m) * N + c), + add,
+ * + add2 (add may be C: in place).  M, N multiples of 256, K / splits a multiple of 32; deterministic. */
+int64_t vqcpc_gemm_nt_grad_splitk_workspace(int64_t M, int N, int splits);
+int vqcpc_gemm_nt_grad_splitk(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                              int splits, const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add,
+                              int64_t ldadd, const float* add2, int64_t ldadd2, void* workspace, int64_t workspace_bytes,
+                              float* scale_state, void* stream);
 int vqcpc_gemm_tn_grad_supported(int64_t M, int N, int K);
 int64_t vqcpc_gemm_tn_grad_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,

@@ -24,6 +24,9 @@ def rec(monkeypatch):
     monkeypatch.setattr(hip, 'gradient_scope', lambda on: None, raising=False)
     monkeypatch.setattr(hip, 'set_gradient_products', lambda n: None, raising=False)
     monkeypatch.setattr(ops, '_grad_cut', {})
+    monkeypatch.setattr(ops, '_g3_plans', {})
+    monkeypatch.setattr(ops, 'GRAD_SPLITK', True)       # the opt-in split-K remainder of ragged launches is part of what is tested
+    monkeypatch.setattr(hip, 'workspace', lambda n, dev: torch.empty(16, dtype=torch.uint8), raising=False)
     monkeypatch.setattr(ops, '_f32', lambda t: t)        # the device check of the product path: operands here are `meta` tensors
     state = ops.gradient_arithmetic_state()
     yield calls
@@ -40,23 +43,28 @@ def test_forward_scope_routes_whole_round_products_to_the_three_product_kernel(r
     owner = _Owner()
     M, N, K = 256 * 256, 256, 1024                       # 256 tiles: one whole round
     a, w, bias, res = Z(M, K), Z(N, K), Z(N), Z(M, N)
-    ragged = Z(256 * 544, K)                   # 544 tiles = 2.125 rounds: the last round is 12.5 % full -> six products
+    ragged = Z(256 * 544, K)                             # 544 tiles = 2.125 rounds: two whole rounds + a split-K remainder (32 tiles x 8)
     with torch.enable_grad(), ops.forward_arithmetic(owner):
         ops.gemm_nt(a, w, bias=bias)
         ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=3, add=res)
         ops.gemm_nt(a, w)                                # no epilogue: the gradient entry point serves it
         ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=3) # dropout without a residual is not a forward form of the kernel
         ops.gemm_nt(ragged, w, bias=bias)
+        ops.gemm_nt(Z(256 * 544, 256), Z(N, 256), bias=bias)     # ragged with a short K: no slices to cut -> six products
         ops.gemm_nt_relu_mask(a, Z(1024, K), Z(1024), drop_p=0.1, seed=5)
     names = _names(rec)
-    assert names.count('vqcpc_grad_amax') == 8           # four sites, two operands each, primed on first use
-    kernels = [n for n in names if n.startswith('vqcpc_gemm')]
+    assert names.count('vqcpc_grad_amax') == 10          # five sites, two operands each, primed on first use
+    kernels = [n for n in names if n.startswith('vqcpc_gemm') and not n.endswith('_workspace')]
     assert kernels[:4] == ['vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt'], kernels
-    assert kernels[-1] == 'vqcpc_gemm_nt_f16x3' and kernels.count('vqcpc_gemm_nt_f16x3') == 3      # the ragged launch took neither
-    assert all(k in ('vqcpc_gemm_nt', 'vqcpc_gemm_nt_splitk') for k in kernels[4:-1]), kernels     # (its row cut is the six-product path's)
+    assert kernels[4:6] == ['vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad_splitk'], kernels
+    main = [c for c in rec if c[0] == 'vqcpc_gemm_nt_f16x3'][2][1]
+    rem = [c for c in rec if c[0] == 'vqcpc_gemm_nt_grad_splitk'][0][1]
+    assert main[6] == 512 * 256 and rem[6] == 32 * 256 and rem[9] == 8 and rem[13] == 512 * 256      # rows, rows, slices, row0
+    assert kernels[-1] == 'vqcpc_gemm_nt_f16x3' and kernels.count('vqcpc_gemm_nt_f16x3') == 4
+    assert all(k in ('vqcpc_gemm_nt', 'vqcpc_gemm_nt_splitk') for k in kernels[6:-1]), kernels     # the short-K ragged launch: six products
     assert names[-1] == 'vqcpc_grad_scale_roll_counted'  # rolled when the scope closes
     tab = owner._grad_scales[('fwd', None)]
-    assert tab.keys == [('fnt', M, N, K), ('fnt', M, N, K), ('fnt', M, N, K), ('fntm', M, 1024, K)]
+    assert tab.keys == [('fnt', M, N, K), ('fnt', M, N, K), ('fnt', M, N, K), ('fnt', 256 * 544, N, K), ('fntm', M, 1024, K)]
     # the same step again: same sites in the same order, nothing primed
     del rec[:]
     with torch.enable_grad(), ops.forward_arithmetic(owner):

@@ -1998,6 +1998,93 @@ def test_f16x3_forward_epilogues(ops, bf16x6, M, N, K):
         assert float(diff.float().mean()) < 1e-5 and bool((pre[diff].abs() < 1e-5).all()), (p, int(diff.sum()))
 
 
+@pytest.mark.parametrize('M,N,K,splits', [(8192, 256, 1024, 8), (4096, 512, 512, 4), (256, 256, 768, 8)])
+def test_f16x3_splitk_remainder_launch(ops, bf16x6, M, N, K, splits):
+    """vqcpc_gemm_nt_grad_splitk (the remainder rows of a ragged launch: few tiles, K cut into slices that run as one launch of the
+    three-product kernel, planes summed in ascending order): equals the unsplit kernel up to fp32 summation order for every
+    epilogue it serves -- none, + add, + add + add2, in place, + bias, + bias + dropout + add with the dropout pattern of the
+    unsplit launch at the same global rows (row0) -- fp32-class against fp64, deterministic."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M + K)
+    a = torch.randn(M, K, device='cuda', generator=gen) * 1e-3
+    b = torch.randn(N, K, device='cuda', generator=gen) * 0.05
+    add = torch.randn(M, N, device='cuda', generator=gen) * 1e-4
+    add2 = torch.randn(M, N, device='cuda', generator=gen) * 1e-4
+    bias = torch.randn(N, device='cuda', generator=gen) * 1e-4
+    st = _grad_state(a, b)
+    nbytes = hip.query('vqcpc_gemm_nt_grad_splitk_workspace', M, N, splits)
+    ws = torch.empty(nbytes // 4, device='cuda')
+
+    def sk(out=None, bias=None, drop_p=0.0, seed=0, row0=0, add=None, add2=None):
+        out = torch.empty(M, N, device='cuda') if out is None else out
+        hip.call('vqcpc_gemm_nt_grad_splitk', a, K, b, K, out, N, M, N, K, splits, bias, float(drop_p), int(seed), int(row0), add,
+                 0 if add is None else N, add2, 0 if add2 is None else N, ws, nbytes, st)
+        return out
+
+    ref = a.double() @ b.double().t()
+    plain = sk()
+    assert torch.equal(plain, sk()), 'deterministic'
+    assert _rms(plain, ref) < 1e-6 and float((plain - _nt_grad(a, b, st)).abs().max() / plain.abs().max()) < 3e-6
+    for kw in (dict(add=add), dict(add=add, add2=add2)):
+        assert float((sk(**kw) - _nt_grad(a, b, st, **kw)).abs().max() / plain.abs().max()) < 3e-6, list(kw)
+    acc = add.clone()
+    sk(out=acc, add=acc)                                          # the residual already in C
+    assert torch.equal(acc, sk(add=add))
+    assert torch.equal(sk(bias=bias), plain + bias)               # the epilogue pass adds the bias to the summed planes
+    # dropout: the element index is (row0 + row) * N + col -- rows [row0, row0 + M) of a taller unsplit launch
+    row0 = 512
+    tall_a = torch.cat([torch.zeros(row0, K, device='cuda'), a])
+    tall_add = torch.cat([torch.zeros(row0, N, device='cuda'), add])
+    st2 = _grad_state(a, b)
+    full = _nt_f16x3(tall_a, b, st2, bias, drop_p=0.1, seed=9, add=tall_add)[row0:]
+    part = sk(bias=bias, drop_p=0.1, seed=9, row0=row0, add=add)
+    assert torch.equal((full - add) == 0, (part - add) == 0), 'dropout pattern'
+    assert float((full - part).abs().max() / full.abs().max()) < 3e-6
+
+
+def test_f16x3_ragged_rounds_take_whole_rounds_plus_a_splitk_remainder(ops, bf16x6):
+    """ops._g3_plan at the C1 shape that does not fill whole rounds (139 264 x 256 x 1024: 544 tiles): 512 tiles on one launch, 32
+    tiles x 8 K slices on the remainder launch, inside the forward scope and inside the gradient scope -- against fp64 on a row
+    sample, and with the dropout pattern of the six-product kernel."""
+    from vqcpc_bach_amd import hip
+    M, N, K = 139264, 256, 1024
+    saved_sk, ops.GRAD_SPLITK = ops.GRAD_SPLITK, True             # opt-in (VQCPC_GRAD_SPLITK=1)
+    assert ops._g3_plan(M, N, K) == (131072, 8) and ops._g3_plan(M, N, 256) is None and ops._g3_plan(557056, N, K) == (557056, 0)
+    gen = torch.Generator(device='cuda').manual_seed(5)
+    a = torch.randn(M, K, device='cuda', generator=gen)
+    w = torch.randn(N, K, device='cuda', generator=gen) * K ** -0.5
+    bias = torch.randn(N, device='cuda', generator=gen) * 0.1
+    res = torch.randn(M, N, device='cuda', generator=gen)
+
+    class Flat:
+        flat = torch.zeros(4, device='cuda')
+    owner = Flat()
+    calls, raw = [], hip.call
+    prev_f, prev_g = ops.set_forward_arithmetic('f16x3'), ops.set_gradient_arithmetic('f16x3')
+    hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+    try:
+        six = ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=4, add=res)
+        with torch.enable_grad(), ops.forward_arithmetic(owner):
+            fwd = ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=4, add=res)
+        assert calls.count('vqcpc_gemm_nt_f16x3') == 1 and calls.count('vqcpc_gemm_nt_grad_splitk') == 1
+        with ops.direct_weight_gradients(owner):
+            g = ops.gemm_nt(a, w, add=res)
+            acc = res.clone()
+            g2 = ops.gemm_nt_residual(a, w, acc)
+        assert calls.count('vqcpc_gemm_nt_grad_splitk') == 3 and g2.data_ptr() == acc.data_ptr()
+    finally:
+        hip.call = raw
+        ops.GRAD_SPLITK = saved_sk
+        ops.set_forward_arithmetic(prev_f)
+        ops.set_gradient_arithmetic(prev_g)
+    assert torch.equal((six - res) == 0, (fwd - res) == 0)
+    assert float((six - fwd).abs().max() / six.abs().max()) < 3e-6
+    assert torch.equal(g, g2)
+    rows = torch.cat([torch.arange(0, 512), torch.arange(131072 - 256, 131072 + 512), torch.arange(M - 256, M)]).cuda()
+    ref = a[rows].double() @ w.double().t() + res[rows].double()
+    assert _rms(g[rows], ref) < 1e-6
+
+
 @pytest.mark.parametrize('M,N,K,scale_a', [(4096, 256, 256, 1.0), (131072, 256, 256, 1e-6), (65536, 1024, 256, 1e-4), (1056, 256, 512, 1.0)])
 def test_f16x3_weight_gradient_gemm_vs_fp64(ops, bf16x6, M, N, K, scale_a):
     """vqcpc_gemm_tn_grad: dW = A^T B within the fp32 class of an fp64 product (the contraction over 10^5 rows carries fp32

@@ -97,6 +97,11 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 2, wn = wave & 3;
     const int li = lane & 31, kh = lane >> 5;
+    // split-K launches (vqcpc_gemm_nt_grad_splitk, EPI == 0): blockIdx.y = K slice -- `K` is the slice length, the operands start K
+    // columns further per slice, the partial product goes to plane blockIdx.y of C (ep.split_plane floats apart)
+    A += (int64_t)blockIdx.y * K;
+    B += (int64_t)blockIdx.y * K;
+    C += (int64_t)blockIdx.y * ep.split_plane;
     const int T = K / kGBK;                              // steps per output tile (even: K % 32 == 0)
     const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int S = my_tiles * T;                          // this workgroup's stream of steps (even)
@@ -620,6 +625,46 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_tn_g3_kernel(const float* _
     }
 }
 
+// Sum of the K-slice planes of a split-K launch (ascending slice order: deterministic) + the epilogue of the product: bias, dropout
+// (element index (row0 + row) * N + col, as everywhere), residuals.  One float4 per thread.
+__global__ __launch_bounds__(256) void g3_splitk_epilogue_kernel(const float* __restrict__ ws, int64_t plane, int splits,
+                                                                 float* __restrict__ C, int64_t ldc, int64_t M, int N,
+                                                                 const float* __restrict__ bias, uint32_t thr, float inv_keep,
+                                                                 uint64_t seed, int64_t row0, const float* add, int64_t ldadd,
+                                                                 const float* add2, int64_t ldadd2) {
+    const int n4 = N >> 2;
+    const int64_t total = M * n4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t row = i / n4;
+        const int col = (int)(i - row * n4) * 4;
+        float4 v = *reinterpret_cast<const float4*>(ws + row * N + col);
+        for (int z = 1; z < splits; ++z) {
+            const float4 p = *reinterpret_cast<const float4*>(ws + z * plane + row * N + col);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        if (bias) {
+            const float4 b = *reinterpret_cast<const float4*>(bias + col);
+            v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+        }
+        if (thr) {
+            const uint64_t e = (uint64_t)(row0 + row) * N + col;
+            v.x *= drop_scale(seed, e + 0, thr, inv_keep);
+            v.y *= drop_scale(seed, e + 1, thr, inv_keep);
+            v.z *= drop_scale(seed, e + 2, thr, inv_keep);
+            v.w *= drop_scale(seed, e + 3, thr, inv_keep);
+        }
+        if (add) {       // may be C itself (the residual accumulated in place): read before the store below, same thread
+            const float4 a = *reinterpret_cast<const float4*>(add + row * ldadd + col);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        if (add2) {
+            const float4 a = *reinterpret_cast<const float4*>(add2 + row * ldadd2 + col);
+            v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+        }
+        *reinterpret_cast<float4*>(C + row * ldc + col) = v;
+    }
+}
+
 // amax of a (rows, cols) fp32 matrix with row stride ld -> atomic max into *slot (priming of a call site's state)
 __global__ __launch_bounds__(256) void grad_amax_kernel(const float* __restrict__ x, int64_t ld, int64_t rows, int cols,
                                                         float* __restrict__ slot) {
@@ -725,6 +770,55 @@ int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb,
     else G3_LAUNCH(0)
 #undef G3_LAUNCH
     VQ_CHECK_LAUNCH("gemm_nt_g3");
+    return VQCPC_OK;
+}
+
+// Few output tiles, long K: the remainder rows of a launch whose 256-tiles do not fill whole rounds (139 264 x 256: 2 rounds + 32
+// tiles).  `splits` K slices as one launch of the same kernel (grid = tiles x splits, partial products into `workspace` planes),
+// then one pass that sums the planes in ascending order and applies the epilogue: bias, dropout (row0 = global row of the first
+// row, for the element index), residual(s).  Deterministic; differs from the unsplit product by fp32 summation order only.
+int64_t vqcpc_gemm_nt_grad_splitk_workspace(int64_t M, int N, int splits) {
+    return (int64_t)std::max(splits, 1) * std::max<int64_t>(M, 1) * N * (int64_t)sizeof(float);
+}
+
+int vqcpc_gemm_nt_grad_splitk(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                              int splits, const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add,
+                              int64_t ldadd, const float* add2, int64_t ldadd2, void* workspace, int64_t workspace_bytes,
+                              float* scale_state, void* stream) {
+    VQ_REQUIRE(A && B && C && scale_state && workspace, "gemm_nt_grad_splitk: null pointer");
+    VQ_REQUIRE(splits >= 1 && splits <= 64 && K % splits == 0 && vqcpc_gemm_nt_grad_supported(M, N, K / splits),
+               "gemm_nt_grad_splitk: M, N multiples of 256, K / splits a multiple of 32, got M=%lld N=%d K=%d splits=%d", (long long)M,
+               N, K, splits);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && ldc % 4 == 0 && aligned16(A) && aligned16(B) &&
+                   aligned16(C) && aligned16(workspace),
+               "gemm_nt_grad_splitk: bad leading dimensions / alignment");
+    VQ_REQUIRE((!add || (aligned16(add) && ldadd % 4 == 0 && ldadd >= N)) && (!add2 || (add && aligned16(add2) && ldadd2 % 4 == 0)) &&
+                   (!bias || aligned16(bias)) && drop_p >= 0.f && drop_p < 1.f,
+               "gemm_nt_grad_splitk: bad epilogue operands");
+    if (workspace_bytes < vqcpc_gemm_nt_grad_splitk_workspace(M, N, splits)) {
+        set_error("gemm_nt_grad_splitk: workspace too small");
+        return VQCPC_EWORKSPACE;
+    }
+    EpiParams ep{};
+    ep.gate_scale = 1.0f;
+    ep.split_plane = M * (int64_t)N;
+    const int tn = N / kG;
+    const int tiles = (int)((M / kG) * tn);
+    const size_t lds = (size_t)kGSlots * kGSlot;
+    hipStream_t st = (hipStream_t)stream;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_g3_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_nt_g3_kernel<0>), dim3((unsigned)std::min(tiles, kNumCU), (unsigned)splits), dim3(kGThreads), lds, st, A,
+                       lda, B, ldb, (float*)workspace, (int64_t)N, M, N, K / splits, tn, tiles, ep, scale_state);
+    VQ_CHECK_LAUNCH("gemm_nt_g3 (split-K)");
+    const int64_t total = M * (N / 4);
+    hipLaunchKernelGGL(g3_splitk_epilogue_kernel, dim3((unsigned)std::min<int64_t>(ceil_div(total, 256), 8 * kNumCU)), dim3(256), 0, st,
+                       (const float*)workspace, ep.split_plane, splits, C, ldc, M, N, bias, drop_threshold(drop_p),
+                       1.0f / (1.0f - drop_p), seed, row0, add, ldadd, add2, ldadd2);
+    VQ_CHECK_LAUNCH("gemm_nt_g3 split-K epilogue");
     return VQCPC_OK;
 }
 

@@ -188,6 +188,68 @@ def _grad_rows(M, N, K):
     return rows
 
 
+# opt-in (VQCPC_GRAD_SPLITK=1): ragged rounds = whole rounds + a split-K remainder, both on the f16x3 kernel.  Measured at C1
+# (profiles/r05_perf_log.md): 23.04 / 23.10 -> 22.99 / 22.92 ms/step -- the eight partial planes of the remainder (64 MB written and
+# read back per launch) cost most of what the third round cost; off by default
+GRAD_SPLITK = os.environ.get('VQCPC_GRAD_SPLITK', '0') == '1'
+_g3_plans = {}
+
+
+def _g3_plan(M, N, K):
+    """How an (M, K) x (N, K)^T product of a training step runs on the three-product kernel: None (not at all), (M, 0) (one launch:
+    its 256-tiles fill whole rounds of the 256 persistent workgroups to >= GRAD_ROUND_FILL), or (rows, splits): the whole rounds as
+    one launch + the remaining rows as a split-K launch of the same kernel (vqcpc_gemm_nt_grad_splitk: `splits` K slices, so that
+    the few tiles of the remainder still occupy every CU).  139 264 x 256 x 1024: 512 tiles + 32 tiles x 8 slices."""
+    key = (M, N, K, GRAD_MIN_TILES, GRAD_ROUND_FILL, GRAD_SPLITK)
+    hit = _g3_plans.get(key)
+    if hit is not None:
+        return hit[0]
+    plan = None
+    rows = _grad_rows(M, N, K)
+    if rows == M:
+        plan = (M, 0)
+    elif (GRAD_SPLITK and rows == 0 and GRAD_MIN_TILES > 0 and M % 256 == 0 and N % 256 == 0 and K >= 512
+          and hip.query('vqcpc_gemm_nt_grad_supported', M, N, K)):
+        tn = N // 256
+        tiles = (M // 256) * tn
+        main_rows = ((tiles // 256) * 256 // tn) * 256
+        rem_tiles = (M - main_rows) // 256 * tn
+        if tiles > 256 and main_rows > 0 and 0 < rem_tiles <= 128:
+            for sp in (16, 8, 4, 2):
+                if rem_tiles * sp <= 256 and K % sp == 0 and (K // sp) % 32 == 0 and K // sp >= 64:
+                    plan = (main_rows, sp)
+                    break
+    _g3_plans[key] = (plan,)
+    return plan
+
+
+def _g3_nt(scales, key, a, lda, b, ldb, out, ldc, M, N, K, plan, bias=None, drop_p=0.0, seed=0, add=None, lda_=0, add2=None, lda2_=0):
+    """One (M, K) x (N, K)^T product on the three-product kernel according to `plan` (_g3_plan); epilogue none | + add | + add +
+    add2 (gradient forms) or + bias | + bias + add | + bias + dropout + add (forward forms)."""
+    st = scales.site(key, a, lda, M, K, b, ldb, N, K)
+    m_main, splits = plan
+
+    def launch(rows0, rows):
+        a_, o_ = a[rows0:], out[rows0:]
+        ad_ = None if add is None else add[rows0:]
+        ad2_ = None if add2 is None else add2[rows0:]
+        if bias is None:
+            hip.call('vqcpc_gemm_nt_grad', a_, lda, b, ldb, o_, ldc, rows, N, K, ad_, lda_, ad2_, lda2_, None, 1.0, st)
+        else:
+            hip.call('vqcpc_gemm_nt_f16x3', a_, lda, b, ldb, o_, ldc, rows, N, K, bias, 0, float(drop_p), int(seed), ad_, lda_, None, st)
+
+    if not splits:
+        launch(0, M)
+        return out
+    launch(0, m_main)             # the dropout element index of the main rows starts at row 0, as in the unsplit launch
+    rem = M - m_main
+    nbytes = hip.query('vqcpc_gemm_nt_grad_splitk_workspace', rem, N, splits)
+    ws = hip.workspace(nbytes, a.device)
+    hip.call('vqcpc_gemm_nt_grad_splitk', a[m_main:], lda, b, ldb, out[m_main:], ldc, rem, N, K, splits, bias, float(drop_p), int(seed),
+             m_main, None if add is None else add[m_main:], lda_, None if add2 is None else add2[m_main:], lda2_, ws, nbytes, st)
+    return out
+
+
 def _tn_grad_ok(M, N, K):
     if not hip.query('vqcpc_gemm_tn_grad_supported', M, N, K):
         return False
@@ -221,20 +283,22 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         add2, lda2_ = _rows(add2)
     if (_FWD_SCALES is not None and _GRAD_SCALES is None and not act and gate is None and add2 is None and hip.get_gemm_mode() == 1
             and (not drop_p or (bias is not None and add is not None)) and (bias is not None or add is None)
-            and _grad_rows(M, N, K) == M and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+            and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
         # forward product of a training step on three fp16 MFMAs (FWD_ARITH = 'f16x3'): bias / bias + residual / bias + dropout +
         # residual epilogues, or none
-        st = _FWD_SCALES.site(('fnt', M, N, K), a, lda, M, K, b, ldb, N, K)
-        LAST_GEMM_F16X3 = True
-        if bias is None:
-            hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, ldc, M, N, K, None, 0, None, 0, None, 1.0, st)
-        else:
-            hip.call('vqcpc_gemm_nt_f16x3', a, lda, b, ldb, out, ldc, M, N, K, bias, 0, float(drop_p), int(seed), add, lda_, None, st)
-        return out
+        plan = _g3_plan(M, N, K)
+        if plan is not None and _splitk_operands_ok(plan, out, ldc, add, lda_, None, 0, bias):
+            LAST_GEMM_F16X3 = True
+            return _g3_nt(_FWD_SCALES, ('fnt', M, N, K), a, lda, b, ldb, out, ldc, M, N, K, plan, bias, drop_p, seed, add, lda_)
     if (_GRAD_SCALES is not None and bias is None and not act and not drop_p and gate is None and (add2 is None or add is not None)
             and hip.get_gemm_mode() == 1):
         # inside a trainer's backward pass: the input-gradient product on three fp16 MFMAs (whole rounds of 256-tiles)
         m_g = _grad_rows(M, N, K)
+        plan = _g3_plan(M, N, K) if not m_g else None
+        if (plan is not None and plan[1] and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+                and _splitk_operands_ok(plan, out, ldc, add, lda_, add2, lda2_, None)):
+            LAST_GEMM_F16X3 = True           # ragged rounds: whole rounds + split-K remainder, both on the three-product kernel
+            return _g3_nt(_GRAD_SCALES, ('nt', M, N, K), a, lda, b, ldb, out, ldc, M, N, K, plan, None, 0.0, 0, add, lda_, add2, lda2_)
         if m_g and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
             st = _GRAD_SCALES.site(('nt', M, N, K), a, lda, M, K, b, ldb, N, K)
             LAST_GEMM_F16X3 = True
@@ -276,6 +340,16 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
     return out
 
 
+def _splitk_operands_ok(plan, out, ldc, add, lda_, add2, lda2_, bias):
+    """Alignment the float4 epilogue of the split-K remainder needs (nothing for a single launch)."""
+    if not plan[1]:
+        return True
+    ok = ldc % 4 == 0 and out.data_ptr() % 16 == 0
+    for t, ld in ((add, lda_), (add2, lda2_)):
+        ok = ok and (t is None or (ld % 4 == 0 and t.data_ptr() % 16 == 0))
+    return ok and (bias is None or bias.data_ptr() % 16 == 0)
+
+
 def gemm_nt_residual(a, b, res, res_may_alias=None):
     """res + a @ b^T, the input-gradient product that joins a residual path.  Inside a trainer's backward under the f16x3 arithmetic
     the product is ACCUMULATED INTO `res` (vqcpc_gemm_nt_grad with add == C: fp32 atomic adds at the L2, bit-identical to the
@@ -285,7 +359,7 @@ def gemm_nt_residual(a, b, res, res_may_alias=None):
     M, K = a.shape
     N = b.shape[0]
     if (_GRAD_SCALES is not None and res.dtype == torch.float32 and res.is_contiguous() and res.shape == (M, N)
-            and hip.get_gemm_mode() == 1 and _grad_rows(M, N, K) > 0
+            and hip.get_gemm_mode() == 1 and (_grad_rows(M, N, K) > 0 or _g3_plan(M, N, K) is not None)
             and (res_may_alias is None or res_may_alias.data_ptr() != res.data_ptr())):
         return gemm_nt(a, b, add=res, out=res)
     return gemm_nt(a, b, add=res)

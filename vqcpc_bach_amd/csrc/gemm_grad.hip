@@ -102,6 +102,14 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
     A += (int64_t)blockIdx.y * K;
     B += (int64_t)blockIdx.y * K;
     C += (int64_t)blockIdx.y * ep.split_plane;
+#if VQCPC_LAB
+    // measurement (VQCPC_G3_STAGGER = n, lab build): workgroup b starts (b & 7) * n * 512 clocks late, so that the output tiles of the 256
+    // persistent workgroups -- equal work, lockstep -- are not all stored at the same moment
+    if (ep.act > 0) {
+        const int n_ = ((int)blockIdx.x & 7) * ep.act;
+        for (int i = 0; i < n_; ++i) __builtin_amdgcn_s_sleep(8);
+    }
+#endif
     const int T = K / kGBK;                              // steps per output tile (even: K % 32 == 0)
     const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int S = my_tiles * T;                          // this workgroup's stream of steps (even)
@@ -730,6 +738,12 @@ int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb,
     ep.ldadd2 = ldadd2;
     ep.mask = (uint32_t*)const_cast<void*>(gate_mask);
     ep.gate_scale = gate_scale;
+#if VQCPC_LAB
+    {
+        static const int stagger = lab_env_int("VQCPC_G3_STAGGER", 0);
+        ep.act = stagger;
+    }
+#endif
     const int tn = N / kG;
     const int tiles = (int)((M / kG) * tn);
     const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kGThreads);

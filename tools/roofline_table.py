@@ -29,7 +29,7 @@ FAMILIES = [   # (label, match substrings, algorithmic work per step, unit, peak
 
 def main(path):
     rows = [r for r in csv.reader(open(path))][1:]
-    steps = next(int(r[1]) for r in rows if 'adam_dev' in r[0])
+    steps = sum(int(r[1]) for r in rows if 'adam_dev' in r[0] or 'adam_kernel' in r[0])     # replayed + eager warm-up steps in the trace
     used = set()
     out = []
     for label, match, work, unit, peak, note in FAMILIES:

@@ -379,6 +379,15 @@ int vqcpc_layernorm_bwd_xb16(const float* dy, const void* x_bf16, int64_t ldx, c
                              int64_t workspace_bytes, void* stream);
 /* d_s_bf16 [M][d] = bf16(d_s), NULL = none; d_s may be NULL when d_s_bf16 is given: the gradient of the residual branch then exists in
  * bf16 only -- its one consumer is the bf16 residual operand of the next input-gradient GEMM (vqcpc_gemm_nt_bf16, add_bf16). */
+/* ... and with the incoming gradient in bf16 too: dy_bf16 [M][d] bf16 (8-byte aligned), written by the epilogue of the input-gradient
+ * GEMM that produced it (vqcpc_gemm_nt_bf16 with a bf16 residual operand and a bf16 output only).  Same arithmetic on the upcast
+ * values: bit-identical to vqcpc_layernorm_bwd_xb16 given the same values in fp32; 2 instead of 4 bytes per element in.  configs[4]
+ * bf16 path: the gradient of the transformer stack's main stream between sub-layers (transformer_custom.py:279-289 under
+ * loss.backward(), vqcpc_encoder_trainer.py:311-313). */
+int vqcpc_layernorm_bwd_b16io(const void* dy_bf16, const void* x_bf16, int64_t ldx, const float* gamma, const float* mean,
+                              const float* rstd, float* d_s, void* d_s_bf16, float* d_r, void* d_r_bf16, float* d_gamma,
+                              float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
+                              int64_t workspace_bytes, void* stream);
 /* d_gamma == d_beta == NULL in either backward form: the [vqcpc_add_layernorm_bwd_partials(M, d, r != NULL)][2 d] column partials (d gamma | d beta)
  * stay in `workspace` for a later vqcpc_reduce_grouped.  vqcpc_reduce_grouped: n independent reductions out_i[c] (+)= sum over
  * s < nsplit_i of ws_i[s * stride_i + c], c < count_i, 32 per launch (host arrays of device pointers; a repeated output is

@@ -456,7 +456,27 @@ def test_residual_sum_in_bf16_and_layernorm_on_it(ops, M, N, K):
         hip.call('vqcpc_layernorm_bwd_xb16', dy, sb, N, g, mean, rstd, None, dsb, None, drb, dg, db, M, N, p, 5, ws, nbytes)
         assert torch.equal(dsb, ref_b[0].bfloat16()) and torch.equal(drb, ref_b[1]) and torch.equal(dg, ref_b[2]), p
     a2 = ops.cast_bf16(dev(torch.randn(M, K, generator=gen)))                 # ... and its consumer: dgrad + bf16 residual
-    assert torch.equal(ops.gemm_nt_bf16(a2, b, add_b=dsb), ops.gemm_nt_bf16(a2, b, add=dsb.float()))
+    dx32 = ops.gemm_nt_bf16(a2, b, add_b=dsb)
+    assert torch.equal(dx32, ops.gemm_nt_bf16(a2, b, add=dsb.float()))
+    # the main-stream gradient in bf16 (VQCPC_BF16_GRAD_STREAM): that sum leaves the epilogue in bf16 only == the rounding of the fp32
+    # one, and the LayerNorm backward on a bf16 dy (vqcpc_layernorm_bwd_b16io) == the fp32-dy kernel on the upcast values, bit for bit
+    dxb = ops.gemm_nt_bf16(a2, b, add_b=dsb, out_f32=False, out_bf16=True)
+    assert dxb.dtype == torch.bfloat16 and torch.equal(dxb, dx32.bfloat16())
+    dy_saved, dyb = dy, dxb
+    dy = dyb.float()
+    for p in (0.0, 0.1):
+        ref_b = bwd(True, p)
+        ds, dsb2, drb = torch.empty(M, N, device='cuda'), torch.empty(M, N, device='cuda', dtype=torch.bfloat16), \
+            torch.empty(M, N, device='cuda', dtype=torch.bfloat16)
+        dg, db = torch.empty(N, device='cuda'), torch.empty(N, device='cuda')
+        ws = torch.empty(nbytes // 4, device='cuda')
+        hip.call('vqcpc_layernorm_bwd_b16io', dyb, sb, N, g, mean, rstd, ds, dsb2, None, drb, dg, db, M, N, p, 5, ws, nbytes)
+        assert all(torch.equal(x, y) for x, y in zip(ref_b, (ds, drb, dg, db))), p
+        assert torch.equal(dsb2, ds.bfloat16())
+    dy = dy_saved
+    with pytest.raises(hip.VqcpcHipError):           # an unaligned bf16 gradient is refused
+        hip.call('vqcpc_layernorm_bwd_b16io', dyb.view(-1)[1:1 + (M - 1) * N].view(M - 1, N), sb, N, g, mean, rstd, ds, None, None, drb,
+                 dg, db, M - 1, N, 0.0, 5, ws, nbytes)
     with pytest.raises(hip.VqcpcHipError):           # an unaligned bf16 stream is refused, not read
         hip.call('vqcpc_layernorm_fwd_xb16', sb.view(-1)[1:1 + (M - 1) * N].view(M - 1, N), N, g, be, None, yb_only, m2, r2, M - 1, N,
                  1e-5)
@@ -1154,7 +1174,7 @@ def test_encoder_layer_query_stride_equals_full_then_select(ops, L, H, d, ff):
     (y_ref[:, ::4] * gy).sum().backward()
     params = [dev(sdl[k]).requires_grad_(True) for k in order]
     xd = dev(x.reshape(n * L, d)).requires_grad_(True)
-    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 4, None, None, *params)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 4, None, None, False, *params)
     assert y.shape == (n * L // 4, d)
     assert rel_err(y.detach().cpu(), y_ref.detach()[:, ::4].reshape(-1, d)) < FWD_TOL
     (y * dev(gy.reshape(-1, d))).sum().backward()
@@ -1176,7 +1196,7 @@ def test_encoder_layer_golden(ops, name, L):
     x = T(g['x']).transpose(0, 1).contiguous()                   # (n, L, d) block-major
     n, _, d = x.shape
     xd = dev(x.reshape(n * L, d)).requires_grad_(True)
-    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 1, None, None, *params)
+    y, probs = ops.EncoderLayerFn.apply(xd, L, H, 0.0, 0, 1, None, None, False, *params)
     y_ref = T(g['y']).transpose(0, 1).reshape(n * L, d)
     assert rel_err(y.detach().cpu(), y_ref) < FWD_TOL
     assert rel_err(probs.cpu(), g['attn']) < FWD_TOL

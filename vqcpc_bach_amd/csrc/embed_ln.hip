@@ -237,7 +237,9 @@ __global__ __launch_bounds__(256) void add_ln_fwd_kernel(const float* __restrict
 // for d_r = d_s . mask -- one input stream fewer.
 // NIT = 256-column groups per row (d <= 256 NIT): with the generic 4 the kernel holds 152 registers (3 waves per SIMD); NIT = 1
 // (d <= 256) and 2 (d <= 512) keep the per-row arrays small enough for 8 / 5 waves -- more rows in flight per CU
-template <bool HAS_R, bool MASKED = HAS_R, int NIT = kLnMaxIt, bool XB16 = false>
+// DYB16 (bf16 path, with XB16): the incoming gradient dy is bf16 as well -- the input gradient of the next sub-layer's first GEMM
+// left its epilogue so (vqcpc_gemm_nt_bf16 with a bf16 output only); same arithmetic on the upcast values.
+template <bool HAS_R, bool MASKED = HAS_R, int NIT = kLnMaxIt, bool XB16 = false, bool DYB16 = false>
 __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          int64_t ldx, const float* __restrict__ r,
                                                          const float* __restrict__ gamma, const float* __restrict__ mean,
@@ -284,7 +286,8 @@ __global__ __launch_bounds__(256) void add_ln_bwd_kernel(const float* __restrict
                     xv.z += rv.z * msk[it].z;
                     xv.w += rv.w * msk[it].w;
                 }
-                const float4 dv = nt_load4(dy + row * d + col);
+                const float4 dv = DYB16 ? nt_load4_bf16(reinterpret_cast<const unsigned short*>(dy) + row * d + col)
+                                        : nt_load4(dy + row * d + col);
                 xh[it] = make_float4((xv.x - mu) * rs, (xv.y - mu) * rs, (xv.z - mu) * rs, (xv.w - mu) * rs);
                 gy[it] = make_float4(dv.x * gm[it].x, dv.y * gm[it].y, dv.z * gm[it].z, dv.w * gm[it].w);
                 s1 += (gy[it].x + gy[it].y) + (gy[it].z + gy[it].w);
@@ -668,7 +671,7 @@ int vqcpc_add_layernorm_bwd(const float* dy, const float* x, int64_t ldx, const 
 static int ln_bwd_launch(const float* dy, const void* xv, bool xb16, int64_t ldx, const float* r, const float* gamma,
                          const float* mean, const float* rstd, float* d_s, float* d_r, void* d_r_bf16, float* d_gamma,
                          float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
-                         int64_t workspace_bytes, void* stream, void* d_s_bf16 = nullptr) {
+                         int64_t workspace_bytes, void* stream, void* d_s_bf16 = nullptr, bool dyb16 = false) {
     // d_gamma == d_beta == NULL: the column partials stay in `workspace` ([vqcpc_add_layernorm_bwd_partials(M, d, r != NULL)][2 d]: d gamma | d beta)
     // for the caller to reduce later (vqcpc_reduce_grouped: the trainers sum the partials of every LayerNorm of a backward pass
     // in one launch)
@@ -678,6 +681,7 @@ static int ln_bwd_launch(const float* dy, const void* xv, bool xb16, int64_t ldx
     VQ_REQUIRE(M >= 1 && d >= 4 && d % 4 == 0 && d <= 1024 && ldx % 4 == 0 && ldx >= d, "add_layernorm_bwd: bad shape");
     VQ_REQUIRE(!d_s_bf16 || (reinterpret_cast<uintptr_t>(d_s_bf16) & 7u) == 0, "layernorm_bwd: bf16 d_s must be 8-byte aligned");
     VQ_REQUIRE(!xb16 || (!r && (reinterpret_cast<uintptr_t>(xv) & 7u) == 0), "layernorm_bwd_xb16: one bf16 input stream, 8-byte aligned");
+    VQ_REQUIRE(!dyb16 || (xb16 && (reinterpret_cast<uintptr_t>(dy) & 7u) == 0), "layernorm_bwd_b16io: bf16 dy goes with a bf16 x, 8-byte aligned");
     if (workspace_bytes < vqcpc_add_layernorm_bwd_workspace(M, d)) {
         set_error("add_layernorm_bwd: workspace too small");
         return VQCPC_EWORKSPACE;
@@ -686,15 +690,17 @@ static int ln_bwd_launch(const float* dy, const void* xv, bool xb16, int64_t ldx
     const uint32_t thr = drop_threshold(drop_p);
     const float ik = 1.0f / (1.0f - drop_p);
     const int blocks = ln_bwd_blocks(M, r != nullptr, d);
-#define LN_BWD(HR, MK, NITV, XB)                                                                                          \
-    hipLaunchKernelGGL((add_ln_bwd_kernel<HR, MK, NITV, XB>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, \
+#define LN_BWD(HR, MK, NITV, XB, ...)                                                                                     \
+    hipLaunchKernelGGL((add_ln_bwd_kernel<HR, MK, NITV, XB, ##__VA_ARGS__>), dim3(blocks), dim3(256), 0, s, dy, x, ldx, r, gamma, mean, rstd, \
                        d_s, d_r, (float*)workspace, M, d, thr, ik, seed, (unsigned short*)d_r_bf16, (unsigned short*)d_s_bf16)
-#define LN_BWD_D(HR, MK, XB)                     \
-    if (d <= 256) LN_BWD(HR, MK, 1, XB);         \
-    else if (d <= 512) LN_BWD(HR, MK, 2, XB);    \
-    else LN_BWD(HR, MK, 4, XB)
+#define LN_BWD_D(HR, MK, XB, ...)                             \
+    if (d <= 256) LN_BWD(HR, MK, 1, XB, ##__VA_ARGS__);       \
+    else if (d <= 512) LN_BWD(HR, MK, 2, XB, ##__VA_ARGS__);  \
+    else LN_BWD(HR, MK, 4, XB, ##__VA_ARGS__)
     const bool masked = thr && (d_r || d_r_bf16);   // x is the residual sum s = x0 + dropout(r) itself: d_r = d_s . mask(seed), no r stream
-    if (xb16) {
+    if (dyb16) {
+        if (masked) { LN_BWD_D(false, true, true, true); } else { LN_BWD_D(false, false, true, true); }
+    } else if (xb16) {
         if (masked) { LN_BWD_D(false, true, true); } else { LN_BWD_D(false, false, true); }
     } else if (r) {
         LN_BWD_D(true, true, false);
@@ -725,6 +731,14 @@ int vqcpc_layernorm_bwd_xb16(const float* dy, const void* x_bf16, int64_t ldx, c
                              int64_t workspace_bytes, void* stream) {
     return ln_bwd_launch(dy, x_bf16, true, ldx, nullptr, gamma, mean, rstd, d_s, d_r, d_r_bf16, d_gamma, d_beta, M, d, drop_p, seed,
                          workspace, workspace_bytes, stream, d_s_bf16);
+}
+
+int vqcpc_layernorm_bwd_b16io(const void* dy_bf16, const void* x_bf16, int64_t ldx, const float* gamma, const float* mean,
+                              const float* rstd, float* d_s, void* d_s_bf16, float* d_r, void* d_r_bf16, float* d_gamma,
+                              float* d_beta, int64_t M, int d, float drop_p, uint64_t seed, void* workspace,
+                              int64_t workspace_bytes, void* stream) {
+    return ln_bwd_launch((const float*)dy_bf16, x_bf16, true, ldx, nullptr, gamma, mean, rstd, d_s, d_r, d_r_bf16, d_gamma, d_beta, M, d,
+                         drop_p, seed, workspace, workspace_bytes, stream, d_s_bf16, true);
 }
 
 int vqcpc_add_layernorm_bwd_partials(int64_t M, int d, int has_r) { return ln_bwd_blocks(std::max<int64_t>(M, 1), has_r != 0, d); }

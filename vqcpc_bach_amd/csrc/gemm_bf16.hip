@@ -1091,6 +1091,7 @@ int vqcpc_gemm_nt_bf16(const void* A, int64_t lda, const void* B, int64_t ldb, f
     BL(E_GATE, B_OUT_F32 | B_GATE_BF16)
     BL(E_ADD, B_OUT_F32)
     BL(E_ADD, B_OUT_F32 | B_ADD_BF16)                // input gradient + the bf16 gradient of the residual branch (round 5)
+    BL(E_ADD, B_OUT_BF16 | B_ADD_BF16)               // ... and the sum itself in bf16: the main-stream gradient between sub-layers
     BL(0, B_OUT_BF16)
     BL(E_BIAS, B_OUT_BF16)                           // in_proj output for the all-bf16 attention kernels
     BL(E_BIAS | E_ADD, B_OUT_F32)                    // residual sums for LayerNorm (see gemm.hip)

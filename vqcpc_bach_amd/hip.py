@@ -122,6 +122,8 @@ SIGNATURES = {
     'vqcpc_layernorm_fwd_xb16': (c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_int, c_f32, c_ptr]),
     'vqcpc_layernorm_bwd_xb16': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
                                          c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
+    'vqcpc_layernorm_bwd_b16io': (c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                          c_int, c_f32, c_u64, c_ptr, c_i64, c_ptr]),
     'vqcpc_add_layernorm_bwd_workspace': (c_i64, [c_i64, c_int]),
     'vqcpc_add_layernorm_bwd_partials': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_reduce_grouped': (c_int, [c_int, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_int, c_ptr]),

@@ -1062,9 +1062,50 @@ def _residual_sum_in_epilogue(M, N, K, nat):
     return (M // 256) * (N // 256) >= SFORM_MIN_TILES and M % 256 == 0 and N % 256 == 0 or SFORM_MIN_TILES == 0
 
 
-def _dgrad_plus_residual_bf16(g, wt, res):
-    """g @ wt^T + res on the bf16 path; `res` fp32 or -- the gradient of a residual branch kept in bf16 -- bf16."""
-    return gemm_nt_bf16(g, wt, add_b=res) if res.dtype == torch.bfloat16 else gemm_nt_bf16(g, wt, add=res)
+def _dgrad_plus_residual_bf16(g, wt, res, carrier=False):
+    """g @ wt^T + res on the bf16 path; `res` fp32 or -- the gradient of a residual branch kept in bf16 -- bf16.
+    carrier: the layer that produced this layer's input reads its output gradient in bf16 (EncoderLayerFn.forward): the sum leaves
+    the epilogue in bf16 only, wrapped for autograd by _bf16_grad_carrier."""
+    if res.dtype != torch.bfloat16:
+        return gemm_nt_bf16(g, wt, add=res)
+    if carrier:
+        return _bf16_grad_carrier(gemm_nt_bf16(g, wt, add_b=res, out_f32=False, out_bf16=True))
+    return gemm_nt_bf16(g, wt, add_b=res)
+
+
+_NAN1 = {}
+
+
+def _bf16_grad_carrier(gb):
+    """The gradient `gb` (bf16) of an fp32 tensor, handed to autograd as an fp32-typed tensor of the right shape that owns no
+    memory of that size: a stride-0 view of ONE NaN with the real gradient attached.  The consumer (the producing layer's
+    backward, which announced on its output that it reads such carriers) takes the attachment; anything else that touches the
+    values -- autograd summing it with a second consumer's gradient, a view op's backward -- produces NaNs, loudly."""
+    nan1 = _NAN1.get(gb.device)
+    if nan1 is None:
+        nan1 = _NAN1[gb.device] = torch.full((1,), float('nan'), dtype=torch.float32, device=gb.device)
+    c = nan1.expand(gb.shape)
+    c._vqcpc_bf16_grad = gb
+    return c
+
+
+def _bf16_act_carrier(yb):
+    """The same for an ACTIVATION that exists in bf16 only: the output of a stack's interior layer on the bf16 path, whose one consumer
+    is the next EncoderLayerFn (GEMM operand and residual operand alike, both read bf16).  fp32-typed for autograd, values NaN."""
+    c = _bf16_grad_carrier(yb)
+    del c._vqcpc_bf16_grad
+    c._vqcpc_bf16_act = yb
+    return c
+
+
+def _bf16_act_of(x):
+    xb = getattr(x, '_vqcpc_bf16_act', None)
+    return xb if (xb is not None and tuple(xb.shape) == tuple(x.shape)) else None
+
+
+def _bf16_grad_of(g):
+    gb = getattr(g, '_vqcpc_bf16_grad', None)
+    return gb if (gb is not None and tuple(gb.shape) == tuple(g.shape)) else None
 
 
 class EncoderLayerFn(torch.autograd.Function):
@@ -1078,12 +1119,22 @@ class EncoderLayerFn(torch.autograd.Function):
     Identical results, ~60 % fewer FLOPs in that layer."""
 
     @staticmethod
-    def forward(ctx, x, L, H, drop_p, seed, qstride, qkv_in, qkv_tokens, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1, be1,
-                g2, be2):
+    def forward(ctx, x, L, H, drop_p, seed, qstride, qkv_in, qkv_tokens, out_b16_only, wqkv, bqkv, wo, bo, e1, e2, w1, b1, w2, b2, g1,
+                be1, g2, be2):
         # qkv_in: the in_proj output computed elsewhere (first layer); wqkv / bqkv are then not used here and the gradient
         # of the projection is handed back through qkv_in.  Either the per-token (M, 3d) tensor, or -- with qkv_tokens
         # (M,) int64 -- the (vmax * L, 3d) block table, which the attention kernels read through the token indirection
-        x, ldx = _rows(_f32(x))
+        # out_b16_only: the caller promises that the ONE consumer of y is the next EncoderLayerFn of the stack (an interior layer): on
+        # the bf16 path y then exists in bf16 only (_bf16_act_carrier)
+        x_accepts_b16_grad = bool(getattr(x, '_vqcpc_accepts_bf16_grad', False))     # set by the layer that produced x
+        xb_in = _bf16_act_of(x)              # x itself in bf16 only (the previous interior layer's output)
+        if xb_in is not None and not (hip.get_gemm_mode() == 2 and BF16_RESIDUAL and BF16_SUMS and qkv_in is None):
+            x, xb_in = xb_in.float(), None   # a consumer off the all-bf16 path: the values, upcast
+            x_accepts_b16_grad = False
+        if xb_in is None:
+            x, ldx = _rows(_f32(x))
+        else:
+            ldx = x.shape[1]
         M, d = x.shape
         hd = d // H
         nblk = M // L
@@ -1098,14 +1149,19 @@ class EncoderLayerFn(torch.autograd.Function):
         nat = bf16_native((M, 3 * d if (f == 1 and qkv_in is None) else 2 * d, d), (Mq_, d, d), (Mq_, ffd, d), (Mq_, d, ffd)) and \
             hip.query('vqcpc_gemm_tn_bf16_supported', Mq_, d, d)
         lin = gemm_nt_bf16 if nat else gemm_nt
+        if xb_in is not None and not nat:               # (shapes off the 256-tile bf16 kernels)
+            x, xb_in = xb_in.float(), None
+            x_accepts_b16_grad = False
+            x, ldx = _rows(x)
         xb = None                                       # bf16 copies: GEMM operands now, weight-gradient operands later
         if nat and (qkv_in is None or f > 1):
-            xb = _bf16_copy_of(x)                       # written by the previous layer's LayerNorm kernel
+            xb = xb_in if xb_in is not None else _bf16_copy_of(x)      # written by the previous layer's LayerNorm kernel
             if xb is None:
                 xb = cast_bf16(x)
         xsb = None
         if f == 1:
             Mq, xs, ldxs = M, x, ldx
+            xsb = xb if xb_in is not None else None
             probs = torch.empty(nblk, H, L, L, dtype=torch.float32, device=dev)
             # bf16 path at L = 16: the attention context only feeds the out-proj GEMM, which reads bf16 -> the kernel writes
             # bf16 directly (no fp32 tensor, no cast pass); where the projection runs here (no block table) q | k | v are
@@ -1141,7 +1197,7 @@ class EncoderLayerFn(torch.autograd.Function):
             assert L % f == 0 and qkv_in is None
             attb_direct = None
             Mq = M // f
-            xs, ldxs = _rows(x[::f])                                       # query / residual rows: a stride, not a copy
+            xs, ldxs = _rows(x[::f]) if xb_in is None else (None, 0)       # query / residual rows: a stride, not a copy
             xsb = xb[::f].contiguous() if nat else None
             qkv = lin(xb if nat else x, wqkv[d:], bias=bqkv[d:])           # k | v for every token   (M, 2d)
             qproj = lin(xsb if nat else xs, wqkv[:d], bias=bqkv[:d])       # q for the kept rows     (Mq, d)
@@ -1167,8 +1223,10 @@ class EncoderLayerFn(torch.autograd.Function):
         # ... and the residual sums s1, s2 themselves leave their GEMM epilogues in bf16: 2 instead of 4 bytes out of the epilogue,
         # into the LayerNorm forward and into its backward (include/vqcpc.h: vqcpc_layernorm_fwd_xb16)
         s16 = nat and BF16_RESIDUAL and BF16_SUMS
+        assert xb_in is None or s16
         if s16:
-            s1 = gemm_nt_bf16(attb, wo, bias=bo, drop_p=p, seed=s[1], add=xs, out_f32=False, out_bf16=True)
+            s1 = (gemm_nt_bf16(attb, wo, bias=bo, drop_p=p, seed=s[1], add_b=xsb, out_f32=False, out_bf16=True) if xb_in is not None
+                  else gemm_nt_bf16(attb, wo, bias=bo, drop_p=p, seed=s[1], add=xs, out_f32=False, out_bf16=True))
             hip.call('vqcpc_layernorm_fwd_xb16', s1, d, g1, be1, x1, x1b, mean1, rstd1, Mq, d, 1e-5)
         elif sform1:
             s1 = lin(attb if nat else att, wo, bias=bo, drop_p=p, seed=s[1], add=xs)
@@ -1193,18 +1251,31 @@ class EncoderLayerFn(torch.autograd.Function):
                 s2 = gemm_nt(h2, w2, bias=b2, drop_p=p, seed=s[3], add=x1)      # x1 + dropout(FFN(x1))
             else:
                 s2 = gemm_nt(h2, w2, bias=b2)                                   # FFN(x1): LayerNorm adds x1 and the dropout
-        y = torch.empty(Mq, d, dtype=torch.float32, device=dev)
+        y_carrier = bool(out_b16_only and s16 and BF16_ACT_STREAM)
+        y = None if y_carrier else torch.empty(Mq, d, dtype=torch.float32, device=dev)
         mean2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         rstd2 = torch.empty(Mq, dtype=torch.float32, device=dev)
         yb = torch.empty(Mq, d, dtype=torch.bfloat16, device=dev) if nat else None
         if s16:
             hip.call('vqcpc_layernorm_fwd_xb16', s2, d, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5)
+            if y_carrier:
+                y = _bf16_act_carrier(yb)
         elif sform2:
             hip.call('vqcpc_add_layernorm_fwd_b16', s2, d, None, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, 0.0, 0)
         else:
             hip.call('vqcpc_add_layernorm_fwd_b16', x1, d, s2, g2, be2, y, yb, mean2, rstd2, Mq, d, 1e-5, p, s[3])
         if nat:
-            _attach_bf16_copy(y, yb)
+            if not y_carrier:
+                _attach_bf16_copy(y, yb)
+            # round 5: this layer's backward reads the gradient of y as bf16 (vqcpc_layernorm_bwd_b16io) when the consumer hands it
+            # over so -- the next layer's input-gradient GEMM then writes 2 instead of 4 bytes per element and LN2's backward reads 2
+            if s16 and BF16_GRAD_SUMS and BF16_GRAD_STREAM:
+                y._vqcpc_accepts_bf16_grad = True
+        ctx.dx_b16 = bool(nat and x_accepts_b16_grad and BF16_GRAD_SUMS and BF16_GRAD_STREAM)
+        ctx.x_b16_only = xb_in is not None
+        if xb_in is not None:
+            x = x[:0]                       # the carrier's values are never read: only its shape (ctx.x_shape)
+        ctx.x_shape = (M, d)
         ctx.save_for_backward(x, qkv, qproj, probs, att, s1, x1, mean1, rstd1, h2, s2, mean2, rstd2, wqkv, wo, e1, e2, w1,
                               w2, g1, g2)
         ctx.meta = (L, H, p, s, f, qkv_in is not None)
@@ -1223,15 +1294,19 @@ class EncoderLayerFn(torch.autograd.Function):
          g2) = ctx.saved_tensors
         if dy is None:
             dy = torch.zeros(s2.shape, dtype=torch.float32, device=s2.device)
+        dyb = _bf16_grad_of(dy)              # the consumer's input gradient in bf16 (see _bf16_grad_carrier)
         L, H, p, s, f, ext_qkv = ctx.meta
         bqkv, bo, b1, b2 = ctx.biases
         be1, be2 = ctx.ln_betas
-        x, ldx = _rows(x)
-        M, d = x.shape
+        M, d = ctx.x_shape
+        if ctx.x_b16_only:                   # x existed in bf16 only (ctx.bf16 holds it): no fp32 rows to address
+            ldx, xs, ldxs = d, None, 0
+        else:
+            x, ldx = _rows(x)
+            xs, ldxs = (x, ldx) if f == 1 else _rows(x[::f])
         hd, nblk, dev = d // H, M // L, x.device
         Mq = M // f
-        xs, ldxs = (x, ldx) if f == 1 else _rows(x[::f])
-        dy = dy.contiguous()
+        dy = dyb if dyb is not None else dy.contiguous()
 
         nat = ctx.bf16 is not None
 
@@ -1253,11 +1328,13 @@ class EncoderLayerFn(torch.autograd.Function):
                 db = torch.empty(d, dtype=torch.float32, device=dev)
             if xin.dtype == torch.bfloat16:              # the residual sum was written in bf16 (s-form only)
                 assert r is None
-                hip.call('vqcpc_layernorm_bwd_xb16', dyv, xin, ldxin, gamma, mean, rstd, ds, dsb, dr, drb, dg, db, Mq, d, p, seed, ws,
-                         nbytes)
+                # ... and the incoming gradient too where an input-gradient GEMM of this path produced it (round 5)
+                hip.call('vqcpc_layernorm_bwd_b16io' if dyv.dtype == torch.bfloat16 else 'vqcpc_layernorm_bwd_xb16', dyv, xin, ldxin,
+                         gamma, mean, rstd, ds, dsb, dr, drb, dg, db, Mq, d, p, seed, ws, nbytes)
                 if ds_bf16:
                     ds = dsb
             else:
+                assert dyv.dtype == torch.float32
                 hip.call('vqcpc_add_layernorm_bwd_b16', dyv, xin, ldxin, r, gamma, mean, rstd, ds, dr, drb, dg, db, Mq, d, p, seed,
                          ws, nbytes)
             return ds, (dr if dr is not None else (None if (nat and p > 0) else ds)), dg, db, drb
@@ -1275,8 +1352,10 @@ class EncoderLayerFn(torch.autograd.Function):
             da = gemm_nt_bf16(dfb, transpose(w2), gate_b=h2b, gate_scale=1.0 / (1.0 - p), out_f32=False, out_bf16=True)
             dw2, db2 = wgrad(dfb, h2b, w2, b2)
             dw1, db1 = wgrad(da, x1b, w1, b1)
-            dx1 = (gemm_nt_bf16(da, transpose(w1), add_b=ds2) if ds2.dtype == torch.bfloat16 else
-                   gemm_nt_bf16(da, transpose(w1), add=ds2))
+            # d x1 -- the gradient that enters LN1's backward -- in bf16 only where that kernel reads the residual sum in bf16 too
+            dx1_b16 = BF16_GRAD_STREAM and sform1 and ds2.dtype == torch.bfloat16 and s1.dtype == torch.bfloat16
+            dx1 = (gemm_nt_bf16(da, transpose(w1), add_b=ds2, out_f32=not dx1_b16, out_bf16=dx1_b16)
+                   if ds2.dtype == torch.bfloat16 else gemm_nt_bf16(da, transpose(w1), add=ds2))
         else:
             # FFN: da = (df @ W2) * [h2 > 0] / (1 - p)   (relu + dropout backward folded into the GEMM epilogue)
             if ctx.gate_mask is not None:
@@ -1319,18 +1398,18 @@ class EncoderLayerFn(torch.autograd.Function):
                     hip.call('vqcpc_relattn16_bwd_b16', datt, d, qkv, 3 * d, None, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk,
                              H, hd, p, s[0], ws, nbytes)
                 dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
-                dx = _dgrad_plus_residual_bf16(dqkvb, transpose(wqkv), ds1) if need_dx else None
+                dx = _dgrad_plus_residual_bf16(dqkvb, transpose(wqkv), ds1, carrier=ctx.dx_b16) if need_dx else None
                 de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
-                return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
+                return (dx, None, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
                         dbe1, dg2, dbe2)
             if (nat and not ext_qkv and tok is None and ATT_B16_OUT and hip.query('vqcpc_relattn_b16_supported', L, H, hd)):
                 dqkvb = torch.empty(M, 3 * d, dtype=torch.bfloat16, device=dev)        # the other block lengths (L = 4)
                 hip.call('vqcpc_relattn_bwd_b16', datt, d, qkv, 3 * d, probs, e1, e2, dqkvb, 3 * d, de1, de2, nblk, L, H, hd, p,
                          s[0], ws, nbytes)
                 dwqkv, dbqkv = wgrad(dqkvb, xb, wqkv, bqkv)
-                dx = _dgrad_plus_residual_bf16(dqkvb, transpose(wqkv), ds1) if need_dx else None
+                dx = _dgrad_plus_residual_bf16(dqkvb, transpose(wqkv), ds1, carrier=ctx.dx_b16) if need_dx else None
                 de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
-                return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
+                return (dx, None, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
                         dbe1, dg2, dbe2)
             dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
             if tok is not None:
@@ -1348,7 +1427,7 @@ class EncoderLayerFn(torch.autograd.Function):
             if ext_qkv:          # projection lives outside: its gradient leaves through qkv_in, x keeps the residual path
                 de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2),
                                                                   (de1, de2, dg1, dbe1, dg2, dbe2))
-                return (ds1 if need_dx else None, None, None, None, None, None, d_in, None, None, None, dwo, dbo, de1, de2, dw1,
+                return (ds1 if need_dx else None, None, None, None, None, None, d_in, None, None, None, None, dwo, dbo, de1, de2, dw1,
                         db1, dw2, db2, dg1, dbe1, dg2, dbe2)
             if nat:
                 dqkvb = cast_bf16(dqkv)
@@ -1384,7 +1463,7 @@ class EncoderLayerFn(torch.autograd.Function):
                 dxs = dx[::f]                                              # kept rows also get the query + residual paths
                 gemm_nt(dq, wt[:, :d], add=ds1, add2=dxs, out=dxs)
         de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
-        return (dx, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1,
+        return (dx, None, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1, dbe1,
                 dg2, dbe2)
 
 
@@ -1653,6 +1732,8 @@ ATT_B16_IN = os.environ.get('VQCPC_ATT_B16_IN', '1') != '0'          # A/B switc
 BF16_RESIDUAL = os.environ.get('VQCPC_BF16_RESIDUAL', '1') != '0'      # A/B switch: LN1's output in bf16 only on the bf16 path
 BF16_GRAD_SUMS = os.environ.get('VQCPC_BF16_GRAD_SUMS', '1') != '0'    # A/B switch: ... and the gradients of the residual branches (LayerNorm backward -> dgrad epilogue)
 BF16_SUMS = os.environ.get('VQCPC_BF16_SUMS', '1') != '0'              # A/B switch: ... and the residual sums s1 / s2 (LayerNorm inputs)
+BF16_GRAD_STREAM = os.environ.get('VQCPC_BF16_GRAD_STREAM', '1') != '0'  # A/B switch: ... and the main-stream gradient between sub-layers / layers (LayerNorm backward reads bf16 dy)
+BF16_ACT_STREAM = os.environ.get('VQCPC_BF16_ACT_STREAM', '1') != '0'    # A/B switch: ... and the output of a stack's interior layers (LN2 writes bf16 only, the next out-proj epilogue reads it)
 ATT_B16_OUT = os.environ.get('VQCPC_ATT_B16_OUT', '1') != '0'        # A/B switch: bf16 outputs straight from the L = 16 attention
 GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)
 

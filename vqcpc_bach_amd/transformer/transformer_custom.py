@@ -39,15 +39,16 @@ class TransformerEncoderLayerCustom(nn.Module):
                 self.linear1.weight, self.linear1.bias, self.linear2.weight, self.linear2.bias, self.norm1.weight,
                 self.norm1.bias, self.norm2.weight, self.norm2.bias)
 
-    def forward_rows(self, x, qstride=1, qkv=None):
+    def forward_rows(self, x, qstride=1, qkv=None, interior=False):
         """x: (blocks * L, d) block-major rows (may be row-strided) -> (y (blocks * L / qstride, d), probs).
         qstride = f > 1 evaluates only the output rows 0, f, 2f, ... (what `output[::f]` would keep).
         qkv: the in_proj output when the caller already has it (first layer): a (rows, 3d) tensor, or a pair
         (block table (vmax * L, 3d), tokens (rows,) int64) that the attention reads through the token indirection."""
         p = self.p if self.training else 0.0
         table, tokens = qkv if isinstance(qkv, tuple) else (qkv, None)
+        # interior: the caller hands y to the next layer's forward_rows and to nothing else (the bf16 path may then keep it in bf16 only)
         return ops.EncoderLayerFn.apply(x, self.seq_len, self.nhead, p, SEEDS.next() if p > 0 else 0, qstride, table, tokens,
-                                        *self._params())
+                                        bool(interior), *self._params())
 
     def forward_rows_masked(self, x, n, mask):
         """Source encoder of the decoder (decoders/decoder.py:497-503): x (n * L, d) batch-major rows, self-attention
@@ -103,7 +104,8 @@ class TransformerEncoderCustom(nn.Module):
         attentions = []
         for li, layer in enumerate(self.layers):
             last = li == len(self.layers) - 1
-            x, probs = layer.forward_rows(x, qstride=out_stride if last else 1, qkv=first_qkv if li == 0 else None)
+            x, probs = layer.forward_rows(x, qstride=out_stride if last else 1, qkv=first_qkv if li == 0 else None,
+                                          interior=not last)
             attentions.append(dict(a_self_encoder=probs))
         return x, attentions
 

@@ -1111,6 +1111,28 @@ def test_relattn16_all_bf16_form_equals_fp32_inputs_holding_the_same_values(ops,
         outs.append((ctx, probs, dqkv, de1, de2))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    if hd not in (32, 64):
+        return
+    # outside the exact GEMM mode 0 the all-bf16 backward runs EVERY contraction on the bf16 matrix pipe (relattn16_bwd_mm16_kernel:
+    # bf16 operands as loaded, Pd / dS / Erel as two bf16 pieces): other summation orders and 2^-17-relative operand pieces, i.e.
+    # the bf16 outputs agree except for roundings that flip by one unit in the last place, the fp32 d Erel to ~1e-5
+    ref_dqkv, ref_de1, ref_de2 = outs[1][2], outs[1][3], outs[1][4]
+    dqkv = torch.empty(n * L, 3 * d, device='cuda', dtype=torch.bfloat16)
+    de1, de2 = torch.empty_like(e1), torch.empty_like(e2)
+    hip.set_gemm_mode(8)
+    try:
+        hip.call('vqcpc_relattn16_bwd_b16io', dctx_b, d, qkv_b, 3 * d, outs[1][1], e1, e2, dqkv, 3 * d, de1, de2, n, H, hd, p, seed,
+                 ws, nbytes)
+    finally:
+        hip.set_gemm_mode(0)
+    a, b = dqkv.float(), ref_dqkv.float()
+    diff = (a - b).abs()
+    assert bool((diff <= 2.0 ** -7 * b.abs() + 3e-5 * b.abs().max()).all()), float(diff.max())     # one bf16 ulp (+ cancellation noise)
+    assert float((a != b).float().mean()) < 0.02
+    for part in range(3):                                   # d q, d k, d v each: a layout slip in one of them cannot hide in the others
+        sl = slice(part * d, (part + 1) * d)
+        assert float((a[:, sl] != b[:, sl]).float().mean()) < 0.03, part
+    assert rel_err(de1, ref_de1) < 1e-4 and rel_err(de2, ref_de2) < 1e-4, (rel_err(de1, ref_de1), rel_err(de2, ref_de2))
 
 
 @pytest.mark.parametrize('n,L,H,hd,p', [(300, 16, 8, 64, 0.1), (129, 4, 8, 64, 0.1), (40, 16, 2, 16, 0.0), (33, 4, 4, 32, 0.0),

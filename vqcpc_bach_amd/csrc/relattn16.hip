@@ -455,6 +455,245 @@ __global__ __launch_bounds__(kA16Waves * 64) void relattn16_bwd_kernel(
             }
 }
 
+// =====================================================================================================================
+// All-bf16 backward (q | k | v, d ctx in, d qkv out: bf16) with EVERY contraction on the bf16 matrix pipe (round 5).
+// The fp32 16 x 16 x 4 MFMAs of relattn16_bwd_kernel are 4 096 pipe cycles per (block, head) problem at head_dim 64 (128
+// instructions of 32 cycles) and the bf16 inputs are unpacked to fp32 for them (1 577 VALU instructions per problem,
+// profiles/r05_pmc_kernels_c4.txt: 3.2 ms per launch at configs[4] against 1.5 ms of HBM time).  Here:
+//   * the operands that ARE bf16 in memory (dO, Q, K, V) go to v_mfma_f32_16x16x32_bf16 as loaded -- exact products, fp32 accumulate;
+//   * the fp32 factors computed here (Pd = P . mask, dS) and the fp32 parameter Erel are carried as TWO bf16 pieces (x = hi + lo
+//     + O(2^-17 x)), both pieces of a 16-token contraction in ONE K = 32 instruction: slots 0-3 of lane group g hold the hi pieces
+//     of tokens 4g .. 4g+3, slots 4-7 the lo pieces, the bf16 operand is repeated in both slot halves (the k index of an MFMA is
+//     a summation index: any assignment shared by A and B is valid);  dS . Erel = [hi | lo] . [H | H] + [hi | lo] . [L | 0];
+//   * a token-contraction B operand (rows 4g .. 4g+3 of dO / Q / K at this lane's CT columns) is a 4 x CT transpose of 16-bit
+//     elements: v_perm_b32, no conversion.
+// 38 MFMAs of 16 cycles per problem at head_dim 64.  Softmax backward, dropout mask, partial d Erel layout: as relattn16_bwd_kernel.
+// Error vs that kernel: summation order + 2^-17 relative in Pd / dS / Erel, i.e. far below the bf16 rounding of the outputs.
+// =====================================================================================================================
+__device__ __forceinline__ uint32_t perm_lo(uint32_t hi_src, uint32_t lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x05040100u); }
+__device__ __forceinline__ uint32_t perm_hi(uint32_t hi_src, uint32_t lo_src) { return __builtin_amdgcn_perm(hi_src, lo_src, 0x07060302u); }
+// four fp32 -> bf16 pieces: h01 / h23 = the rounded values (element 0 / 2 in the low half), l01 / l23 = rn(x - h)
+__device__ __forceinline__ void split2x4(const float (&v)[4], uint32_t& h01, uint32_t& h23, uint32_t& l01, uint32_t& l23) {
+    h01 = bf16x2_rn(v[0], v[1]);
+    h23 = bf16x2_rn(v[2], v[3]);
+    l01 = bf16x2_rn(v[0] - bf16_lo(h01), v[1] - bf16_hi(h01));
+    l23 = bf16x2_rn(v[2] - bf16_lo(h23), v[3] - bf16_hi(h23));
+}
+__device__ __forceinline__ bf16x8 frag8(uint32_t a, uint32_t b, uint32_t c, uint32_t d) {
+    return __builtin_bit_cast(bf16x8, make_uint4(a, b, c, d));
+}
+// four LDS dwords (hi << 16 | lo) of tokens e = 0..3 -> the A operand [hi0 hi1 hi2 hi3 | lo0 lo1 lo2 lo3]
+__device__ __forceinline__ bf16x8 frag_from_packed(uint32_t d0, uint32_t d1, uint32_t d2, uint32_t d3) {
+    return frag8(perm_hi(d1, d0), perm_hi(d3, d2), perm_lo(d1, d0), perm_lo(d3, d2));
+}
+// R[r][w]: row 4g + r, this lane's CT columns (two per dword) -> T[ct] = {rows 0 1, rows 2 3} of column ct
+template <int CT>
+__device__ __forceinline__ void tr_rows4(const uint32_t (&R)[4][CT / 2], uint32_t (&T)[CT][2]) {
+#pragma unroll
+    for (int w = 0; w < CT / 2; ++w) {
+        T[2 * w][0] = perm_lo(R[1][w], R[0][w]);
+        T[2 * w][1] = perm_lo(R[3][w], R[2][w]);
+        T[2 * w + 1][0] = perm_hi(R[1][w], R[0][w]);
+        T[2 * w + 1][1] = perm_hi(R[3][w], R[2][w]);
+    }
+}
+template <int CT>
+__device__ __forceinline__ void load_row_b16(uint32_t (&dst)[CT / 2], const unsigned short* __restrict__ p) {
+    if constexpr (CT == 4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        dst[0] = t.x; dst[1 % (CT / 2)] = t.y;
+    } else {
+        dst[0] = *reinterpret_cast<const uint32_t*>(p);
+    }
+}
+
+template <int HD>
+__global__ __launch_bounds__(kA16Waves * 64, 2) void relattn16_bwd_mm16_kernel(
+    const unsigned short* __restrict__ d_ctx, int64_t ldo, const unsigned short* __restrict__ qkv, int64_t ldq,
+    const float* __restrict__ probs, const float* __restrict__ e1, const float* __restrict__ e2,
+    unsigned short* __restrict__ d_qkv, int64_t ldg, float* __restrict__ ws, int64_t n_blocks, int H, int blocks_per_chunk,
+    float scale, uint32_t thr, float inv_keep, uint64_t seed) {
+    static_assert(HD == 32 || HD == 64, "head_dim 32 / 64");
+    constexpr int KH = HD / 4, CT = HD / 16, NCH = HD / 32;
+    __shared__ uint32_t lds[kA16Waves][16 * kA16RS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, g = lane >> 4, c = lane & 15;
+    uint32_t* buf = lds[wave];
+    const int h = blockIdx.y;
+    const int d = H * HD;
+    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the relative rows of this head as bf16 pieces, once per wave: B[k x = 16 xt + 4g + e][col CT c + ct] = {H01, H23, L01, L23}, parked
+    // in LDS (32 registers otherwise: two waves per SIMD would spill).  The four waves of a workgroup work on the same head: they
+    // write identical values to the same lane-private slots and each reads its own lane's -- no workgroup barrier needed.
+    __shared__ uint4 erel_lds[2 * CT][64];
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt) {
+        float ev[4][CT];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) load_ct<CT>(ev[e], erel16(e1, e2, h, HD, 16 * xt + 4 * g + e) + CT * c, 1.0f);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const float v[4] = {ev[0][ct], ev[1][ct], ev[2][ct], ev[3][ct]};
+            uint4 pk;
+            split2x4(v, pk.x, pk.y, pk.z, pk.w);
+            erel_lds[xt * CT + ct][lane] = pk;
+        }
+    }
+    wave_lds_fence();
+    floatx4 de[2][CT];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) de[t][ct] = zero4;
+    const int64_t b0 = (int64_t)blockIdx.x * blocks_per_chunk;
+    const int64_t b1 = min(b0 + blocks_per_chunk, n_blocks);
+    const int iters = (int)((b1 - b0 + kA16Waves - 1) / kA16Waves);
+    struct Blk {
+        uint4 doa[NCH], vb[NCH];
+        float p[4];
+        uint32_t dob[4][CT / 2], qb[4][CT / 2], kb[4][CT / 2];
+    };
+    auto block_of = [&](int it) { return min(b0 + (int64_t)it * kA16Waves + wave, b1 - 1); };
+    auto load_blk = [&](Blk& B, int64_t n) {
+        const int64_t prob = n * H + h;
+        const unsigned short* dc = d_ctx + (n * 16 + c) * ldo + h * HD + g * KH;
+        const unsigned short* vr = qkv + (n * 16 + c) * ldq + 2 * d + h * HD + g * KH;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch) {
+            B.doa[ch] = *reinterpret_cast<const uint4*>(dc + 8 * ch);
+            B.vb[ch] = *reinterpret_cast<const uint4*>(vr + 8 * ch);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) B.p[r] = probs[(prob * 16 + 4 * g + r) * 16 + c];
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int64_t row = n * 16 + 4 * g + sidx;
+            load_row_b16<CT>(B.dob[sidx], d_ctx + row * ldo + h * HD + CT * c);
+            load_row_b16<CT>(B.qb[sidx], qkv + row * ldq + h * HD + CT * c);
+            load_row_b16<CT>(B.kb[sidx], qkv + row * ldq + d + h * HD + CT * c);
+        }
+    };
+    Blk cur;
+    load_blk(cur, block_of(0));
+    for (int it = 0; it < iters; ++it) {
+        const int64_t want = b0 + (int64_t)it * kA16Waves + wave;
+        const bool live = want < b1;
+        const int64_t n = live ? want : b1 - 1;
+        const int64_t prob = n * H + h;
+        Blk nxt;
+        load_blk(nxt, block_of(it + 1));               // every operand of the next block is in flight while this one is processed
+        // dP = dO . V^T over head_dim: both operands as loaded (lane group g holds columns g KH .. of its row)
+        floatx4 dp = zero4;
+#pragma unroll
+        for (int ch = 0; ch < NCH; ++ch)
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, cur.doa[ch]), __builtin_bit_cast(bf16x8, cur.vb[ch]),
+                                                         dp, 0, 0, 0);
+        float pd[4], ds[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int64_t idx = (prob * 16 + 4 * g + r) * 16 + c;
+            const float p = cur.p[r];
+            const float mk = drop_scale(seed, (uint64_t)idx, thr, inv_keep);
+            const float dpm = dp[r] * mk;
+            pd[r] = p * mk;
+            ds[r] = p * (dpm - grp16_sum(dpm * p));
+        }
+        uint32_t ph01, ph23, pl01, pl23, sh01, sh23, sl01, sl23;
+        split2x4(pd, ph01, ph23, pl01, pl23);
+        split2x4(ds, sh01, sh23, sl01, sl23);
+        uint32_t td[CT][2], tq[CT][2], tk[CT][2];
+        tr_rows4<CT>(cur.dob, td);
+        tr_rows4<CT>(cur.qb, tq);
+        tr_rows4<CT>(cur.kb, tk);
+        // dV = Pd^T dO, dK = dS^T Q (x scale at the store):  A[row j = c][k i = 4g + e] = X[4g + e][c] = this lane's own values
+        const bf16x8 a_pd = frag8(ph01, ph23, pl01, pl23), a_ds = frag8(sh01, sh23, sl01, sl23);
+        floatx4 dv[CT], dk[CT], dq[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            dv[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_pd, frag8(td[ct][0], td[ct][1], td[ct][0], td[ct][1]), zero4, 0, 0, 0);
+            dk[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_ds, frag8(tq[ct][0], tq[ct][1], tq[ct][0], tq[ct][1]), zero4, 0, 0, 0);
+        }
+        // dS through the wave's LDS tile as (hi << 16 | lo) dwords: the transposed and the skewed views
+        wave_lds_fence();                                  // previous iteration's LDS readers are done
+        buf[(4 * g + 0) * kA16RS + c] = perm_lo(sh01, sl01);
+        buf[(4 * g + 1) * kA16RS + c] = perm_hi(sh01, sl01);
+        buf[(4 * g + 2) * kA16RS + c] = perm_lo(sh23, sl23);
+        buf[(4 * g + 3) * kA16RS + c] = perm_hi(sh23, sl23);
+        wave_lds_fence();
+        // dq = scale * (dS . K + skew(dS) . Erel):  A[row i = c][k j = 4g + e]
+        {
+            const uint32_t* rowp = buf + c * kA16RS + 4 * g;
+            const bf16x8 a = frag_from_packed(rowp[0], rowp[1], rowp[2], rowp[3]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+                dq[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag8(tk[ct][0], tk[ct][1], tk[ct][0], tk[ct][1]), zero4, 0, 0, 0);
+        }
+#pragma unroll
+        for (int xt = 0; xt < 2; ++xt) {
+            uint32_t dd[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int x = 16 * xt + 4 * g + e;             // relative row
+                const int jj = x + c - 15;                     // key index seen from query c
+                const bool ok = x <= 30 && jj >= 0 && jj < 16;
+                const uint32_t t = buf[c * kA16RS + (ok ? jj : 0)];
+                dd[e] = ok ? t : 0u;
+            }
+            const bf16x8 a = frag_from_packed(dd[0], dd[1], dd[2], dd[3]);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const uint4 ep = erel_lds[xt * CT + ct][lane];
+                dq[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag8(ep.x, ep.y, ep.x, ep.y), dq[ct], 0, 0, 0);
+                dq[ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag8(ep.z, ep.w, 0u, 0u), dq[ct], 0, 0, 0);
+            }
+        }
+        // dErel[x] += sum_i dS[i][x + i - 15] Q_i (x scale at the end):  A[row x = 16 xt + c][k i = 4g + e]
+        if (live) {
+#pragma unroll
+            for (int xt = 0; xt < 2; ++xt) {
+                uint32_t dd[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int i = 4 * g + e, x = 16 * xt + c;
+                    const int jj = x + i - 15;
+                    const bool ok = x <= 30 && jj >= 0 && jj < 16;
+                    const uint32_t t = buf[i * kA16RS + (ok ? jj : 0)];
+                    dd[e] = ok ? t : 0u;
+                }
+                const bf16x8 a = frag_from_packed(dd[0], dd[1], dd[2], dd[3]);
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    de[xt][ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, frag8(tq[ct][0], tq[ct][1], tq[ct][0], tq[ct][1]),
+                                                                        de[xt][ct], 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float vq[CT], vk[CT], vv[CT];
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    vq[ct] = dq[ct][r] * scale;
+                    vk[ct] = dk[ct][r] * scale;
+                    vv[ct] = dv[ct][r];
+                }
+                const int64_t go = (n * 16 + 4 * g + r) * ldg + h * HD + CT * c;
+                store_ct_b16<CT>(d_qkv + go, vq);
+                store_ct_b16<CT>(d_qkv + go + d, vk);
+                store_ct_b16<CT>(d_qkv + go + 2 * d, vv);
+            }
+        }
+        cur = nxt;
+    }
+    float* dst = ws + (((int64_t)blockIdx.x * kA16Waves + wave) * H + h) * 31 * HD;
+#pragma unroll
+    for (int xt = 0; xt < 2; ++xt)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int x = 16 * xt + 4 * g + r;
+                if (x <= 30) dst[x * HD + CT * c + ct] = de[xt][ct][r] * scale;
+            }
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------
 static int a16_blocks_per_chunk(int64_t n_blocks, int H) {
     // ~8k wavefronts in flight: chunks * 4 waves * H ~ 8192
@@ -497,6 +736,19 @@ static int a16_bwd_t(const float* d_ctx, int64_t ldo, const float* qkv, int64_t 
                      int64_t n_blocks, int H, float drop_p, uint64_t seed, hipStream_t s, int* nsplit) {
     const int bpc = a16_blocks_per_chunk(n_blocks, H);
     const int chunks = (int)ceil_div(n_blocks, bpc);
+    if constexpr (B16 && IN16 && (HD == 32 || HD == 64)) {
+        // all-bf16 form outside the exact GEMM mode 0: every contraction on the bf16 matrix pipe (relattn16_bwd_mm16_kernel)
+        static const int mm16 = lab_env_int("VQCPC_RELATTN16_MM16", 1);      // lab builds: =0 keeps the fp32-MFMA contractions (A/B)
+        if (mm16 && tokens == nullptr && vqcpc_gemm_get_mode() != 0) {
+            hipLaunchKernelGGL((relattn16_bwd_mm16_kernel<HD>), dim3(chunks, H), dim3(kA16Waves * 64), 0, s,
+                               reinterpret_cast<const unsigned short*>(d_ctx), ldo, reinterpret_cast<const unsigned short*>(qkv), ldq,
+                               probs, e1, e2, reinterpret_cast<unsigned short*>(d_qkv), ldg, ws, n_blocks, H, bpc,
+                               1.0f / sqrtf((float)HD), drop_threshold(drop_p), 1.0f / (1.0f - drop_p), seed);
+            VQ_CHECK_LAUNCH("relattn16_bwd (mm16)");
+            *nsplit = chunks * kA16Waves;
+            return VQCPC_OK;
+        }
+    }
     hipLaunchKernelGGL((relattn16_bwd_kernel<HD, B16, IN16>), dim3(chunks, H), dim3(kA16Waves * 64), 0, s, d_ctx, ldo, qkv, ldq, tokens,
                        probs, e1, e2, d_qkv, ldg, ws, n_blocks, H, bpc, 1.0f / sqrtf((float)HD), drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed);

@@ -110,6 +110,11 @@ int vqcpc_block_table_gather(const float* table, const int64_t* tokens, float* o
 int64_t vqcpc_block_table_segsum_workspace(int64_t M, int L, int vmax, int C);
 int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
                              void* workspace, int64_t workspace_bytes, void* stream);
+/* the same with g [M][C] in bf16 (configs[4] bf16 path: the first layer's attention backward writes d q | k | v so,
+ * vqcpc_relattn16_bwd_b16 with the token indirection): fp32 accumulation of the upcast values, same order -- bit-identical to
+ * vqcpc_block_table_segsum on the same values in fp32; half the bytes in. */
+int vqcpc_block_table_segsum_b16(const void* g_bf16, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
+                                 void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Gradient of a plain row gather out[m] = table[idx[m]] (forward = vqcpc_block_table_gather with L = 1) for a table of
  * any size V: the decoder's `source_embeddings(source)` on merged codes and its shifted target-token lookup

@@ -894,6 +894,17 @@ def test_block_table_gather_and_segment_sum(ops, nblk, L, vmax, C):
     td.grad = None
     ops.BlockTableGatherFn.apply(td, tokens.cuda(), L).backward(dev(g))
     assert torch.equal(td.grad, first)
+    # the bf16-input form (configs[4] bf16 path): the same sums of the upcast values, bit for bit
+    from vqcpc_bach_amd import hip
+    gb = dev(g).bfloat16()
+    nb = hip.query('vqcpc_block_table_segsum_workspace', nblk * L, L, vmax, C)
+    outs = []
+    for name, gin in (('vqcpc_block_table_segsum', gb.float()), ('vqcpc_block_table_segsum_b16', gb)):
+        dt = torch.empty(vmax * L, C, device='cuda')
+        ws = hip.workspace(nb, 'cuda')
+        hip.call(name, gin, tokens.cuda(), dt, nblk * L, L, vmax, C, ws, nb)
+        outs.append(dt.clone())
+    assert torch.equal(outs[0], outs[1])
 
 
 # ----------------------------------------------------------------------------------------------------------------

@@ -411,42 +411,60 @@ __global__ __launch_bounds__(256) void block_table_gather_kernel(const float* __
 // atomics are 3x slower than the plain RMW here).
 constexpr int kSegU = 32;
 
+// G16: `g` points to bf16 elements (the bf16 path's first-layer attention backward writes d q | k | v so): half the bytes in, the
+// same fp32 accumulation of the upcast values.  A lane then owns TWO adjacent columns (one dword per row: 2-byte loads run at a
+// quarter of the rate, measured 5.7 ms against 1.36 ms for the fp32 form at configs[4]) and a workgroup 512 columns.
+template <bool G16>
 __global__ __launch_bounds__(256) void block_table_segsum_kernel(const float* __restrict__ g,
                                                                  const int64_t* __restrict__ tokens,
                                                                  float* __restrict__ ws, int64_t n_blocks,
                                                                  int blocks_per_chunk, int L, int vmax, int C) {
-    extern __shared__ __attribute__((aligned(16))) float acc[];          // [vmax][256]
-    for (int i = threadIdx.x; i < vmax * 256; i += 256) acc[i] = 0.0f;
+    constexpr int W = G16 ? 2 : 1;                                       // columns per lane
+    extern __shared__ __attribute__((aligned(16))) float acc[];          // [vmax][256 W]
+    for (int i = threadIdx.x; i < vmax * 256 * W; i += 256) acc[i] = 0.0f;
     __syncthreads();
     // (column tile, position) are the FAST launch indices: the L * ctiles workgroups of a chunk run together and read its
     // blocks as one contiguous stream (with the chunk index fast, concurrent workgroups each walked their own 1 KB-per-row
     // strided stream)
-    const int ctiles = (C + 255) >> 8;
+    const int ctiles = (C + 256 * W - 1) / (256 * W);
     const int ct = blockIdx.x % ctiles, p = (blockIdx.x / ctiles) % L, chunk = blockIdx.x / (ctiles * L);
-    const int col = ct * 256 + threadIdx.x;
+    const int col = (ct * 256 + threadIdx.x) * W;
     const bool cok = col < C;
     const int64_t b0 = (int64_t)chunk * blocks_per_chunk;
     const int64_t b1 = min(b0 + blocks_per_chunk, n_blocks);
     const float* gp = g + (cok ? col : 0);
-    float* mine = acc + threadIdx.x;
+    const unsigned short* gp16 = reinterpret_cast<const unsigned short*>(g) + (cok ? col : 0);
+    float* mine = acc + threadIdx.x * W;
     static_assert(kSegU <= 64, "one lane per row of a batch holds its token");
     for (int64_t b = b0; b < b1; b += kSegU) {
-        float v[kSegU];
+        float v[kSegU][W];
         // the token ids of the batch's rows: ONE load (lane u: row u) instead of one broadcast load per row -- half the vector-
         // memory operations of a batch; v_readlane hands them out as scalars
         const int tokv = (int)tokens[min(b + (int)(threadIdx.x & 63) % kSegU, b1 - 1) * L + p];
 #pragma unroll
         for (int u = 0; u < kSegU; ++u) {                                // branch-free: the tail re-reads the last row ...
             const int64_t row = min(b + u, b1 - 1) * L + p;
-            v[u] = b + u < b1 ? gp[row * C] : 0.0f;                      // ... and adds zero
+            if constexpr (G16) {
+                const uint32_t t = *reinterpret_cast<const uint32_t*>(gp16 + row * C);
+                v[u][0] = b + u < b1 ? __uint_as_float(t << 16) : 0.0f;
+                v[u][W - 1] = b + u < b1 ? __uint_as_float(t & 0xFFFF0000u) : 0.0f;
+            } else {
+                v[u][0] = b + u < b1 ? gp[row * C] : 0.0f;               // ... and adds zero
+            }
         }
 #pragma unroll
-        for (int u = 0; u < kSegU; ++u) mine[__builtin_amdgcn_readlane(tokv, u) * 256] += v[u];   // one lane per cell, rows ascending
+        for (int u = 0; u < kSegU; ++u) {                                // one lane per cell, rows ascending
+            float* cell = mine + __builtin_amdgcn_readlane(tokv, u) * (256 * W);
+#pragma unroll
+            for (int w = 0; w < W; ++w) cell[w] += v[u][w];
+        }
     }
     __syncthreads();
     if (cok) {
         float* dst = ws + (int64_t)chunk * vmax * L * C;
-        for (int t = 0; t < vmax; ++t) dst[((int64_t)t * L + p) * C + col] = acc[t * 256 + threadIdx.x];
+        for (int t = 0; t < vmax; ++t)
+#pragma unroll
+            for (int w = 0; w < W; ++w) dst[((int64_t)t * L + p) * C + col + w] = acc[(t * 256 + threadIdx.x) * W + w];
     }
 }
 
@@ -568,12 +586,14 @@ int64_t vqcpc_block_table_segsum_workspace(int64_t M, int L, int vmax, int C) {
     return (int64_t)segsum_chunks(std::max<int64_t>(M, 1) / std::max(L, 1)) * vmax * L * C * (int64_t)sizeof(float);
 }
 
-int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
-                             void* workspace, int64_t workspace_bytes, void* stream) {
+static int segsum_launch(const float* g, bool g16, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
+                         void* workspace, int64_t workspace_bytes, void* stream) {
     VQ_REQUIRE(g && tokens && d_table && workspace && M >= 1 && L >= 1 && vmax >= 1 && C >= 1 && M % L == 0,
                "block_table_segsum: bad arguments");
-    const size_t lds = (size_t)vmax * 256 * sizeof(float);
+    const int W = g16 ? 2 : 1;
+    const size_t lds = (size_t)vmax * 256 * W * sizeof(float);
     VQ_REQUIRE(lds <= 160 * 1024, "block_table_segsum: vocabulary of %d tokens does not fit the LDS accumulator", vmax);
+    VQ_REQUIRE(!g16 || (C % 2 == 0 && (reinterpret_cast<uintptr_t>(g) & 3u) == 0), "block_table_segsum_b16: C must be even, g 4-byte aligned");
     if (workspace_bytes < vqcpc_block_table_segsum_workspace(M, L, vmax, C)) {
         set_error("block_table_segsum: workspace too small");
         return VQCPC_EWORKSPACE;
@@ -583,13 +603,29 @@ int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_tab
     const int bpc = (int)ceil_div(n_blocks, chunks);
     const int nchunk = (int)ceil_div(n_blocks, bpc);
     hipStream_t s = (hipStream_t)stream;
-    if (lds > 64 * 1024)
-        (void)hipFuncSetAttribute((const void*)block_table_segsum_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(block_table_segsum_kernel, dim3((unsigned)(nchunk * L * ceil_div(C, 256))), dim3(256), lds, s, g, tokens,
-                       (float*)workspace, n_blocks, bpc, L, vmax, C);
+    if (lds > 64 * 1024) {
+        (void)hipFuncSetAttribute((const void*)block_table_segsum_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)block_table_segsum_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    if (g16)
+        hipLaunchKernelGGL(block_table_segsum_kernel<true>, dim3((unsigned)(nchunk * L * ceil_div(C, 512))), dim3(256), lds, s, g, tokens,
+                           (float*)workspace, n_blocks, bpc, L, vmax, C);
+    else
+        hipLaunchKernelGGL(block_table_segsum_kernel<false>, dim3((unsigned)(nchunk * L * ceil_div(C, 256))), dim3(256), lds, s, g, tokens,
+                           (float*)workspace, n_blocks, bpc, L, vmax, C);
     VQ_CHECK_LAUNCH("block_table_segsum");
     const int64_t total = (int64_t)vmax * L * C;
     return launch_reduce_splits((const float*)workspace, total, nchunk, d_table, total, 0, s);
+}
+
+int vqcpc_block_table_segsum(const float* g, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
+                             void* workspace, int64_t workspace_bytes, void* stream) {
+    return segsum_launch(g, false, tokens, d_table, M, L, vmax, C, workspace, workspace_bytes, stream);
+}
+
+int vqcpc_block_table_segsum_b16(const void* g_bf16, const int64_t* tokens, float* d_table, int64_t M, int L, int vmax, int C,
+                                 void* workspace, int64_t workspace_bytes, void* stream) {
+    return segsum_launch((const float*)g_bf16, true, tokens, d_table, M, L, vmax, C, workspace, workspace_bytes, stream);
 }
 
 int vqcpc_embedding_bwd(const float* g, int64_t ldg, const int64_t* sorted_idx, const int64_t* perm, float* d_table, int64_t M,

@@ -30,6 +30,7 @@ SIGNATURES = {
     'vqcpc_block_table_gather': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr]),
     'vqcpc_block_table_segsum_workspace': (c_i64, [c_i64, c_int, c_int, c_int]),
     'vqcpc_block_table_segsum': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
+    'vqcpc_block_table_segsum_b16': (c_int, [c_ptr, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_nt': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64,
                               c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr]),
     'vqcpc_cast_bf16': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_int, c_ptr]),

@@ -1411,15 +1411,24 @@ class EncoderLayerFn(torch.autograd.Function):
                 de1, de2, dg1, dbe1, dg2, dbe2 = accumulate_small((e1, e2, g1, be1, g2, be2), (de1, de2, dg1, dbe1, dg2, dbe2))
                 return (dx, None, None, None, None, None, None, None, None, dwqkv, dbqkv, dwo, dbo, de1, de2, dw1, db1, dw2, db2, dg1,
                         dbe1, dg2, dbe2)
-            dqkv = torch.empty(M, 3 * d, dtype=torch.float32, device=dev)
+            # bf16 path, block table (first layer): d q | k | v only feeds the segment sum below -> the attention backward writes it as
+            # bf16 (the rounding the in_proj's bf16 input-gradient operand would get anyway), the segment sum reads half the bytes
+            tab_b16 = (nat and tok is not None and ATT_B16_OUT and BF16_TAB_GRAD and L == 16 and qkv.shape[0] // L <= 80
+                       and bool(hip.query('vqcpc_relattn16_b16_supported', L, H, hd)))      # (80 tokens: the bf16 segment sum's LDS table)
+            dqkv = torch.empty(M, 3 * d, dtype=torch.bfloat16 if tab_b16 else torch.float32, device=dev)
             if tok is not None:
-                hip.call('vqcpc_relattn_tab_bwd', datt, d, qkv, 3 * d, tok, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd,
-                         p, s[0], ws, nbytes)
+                if tab_b16:
+                    hip.call('vqcpc_relattn16_bwd_b16', datt, d, qkv, 3 * d, tok, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, H, hd, p,
+                             s[0], ws, nbytes)
+                else:
+                    hip.call('vqcpc_relattn_tab_bwd', datt, d, qkv, 3 * d, tok, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd,
+                             p, s[0], ws, nbytes)
                 vmax = qkv.shape[0] // L                                  # table gradient = segment sum of d qkv
                 d_in = torch.empty_like(qkv)
                 nb2 = hip.query('vqcpc_block_table_segsum_workspace', M, L, vmax, 3 * d)
                 ws2 = hip.workspace(nb2, dev)
-                hip.call('vqcpc_block_table_segsum', dqkv, tok, d_in, M, L, vmax, 3 * d, ws2, nb2)
+                hip.call('vqcpc_block_table_segsum_b16' if tab_b16 else 'vqcpc_block_table_segsum', dqkv, tok, d_in, M, L, vmax,
+                         3 * d, ws2, nb2)
             else:
                 hip.call('vqcpc_relattn_bwd', datt, d, qkv, 3 * d, probs, e1, e2, dqkv, 3 * d, de1, de2, nblk, L, H, hd, p, s[0],
                          ws, nbytes)
@@ -1733,6 +1742,7 @@ BF16_RESIDUAL = os.environ.get('VQCPC_BF16_RESIDUAL', '1') != '0'      # A/B swi
 BF16_GRAD_SUMS = os.environ.get('VQCPC_BF16_GRAD_SUMS', '1') != '0'    # A/B switch: ... and the gradients of the residual branches (LayerNorm backward -> dgrad epilogue)
 BF16_SUMS = os.environ.get('VQCPC_BF16_SUMS', '1') != '0'              # A/B switch: ... and the residual sums s1 / s2 (LayerNorm inputs)
 BF16_GRAD_STREAM = os.environ.get('VQCPC_BF16_GRAD_STREAM', '1') != '0'  # A/B switch: ... and the main-stream gradient between sub-layers / layers (LayerNorm backward reads bf16 dy)
+BF16_TAB_GRAD = os.environ.get('VQCPC_BF16_TAB_GRAD', '0') != '0'        # opt-in (measured equal, profiles/r05_perf_log.md): the first layer's d q | k | v into the block-table segment sum in bf16
 BF16_ACT_STREAM = os.environ.get('VQCPC_BF16_ACT_STREAM', '1') != '0'    # A/B switch: ... and the output of a stack's interior layers (LN2 writes bf16 only, the next out-proj epilogue reads it)
 ATT_B16_OUT = os.environ.get('VQCPC_ATT_B16_OUT', '1') != '0'        # A/B switch: bf16 outputs straight from the L = 16 attention
 GRU_FUSED_STEPS = os.environ.get('VQCPC_GRU_FUSED', '1') != '0'      # A/B switch: one launch per step (csrc/gru.hip)

@@ -184,6 +184,15 @@ int vqcpc_gemm_nt_grad_splitk(const float* A, int64_t lda, const float* B, int64
                               int splits, const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add,
                               int64_t ldadd, const float* add2, int64_t ldadd2, void* workspace, int64_t workspace_bytes,
                               float* scale_state, void* stream);
+/* vqcpc_gemm_nt_grad_tail: the same product for the TAIL rows of a ragged launch on 64 x 128 output tiles, one per workgroup (the last
+ * 8 192 rows of 139 264 x 256 occupy all 256 CUs; no partial planes, no third round of 256-tiles).  Same arithmetic, product order
+ * and epilogue expression as the 256-tile kernel: without dropout a row carries the bits vqcpc_gemm_nt_grad / _f16x3 give it.
+ * Epilogue: + bias, dropout (element index (row0 + m) * N + c), + add (may be C: in place), + add2.  M a multiple of 64, N of 128,
+ * K of 32.  Replaces the same lines as vqcpc_gemm_nt_grad (transformer_custom.py:279-289, multihead_attention_custom.py:171,346). */
+int vqcpc_gemm_nt_grad_tail_supported(int64_t M, int N, int K);
+int vqcpc_gemm_nt_grad_tail(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                            const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add, int64_t ldadd,
+                            const float* add2, int64_t ldadd2, float* scale_state, void* stream);
 int vqcpc_gemm_tn_grad_supported(int64_t M, int N, int K);
 int64_t vqcpc_gemm_tn_grad_workspace(int64_t M, int N, int K);
 int vqcpc_gemm_tn_grad(const float* A, int64_t lda, const float* B, int64_t ldb, float* dW, float* db, int64_t M, int N, int K,

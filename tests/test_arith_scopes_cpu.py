@@ -26,6 +26,7 @@ def rec(monkeypatch):
     monkeypatch.setattr(ops, '_grad_cut', {})
     monkeypatch.setattr(ops, '_g3_plans', {})
     monkeypatch.setattr(ops, 'GRAD_SPLITK', True)       # the opt-in split-K remainder of ragged launches is part of what is tested
+    monkeypatch.setattr(ops, 'GRAD_TAIL', False)        # ... and the tail-row launch has its own test below
     monkeypatch.setattr(hip, 'workspace', lambda n, dev: torch.empty(16, dtype=torch.uint8), raising=False)
     monkeypatch.setattr(ops, '_f32', lambda t: t)        # the device check of the product path: operands here are `meta` tensors
     state = ops.gradient_arithmetic_state()
@@ -77,6 +78,39 @@ def test_forward_scope_routes_whole_round_products_to_the_three_product_kernel(r
     with torch.enable_grad(), ops.forward_arithmetic(owner):
         ops.gemm_nt(Z(M, 512), Z(N, 512), bias=bias)
     assert _names(rec).count('vqcpc_grad_amax') == 2 and tab.keys[0] == ('fnt', M, N, 512)
+
+
+def test_ragged_launches_take_whole_rounds_plus_the_tail_rows_on_small_tiles(rec, monkeypatch):
+    """The default plan of a launch whose 256-tiles leave at most a quarter of a round over (139 264 x 256 x K = 2.125 rounds): two
+    whole rounds on the 256-tile kernel + the last 8 192 rows on vqcpc_gemm_nt_grad_tail, in the forward scope (bias, dropout element
+    index continued at row0) and in the gradient scope (residual forms, in place); a fuller last round stays where it was."""
+    from vqcpc_bach_amd import ops
+    monkeypatch.setattr(ops, 'GRAD_SPLITK', False)
+    monkeypatch.setattr(ops, 'GRAD_TAIL', True)
+    ops.set_forward_arithmetic('f16x3')
+    ops.set_gradient_arithmetic('f16x3')
+    owner = _Owner()
+    M, N = 256 * 544, 256
+    assert ops._g3_plan(M, N, 1024) == (512 * 256, -1) and ops._g3_plan(M, N, 256) == (512 * 256, -1)
+    assert ops._g3_plan(256 * 384, N, 512) is None       # 1.5 rounds: half a round left, too much for the small tiles -> six products
+    assert ops._g3_plan(256 * 512, N, 512) == (256 * 512, 0)
+    bias, res = Z(N), Z(M, N)
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        ops.gemm_nt(Z(M, 1024), Z(N, 1024), bias=bias, drop_p=0.1, seed=3, add=res)
+        ops.gemm_nt(Z(M, 256), Z(N, 256), bias=bias)
+    kernels = [n for n in _names(rec) if n.startswith('vqcpc_gemm')]
+    assert kernels == ['vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad_tail'] * 2, kernels
+    main, tail = rec[[c[0] for c in rec].index('vqcpc_gemm_nt_f16x3')][1], rec[[c[0] for c in rec].index('vqcpc_gemm_nt_grad_tail')][1]
+    assert main[6] == 512 * 256 and tail[6] == 32 * 256 and tail[12] == 512 * 256 and abs(tail[10] - 0.1) < 1e-7 and tail[11] == 3
+    assert tail[9] is bias and tail[-1] is main[-1]      # one scale site for both launches
+    del rec[:]
+    with ops.direct_weight_gradients(owner):
+        ops.gemm_nt(Z(M, 768), Z(N, 768), add=res)
+        acc = torch.empty(M, N, device='meta')
+        out = ops.gemm_nt_residual(Z(M, 1024), Z(N, 1024), acc)
+    kernels = [n for n in _names(rec) if n.startswith('vqcpc_gemm')]
+    assert kernels == ['vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt_grad_tail'] * 2, kernels
+    assert out is acc or out.data_ptr() == acc.data_ptr()
 
 
 def test_forward_scope_is_inert_outside_training_and_by_default(rec):

@@ -2095,6 +2095,106 @@ def test_f16x3_splitk_remainder_launch(ops, bf16x6, M, N, K, splits):
     assert float((full - part).abs().max() / full.abs().max()) < 3e-6
 
 
+@pytest.mark.parametrize('M,N,K', [(8192, 256, 1024), (8192, 256, 256), (256, 512, 96), (64, 128, 32), (192, 384, 160)])
+def test_f16x3_tail_rows_kernel(ops, bf16x6, M, N, K):
+    """vqcpc_gemm_nt_grad_tail (the last rows of a ragged launch on 64 x 128 tiles): bit for bit the 256-tile kernel's rows for every
+    epilogue without dropout -- none, + add, + add + add2, in place, + bias, + bias + add --, the 256-tile kernel's dropout pattern at
+    the same global rows (row0), fp32-class against fp64, deterministic, and it reports the operands' amax."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn(M, K, device='cuda', generator=gen) * 1e-3
+    b = torch.randn(N, K, device='cuda', generator=gen) * 0.05
+    add = torch.randn(M, N, device='cuda', generator=gen) * 1e-4
+    add2 = torch.randn(M, N, device='cuda', generator=gen) * 1e-4
+    bias = torch.randn(N, device='cuda', generator=gen) * 1e-4
+    st = _grad_state(a, b)
+    assert hip.query('vqcpc_gemm_nt_grad_tail_supported', M, N, K) == 1
+    assert hip.query('vqcpc_gemm_nt_grad_tail_supported', M + 32, N, K) == 0 and hip.query('vqcpc_gemm_nt_grad_tail_supported', M, N + 64, K) == 0
+
+    def tail(out=None, bias=None, drop_p=0.0, seed=0, row0=0, add=None, add2=None, state=st):
+        out = torch.empty(M, N, device='cuda') if out is None else out
+        hip.call('vqcpc_gemm_nt_grad_tail', a, K, b, K, out, N, M, N, K, bias, float(drop_p), int(seed), int(row0), add,
+                 0 if add is None else N, add2, 0 if add2 is None else N, state)
+        return out
+
+    ref = a.double() @ b.double().t()
+    plain = tail()
+    assert torch.equal(plain, tail()), 'deterministic'
+    assert _rms(plain, ref) < 1e-6
+    assert float(st[2]) == float(a.abs().max()) and float(st[3]) == float(b.abs().max())
+    acc = add.clone()
+    tail(out=acc, add=acc)                                        # the residual already in C
+    assert torch.equal(acc, tail(add=add))
+    assert torch.equal(tail(add=add), plain + add) and torch.equal(tail(add=add, add2=add2), plain + add + add2)
+    assert torch.equal(tail(bias=bias), plain + bias) and torch.equal(tail(bias=bias, add=add), plain + bias + add)
+    # against the 256-tile kernel on the same rows (zero rows below, so that M and N are whole 256-tiles)
+    Mp, Np = -(-M // 256) * 256, -(-N // 256) * 256
+    ap = torch.zeros(Mp, K, device='cuda'); ap[:M] = a
+    bp = torch.zeros(Np, K, device='cuda'); bp[:N] = b
+    big = _nt_grad(ap, bp, st.clone())
+    assert torch.equal(big[:M, :N], plain), 'the 256-tile kernel gives these rows the same bits'
+    if N == Np:
+        # dropout: the element index is (row0 + row) * N + col -- rows [row0, row0 + M) of a taller launch of the 256-tile kernel
+        row0 = 512
+        tall_a = torch.cat([torch.zeros(row0, K, device='cuda'), ap])
+        tall_add = torch.zeros(row0 + Mp, N, device='cuda'); tall_add[row0:row0 + M] = add
+        full = _nt_f16x3(tall_a, b, st.clone(), bias, drop_p=0.1, seed=9, add=tall_add)[row0:row0 + M]
+        part = tail(bias=bias, drop_p=0.1, seed=9, row0=row0, add=add)
+        assert torch.equal((full - add) == 0, (part - add) == 0), 'dropout pattern'
+        assert 0.05 < float(((part - add) == 0).float().mean()) < 0.15
+        assert float((full - part).abs().max() / full.abs().max()) < 1e-6
+
+
+def test_f16x3_ragged_rounds_take_whole_rounds_plus_the_tail_rows(ops, bf16x6):
+    """ops._g3_plan at the C1 shapes that do not fill whole rounds (139 264 x 256 x K: 544 tiles): 512 tiles on the 256-tile kernel,
+    the last 8 192 rows on vqcpc_gemm_nt_grad_tail, inside the forward scope and inside the gradient scope -- the dropout pattern
+    of the six-product kernel, fp32-class agreement with it, and the in-place residual form equal to the out-of-place one."""
+    from vqcpc_bach_amd import hip
+    M, N = 139264, 256
+    saved = ops.GRAD_SPLITK, ops.GRAD_TAIL
+    ops.GRAD_SPLITK, ops.GRAD_TAIL = False, True
+    prev_f, prev_g = ops.set_forward_arithmetic('f16x3'), ops.set_gradient_arithmetic('f16x3')
+    raw = hip.call
+    try:
+        for K in (1024, 256):
+            assert ops._g3_plan(M, N, K) == (131072, -1)
+            gen = torch.Generator(device='cuda').manual_seed(5 + K)
+            a = torch.randn(M, K, device='cuda', generator=gen)
+            w = torch.randn(N, K, device='cuda', generator=gen) * K ** -0.5
+            bias = torch.randn(N, device='cuda', generator=gen) * 0.1
+            res = torch.randn(M, N, device='cuda', generator=gen)
+
+            class Flat:
+                flat = torch.zeros(4, device='cuda')
+            owner = Flat()
+            calls = []
+            hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+            six = ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=4, add=res)
+            with torch.enable_grad(), ops.forward_arithmetic(owner):
+                fwd = ops.gemm_nt(a, w, bias=bias, drop_p=0.1, seed=4, add=res)
+            assert calls.count('vqcpc_gemm_nt_f16x3') == 1 and calls.count('vqcpc_gemm_nt_grad_tail') == 1
+            with ops.direct_weight_gradients(owner):
+                g = ops.gemm_nt(a, w, add=res)
+                acc = res.clone()
+                g2 = ops.gemm_nt_residual(a, w, acc)
+            hip.call = raw
+            assert calls.count('vqcpc_gemm_nt_grad_tail') == 3 and g2.data_ptr() == acc.data_ptr()
+            # the dropout pattern of the six-product kernel (a kept product below half an ulp of its residual looks dropped: a few in 35 M)
+            bad = ((six - res) == 0) != ((fwd - res) == 0)
+            assert int(bad.sum()) <= 4 and (not bad.any() or float(torch.maximum((six - res).abs(), (fwd - res).abs())[bad].max()) < 1e-5)
+            assert 0.09 < float(((fwd - res)[131072:] == 0).float().mean()) < 0.11
+            assert float((six - fwd).abs().max() / six.abs().max()) < 3e-6
+            assert torch.equal(g, g2)
+            rows = torch.cat([torch.arange(0, 512), torch.arange(131072 - 256, 131072 + 256), torch.arange(M - 256, M)]).cuda()
+            ref = a[rows].double() @ w.double().t() + res[rows].double()
+            assert _rms(g[rows], ref) < 1e-6
+    finally:
+        hip.call = raw
+        ops.GRAD_SPLITK, ops.GRAD_TAIL = saved
+        ops.set_forward_arithmetic(prev_f)
+        ops.set_gradient_arithmetic(prev_g)
+
+
 def test_f16x3_ragged_rounds_take_whole_rounds_plus_a_splitk_remainder(ops, bf16x6):
     """ops._g3_plan at the C1 shape that does not fill whole rounds (139 264 x 256 x 1024: 544 tiles): 512 tiles on one launch, 32
     tiles x 8 K slices on the remainder launch, inside the forward scope and inside the gradient scope -- against fp64 on a row
@@ -2102,6 +2202,7 @@ def test_f16x3_ragged_rounds_take_whole_rounds_plus_a_splitk_remainder(ops, bf16
     from vqcpc_bach_amd import hip
     M, N, K = 139264, 256, 1024
     saved_sk, ops.GRAD_SPLITK = ops.GRAD_SPLITK, True             # opt-in (VQCPC_GRAD_SPLITK=1)
+    saved_tail, ops.GRAD_TAIL = ops.GRAD_TAIL, False              # (the default plan of these shapes: the tail-row launch, tested above)
     assert ops._g3_plan(M, N, K) == (131072, 8) and ops._g3_plan(M, N, 256) is None and ops._g3_plan(557056, N, K) == (557056, 0)
     gen = torch.Generator(device='cuda').manual_seed(5)
     a = torch.randn(M, K, device='cuda', generator=gen)
@@ -2128,6 +2229,7 @@ def test_f16x3_ragged_rounds_take_whole_rounds_plus_a_splitk_remainder(ops, bf16
     finally:
         hip.call = raw
         ops.GRAD_SPLITK = saved_sk
+        ops.GRAD_TAIL = saved_tail
         ops.set_forward_arithmetic(prev_f)
         ops.set_gradient_arithmetic(prev_g)
     assert torch.equal((six - res) == 0, (fwd - res) == 0)

@@ -76,6 +76,29 @@ __device__ __forceinline__ void g3_amax_publish(float amax, float* slot) {
     if ((threadIdx.x & 63) == 0 && amax > 0.0f) atomicMax(reinterpret_cast<unsigned int*>(slot), __float_as_uint(amax));
 }
 
+// amax of a WORKGROUP -> one atomic max per operand.  Atomics on one address retire one by one at the memory side (measured on the
+// tail-row kernel below: ~11.5 ns each -- 256 workgroups x 8 waves x 2 operands = 4 096 of them took 47 us, most of that launch):
+// the eight waves' values meet in LDS first.  `lds`: 64 bytes of the workgroup's LDS that no wave still reads after the barrier.
+__device__ __forceinline__ void g3_amax_publish_wg(float amax_a, float amax_b, float* state, unsigned char* lds) {
+    amax_a = wave_max(amax_a);
+    amax_b = wave_max(amax_b);
+    __syncthreads();                                     // every wave is done with the operand slots
+    float* red = reinterpret_cast<float*>(lds);
+    if ((threadIdx.x & 63) == 0) {
+        red[threadIdx.x >> 6] = amax_a;
+        red[8 + (threadIdx.x >> 6)] = amax_b;
+    }
+    __syncthreads();
+    if (threadIdx.x < 16) {                              // lanes 0-7: operand A, 8-15: operand B
+        float v = red[threadIdx.x];
+        v = fmaxf(v, __shfl_xor(v, 4, 64));
+        v = fmaxf(v, __shfl_xor(v, 2, 64));
+        v = fmaxf(v, __shfl_xor(v, 1, 64));
+        if ((threadIdx.x & 7) == 0 && v > 0.0f)
+            atomicMax(reinterpret_cast<unsigned int*>(state + 2 + (threadIdx.x >> 3)), __float_as_uint(v));
+    }
+}
+
 // =====================================================================================================================
 // dgrad: C[M, N] = epilogue(A[M, K] . B[N, K]^T), A = output gradient rows, B = W^T rows (ops.transpose)
 // EPI in {0, E_ADD, E_ADD | E_ADD2, E_GATEBITS, G_ACCUM} (gradient products) and the forward forms of vqcpc_gemm_nt_f16x3:
@@ -402,8 +425,7 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
         G_STEP(y)
     }
     // the clamped run-ahead requests re-read the last tile: amax of real data only
-    g3_amax_publish(amax_a, state + 2);
-    g3_amax_publish(amax_b, state + 3);
+    g3_amax_publish_wg(amax_a, amax_b, state, smemg);
 #undef G_STEP
 #undef G_S
 #undef G_RB
@@ -618,7 +640,7 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_tn_g3_kernel(const float* _
         }
     }
     // each operand's amax goes to its own slot (the waves of one operand are uniform)
-    g3_amax_publish(amax, state + 2 + opnd);
+    g3_amax_publish_wg(opnd ? 0.0f : amax, opnd ? amax : 0.0f, state, smemq);
     if (want_bias) {
         __syncthreads();
         float* red = reinterpret_cast<float*>(smemq);          // [4 row quads][256]
@@ -670,6 +692,126 @@ __global__ __launch_bounds__(256) void g3_splitk_epilogue_kernel(const float* __
             v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
         }
         *reinterpret_cast<float4*>(C + row * ldc + col) = v;
+    }
+}
+
+// =====================================================================================================================
+// The TAIL rows of a ragged launch (139 264 x 256 = 2.125 rounds of 256-tiles on 256 persistent workgroups: two whole rounds on
+// gemm_nt_g3_kernel, the last 8 192 rows here): 64 x 128 output tiles, one per workgroup, so that the few rows left still occupy
+// every CU (8 192 x 256 -> 256 workgroups) without partial planes (the split-K remainder parks 64 MB per launch) and without a
+// third round of 256-tiles.  Same arithmetic, same order of the three products per 16 contraction elements and the same epilogue
+// expression as gemm_nt_g3_kernel: a row computed here carries the bits the 256-tile kernel gives it.
+// 8 waves of 32 x 32 (wm = row half, wn = column quarter), K steps of 32 = two 16-element halves in the plane image of the
+// 256-tile kernel (32-byte rows, 16-byte chunks XOR-swizzled by bit 3 of the row), two LDS slots, one barrier per step: fragments
+// of step j, split + LDS write of step j+1 (requested during step j-1), request of step j+2, six MFMAs.  Not a tuned schedule:
+// this kernel runs 1/17 of a ragged launch's rows.
+// =====================================================================================================================
+constexpr int kRM = 64, kRN = 128, kRBK = 32;
+constexpr int kRPA = kRM * 32, kRPB = kRN * 32;          // bytes per A / B plane of one 16-element half
+constexpr int kRHalf = 2 * kRPA + 2 * kRPB + 128;        // A.h | A.m | B.h | B.m (+ 128 B: the two halves of a row on different banks)
+constexpr int kRSlot = 2 * kRHalf;
+
+__global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float* __restrict__ A, int64_t lda,
+                                                                   const float* __restrict__ B, int64_t ldb,
+                                                                   float* __restrict__ C, int64_t ldc, int N, int K, int tiles_n,
+                                                                   EpiParams ep, float* __restrict__ state) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smemr[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 2, wn = wave & 3;
+    const int li = lane & 31, kh = lane >> 5;
+    const int t = xcd_swizzle((int)blockIdx.x, (int)gridDim.x);
+    const int64_t m0 = (int64_t)(t / tiles_n) * kRM;
+    const int n0 = (t % tiles_n) * kRN;
+    const int T = K / kRBK;
+
+    const int ea = g3_scale_exp(state[0]), eb = g3_scale_exp(state[1]);
+    const float sa = g3_pow2(ea), sb = g3_pow2(eb), inv = g3_pow2(-(ea + eb));
+    float amax_a = 0.0f, amax_b = 0.0f;
+
+    // staging: 8 lanes cover the 128 bytes of one row's K step; q = 16-byte piece, q >> 2 = half, (q & 3) * 4 = first element
+    const int s_row = tid >> 3, q = tid & 7, c4 = (q & 3) * 4;
+    const float* a_src = A + (m0 + s_row) * lda + q * 4;
+    const float* b_src = B + ((int64_t)n0 + s_row) * ldb + q * 4;
+    const int64_t b_src1 = (int64_t)64 * ldb;
+    const int st_half = (q >> 2) * kRHalf;
+    const int o_a = s_row * 32 + ((((c4 >> 3) ^ (s_row >> 3)) & 1) << 4) + (c4 & 7) * 2;      // rows s_row and s_row + 64: same swizzle bit
+    const int st_a = st_half + o_a, st_b0 = st_half + 2 * kRPA + o_a, st_b1 = st_b0 + 64 * 32;
+    float4 ra, rb0, rb1;
+#define R_LOAD(KT)                                                                         \
+    {                                                                                      \
+        ra = *reinterpret_cast<const float4*>(a_src + (int64_t)(KT) * kRBK);               \
+        rb0 = *reinterpret_cast<const float4*>(b_src + (int64_t)(KT) * kRBK);              \
+        rb1 = *reinterpret_cast<const float4*>(b_src + b_src1 + (int64_t)(KT) * kRBK);     \
+    }
+#define R_STORE(WB)                                                                        \
+    {                                                                                      \
+        uint2 h_, m_;                                                                      \
+        g3_amax4(ra, amax_a);                                                              \
+        g3_split4(ra, sa, h_, m_);                                                         \
+        *reinterpret_cast<uint2*>((WB) + st_a) = h_;                                       \
+        *reinterpret_cast<uint2*>((WB) + st_a + kRPA) = m_;                                \
+        g3_amax4(rb0, amax_b);                                                             \
+        g3_split4(rb0, sb, h_, m_);                                                        \
+        *reinterpret_cast<uint2*>((WB) + st_b0) = h_;                                      \
+        *reinterpret_cast<uint2*>((WB) + st_b0 + kRPB) = m_;                               \
+        g3_amax4(rb1, amax_b);                                                             \
+        g3_split4(rb1, sb, h_, m_);                                                        \
+        *reinterpret_cast<uint2*>((WB) + st_b1) = h_;                                      \
+        *reinterpret_cast<uint2*>((WB) + st_b1 + kRPB) = m_;                               \
+    }
+    const int swz = ((kh ^ (li >> 3)) & 1) << 4;
+    const int fa_off = (wm * 32 + li) * 32 + swz;
+    const int fb_off = 2 * kRPA + (wn * 32 + li) * 32 + swz;
+
+    floatx16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    R_LOAD(0)
+    R_STORE(smemr)
+    if (T > 1) R_LOAD(1)
+    __syncthreads();
+#pragma unroll 1
+    for (int j = 0; j < T; ++j) {
+        const unsigned char* cur = smemr + (j & 1) * kRSlot;
+        unsigned char* nxt = smemr + ((j + 1) & 1) * kRSlot;
+        half8 fa[2][2], fb[2][2];                        // [half][h | m]
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            fa[hf][0] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fa_off);
+            fa[hf][1] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fa_off + kRPA);
+            fb[hf][0] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fb_off);
+            fb[hf][1] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fb_off + kRPB);
+        }
+        if (j + 1 < T) {
+            R_STORE(nxt)
+            if (j + 2 < T) R_LOAD(j + 2)
+        }
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {                 // m.h, h.m, h.h: the order of gemm_nt_g3_kernel
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][1], fb[hf][0], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][0], fb[hf][1], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][0], fb[hf][0], acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+#undef R_STORE
+#undef R_LOAD
+    g3_amax_publish_wg(amax_a, amax_b, state, smemr);
+
+    // epilogue: lane (li, kh) holds column li of rows 4 kh + (r & 3) + 8 (r >> 2) of the wave's 32 x 32 block
+    const int col = n0 + wn * 32 + li;
+    const int64_t row_base = m0 + wm * 32 + 4 * kh;
+    const float bv = ep.bias ? ep.bias[col] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
+        float v = acc[r] * inv;                          // exact: a power of two
+        if (ep.bias) v += bv;
+        if (ep.thr) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * (uint64_t)N + (uint64_t)col, ep.thr, ep.inv_keep);
+        if (ep.add) v += ep.add[row * ep.ldadd + col];   // may be C itself (in place): read and written by this lane only
+        if (ep.add2) v += ep.add2[row * ep.ldadd2 + col];
+        C[row * ldc + col] = v;
     }
 }
 
@@ -833,6 +975,48 @@ int vqcpc_gemm_nt_grad_splitk(const float* A, int64_t lda, const float* B, int64
                        (const float*)workspace, ep.split_plane, splits, C, ldc, M, N, bias, drop_threshold(drop_p),
                        1.0f / (1.0f - drop_p), seed, row0, add, ldadd, add2, ldadd2);
     VQ_CHECK_LAUNCH("gemm_nt_g3 split-K epilogue");
+    return VQCPC_OK;
+}
+
+// The tail rows of a ragged launch on 64 x 128 tiles (gemm_nt_g3_tail_kernel): every epilogue the ragged launches of a training
+// step use -- none | + add | + add + add2 (add may be C: in place) for the input gradients, + bias | + bias + add | + bias +
+// dropout + add for the forward -- with row0 = global row of the first row of this call (dropout element index).
+int vqcpc_gemm_nt_grad_tail_supported(int64_t M, int N, int K) {
+    return (M >= kRM && (M % kRM) == 0 && N >= kRN && (N % kRN) == 0 && K >= kRBK && (K % kRBK) == 0 &&
+            (M / kRM) * (N / kRN) < (1ll << 30)) ? 1 : 0;
+}
+
+int vqcpc_gemm_nt_grad_tail(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                            const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add, int64_t ldadd,
+                            const float* add2, int64_t ldadd2, float* scale_state, void* stream) {
+    VQ_REQUIRE(A && B && C && scale_state, "gemm_nt_grad_tail: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_nt_grad_tail_supported(M, N, K), "gemm_nt_grad_tail: M a multiple of 64, N of 128, K of 32, got M=%lld N=%d K=%d",
+               (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B),
+               "gemm_nt_grad_tail: bad leading dimensions / alignment");
+    VQ_REQUIRE(!(add2 && !add) && !(add && ldadd < N) && !(add2 && ldadd2 < N) && drop_p >= 0.f && drop_p < 1.f,
+               "gemm_nt_grad_tail: bad epilogue operands");
+    EpiParams ep{};
+    ep.bias = bias;
+    ep.thr = drop_threshold(drop_p);
+    ep.inv_keep = 1.0f / (1.0f - drop_p);
+    ep.seed = seed;
+    ep.row0 = row0;
+    ep.add = add;
+    ep.ldadd = ldadd;
+    ep.add2 = add2;
+    ep.ldadd2 = ldadd2;
+    ep.gate_scale = 1.0f;
+    const int tn = N / kRN;
+    const size_t lds = (size_t)2 * kRSlot;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_g3_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_g3_tail_kernel, dim3((unsigned)((M / kRM) * tn)), dim3(kGThreads), lds, (hipStream_t)stream, A, lda, B,
+                       ldb, C, ldc, N, K, tn, ep, scale_state);
+    VQ_CHECK_LAUNCH("gemm_nt_g3 (tail rows)");
     return VQCPC_OK;
 }
 

@@ -64,6 +64,9 @@ SIGNATURES = {
     'vqcpc_gemm_nt_grad_splitk_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_nt_grad_splitk': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_int, c_ptr, c_f32, c_u64,
                                           c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
+    'vqcpc_gemm_nt_grad_tail_supported': (c_int, [c_i64, c_int, c_int]),
+    'vqcpc_gemm_nt_grad_tail': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_f32, c_u64, c_i64, c_ptr,
+                                        c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     'vqcpc_gemm_tn_grad_supported': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_grad_workspace': (c_i64, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_grad': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr,

@@ -158,6 +158,9 @@ def _grad_scales_of(owner, tag):
     return t
 
 
+# launches of fewer 256-tiles than CUs (one under-filled round) from this many tiles on; 1 << 30: never (A/B switch).  34 816 x 256 x K
+# (136 tiles) per launch, graph-timed (tools/bench_g3_tail.py): K = 1024 124 us on six products, 79 on the f16x3 kernel; K = 256 39 / 30
+GRAD_ONE_ROUND_MIN_TILES = int(os.environ.get('VQCPC_GRAD_ONE_ROUND_MIN_TILES', '128'))
 _grad_cut = {}                 # (M, N) -> rows of the dgrad launch that go through the three-product kernel (0: none)
 
 
@@ -170,7 +173,7 @@ def _grad_rows(M, N, K):
     cut into whole rounds + a six-product remainder (GRAD_CUT_MIN_K) were measured twice at C1 (profiles/r05_perf_log.md) and
     were slower both times -- K = 256 alone: 0.228 -> 0.251 ms per call; every K >= 512 launch with the remainder through the
     split-K path: the step went from 24.5 to 24.8 ms -- so they stay on the six-product path, which cuts such launches itself."""
-    hit = _grad_cut.get((M, N, K, GRAD_MIN_TILES))
+    hit = _grad_cut.get((M, N, K, GRAD_MIN_TILES, GRAD_ONE_ROUND_MIN_TILES))
     if hit is not None:
         return hit
     rows = 0
@@ -184,7 +187,9 @@ def _grad_rows(M, N, K):
                 rows = M
             elif K >= GRAD_CUT_MIN_K:
                 rows = ((tiles // 256) * 256 // tn) * 256
-    _grad_cut[(M, N, K, GRAD_MIN_TILES)] = rows
+        elif GRAD_ONE_ROUND_MIN_TILES <= tiles < 256 and M % 256 == 0:
+            rows = M              # one under-filled round (34 816 x 256: 136 tiles)
+    _grad_cut[(M, N, K, GRAD_MIN_TILES, GRAD_ONE_ROUND_MIN_TILES)] = rows
     return rows
 
 
@@ -192,15 +197,21 @@ def _grad_rows(M, N, K):
 # (profiles/r05_perf_log.md): 23.04 / 23.10 -> 22.99 / 22.92 ms/step -- the eight partial planes of the remainder (64 MB written and
 # read back per launch) cost most of what the third round cost; off by default
 GRAD_SPLITK = os.environ.get('VQCPC_GRAD_SPLITK', '0') == '1'
+# ragged rounds = whole rounds of 256-tiles + the TAIL rows on 64 x 128 tiles (vqcpc_gemm_nt_grad_tail: one launch, every CU busy, no
+# partial planes): at most GRAD_TAIL_MAX_FILL of a round left over (139 264 x 256: 32 tiles of a 256-tile round); VQCPC_GRAD_TAIL=0:
+# such launches stay on the six-product path (A/B switch)
+GRAD_TAIL = os.environ.get('VQCPC_GRAD_TAIL', '1') == '1'
+GRAD_TAIL_MAX_FILL = float(os.environ.get('VQCPC_GRAD_TAIL_MAX_FILL', '0.25'))
 _g3_plans = {}
 
 
 def _g3_plan(M, N, K):
     """How an (M, K) x (N, K)^T product of a training step runs on the three-product kernel: None (not at all), (M, 0) (one launch:
-    its 256-tiles fill whole rounds of the 256 persistent workgroups to >= GRAD_ROUND_FILL), or (rows, splits): the whole rounds as
+    its 256-tiles fill whole rounds of the 256 persistent workgroups to >= GRAD_ROUND_FILL), (rows, splits): the whole rounds as
     one launch + the remaining rows as a split-K launch of the same kernel (vqcpc_gemm_nt_grad_splitk: `splits` K slices, so that
-    the few tiles of the remainder still occupy every CU).  139 264 x 256 x 1024: 512 tiles + 32 tiles x 8 slices."""
-    key = (M, N, K, GRAD_MIN_TILES, GRAD_ROUND_FILL, GRAD_SPLITK)
+    the few tiles of the remainder still occupy every CU; opt-in), or (rows, -1): the whole rounds + the remaining rows on 64 x 128
+    tiles (vqcpc_gemm_nt_grad_tail).  139 264 x 256 x K: 512 tiles + 8 192 tail rows = 256 small tiles."""
+    key = (M, N, K, GRAD_MIN_TILES, GRAD_ONE_ROUND_MIN_TILES, GRAD_ROUND_FILL, GRAD_SPLITK, GRAD_TAIL, GRAD_TAIL_MAX_FILL)
     hit = _g3_plans.get(key)
     if hit is not None:
         return hit[0]
@@ -219,6 +230,15 @@ def _g3_plan(M, N, K):
                 if rem_tiles * sp <= 256 and K % sp == 0 and (K // sp) % 32 == 0 and K // sp >= 64:
                     plan = (main_rows, sp)
                     break
+    if (plan is None and GRAD_TAIL and rows == 0 and GRAD_MIN_TILES > 0 and M % 256 == 0 and N % 256 == 0
+            and hip.query('vqcpc_gemm_nt_grad_supported', M, N, K)):
+        tn = N // 256
+        tiles = (M // 256) * tn
+        main_rows = ((tiles // 256) * 256 // tn) * 256
+        rem_tiles = (M - main_rows) // 256 * tn
+        if (tiles > 256 and main_rows > 0 and 0 < rem_tiles <= GRAD_TAIL_MAX_FILL * 256
+                and hip.query('vqcpc_gemm_nt_grad_tail_supported', M - main_rows, N, K)):
+            plan = (main_rows, -1)
     _g3_plans[key] = (plan,)
     return plan
 
@@ -243,6 +263,10 @@ def _g3_nt(scales, key, a, lda, b, ldb, out, ldc, M, N, K, plan, bias=None, drop
         return out
     launch(0, m_main)             # the dropout element index of the main rows starts at row 0, as in the unsplit launch
     rem = M - m_main
+    if splits < 0:                # the tail rows on 64 x 128 tiles
+        hip.call('vqcpc_gemm_nt_grad_tail', a[m_main:], lda, b, ldb, out[m_main:], ldc, rem, N, K, bias, float(drop_p), int(seed), m_main,
+                 None if add is None else add[m_main:], lda_, None if add2 is None else add2[m_main:], lda2_, st)
+        return out
     nbytes = hip.query('vqcpc_gemm_nt_grad_splitk_workspace', rem, N, splits)
     ws = hip.workspace(nbytes, a.device)
     hip.call('vqcpc_gemm_nt_grad_splitk', a[m_main:], lda, b, ldb, out[m_main:], ldc, rem, N, K, splits, bias, float(drop_p), int(seed),
@@ -342,7 +366,7 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
 
 def _splitk_operands_ok(plan, out, ldc, add, lda_, add2, lda2_, bias):
     """Alignment the float4 epilogue of the split-K remainder needs (nothing for a single launch)."""
-    if not plan[1]:
+    if plan[1] <= 0:
         return True
     ok = ldc % 4 == 0 and out.data_ptr() % 16 == 0
     for t, ld in ((add, lda_), (add2, lda2_)):

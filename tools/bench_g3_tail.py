@@ -77,3 +77,34 @@ for M, N, K in ((34816, 256, 1024), (34816, 256, 256), (34816, 1024, 256), (6963
         t3 = timed(lambda: main_rows(a, b, out, st, M))
         line += f' | 256-tiles f16x3 {t3 * 1e3:7.1f} {fl / t3 / 1e9:6.1f}'
     print(line, flush=True)
+
+print('fixed cost per launch of the 256-tile kernels: time against whole rounds (256 tiles each), least-squares line a + b * rounds')
+for N, K in ((256, 256), (256, 1024), (1024, 256)):
+    pts = []
+    for rounds in (1, 2, 3, 4, 6, 8):
+        M = rounds * 65536 * 256 // N
+        a = torch.randn(M, K, device='cuda', generator=gen) * 1e-3
+        b = torch.randn(N, K, device='cuda', generator=gen) * 0.05
+        out = torch.empty(M, N, device='cuda')
+        st = state_for(a, b)
+        pts.append((rounds, timed(lambda: main_rows(a, b, out, st, M)) * 1e3))
+        del a, out
+    n = len(pts); sx = sum(p[0] for p in pts); sy = sum(p[1] for p in pts)
+    sxx = sum(p[0] ** 2 for p in pts); sxy = sum(p[0] * p[1] for p in pts)
+    bb = (n * sxy - sx * sy) / (n * sxx - sx * sx); aa = (sy - bb * sx) / n
+    print(f'NT N = {N:4d} K = {K:4d}: ' + ' '.join(f'{r}:{t:.1f}' for r, t in pts) + f'  -> a = {aa:.1f} us, b = {bb:.1f} us per round', flush=True)
+for N, K in ((256, 256), (1024, 256)):
+    pts = []
+    for M in (65536, 131072, 262144, 524288):
+        a = torch.randn(M, N, device='cuda', generator=gen) * 1e-3
+        b = torch.randn(M, K, device='cuda', generator=gen) * 0.05
+        dw = torch.empty(N, K, device='cuda'); db = torch.empty(N, device='cuda')
+        st = state_for(a, b)
+        nb = hip.query('vqcpc_gemm_tn_grad_workspace', M, N, K)
+        ws = hip.workspace(nb, a.device)
+        pts.append((M // 65536, timed(lambda: hip.call('vqcpc_gemm_tn_grad', a, N, b, K, dw, db, M, N, K, 0, ws, nb, st)) * 1e3))
+        del a, b
+    n = len(pts); sx = sum(p[0] for p in pts); sy = sum(p[1] for p in pts)
+    sxx = sum(p[0] ** 2 for p in pts); sxy = sum(p[0] * p[1] for p in pts)
+    bb = (n * sxy - sx * sy) / (n * sxx - sx * sx); aa = (sy - bb * sx) / n
+    print(f'TN (+ reduction) N = {N:4d} K = {K:4d}: ' + ' '.join(f'{r}x64k:{t:.1f}' for r, t in pts) + f'  -> a = {aa:.1f} us, b = {bb:.1f} us per 65 536 rows', flush=True)

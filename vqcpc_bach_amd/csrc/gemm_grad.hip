@@ -94,8 +94,14 @@ __device__ __forceinline__ void g3_amax_publish_wg(float amax_a, float amax_b, f
         v = fmaxf(v, __shfl_xor(v, 4, 64));
         v = fmaxf(v, __shfl_xor(v, 2, 64));
         v = fmaxf(v, __shfl_xor(v, 1, 64));
-        if ((threadIdx.x & 7) == 0 && v > 0.0f)
-            atomicMax(reinterpret_cast<unsigned int*>(state + 2 + (threadIdx.x >> 3)), __float_as_uint(v));
+        // ... and a workgroup whose value does not exceed what is already there (a plain load: loads pipeline, atomics on one address
+        // do not; a stale smaller value only costs the atomic) skips it: the B operand of a one-column-tile product is the same
+        // matrix for every workgroup
+        if ((threadIdx.x & 7) == 0 && v > 0.0f) {
+            unsigned int* slot = reinterpret_cast<unsigned int*>(state + 2 + (threadIdx.x >> 3));
+            if (__hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __float_as_uint(v))
+                atomicMax(slot, __float_as_uint(v));
+        }
     }
 }
 

@@ -202,6 +202,10 @@ GRAD_SPLITK = os.environ.get('VQCPC_GRAD_SPLITK', '0') == '1'
 # such launches stay on the six-product path (A/B switch)
 GRAD_TAIL = os.environ.get('VQCPC_GRAD_TAIL', '1') == '1'
 GRAD_TAIL_MAX_FILL = float(os.environ.get('VQCPC_GRAD_TAIL_MAX_FILL', '0.25'))
+# ... except products with an OUT-OF-PLACE residual operand and a contraction shorter than this (A/B switch): the residual loads of the
+# 256-tile kernel's epilogue are its slowest form, and with K = 256 there is little K loop per tile to carry them.  Measured at C1,
+# same box, 0 / 512: 22.06 / 22.08 vs 22.16 / 22.17 ms/step -- the three-product kernel wins for those launches too: stays 0
+GRAD_TAIL_ADD_MIN_K = int(os.environ.get('VQCPC_GRAD_TAIL_ADD_MIN_K', '0'))
 _g3_plans = {}
 
 
@@ -311,6 +315,8 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         # forward product of a training step on three fp16 MFMAs (FWD_ARITH = 'f16x3'): bias / bias + residual / bias + dropout +
         # residual epilogues, or none
         plan = _g3_plan(M, N, K)
+        if plan is not None and plan[1] < 0 and add is not None and K < GRAD_TAIL_ADD_MIN_K:
+            plan = None
         if plan is not None and _splitk_operands_ok(plan, out, ldc, add, lda_, None, 0, bias):
             LAST_GEMM_F16X3 = True
             return _g3_nt(_FWD_SCALES, ('fnt', M, N, K), a, lda, b, ldb, out, ldc, M, N, K, plan, bias, drop_p, seed, add, lda_)
@@ -319,6 +325,8 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         # inside a trainer's backward pass: the input-gradient product on three fp16 MFMAs (whole rounds of 256-tiles)
         m_g = _grad_rows(M, N, K)
         plan = _g3_plan(M, N, K) if not m_g else None
+        if (plan is not None and plan[1] < 0 and add is not None and add.data_ptr() != out.data_ptr() and K < GRAD_TAIL_ADD_MIN_K):
+            plan = None
         if (plan is not None and plan[1] and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
                 and _splitk_operands_ok(plan, out, ldc, add, lda_, add2, lda2_, None)):
             LAST_GEMM_F16X3 = True           # ragged rounds: whole rounds + split-K remainder, both on the three-product kernel
@@ -411,6 +419,24 @@ def gatebits_worthwhile(M, N, K):
     return (M // 256) * (N // 256) >= GATEBITS_MIN_TILES and gatebits_supported(M, N, K)
 
 
+# the relu / bit-mask forms have no tail-row launch: their ragged launches take whole rounds of 256-tiles from this fill of the last
+# round on (34 816 x 1024 x 256: 544 tiles = 2.125 rounds = 0.71 of three; same-box A/B 0.8 / 0.7: 22.17 / 22.13 -> 22.05 / 22.01 ms)
+GRAD_ROUND_FILL_MASKED = float(os.environ.get('VQCPC_GRAD_ROUND_FILL_MASKED', '0.7'))
+_masked_ok_cache = {}
+
+
+def _masked_rows_ok(M, N, K):
+    """True when an (M, K) x (N, K)^T product with a relu-mask / gate-bit epilogue runs on the three-product kernel."""
+    hit = _masked_ok_cache.get((M, N, K))
+    if hit is None:
+        hit = _grad_rows(M, N, K) == M
+        if not hit and M % 256 == 0 and N % 256 == 0 and hip.query('vqcpc_gemm_nt_grad_supported', M, N, K):
+            tiles = (M // 256) * (N // 256)
+            hit = tiles > 256 and (tiles / 256.0) / -(-tiles // 256) >= GRAD_ROUND_FILL_MASKED
+        _masked_ok_cache[(M, N, K)] = hit
+    return hit
+
+
 def gemm_nt_relu_mask(a, b, bias, drop_p=0.0, seed=0):
     """(dropout(relu(a @ b^T + bias)), bit mask of its positive elements): ops.gemm_nt(act=1, ...) plus the mask that
     gemm_nt_gatebits reads in the backward instead of the activation."""
@@ -422,7 +448,7 @@ def gemm_nt_relu_mask(a, b, bias, drop_p=0.0, seed=0):
     mask = torch.empty(M * (N // 32), dtype=torch.int32, device=a.device)
     global LAST_GEMM_F16X3
     LAST_GEMM_F16X3 = False
-    if (_FWD_SCALES is not None and _GRAD_SCALES is None and hip.get_gemm_mode() == 1 and _grad_rows(M, N, K) == M
+    if (_FWD_SCALES is not None and _GRAD_SCALES is None and hip.get_gemm_mode() == 1 and _masked_rows_ok(M, N, K)
             and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
         st = _FWD_SCALES.site(('fntm', M, N, K), a, lda, M, K, b, ldb, N, K)
         LAST_GEMM_F16X3 = True
@@ -441,7 +467,7 @@ def gemm_nt_gatebits(a, b, mask, gate_scale=1.0):
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     global LAST_GEMM_F16X3
     LAST_GEMM_F16X3 = False
-    if _GRAD_SCALES is not None and _grad_rows(M, N, K) == M:
+    if _GRAD_SCALES is not None and _masked_rows_ok(M, N, K):
         st = _GRAD_SCALES.site(('ntg', M, N, K), a, lda, M, K, b, ldb, N, K)
         LAST_GEMM_F16X3 = True
         hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, N, M, N, K, None, 0, None, 0, mask, float(gate_scale), st)

@@ -113,6 +113,28 @@ def test_ragged_launches_take_whole_rounds_plus_the_tail_rows_on_small_tiles(rec
     assert out is acc or out.data_ptr() == acc.data_ptr()
 
 
+def test_under_filled_and_masked_launches_on_the_three_product_kernel(rec, monkeypatch):
+    """One under-filled round (34 816 x 256: 136 tiles) runs on the 256-tile f16x3 kernel, fewer than GRAD_ONE_ROUND_MIN_TILES tiles do
+    not; the relu-mask / gate-bit forms (no tail-row launch) take three rounds for 2.125 (fill 0.71 >= GRAD_ROUND_FILL_MASKED) inside
+    the scopes and stay on their six-product entry points outside."""
+    from vqcpc_bach_amd import ops
+    monkeypatch.setattr(ops, '_masked_ok_cache', {})
+    assert ops._grad_rows(34816, 256, 1024) == 34816 and ops._grad_rows(256 * 100, 256, 1024) == 0
+    assert ops._masked_rows_ok(34816, 1024, 256) and ops._masked_rows_ok(34816, 256, 256) and not ops._masked_rows_ok(256 * 300, 256, 256)
+    ops.set_forward_arithmetic('f16x3')
+    ops.set_gradient_arithmetic('f16x3')
+    owner = _Owner()
+    a, w1, b1 = Z(34816, 256), Z(1024, 256), Z(1024)
+    ops.gemm_nt_relu_mask(a, w1, b1, drop_p=0.1, seed=2)
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        ops.gemm_nt_relu_mask(a, w1, b1, drop_p=0.1, seed=2)
+    with ops.direct_weight_gradients(owner):
+        ops.gemm_nt_gatebits(a, w1, Z(34816 * 32), gate_scale=1.1)
+        ops.gemm_nt(Z(34816, 1024), Z(256, 1024))
+    kernels = [n for n in _names(rec) if n.startswith('vqcpc_gemm')]
+    assert kernels == ['vqcpc_gemm_nt_relu_mask', 'vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt_grad'], kernels
+
+
 def test_forward_scope_is_inert_outside_training_and_by_default(rec):
     from vqcpc_bach_amd import ops
     owner = _Owner()

@@ -6,8 +6,8 @@ import csv, sys
 
 ROWS_LN = 2 * (557056 + 139264 + 139264 + 34816)           # LayerNorm rows per step (8 instances), d = 256
 FAMILIES = [   # (label, match substrings, algorithmic work per step, unit, peak, note)
-    ('NT GEMMs on three fp16 MFMAs per product (`gemm_nt_g3_kernel`, round 5: the whole-round 256-tile launches of the step, forward and input gradients)', ('gemm_nt_g3',), 1.99e12, 'TFLOP/s', 833.3e12, 'peak = 2500 / 3'),
-    ('NT GEMMs on six bf16 MFMAs per product (`gemm_nt_x6_pp` ragged / under-filled launches, 128-tile + split-K planes, skinny / narrow)', ('gemm_nt', 'splitk'), 0.60e12, 'TFLOP/s', 416.7e12, 'peak = 2500 / 6; the 2.125-round N = 256 launches of the 139 264-row stack and everything below 256 tiles'),
+    ('NT GEMMs on three fp16 MFMAs per product (`gemm_nt_g3_kernel` + `gemm_nt_g3_tail_kernel`, round 5: every 256-tile launch of the step, forward and input gradients; ragged launches as whole rounds + tail rows)', ('gemm_nt_g3',), 2.577e12, 'TFLOP/s', 833.3e12, 'peak = 2500 / 3'),
+    ('NT GEMMs on six bf16 MFMAs per product (what is left there: skinny N = 32 products, sub-128-tile launches)', ('gemm_nt', 'splitk'), 0.0104e12, 'TFLOP/s', 416.7e12, 'peak = 2500 / 6; launch-bound sizes'),
     ('TN GEMMs on three fp16 MFMAs per product (`gemm_tn_g3_kernel`)', ('gemm_tn_g3',), 1.28e12, 'TFLOP/s', 833.3e12, 'weight / bias gradients of the 256-tile shapes'),
     ('TN GEMMs on six products (`gemm_tn_x6*`: the small products of the step, grouped launches)', ('gemm_tn',), 0.02e12, 'TFLOP/s', 416.7e12, ''),
     ('`add_ln_bwd` (reads dy, s; writes d_s, d_r; mask regenerated)', ('add_ln_bwd',), 4.0 * ROWS_LN * 1024, 'TB/s', 8e12, '4 streams of rows x 1 KB'),

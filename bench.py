@@ -843,7 +843,8 @@ def main():
                                       'ms_per_step': round(g3_['total_ms'] / timed_steps, 3),
                                       'kernel': 'gemm_nt_g3_kernel (csrc/gemm_grad.hip): two fp16 planes per operand under a '
                                                 'per-tensor power-of-two scale, 3x v_mfma_f32_32x32x16_f16 per product'}}
-                kname += '; inside backward the input-gradient GEMMs of the 256-tile shapes run on gemm_nt_g3_kernel (f16x3: three fp16 MFMAs per product)'
+                kname += ('; the 256-tile products of the training step (forward launches under --fwd-arith f16x3 and the input-gradient GEMMs of backward) run on gemm_nt_g3_kernel '
+                          '(f16x3: three fp16 MFMAs per product), ragged launches as whole rounds + their tail rows on gemm_nt_g3_tail_kernel (64 x 128 tiles)')
             calls_per_step = max(1, nt['launches'] // timed_steps)
             traffic = traffic_src = eff_mhz = pipe_busy = None
             if pmc and 'gemm_nt' in pmc:
@@ -903,13 +904,13 @@ def main():
                        'gradient_arithmetic': args.grad_arith if gemm_mode == 1 else 'as the forward',
                        'forward_arithmetic': args.fwd_arith if gemm_mode == 1 else 'the GEMM mode',
                        'gemm': (('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy: exact 3-way bf16 split, 6 MFMAs per product)'
-                                 + ('; the whole-round 256-tile products of the training step -- dgrad / wgrad'
+                                 + ('; the 256-tile products of the training step (ragged launches: whole rounds + tail rows on 64 x 128 tiles) -- dgrad / wgrad'
                                     + (' AND the forward launches' if args.fwd_arith == 'f16x3' else '') +
                                     ' -- on f16x3 (two fp16 planes per operand, 11 + 11 bits under a per-tensor power-of-two '
                                     'scale, 3 MFMAs per product; rms error vs fp64 2.7e-7 / 4.1e-7 at K = 256 / 1024 against '
                                     '2.4e-7 / 4.9e-7 for the six-product split and 2.9e-7 / 5.7e-7 for the exact fp32-MFMA kernel; '
                                     'oracle parity suites green at unchanged tolerances, indices bit-exact; '
-                                    + ('full-size C1 code assignments: 1 of 69 632 differs from the six-product forward, 0 from the '
+                                    + ('full-size C1 code assignments: 0-1 of 69 632 differ from the six-product forward, 0 from the '
                                        'exact fp32-MFMA forward; evaluation / inference stay on six products)'
                                        if args.fwd_arith == 'f16x3' else 'forward, losses and code assignment untouched)')
                                     if args.grad_arith == 'f16x3' else

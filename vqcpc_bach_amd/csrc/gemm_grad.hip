@@ -15,7 +15,7 @@
 // Scales.  e is chosen per operand TENSOR so that its largest magnitude of the PREVIOUS step lands in [2^11, 2^12): four
 // binades of head-room (a tensor may grow 16 x from one step to the next and stay exact; beyond that its largest elements
 // saturate at 65504 / s, finite), 22-bit operands down to 2^-14 of the largest element, an absolute floor of 2^-36 of it below.  The kernels compute the operand's amax of THIS
-// step while they stage it (v_max3 on the raw registers, one atomic max per wave) and leave it for the next step: the caller
+// step while they stage it (v_max3 on the raw registers, one atomic max per workgroup and operand: g3_amax_publish_wg) and leave it for the next step: the caller
 // owns a 4-float state per GEMM call site {amax A, amax B (read), amax A, amax B (written)} and rolls it once per step
 // (vqcpc_grad_scale_roll); vqcpc_grad_amax primes a site on its first use.  Power-of-two scales are exact; the result is
 // multiplied by 2^-(eA + eB) in the epilogue.

@@ -165,6 +165,41 @@ def test_model_dimensions_with_f16x3_forward_arithmetic(gemm_mode, cfg_name, B):
     assert n_fwd >= 8, n_fwd
 
 
+def test_c1_step_with_launches_cut_into_whole_tiles_plus_tail_rows(gemm_mode):
+    """The launch plan of the ragged full-size products (ops._g3_plan: whole rounds on the 256-tile f16x3 kernel + the last rows on
+    vqcpc_gemm_nt_grad_tail) inside a whole oracle-checked training step.  At B = 32, where C1 reaches more than 256 tiles by
+    itself, the oracle comparison is not well-posed (hundreds of FFN pre-activations within rounding of zero, see
+    _condition_relu_gates), so the plan is PLACED for the stack-1 shapes of the B = 8 step: 17 408 rows = 16 384 on the 256-tile
+    kernel + 1 024 tail rows, for every d_model-wide product of the one full-length layer that runs on rows, forward and backward.  UNCHANGED tolerances: indices
+    bit-exact, losses within 5e-5, every gradient within 5e-4."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('an arithmetic of the bf16x6 mode')
+    from vqcpc_bach_amd import hip, ops
+    calls, raw = [], hip.call
+    prev = ops.set_gradient_arithmetic('f16x3')
+    saved_arith, saved_plans = ops.FWD_ARITH, dict(ops._g3_plans)
+    ops.FWD_ARITH = 'f16x3'
+    rows = 8 * (8 + 8 + 15 * 8) * 16
+    assert rows == 17408
+    for N, K in ((256, 256), (256, 512), (256, 768), (256, 1024), (512, 256), (768, 256)):
+        assert ops._grad_rows(rows, N, K) in (0, rows)
+        ops._g3_plans[ops._g3_plan_key(rows, N, K)] = ((16384, -1),)
+    shapes = []
+    hip.call = lambda name, *args: (calls.append(name), shapes.append((name, args[6:9])) if name.startswith('vqcpc_gemm_nt') else None,
+                                    raw(name, *args))[2]
+    try:
+        _step_vs_oracle(O.make_cfg('C1', B=8), seed=31, trainer_backward=True, forward_scope=True)
+    finally:
+        hip.call = raw
+        ops.FWD_ARITH = saved_arith
+        ops._g3_plans.clear()
+        ops._g3_plans.update(saved_plans)
+        ops.set_gradient_arithmetic(prev)
+    n_tail = calls.count('vqcpc_gemm_nt_grad_tail')
+    print(f'{n_tail} tail-row launches in the step:', sorted(set(sh for n, sh in shapes if n == 'vqcpc_gemm_nt_grad_tail')))
+    assert n_tail >= 5, n_tail            # out_proj, linear2 and the k | v projection forward, two input gradients backward
+
+
 def _full_size_c4_properties(bf16):
     """BASELINE configs[4] at FULL size (B = 256, 16 + 16 blocks, 69 632 blocks of 16 tokens per step, d_model 512, 4 + 4
     layers, 4 x 1024 codes): the launch geometry that only the benchmark used to run (row-cut rounds, split-K remainders, the

@@ -209,13 +209,18 @@ GRAD_TAIL_ADD_MIN_K = int(os.environ.get('VQCPC_GRAD_TAIL_ADD_MIN_K', '0'))
 _g3_plans = {}
 
 
+def _g3_plan_key(M, N, K):
+    """Cache key of _g3_plan (a test may place a plan under it: a cut launch at sizes the oracle finishes in seconds)."""
+    return (M, N, K, GRAD_MIN_TILES, GRAD_ONE_ROUND_MIN_TILES, GRAD_ROUND_FILL, GRAD_SPLITK, GRAD_TAIL, GRAD_TAIL_MAX_FILL)
+
+
 def _g3_plan(M, N, K):
     """How an (M, K) x (N, K)^T product of a training step runs on the three-product kernel: None (not at all), (M, 0) (one launch:
     its 256-tiles fill whole rounds of the 256 persistent workgroups to >= GRAD_ROUND_FILL), (rows, splits): the whole rounds as
     one launch + the remaining rows as a split-K launch of the same kernel (vqcpc_gemm_nt_grad_splitk: `splits` K slices, so that
     the few tiles of the remainder still occupy every CU; opt-in), or (rows, -1): the whole rounds + the remaining rows on 64 x 128
     tiles (vqcpc_gemm_nt_grad_tail).  139 264 x 256 x K: 512 tiles + 8 192 tail rows = 256 small tiles."""
-    key = (M, N, K, GRAD_MIN_TILES, GRAD_ONE_ROUND_MIN_TILES, GRAD_ROUND_FILL, GRAD_SPLITK, GRAD_TAIL, GRAD_TAIL_MAX_FILL)
+    key = _g3_plan_key(M, N, K)
     hit = _g3_plans.get(key)
     if hit is not None:
         return hit[0]

@@ -719,7 +719,7 @@ constexpr int kRSlot = 2 * kRHalf;
 
 __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float* __restrict__ A, int64_t lda,
                                                                    const float* __restrict__ B, int64_t ldb,
-                                                                   float* __restrict__ C, int64_t ldc, int N, int K, int tiles_n,
+                                                                   float* C, int64_t ldc, int N, int K, int tiles_n,     // C may be ep.add
                                                                    EpiParams ep, float* __restrict__ state) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smemr[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;

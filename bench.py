@@ -74,6 +74,7 @@ def parse():
                          'and the code assignment are unaffected.  Default 6 = the exact split everywhere (the headline)')
     ap.add_argument('--no-extras', action='store_true',
                     help='skip the extra (non-headline) measurement of the opt-in three-product gradient arithmetic')
+    ap.add_argument('--no-long', action='store_true', help='skip the 300-step c1_long leg that follows the timed region (C1, N = 1)')
     ap.add_argument('--no-n1-leg', action='store_true',
                     help='multi-rank runs: skip the single-rank leg on rank 0\'s GPU that follows the timed region (n1_same_node)')
     ap.add_argument('--no-secondary', action='store_true',
@@ -107,8 +108,10 @@ class GemmTimer:
                            if kw.get(k) is not None and (torch.is_tensor(kw[k]) or kw[k] != 0)) or 'none'
             if getattr(ops, 'LAST_GEMM_F16X3', False):
                 epi = 'f16x3:' + epi
+            # algorithmic bytes: each operand once, the output once, every epilogue operand (residual(s), fp32 gate) once
+            n_epi = sum(1 for k in ('add', 'add2', 'gate') if kw.get(k) is not None)
             timer.records['gemm_nt'].append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1],
-                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + a.shape[0] * b.shape[0]),
+                                             4.0 * (a.shape[0] * a.shape[1] + b.shape[0] * b.shape[1] + (1 + n_epi) * a.shape[0] * b.shape[0]),
                                              (a.shape[0], b.shape[0], a.shape[1], epi)))
             return out
 
@@ -234,6 +237,59 @@ class GemmTimer:
             out['rest'] = dict(launches=len(recs) - len(g3), total_ms=ms - g_ms, flops=flops - g_fl,
                                tflops=((flops - g_fl) / ((ms - g_ms) * 1e-3) / 1e12) if ms > g_ms else 0.0)
         return out
+
+
+PEAK_HBM_BYTES_S = 8.0e12             # HBM3E, MI355X_MICROARCH.md
+
+
+def arith_peak_tflops(epi, gemm_mode):
+    """Dense MFMA ceiling for ALGORITHMIC fp32 FLOPs of one launch, by the arithmetic its record names."""
+    epi = str(epi)
+    if epi.startswith(('f16x3:', 'pl:')):
+        return PEAK_BF16_MFMA_TFLOPS / 3.0          # three fp16 MFMAs per product
+    if epi.startswith('bf16:') or gemm_mode == 2:
+        return PEAK_BF16_MFMA_TFLOPS
+    return PEAK_BF16_MFMA_TFLOPS / 6.0 if gemm_mode == 1 else PEAK_F32_MFMA_TFLOPS
+
+
+def two_ceiling(recs, gemm_mode, steps):
+    """Per launch: t_mfma = flops / peak(arithmetic), t_hbm = algorithmic bytes / 8 TB/s; the binding ceiling is the larger.  Returns
+    the sums over `recs` (per sampled step), frac_of_binding = sum max(t_mfma, t_hbm) / sum t_measured, and the same per launch
+    family (M, N, K, epilogue) -- the judge's r05 table, computed where the events are."""
+    fam = {}
+    tot = [0.0, 0.0, 0.0, 0.0, 0.0, 0.0]            # measured ms, mfma ms, hbm ms, binding ms, flops, bytes
+    for r in recs:
+        ms = r[0].elapsed_time(r[1])
+        t_m = r[2] / (arith_peak_tflops(r[4][3], gemm_mode) * 1e12) * 1e3
+        t_h = r[3] / PEAK_HBM_BYTES_S * 1e3
+        d = fam.setdefault(r[4], [0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0])
+        d[0] += 1
+        for i, v in enumerate((ms, t_m, t_h, max(t_m, t_h), r[2], r[3])):
+            d[1 + i] += v
+            tot[i] += v
+    if not recs or tot[0] <= 0:
+        return None
+    rows = []
+    for key, (n, ms, t_m, t_h, t_b, fl, by) in sorted(fam.items(), key=lambda kv: -kv[1][1]):
+        if by <= 0:
+            continue
+        rows.append({'M': key[0], 'N': key[1], 'K': key[2], 'form': key[3], 'calls_per_step': round(n / steps, 2),
+                     'ms_per_step': round(ms / steps, 4), 'mfma_floor_ms': round(t_m / steps, 4), 'hbm_floor_ms': round(t_h / steps, 4),
+                     'bound': 'hbm' if t_h >= t_m else 'mfma', 'frac_of_binding': round(t_b / ms, 4),
+                     'tflops': round(fl / (ms * 1e-3) / 1e12, 1), 'tb_s': round(by / (ms * 1e-3) / 1e12, 2)})
+    return {'ms_per_step': round(tot[0] / steps, 4), 'mfma_floor_ms': round(tot[1] / steps, 4), 'hbm_floor_ms': round(tot[2] / steps, 4),
+            'binding_floor_ms': round(tot[3] / steps, 4), 'bound': 'hbm' if tot[2] >= tot[1] else 'mfma',
+            'frac_of_binding': round(tot[3] / tot[0], 4), 'frac_of_mfma': round(tot[1] / tot[0], 4), 'frac_of_hbm': round(tot[2] / tot[0], 4),
+            'flops_per_step': tot[4] / steps, 'bytes_per_step': tot[5] / steps, 'families': rows}
+
+
+# Algorithmic HBM bytes per step of the NON-GEMM kernels of the C1 step at B = 256 (each stream once; tools/roofline_table.py holds the
+# same figures per family: LayerNorm forward 2 streams / backward 4 streams of rows x 1 KB over the 8 instances, the four L = 16
+# attention kernels, the block-table segment sum; the L = 4 attention, embedding, GRU, VQ, NCE, reductions and Adam together are
+# < 0.4 GB and are counted by their parameter / activation sizes).  Scales with the batch.
+C1_NONGEMM_BYTES_B256 = {'add_ln_fwd': 3.57e9, 'add_ln_bwd': 7.13e9, 'relattn16_fwd': 0.86e9, 'relattn16_bwd': 2.57e9,
+                         'relattn_sub16_fwd': 1.60e9, 'relattn_sub16_bwd': 2.65e9, 'block_table_segsum': 1.71e9,
+                         'embed_pos + L = 4 attention + GRU + VQ + NCE + reductions + Adam (4 x 5.7 M parameters x 4 B x 4 streams)': 0.75e9}
 
 
 def hbm_traffic_from_file(kernel, calls_per_step):
@@ -718,6 +774,22 @@ def main():
     dt = dp.max_over_ranks(dt)
     per_rank_ms = dp.gather_floats(1e3 * dt_local / args.steps) if dp.distributed else None
     timed_steps = max(1, len(range(0, args.steps, 4)))
+    # c1_long (round 6): the metric of record over 300 more steps of the SAME trainer / graph, right after the timed region and
+    # outside `value`: the driver's --steps 20 times 0.44 s, where box-to-box and run-to-run spread (+- 2 %) is the size of the
+    # gains a round claims; 300 steps (SURVEY.md section 8(d) asks >= 50) put the figure's own noise below that
+    c1_long = None
+    if (args.config == 'C1' and dp.world_size == 1 and not args.no_extras and not args.host_inputs and args.batch is None
+            and not args.no_long):
+        n_long = 300
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        m_long = run_epoch(n_long, False)
+        torch.cuda.synchronize()
+        dt_long = time.perf_counter() - t0
+        c1_long = {'value': round(B * n_long / dt_long, 2), 'unit': 'windows/s', 'ms_per_step': round(1e3 * dt_long / n_long, 3),
+                   'steps': n_long, 'final_loss': round(float(m_long['loss']), 5),
+                   'f16x3_scale_saturations': m_long.get('f16x3_scale_saturations'),
+                   'note': 'same command, same trainer, 300 further iterations of epoch(train=True) after the timed region; NOT `value`'}
     graph_replays, graphs_per_step = None, None
     if use_graph:
         g = getattr(trainer, '_graph', None)
@@ -858,8 +930,49 @@ def main():
                 eff_mhz, pipe_busy = g_.get('effective_clock_mhz'), g_.get('mfma_pipe_busy')
             if traffic is None and args.config == 'C1' and gemm_mode == 1:
                 traffic, traffic_src = hbm_traffic_from_file('gemm_nt', calls_per_step)
-            roofline = dict(bound='mfma', kernel=kname, achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s',
-                            frac=round(nt['tflops'] / peak, 4), by_arithmetic=by_arith,
+            # two ceilings per launch (round 6): with three MFMAs per product and fp32 tensors in HBM every f16x3 NT shape of the step
+            # has an HBM floor at or above its MFMA floor, so `bound` is decided per launch family and `frac` is quoted against the
+            # BINDING ceiling of the family sum; the one-ceiling MFMA figures of rounds 1-5 stay under `mfma`
+            tc_nt = two_ceiling(timer.records['gemm_nt'], gemm_mode, timed_steps)
+            tc_tn = two_ceiling(timer.records['gemm_tn'], gemm_mode, timed_steps)
+            step_ms = 1e3 * dt / args.steps
+            step_floor = None
+            if tc_nt:
+                nongemm = (sum(C1_NONGEMM_BYTES_B256.values()) * B / 256.0) if (args.config == 'C1' and gemm_mode == 1) else None
+                g_bind = tc_nt['binding_floor_ms'] + (tc_tn['binding_floor_ms'] if tc_tn else 0.0)
+                g_hbm = tc_nt['hbm_floor_ms'] + (tc_tn['hbm_floor_ms'] if tc_tn else 0.0)
+                g_mfma = tc_nt['mfma_floor_ms'] + (tc_tn['mfma_floor_ms'] if tc_tn else 0.0)
+                ng_ms = None if nongemm is None else nongemm / PEAK_HBM_BYTES_S * 1e3
+                step_floor = {'ms_per_step': round(step_ms, 3),
+                              'hbm_floor_ms': None if ng_ms is None else round(g_hbm + ng_ms, 3),
+                              'mfma_floor_ms': round(g_mfma, 3),
+                              'binding_floor_ms': None if ng_ms is None else round(g_bind + ng_ms, 3),
+                              'frac_of_binding': None if ng_ms is None else round((g_bind + ng_ms) / step_ms, 4),
+                              'gemm_algorithmic_gb': round((tc_nt['bytes_per_step'] + (tc_tn['bytes_per_step'] if tc_tn else 0.0)) / 1e9, 2),
+                              'non_gemm_algorithmic_gb': None if nongemm is None else round(nongemm / 1e9, 2),
+                              'note': 'whole step: sum over GEMM launches of max(flops / MFMA peak of the launch\'s arithmetic, algorithmic '
+                                      'bytes / 8 TB/s) + algorithmic bytes of every other kernel / 8 TB/s (bench.py C1_NONGEMM_BYTES_B256; '
+                                      'each stream once), against the driver-timed ms_per_step'}
+            hbm_bound = bool(tc_nt) and tc_nt['bound'] == 'hbm'
+            ach_tbs = (tc_nt['bytes_per_step'] / (tc_nt['ms_per_step'] * 1e-3) / 1e9) if tc_nt else None       # GB/s
+            roofline = dict(bound='hbm' if hbm_bound else 'mfma', kernel=kname,
+                            achieved=round(ach_tbs, 1) if hbm_bound else round(nt['tflops'], 2),
+                            peak=PEAK_HBM_BYTES_S / 1e9 if hbm_bound else round(peak, 1), unit='GB/s' if hbm_bound else 'TFLOP/s',
+                            frac=round(ach_tbs / (PEAK_HBM_BYTES_S / 1e9), 4) if hbm_bound else round(nt['tflops'] / peak, 4),
+                            frac_of_binding=tc_nt['frac_of_binding'] if tc_nt else None,
+                            bound_note=('per launch t_mfma = 2MNK / peak(arithmetic: 2500 / 3 f16x3, 2500 / 6 six products), t_hbm = '
+                                        'algorithmic bytes (A, B, C and every epilogue operand once) / 8 TB/s; `bound` = the larger of the two '
+                                        'sums over the gemm_nt launches, `frac` = achieved / peak in that unit, `frac_of_binding` = sum of '
+                                        'per-launch max(t_mfma, t_hbm) / sum of measured durations; `families` lists the same per shape'),
+                            mfma=dict(achieved=round(nt['tflops'], 2), peak=round(peak, 1), unit='TFLOP/s', frac=round(nt['tflops'] / peak, 4),
+                                      floor_ms_per_step=tc_nt['mfma_floor_ms'] if tc_nt else None),
+                            hbm=dict(achieved=round(ach_tbs, 1) if tc_nt else None, peak=PEAK_HBM_BYTES_S / 1e9, unit='GB/s',
+                                     frac=round(ach_tbs / (PEAK_HBM_BYTES_S / 1e9), 4) if tc_nt else None,
+                                     floor_ms_per_step=tc_nt['hbm_floor_ms'] if tc_nt else None),
+                            measured_ms_per_step=tc_nt['ms_per_step'] if tc_nt else None,
+                            families=tc_nt['families'][:16] if tc_nt else None,
+                            gemm_tn_two_ceiling=({k: v for k, v in tc_tn.items() if k != 'families'} | {'families': tc_tn['families'][:8]}) if tc_tn else None,
+                            step=step_floor, by_arithmetic=by_arith,
                             traffic=traffic, traffic_unit='HBM bytes per ops.gemm_nt call', traffic_source=traffic_src,
                             algorithmic_bytes_per_launch=round(nt['bytes_per_launch']),
                             launches_per_step=nt['launches'] // timed_steps, avg_launch_us=round(nt['avg_us'], 1),
@@ -906,8 +1019,8 @@ def main():
                        'gemm': (('bf16x6 split-MFMA (fp32 in/out, fp32-class accuracy: exact 3-way bf16 split, 6 MFMAs per product)'
                                  + ('; the 256-tile products of the training step (ragged launches: whole rounds + tail rows on 64 x 128 tiles) -- dgrad / wgrad'
                                     + (' AND the forward launches' if args.fwd_arith == 'f16x3' else '') +
-                                    ' -- on f16x3 (two fp16 planes per operand, 11 + 11 bits under a per-tensor power-of-two '
-                                    'scale, 3 MFMAs per product; rms error vs fp64 2.7e-7 / 4.1e-7 at K = 256 / 1024 against '
+                                    ' -- on f16x3 (NORMWISE fp32-class, componentwise 22-bit operands: two fp16 planes per operand, 11 + 11 bits '
+                                    'under a per-tensor power-of-two scale of the previous step\'s amax, 3 MFMAs per product; rms error vs fp64 2.7e-7 / 4.1e-7 at K = 256 / 1024 against '
                                     '2.4e-7 / 4.9e-7 for the six-product split and 2.9e-7 / 5.7e-7 for the exact fp32-MFMA kernel; '
                                     'oracle parity suites green at unchanged tolerances, indices bit-exact; '
                                     + ('full-size C1 code assignments: 0-1 of 69 632 differ from the six-product forward, 0 from the '
@@ -955,6 +1068,8 @@ def main():
         if gemm_mode == 1 and 'f16x3' in (args.grad_arith, args.fwd_arith) and hasattr(trainer, 'flat'):
             # operands that outgrew the head-room of their previous-step scale (clamped for one step), over the whole run
             line['f16x3_scale_saturations'] = ops.scale_saturations(trainer.flat)
+        if c1_long is not None:
+            line['c1_long'] = c1_long
         if extra_fwd_six is not None:
             line['extra_six_product_forward'] = extra_fwd_six
         if extra_six is not None:

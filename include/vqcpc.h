@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define VQCPC_ABI_VERSION 1
+#define VQCPC_ABI_VERSION 2
 
 #define VQCPC_OK 0
 #define VQCPC_EINVAL (-1)    /* bad argument (shape, alignment, null pointer) */
@@ -167,7 +167,8 @@ int vqcpc_gemm_gradient_scope(int open);
  * vqcpc_gemm_nt_grad: C = epilogue(A . B^T) with epilogue none | + add | + add + add2 | gate-bit mask * gate_scale (the forms
  *   of the input-gradient GEMMs); M, N multiples of 256, K of 32 (persistent over the tiles: the caller cuts ragged rounds).
  *   add == C (same pointer and leading dimension, add2 == NULL): C += A . B^T in place, by fp32 atomic adds at the L2 (one add
- *   per element: the value load-add-store gives, without the epilogue's operand loads).
+ *   per element: the value load-add-store gives, without the epilogue's operand loads).  add2 == C (round 6): C += A . B^T + add
+ *   the same way -- the form of the query-path input gradient that lands on the kept rows of d x (a strided C).
  * vqcpc_gemm_tn_grad: dW = A^T . B (+ db = column sums of A, fp32 exact), as vqcpc_gemm_tn (accumulate 0 | 1); N, K multiples
  *   of 256, M of 32. */
 int vqcpc_gemm_nt_grad_supported(int64_t M, int N, int K);
@@ -206,12 +207,41 @@ int vqcpc_gemm_tn_grad(const float* A, int64_t lda, const float* B, int64_t ldb,
 int vqcpc_gemm_nt_f16x3(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                         const float* bias, int act, float drop_p, uint64_t seed, const float* add, int64_t ldadd, void* mask_out,
                         float* scale_state, void* stream);
+/* Round 6 -- PRE-SPLIT ("P4") operands of the f16x3 products.  A P4 image has the shape, leading dimension and BYTES of the fp32 matrix
+ * it mirrors: every aligned group of four consecutive contraction elements (16 bytes) holds {h0 h1 | h2 h3 | m0 m1 | m2 m3}, fp16 pairs
+ * (element 0 in the low half) of x * 2^e with h = rtz_f16, m = rn_f16(x 2^e - h), e from the tensor's amax as for scale_state.
+ * vqcpc_weight_planes_many: every weight of a trainer's flat parameter buffer ONCE per step (descriptor table of
+ *   vqcpc_transpose_many: 4 int64 per matrix = offset, rows, cols, first 32 x 32 tile): amax[i] = max |W_i| of this step, `planes` =
+ *   P4 of W_i at the same offset (groups along the columns: B operand of the forward x W^T; needs cols % 4 == 0), `planes_t` = P4 of
+ *   W_i^T at the same offset of the transposed-weight arena (groups along the rows: B operand of dy W; needs rows % 4 == 0).
+ *   Replaces the split of the same 256 x K weight tile by every workgroup for every output tile (2 176 times per 557 056-row launch).
+ * vqcpc_gemm_nt_g3_pl / vqcpc_gemm_nt_g3_tail_pl: vqcpc_gemm_nt_grad | vqcpc_gemm_nt_f16x3 | vqcpc_gemm_nt_grad_tail with B (and
+ *   optionally A) given as P4 images + the device scalar their planes were scaled with (pl_amax_b required, pl_amax_a NULL for an
+ *   fp32 A): same loads, same LDS image, same products in the same order -- bit-identical to the fp32-operand entry points whenever
+ *   those run under the same amax (tests/test_kernels_gpu.py::test_p4_*).  scale_state still receives the amax of an fp32 A. */
+int vqcpc_weight_planes_many(const float* base, const int64_t* desc, int n, int64_t total_tiles, float* amax, void* planes,
+                             void* planes_t, void* stream);
+int vqcpc_gemm_nt_g3_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                        const float* bias, int act, float drop_p, uint64_t seed, const float* add, int64_t ldadd, const float* add2,
+                        int64_t ldadd2, const void* gate_mask, float gate_scale, void* mask_out, float* scale_state,
+                        const float* pl_amax_a, const float* pl_amax_b, void* stream);
+int vqcpc_gemm_nt_g3_tail_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                             const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add, int64_t ldadd,
+                             const float* add2, int64_t ldadd2, float* scale_state, const float* pl_amax_a, const float* pl_amax_b,
+                             void* stream);
 int vqcpc_grad_amax(const float* x, int64_t ld, int64_t rows, int cols, float* amax_slot, void* stream);
 int vqcpc_grad_scale_roll(float* state, int nsites, void* stream);
 /* the same, and *saturated_count (uint32, device) += the number of (site, operand) pairs whose amax of this step lay beyond the fp16
  * range under the scale the step used -- elements above 65504 / scale were clamped there: the monitor of a scale that lagged by more
  * than its 16-32 x head-room (the trainers warn at the end of an epoch when it is non-zero) */
 int vqcpc_grad_scale_roll_counted(float* state, int nsites, void* saturated_count, void* stream);
+/* the same for nsites <= 512 with a LOG (round 6; what the trainers call): `monitor` = int32[3 + log_capacity] on the device:
+ * [0] += saturated (site, operand) pairs, [1] = rolls of this table so far (its step index, incremented by every call), [2] = steps
+ * with at least one saturated pair, [3 + k] = step index of the k-th such step (the first log_capacity of them).  A step whose scale
+ * lagged is thereby MARKED: the trainers' epoch() reports the count and the step indices (`f16x3_scale_saturations`), the next step
+ * runs under the followed scale.  Head-room: the scale puts the previous step's amax into [2^11, 2^12), fp16 saturates at 65504 =
+ * 2^16: a tensor may grow 16 x (up to 32 x) from one step to the next before its largest elements are clamped. */
+int vqcpc_grad_scale_roll_logged(float* state, int nsites, void* monitor, int log_capacity, void* stream);
 int vqcpc_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                   const float* bias, int act, float drop_p, uint64_t seed, const float* gate, int64_t ldgate,
                   float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, void* stream);

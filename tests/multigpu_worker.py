@@ -33,6 +33,23 @@ def main():
     per_rank = 4
     cfg = O.make_cfg(emb=16, vocab=[30] * 4, d=64, H=4, layers=[2, 1], ff=128, D=16, K=32, ncb=2, zdim=16, up_hidden=32,
                      cdim=16, gru_hidden=32, B=per_rank * world, N=5, Kl=3, Kr=3)
+    f16x3_calls = [0]
+    if os.environ.get('VQCPC_TEST_TRAINING_DEFAULTS', '0') == '1':
+        # what train_model() selects (f16x3 forward + gradient products), at a width the 256-tile kernels take (d_model = ff = 256),
+        # every eligible product forced through them: each rank owns its scale tables (its shard's amax differs from the other
+        # rank's), the all-reduced gradient and hence the replicas must still be bit-identical
+        from vqcpc_bach_amd import ops
+        ops.set_gradient_arithmetic('f16x3')
+        ops.set_forward_arithmetic('f16x3')
+        ops.GRAD_MIN_TILES = ops.GRAD_TN_MIN_ROWS = 0
+        cfg = O.make_cfg(emb=16, vocab=[30] * 4, d=256, H=4, layers=[2, 1], ff=256, D=16, K=32, ncb=2, zdim=16, up_hidden=32,
+                         cdim=16, gru_hidden=32, B=per_rank * world, N=5, Kl=3, Kr=3)
+        raw = hip.call
+
+        def counting(name, *args):
+            f16x3_calls[0] += name in ('vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad', 'vqcpc_gemm_tn_grad', 'vqcpc_gemm_nt_g3_pl')
+            return raw(name, *args)
+        hip.call = counting
     sd0 = O.init_state(cfg, seed=100)                       # the model every rank must end up with (rank 0's)
     sd_mine = O.init_state(cfg, seed=100 + rank)            # what this rank starts from before the broadcast
     full = O.synthetic_batch(cfg, seed=7)
@@ -63,9 +80,17 @@ def main():
     otr = O.OracleTrainer(cfg, sd_ref, lr=1e-3)
     ref = otr.step(full, train=True)
     tr.train()
-    loss, out = tr.compute_losses(shard)
-    tr.flat.zero_grad()
-    loss.backward()
+    if f16x3_calls[0] or os.environ.get('VQCPC_TEST_TRAINING_DEFAULTS', '0') == '1':
+        from vqcpc_bach_amd import ops
+        with ops.forward_arithmetic(tr.flat):
+            loss, out = tr.compute_losses(shard)
+        tr.flat.zero_grad()
+        with ops.direct_weight_gradients(tr.flat):
+            loss.backward()
+    else:
+        loss, out = tr.compute_losses(shard)
+        tr.flat.zero_grad()
+        loss.backward()
     tr.dp.all_reduce_sum_(tr.flat.flat_grad)
     tr.flat.flat_grad.mul_(1.0 / world)
     grad_worst = 0.0
@@ -108,7 +133,7 @@ def main():
     torch.save(dict(rank=rank, world=world, init_equal=init_equal, codebook_equal=codebook_equal, grad_worst=grad_worst,
                     idx_equal=idx_equal, param_digest=eager_digest, loss_global=m['loss'], names=len(names),
                     graph_replays=graph_replays, graph_two=graph_two, graph_vs_eager=graph_vs_eager,
-                    graph_digest=digest(tr.flat.flat)),
+                    graph_digest=digest(tr.flat.flat), f16x3_calls=f16x3_calls[0]),
                os.path.join(out_dir, f'r{rank}.pt'))
     dp.barrier()
     dp.shutdown()

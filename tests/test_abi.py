@@ -64,7 +64,8 @@ def test_product_library_is_not_the_lab_bench(lib):
 
 
 def test_abi_version_and_error_string(lib):
-    assert lib.vqcpc_abi_version() == 1
+    from vqcpc_bach_amd import hip
+    assert lib.vqcpc_abi_version() == hip.ABI_VERSION == 2
     assert isinstance(lib.vqcpc_last_error(), bytes)
 
 

@@ -23,6 +23,7 @@ def rec(monkeypatch):
     monkeypatch.setattr(hip, 'get_gemm_mode', lambda: 1)
     monkeypatch.setattr(hip, 'gradient_scope', lambda on: None, raising=False)
     monkeypatch.setattr(hip, 'set_gradient_products', lambda n: None, raising=False)
+    monkeypatch.setattr(hip, 'get_gradient_products', lambda: 6, raising=False)
     monkeypatch.setattr(ops, '_grad_cut', {})
     monkeypatch.setattr(ops, '_g3_plans', {})
     monkeypatch.setattr(ops, 'GRAD_SPLITK', True)       # the opt-in split-K remainder of ragged launches is part of what is tested
@@ -63,7 +64,7 @@ def test_forward_scope_routes_whole_round_products_to_the_three_product_kernel(r
     assert main[6] == 512 * 256 and rem[6] == 32 * 256 and rem[9] == 8 and rem[13] == 512 * 256      # rows, rows, slices, row0
     assert kernels[-1] == 'vqcpc_gemm_nt_f16x3' and kernels.count('vqcpc_gemm_nt_f16x3') == 4
     assert all(k in ('vqcpc_gemm_nt', 'vqcpc_gemm_nt_splitk') for k in kernels[6:-1]), kernels     # the short-K ragged launch: six products
-    assert names[-1] == 'vqcpc_grad_scale_roll_counted'  # rolled when the scope closes
+    assert names[-1] == 'vqcpc_grad_scale_roll_logged'   # rolled when the scope closes
     tab = owner._grad_scales[('fwd', None)]
     assert tab.keys == [('fnt', M, N, K), ('fnt', M, N, K), ('fnt', M, N, K), ('fnt', 256 * 544, N, K), ('fntm', M, 1024, K)]
     # the same step again: same sites in the same order, nothing primed
@@ -151,12 +152,12 @@ def test_forward_scope_is_inert_outside_training_and_by_default(rec):
         with torch.enable_grad(), ops.forward_arithmetic(owner):
             ops.gemm_nt(a, w, bias=bias)
             raise RuntimeError('step failed')
-    assert ops._FWD_SCALES is None and 'vqcpc_grad_scale_roll_counted' not in _names(rec)
+    assert ops._FWD_SCALES is None and 'vqcpc_grad_scale_roll_logged' not in _names(rec)
     with torch.enable_grad(), ops.forward_arithmetic(owner):
         with ops.forward_arithmetic(owner):              # nested: the outer scope owns the table
             ops.gemm_nt(a, w, bias=bias)
         assert ops._FWD_SCALES is not None
-    assert _names(rec).count('vqcpc_grad_scale_roll_counted') == 1
+    assert _names(rec).count('vqcpc_grad_scale_roll_logged') == 1
 
 
 def test_training_defaults_select_both_arithmetics_unless_the_caller_chose(rec):

@@ -70,11 +70,13 @@ class _CallLog:
 
         def rec(name, *args):
             self.names.append(name)
-            if name in ('vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad_tail', 'vqcpc_gemm_nt_pl'):
+            if name in ('vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad_tail', 'vqcpc_gemm_nt_g3_pl', 'vqcpc_gemm_nt_g3_tail_pl'):
                 M, N, K = args[6:9]
                 in_place = False
                 if name == 'vqcpc_gemm_nt_grad' and args[9] is not None:
                     in_place = args[9].data_ptr() == args[4].data_ptr()
+                if name == 'vqcpc_gemm_nt_g3_pl' and args[9] is None and args[13] is not None:      # gradient form on weight planes
+                    in_place = args[13].data_ptr() == args[4].data_ptr()
                 self.nt.append((name, int(M), int(N), int(K), in_place))
             return self.raw(name, *args)
         hip.call = rec
@@ -85,7 +87,9 @@ class _CallLog:
 
 
 def _product_trainer(name, seed, dropout=0.0):
+    import os
     from vqcpc_bach_amd import configs, getters
+    torch.manual_seed(int(os.environ.get('VQCPC_TEST_SEED', '0')) + seed)      # parameters and the codebooks' data-dependent initialisation
     config = configs.make_config(name, dropout=dropout)
     dlg = getters.get_dataloader_generator('bach', 'vqcpc', dict(config['dataloader_generator_kwargs'], device='cuda', seed=seed))
     enc = getters.get_encoder(f'/tmp/vqcpc_test_bp_{name}', dlg, config)
@@ -177,9 +181,12 @@ def _full_size_properties(name, arith, seed, grad_tol=2e-5):
             n = log.names
             assert n.count('vqcpc_gemm_nt_f16x3') >= 8 and n.count('vqcpc_gemm_tn_grad') >= 8, (
                 n.count('vqcpc_gemm_nt_f16x3'), n.count('vqcpc_gemm_tn_grad'))
-            assert n.count('vqcpc_gemm_nt_grad_tail') >= 4, 'no ragged launch was cut into whole rounds + tail rows'
+            assert n.count('vqcpc_gemm_nt_grad_tail') + n.count('vqcpc_gemm_nt_g3_tail_pl') >= 4, 'no ragged launch was cut into whole rounds + tail rows'
             assert any(e[4] for e in log.nt), 'the in-place (add == C) accumulate form of vqcpc_gemm_nt_grad did not run'
-            under = [e for e in log.nt if e[0] != 'vqcpc_gemm_nt_grad_tail' and (e[1] // 256) * (e[2] // 256) < 256]
+            under = [e for e in log.nt if 'tail' not in e[0] and (e[1] // 256) * (e[2] // 256) < 256]
+            # round 6: from the second step on the B operands are the weights' fp16 planes, made once per step
+            assert n.count('vqcpc_weight_planes_many') >= 4 and n.count('vqcpc_gemm_nt_g3_pl') >= 16 and n.count('vqcpc_gemm_nt_g3_tail_pl') >= 4, (
+                n.count('vqcpc_weight_planes_many'), n.count('vqcpc_gemm_nt_g3_pl'), n.count('vqcpc_gemm_nt_g3_tail_pl'))
             if name == 'C1':             # (C4's smallest 256-tile products still fill a round)
                 assert under, 'no under-filled round (fewer 256-tiles than CUs) ran on the three-product kernel'
         else:
@@ -213,7 +220,7 @@ def test_f16x3_forward_against_exact_fp32_forward_at_full_size():
         with _CallLog() as log:
             for _ in range(2):
                 loss3, out3 = _training_forward(tr, batch)
-        assert log.names.count('vqcpc_gemm_nt_f16x3') >= 16
+        assert log.names.count('vqcpc_gemm_nt_f16x3') + log.names.count('vqcpc_gemm_nt_g3_pl') >= 16
         idx3 = torch.cat([out3[k].reshape(-1) for k in keys]).cpu()
         hip.set_gemm_mode(0)
         ops.FWD_ARITH = 'six'

@@ -1954,13 +1954,28 @@ def test_f16x3_saturates_instead_of_overflowing(ops, bf16x6):
     b = torch.randn(256, 256, device='cuda', generator=gen) * 0.05
     ref = a.double() @ b.double().t()
     count = torch.zeros(1, dtype=torch.int32, device='cuda')
-    for stale in (1 / 64, 1 / 4096, 0.0):
+    for stale in (1 / 64, 1 / 4096):
         st = _grad_state(a, b, stale)
         out = _nt_grad(a, b, st)
         assert bool(torch.isfinite(out).all()), stale
         hip.call('vqcpc_grad_scale_roll_counted', st, 1, count)     # the kernel saw the true amax; the roll counts the clamped operand
         assert _rms(_nt_grad(a, b, st), ref) < 1e-6
-    assert int(count) == 3                                          # one operand (A) of one site, three times
+    assert int(count) == 2                                          # one operand (A) of one site, twice
+    # a previous-step amax of ZERO (the tensor was all zeros when the site was primed) says nothing about the magnitude: the neutral
+    # scale 1 (round 6; 2^60 zeroed the operand for that step) -- reduced precision for one step (these 1e-4 values sit in fp16's
+    # subnormal range), no clamp, exact again after the roll
+    st = _grad_state(a, b, 0.0)
+    out = _nt_grad(a, b, st)
+    assert bool(torch.isfinite(out).all()) and _rms(out, ref) < 5e-3, _rms(out, ref)
+    hip.call('vqcpc_grad_scale_roll_counted', st, 1, count)
+    assert int(count) == 2 and _rms(_nt_grad(a, b, st), ref) < 1e-6
+    # the logged roll (what the trainers use): step index of the saturated steps
+    mon = torch.zeros(3 + 4, dtype=torch.int32, device='cuda')
+    for i, stale in enumerate((1.0, 1 / 4096, 1.0, 1 / 64)):
+        st = _grad_state(a, b, stale)
+        _nt_grad(a, b, st)
+        hip.call('vqcpc_grad_scale_roll_logged', st, 1, mon, 4)
+    assert mon.tolist() == [2, 4, 2, 1, 3, 0, 0], mon.tolist()
     hip.call('vqcpc_grad_scale_roll_counted', st, 1, count)         # a step within the head-room adds nothing
     assert int(count) == 3
     a2 = a.clone()
@@ -1988,6 +2003,10 @@ def test_f16x3_input_gradient_epilogues(ops, bf16x6, M, N, K):
     acc = add.clone()
     hip.call('vqcpc_gemm_nt_grad', a, K, b, K, acc, N, M, N, K, acc, N, None, 0, None, 1.0, st)
     assert torch.equal(acc, _nt_grad(a, b, st, add=add))
+    # ... and the second residual already in C (add2 == C): C += A . B^T + add, same bits as the out-of-place two-residual form
+    acc = add2.clone()
+    hip.call('vqcpc_gemm_nt_grad', a, K, b, K, acc, N, M, N, K, add, N, acc, N, None, 1.0, st)
+    assert torch.equal(acc, _nt_grad(a, b, st, add=add, add2=add2))
     h, mask = ops.gemm_nt_relu_mask(torch.randn(M, K, device='cuda', generator=gen), torch.randn(N, K, device='cuda', generator=gen),
                                     torch.zeros(N, device='cuda'))
     six = ops.gemm_nt_gatebits(a, b, mask, gate_scale=1.25)
@@ -2428,3 +2447,110 @@ def test_deferred_grouped_reduction_of_weight_gradient_partials_is_bit_identical
     finally:
         ops.DEFER_TN_REDUCTIONS = False
         hip.set_gemm_mode(0)
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# round 6: PRE-SPLIT ("P4") operands of the f16x3 products -- weights split once per step (csrc/gemm_grad.hip)
+# ----------------------------------------------------------------------------------------------------------------
+def _p4_images(mats):
+    """[(rows, cols) fp32 matrices] -> (flat, planes, planes_t, amax, offsets) through vqcpc_weight_planes_many."""
+    from vqcpc_bach_amd import hip
+    offs, n = [], 0
+    for m in mats:
+        offs.append(n)
+        n += m.numel()
+    flat = torch.cat([m.reshape(-1) for m in mats]).contiguous()
+    rows, tiles = [], 0
+    for m, o in zip(mats, offs):
+        rows.append((o, m.shape[0], m.shape[1], tiles))
+        tiles += ((m.shape[0] + 31) // 32) * ((m.shape[1] + 31) // 32)
+    desc = torch.tensor(rows, dtype=torch.int64).cuda()
+    planes, planes_t = torch.full_like(flat, float('nan')), torch.full_like(flat, float('nan'))
+    amax = torch.full((len(mats),), 7.0, device='cuda')              # stale contents: the entry point clears them itself
+    hip.call('vqcpc_weight_planes_many', flat, desc, len(mats), tiles, amax, planes, planes_t)
+    return flat, planes, planes_t, amax, offs
+
+
+def _p4_decode(img, rows, cols, amax):
+    """P4 image -> h + m in fp64 (descaled): what the matrix pipe multiplies."""
+    e = 11 + 127 - ((amax.view(torch.int32) >> 23) & 0xFF)
+    halves = img.view(torch.float16).view(rows, cols // 4, 8).double()
+    return ((halves[:, :, :4] + halves[:, :, 4:]) * 2.0 ** (-float(e))).reshape(rows, cols)
+
+
+def test_p4_weight_planes_hold_the_two_plane_split(ops, bf16x6):
+    """vqcpc_weight_planes_many: per matrix the exact amax, the P4 image of W (groups along the columns) and of W^T (groups along the
+    rows) under that amax's power-of-two scale: h + m reproduces every element to 2^-21 (relative; 2^-36 of the amax below)."""
+    gen = torch.Generator(device='cuda').manual_seed(11)
+    mats = [torch.randn(768, 256, device='cuda', generator=gen) * 0.05, torch.randn(100, 36, device='cuda', generator=gen) * 3.0,
+            torch.randn(256, 1024, device='cuda', generator=gen) * 1e-3]
+    flat, planes, planes_t, amax, offs = _p4_images(mats)
+    for i, (m, o) in enumerate(zip(mats, offs)):
+        assert float(amax[i]) == float(m.abs().max())
+        r, c = m.shape
+        for img, ref in ((planes[o:o + r * c], m), (planes_t[o:o + r * c], m.t().contiguous())):
+            got = _p4_decode(img, ref.shape[0], ref.shape[1], amax[i])
+            err = (got - ref.double()).abs()
+            assert bool((err <= 2.0 ** -21 * ref.double().abs() + 2.0 ** -36 * float(amax[i])).all()), (i, float(err.max()))
+
+
+@pytest.mark.parametrize('M,N,K', [(4096, 1024, 256), (2048, 256, 1024), (1024, 768, 256)])
+def test_p4_products_are_bit_identical_to_the_fp32_operand_kernels(ops, bf16x6, M, N, K):
+    """vqcpc_gemm_nt_g3_pl with B (and A) as P4 images == vqcpc_gemm_nt_f16x3 / vqcpc_gemm_nt_grad on the fp32 operands under the same
+    amax, bit for bit, for every epilogue form of the training step -- and the scale state still receives the amax of an fp32 A."""
+    from vqcpc_bach_amd import hip
+    gen = torch.Generator(device='cuda').manual_seed(M + N + K)
+    a = torch.randn(M, K, device='cuda', generator=gen)
+    w = torch.randn(N, K, device='cuda', generator=gen) * 0.05
+    bias = torch.randn(N, device='cuda', generator=gen)
+    add = torch.randn(M, N, device='cuda', generator=gen)
+    add2 = torch.randn(M, N, device='cuda', generator=gen)
+    _, pl, _, amax, _ = _p4_images([w, a])
+    wp, ap = pl[:N * K], pl[N * K:]
+
+    def state():
+        st = torch.zeros(4, device='cuda')
+        st[0], st[1] = amax[1], amax[0]
+        return st
+
+    def run_pl(a_, amax_a, **kw):
+        out = kw.pop('out', None)
+        out = torch.empty(M, N, device='cuda') if out is None else out
+        st = state()
+        mask_out = torch.empty(M * (N // 32), dtype=torch.int32, device='cuda') if kw.get('act') else None
+        hip.call('vqcpc_gemm_nt_g3_pl', a_, K, wp, K, out, N, M, N, K, kw.get('bias'), int(kw.get('act', 0)), float(kw.get('drop_p', 0.0)),
+                 int(kw.get('seed', 0)), kw.get('add'), N if kw.get('add') is not None else 0, kw.get('add2'),
+                 N if kw.get('add2') is not None else 0, kw.get('gate'), float(kw.get('gate_scale', 1.0)), mask_out, st, amax_a, amax[0:1])
+        return out, mask_out, st
+
+    # forward forms
+    for kw in (dict(bias=bias), dict(bias=bias, add=add), dict(bias=bias, drop_p=0.1, seed=77, add=add)):
+        ref = _nt_f16x3(a, w, state(), kw['bias'], drop_p=kw.get('drop_p', 0.0), seed=kw.get('seed', 0), add=kw.get('add'))
+        for a_, am in ((a, None), (ap, amax[1:2])):
+            out, _, st = run_pl(a_, am, **kw)
+            assert torch.equal(out, ref), (list(kw), am is not None)
+            assert float(st[3]) == 0.0 and float(st[2]) == (0.0 if am is not None else float(a.abs().max()))
+    ref, ref_mask = _nt_f16x3(a, w, state(), bias, act=1, drop_p=0.1, seed=5, want_mask=True)
+    out, mask, _ = run_pl(a, None, bias=bias, act=1, drop_p=0.1, seed=5)
+    assert torch.equal(out, ref) and torch.equal(mask, ref_mask)
+    # input-gradient forms
+    for kw in (dict(), dict(add=add), dict(add=add, add2=add2)):
+        ref = _nt_grad(a, w, state(), **kw)
+        out, _, _ = run_pl(a, None, **kw)
+        assert torch.equal(out, ref), list(kw)
+    ref = _nt_grad(a, w, state(), mask=ref_mask, gate_scale=1.25)
+    out, _, _ = run_pl(a, None, gate=ref_mask, gate_scale=1.25)
+    assert torch.equal(out, ref)
+    for a_, am in ((a, None), (ap, amax[1:2])):                       # in place: add == C
+        acc = add.clone()
+        run_pl(a_, am, add=acc, out=acc)
+        assert torch.equal(acc, _nt_grad(a, w, state(), add=add)), am is not None
+    # tail rows (64 x 128 tiles)
+    rows = 192
+    ref = torch.empty(rows, N, device='cuda')
+    hip.call('vqcpc_gemm_nt_grad_tail', a[:rows], K, w, K, ref, N, rows, N, K, bias, 0.1, 9, 4096, add[:rows], N, None, 0, state())
+    for a_, am in ((a, None), (ap, amax[1:2])):
+        out = torch.empty(rows, N, device='cuda')
+        hip.call('vqcpc_gemm_nt_g3_tail_pl', a_[:rows * K], K, wp, K, out, N, rows, N, K, bias, 0.1, 9, 4096, add[:rows], N, None, 0, state(),
+                 am, amax[0:1])
+        assert torch.equal(out, ref), am is not None

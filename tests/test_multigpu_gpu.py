@@ -43,13 +43,13 @@ def _launch(world, script, *args, timeout=900):
     return subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=ROOT)
 
 
-def _check_graphed_dp(res, two_graphs=True):
+def _check_graphed_dp(res, two_graphs=True, tol=2e-6):
     """The data-parallel step as graph replays: replays happened on every rank, the replicas are still bit-identical, and
     the result equals the eager twin's (same tolerance as the single-rank graph tests)."""
     for x in res:
         assert x['graph_replays'] >= 4, x['graph_replays']
         assert x['graph_two'] == two_graphs
-        assert x['graph_vs_eager'] < 2e-6, x['graph_vs_eager']
+        assert x['graph_vs_eager'] < tol, x['graph_vs_eager']
         assert x['graph_digest'] == res[0]['graph_digest'], 'replicas must stay bit-identical through graph replays'
 
 
@@ -137,6 +137,30 @@ def test_two_ranks_share_this_gpu_over_gloo(tmp_path):
     _check_graphed_dp(res)                           # two graph replays per step around the (gloo) all-reduce
 
 
+def test_two_ranks_share_this_gpu_over_gloo_under_the_training_defaults(tmp_path):
+    """The same harness with what train_model() selects: f16x3 forward and gradient products (every eligible product forced through
+    the 256-tile kernels at d_model = ff = 256).  Each rank owns its scale tables -- the amax of ITS shard -- so the shard gradients
+    are computed under different scales; the contract is unchanged: mean of shard gradients == oracle gradient of the global batch,
+    indices bit-exact, replicas bit-identical after the eager steps AND after the replayed steps."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', VQCPC_DP_SHARE_GPU='1', VQCPC_DP_BACKEND='gloo',
+               VQCPC_TEST_TRAINING_DEFAULTS='1', PYTHONPATH=ROOT + os.pathsep + os.environ.get('PYTHONPATH', ''))
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), WORKER, str(tmp_path)]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    res = [torch.load(tmp_path / f'r{k}.pt') for k in range(2)]
+    for k, x in enumerate(res):
+        assert x['world'] == 2 and x['rank'] == k and x['f16x3_calls'] > 50, x['f16x3_calls']
+        assert x['init_equal'] and x['codebook_equal'] and x['idx_equal']
+        assert x['grad_worst'] < 5e-4, x['grad_worst']
+    assert res[1]['param_digest'] == res[0]['param_digest'] and res[1]['loss_global'] == res[0]['loss_global']
+    # the eager twin is a NEW trainer: its scale tables are primed with the current amax while the graphed trainer's follow the
+    # previous step's -- another power-of-two scale wherever an amax sits near a binade boundary, i.e. other roundings of the same
+    # fp32-class products, amplified by Adam over six steps (measured 9e-6 of the largest parameter); the replicas themselves
+    # stay bit-identical
+    _check_graphed_dp(res, tol=5e-5)
+
+
 def test_student_step_bucketed_all_reduce_two_ranks_share_this_gpu(tmp_path):
     """StudentEncoderTrainer under data parallelism (BASELINE configs[3] with several ranks): the teacher's gradient range is
     all-reduced asynchronously while the encoder / decoder half runs, the rest afterwards (opt-in: VQCPC_DP_BUCKETS=2; the default is one call).
@@ -153,7 +177,7 @@ def test_student_step_bucketed_all_reduce_two_ranks_share_this_gpu(tmp_path):
         assert x['world'] == 2 and x['rank'] == k
         assert x['grads_equal'], ('bucketed vs single-call all-reduce', x['grad_rel'])
         assert x['stages'] == 3 and x['replays'] == 5, (x['stages'], x['replays'])
-        assert x['graph_vs_eager'] < 2e-6, x['graph_vs_eager']
+        assert x['graph_vs_eager'] < tol, x['graph_vs_eager']
         assert x['single_vs_bucketed'] < 2e-6, x['single_vs_bucketed']       # same gradients, other launch order
     assert res[0]['digest_bucketed'] == res[1]['digest_bucketed'], 'replicas must stay bit-identical (eager)'
     assert res[0]['digest_graph'] == res[1]['digest_graph'], 'replicas must stay bit-identical (graph replays)'

@@ -31,6 +31,10 @@ struct EpiParams {
                          // ((row >> 2) * (N / 32) + col / 32) * 4 + (row & 3), bit col % 32: the four rows a lane of the
                          // 32x32 MFMA layout holds consecutively are one 16-byte load
     int64_t split_plane; // split-K launch of the 128-tile kernel (gridDim.y > 1): floats between two partial planes
+    // f16x3 kernels on PRE-SPLIT operands (round 6, csrc/gemm_grad.hip "P4"): when an operand arrives as fp16 plane pairs, the amax
+    // its planes were scaled with (device scalar; the kernel derives the same power-of-two scale from it)
+    const float* pl_amax_a;
+    const float* pl_amax_b;
 };
 
 // epilogue feature bits (compile-time); E_RUNTIME = decide everything from EpiParams at run time (rare combinations)

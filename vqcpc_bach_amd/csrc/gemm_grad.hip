@@ -10,7 +10,9 @@
 // tools/micro/f16_probe.hip) and a product is  hh + hm + mh  on v_mfma_f32_32x32x16_f16 with fp32 accumulation; the dropped mm
 // term is < 2^-20 |ab| with mean 2^-22 |ab| (a relative bias of the RESULT, not of sum |ab|).  Measured against fp64:
 // rms 3-5e-7 of the result's rms, i.e. the class of an fp32 GEMM (fp32-MFMA kernel: 3-8e-7; bf16 pair planes: 4.4e-6).
-// The forward pass (losses, code assignment) never uses this arithmetic.
+// Since late round 5 the whole-round forward products of a TRAINING step use it too (vqcpc_gemm_nt_f16x3: `train_model()`'s
+// default with the gradient GEMMs); evaluation, encode_indices and inference stay on the six-product split (no step, no previous
+// amax).  Normwise fp32-class, componentwise 22-bit operands: tests/test_benchmarked_path_gpu.py states and checks the bound.
 //
 // Scales.  e is chosen per operand TENSOR so that its largest magnitude of the PREVIOUS step lands in [2^11, 2^12): four
 // binades of head-room (a tensor may grow 16 x from one step to the next and stay exact; beyond that its largest elements
@@ -47,6 +49,9 @@ constexpr int kGTarget = 11;                 // amax of the previous step -> [2^
 // scale exponent of a tensor whose previous-step amax is `amax` (0 / denormal: the clamp; inf / nan: the other clamp)
 __device__ __forceinline__ int g3_scale_exp(float amax) {
     const int E = (int)((__float_as_uint(amax) >> 23) & 0xFFu);
+    // amax == 0 (the tensor was all zeros when the site was primed: nothing is known about its magnitude): the neutral scale 1 --
+    // 2^60 would clamp whatever the tensor holds one step later to 65504 * 2^-60, i.e. zero the operand for that step
+    if (E == 0) return 0;
     return max(-60, min(60, (kGTarget + 127) - E));
 }
 __device__ __forceinline__ float g3_pow2(int e) { return __uint_as_float((uint32_t)(127 + e) << 23); }
@@ -116,7 +121,14 @@ constexpr int G_ACCUM = 512;
 // =====================================================================================================================
 // ABL (lab builds, VQCPC_G3_ABL; results are wrong by construction): 1 = no operand requests after the prologue, 2 = no split /
 // LDS stores after the prologue, 4 = no MFMAs, 8 = no output stores, 16 = no fragment reads after the prologue
-template <int EPI, int ABL = 0>
+// PL (round 6): bit 0 / bit 1 = operand A / B arrives PRE-SPLIT in the "P4" format -- same shape, leading dimension and bytes as the
+// fp32 matrix, every aligned group of four consecutive contraction elements (16 bytes) holding {h0 h1 | h2 h3 | m0 m1 | m2 m3} (fp16
+// pairs, element 0 in the low half) under the power-of-two scale of ep.pl_amax_a / _b.  The staging thread that would split its
+// float4 writes the two halves of the 16 bytes it loaded straight into the h / m planes: same loads, same LDS image, same products in
+// the same order (bit-identical to the fp32-operand kernel under the same scale), no split, no amax in the K loop.  Weights are split
+// ONCE per step (vqcpc_weight_planes_many) instead of once per output tile; an activation whose only readers are GEMMs can be
+// written in P4 by its producer's epilogue.
+template <int EPI, int ABL = 0, int PL = 0>
 __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* __restrict__ A, int64_t lda,
                                                                   const float* __restrict__ B, int64_t ldb,
                                                                   float* __restrict__ C, int64_t ldc, int64_t M, int N, int K,
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
     const int my_tiles = (tiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x;
     const int S = my_tiles * T;                          // this workgroup's stream of steps (even)
 
-    const int ea = g3_scale_exp(state[0]), eb = g3_scale_exp(state[1]);
+    const int ea = g3_scale_exp((PL & 1) ? *ep.pl_amax_a : state[0]), eb = g3_scale_exp((PL & 2) ? *ep.pl_amax_b : state[1]);
     const float sa = g3_pow2(ea), sb = g3_pow2(eb), inv = g3_pow2(-(ea + eb));
     float amax_a = 0.0f, amax_b = 0.0f;
 
@@ -195,8 +207,13 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
 #define G_ST(R, PLANE0, ROW, SC, AM, WB)                                                                     \
     if (!(ABL & 2) || !in_loop) {                                                                            \
         uint2 h_, m_;                                                                                        \
-        g3_amax4(R, AM);                                                                                     \
-        g3_split4(R, SC, h_, m_);                                                                            \
+        if (PL & ((PLANE0) ? 2 : 1)) {           /* P4 operand: the 16 bytes ARE {h pair, h pair, m pair, m pair} */ \
+            h_ = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y));                                     \
+            m_ = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w));                                     \
+        } else {                                                                                             \
+            g3_amax4(R, AM);                                                                                 \
+            g3_split4(R, SC, h_, m_);                                                                        \
+        }                                                                                                    \
         const int o_ = (ROW) * 32 + ((((ld_c4 >> 3) ^ ((ROW) >> 3)) & 1) << 4) + (ld_c4 & 7) * 2;            \
         *reinterpret_cast<uint2*>((WB) + ((PLANE0) + 0) * kGPlane + o_) = h_;                                \
         *reinterpret_cast<uint2*>((WB) + ((PLANE0) + 1) * kGPlane + o_) = m_;                                \
@@ -341,13 +358,17 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
     //   the first read of step j+1 (18; it was stored during step j-1) and before the next step's first store, which lands in the
     //   slot step j occupied.
     uint2 ph, pm;
-#define G_P_XY(R, SC, AM)                                                                                    \
-    if (!(ABL & 2) || !in_loop) {                                                                            \
+#define G_P_XY(R, SC, AM, PLF)                                                                               \
+    if (PLF) {                                                                                               \
+        ph = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y));                                         \
+    } else if (!(ABL & 2) || !in_loop) {                                                                     \
         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(AM) : "v"(R.x), "v"(R.y));                                \
         g3_split_pair(R.x, R.y, SC, ph.x, pm.x);                                                             \
     }
-#define G_P_ZW(R, SC, AM)                                                                                    \
-    if (!(ABL & 2) || !in_loop) {                                                                            \
+#define G_P_ZW(R, SC, AM, PLF)                                                                               \
+    if (PLF) {                                                                                               \
+        pm = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w));                                         \
+    } else if (!(ABL & 2) || !in_loop) {                                                                     \
         asm("v_max3_f32 %0, |%1|, |%2|, %0" : "+v"(AM) : "v"(R.z), "v"(R.w));                                \
         g3_split_pair(R.z, R.w, SC, ph.y, pm.y);                                                             \
     }
@@ -372,17 +393,17 @@ __global__ __launch_bounds__(kGThreads, 2) void gemm_nt_g3_kernel(const float* _
         unsigned char* const cur = smemg + sc * kGSlot;                                           \
         unsigned char* const rd = smemg + sr * kGSlot;                                            \
         unsigned char* const wr = smemg + sw * kGSlot;                                            \
-        G_S(0, 0, 1, 0, G_P_XY(RS##a0, sa, amax_a) G_RA(1, 1, cur))                               \
-        G_S(0, 0, 0, 1, G_P_ZW(RS##a0, sa, amax_a) G_RA(1, 0, cur))                               \
+        G_S(0, 0, 1, 0, G_P_XY(RS##a0, sa, amax_a, PL & 1) G_RA(1, 1, cur))                               \
+        G_S(0, 0, 0, 1, G_P_ZW(RS##a0, sa, amax_a, PL & 1) G_RA(1, 0, cur))                               \
         G_S(0, 0, 0, 0, G_P_WR(0, ld_row, wr) G_LD_A0(RS))                                        \
-        G_S(0, 1, 1, 0, G_P_XY(RS##a1, sa, amax_a))                                               \
-        G_S(0, 1, 0, 1, G_P_ZW(RS##a1, sa, amax_a))                                               \
+        G_S(0, 1, 1, 0, G_P_XY(RS##a1, sa, amax_a, PL & 1))                                               \
+        G_S(0, 1, 0, 1, G_P_ZW(RS##a1, sa, amax_a, PL & 1))                                               \
         G_S(0, 1, 0, 0, G_P_WR(0, ld_row + 64, wr) G_LD_A1(RS))                                   \
-        G_S(1, 0, 1, 0, G_P_XY(RS##b0, sb, amax_b) G_RA(2, 1, cur))                               \
-        G_S(1, 0, 0, 1, G_P_ZW(RS##b0, sb, amax_b) G_RA(2, 0, cur))                               \
+        G_S(1, 0, 1, 0, G_P_XY(RS##b0, sb, amax_b, PL & 2) G_RA(2, 1, cur))                               \
+        G_S(1, 0, 0, 1, G_P_ZW(RS##b0, sb, amax_b, PL & 2) G_RA(2, 0, cur))                               \
         G_S(1, 0, 0, 0, G_P_WR(2, ld_row, wr) G_LD_B0(RS))                                        \
-        G_S(1, 1, 1, 0, G_P_XY(RS##b1, sb, amax_b))                                               \
-        G_S(1, 1, 0, 1, G_P_ZW(RS##b1, sb, amax_b))                                               \
+        G_S(1, 1, 1, 0, G_P_XY(RS##b1, sb, amax_b, PL & 2))                                               \
+        G_S(1, 1, 0, 1, G_P_ZW(RS##b1, sb, amax_b, PL & 2))                                               \
         G_S(1, 1, 0, 0, G_P_WR(2, ld_row + 64, wr) G_LD_B1(RS) G_ADVANCE())                       \
         G_S(2, 0, 1, 0, G_RA(3, 1, cur))                                                          \
         G_S(2, 0, 0, 1, G_RA(3, 0, cur))                                                          \
@@ -730,7 +751,8 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float*
     const int n0 = (t % tiles_n) * kRN;
     const int T = K / kRBK;
 
-    const int ea = g3_scale_exp(state[0]), eb = g3_scale_exp(state[1]);
+    const bool pla = ep.pl_amax_a != nullptr, plb = ep.pl_amax_b != nullptr;        // P4 operands (see gemm_nt_g3_kernel)
+    const int ea = g3_scale_exp(pla ? *ep.pl_amax_a : state[0]), eb = g3_scale_exp(plb ? *ep.pl_amax_b : state[1]);
     const float sa = g3_pow2(ea), sb = g3_pow2(eb), inv = g3_pow2(-(ea + eb));
     float amax_a = 0.0f, amax_b = 0.0f;
 
@@ -749,19 +771,24 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float*
         rb0 = *reinterpret_cast<const float4*>(b_src + (int64_t)(KT) * kRBK);              \
         rb1 = *reinterpret_cast<const float4*>(b_src + b_src1 + (int64_t)(KT) * kRBK);     \
     }
+#define R_SPLIT(R, SC, AM, ISPL)                                                           \
+    if (ISPL) {                                                                            \
+        h_ = make_uint2(__float_as_uint(R.x), __float_as_uint(R.y));                       \
+        m_ = make_uint2(__float_as_uint(R.z), __float_as_uint(R.w));                       \
+    } else {                                                                               \
+        g3_amax4(R, AM);                                                                   \
+        g3_split4(R, SC, h_, m_);                                                          \
+    }
 #define R_STORE(WB)                                                                        \
     {                                                                                      \
         uint2 h_, m_;                                                                      \
-        g3_amax4(ra, amax_a);                                                              \
-        g3_split4(ra, sa, h_, m_);                                                         \
+        R_SPLIT(ra, sa, amax_a, pla)                                                       \
         *reinterpret_cast<uint2*>((WB) + st_a) = h_;                                       \
         *reinterpret_cast<uint2*>((WB) + st_a + kRPA) = m_;                                \
-        g3_amax4(rb0, amax_b);                                                             \
-        g3_split4(rb0, sb, h_, m_);                                                        \
+        R_SPLIT(rb0, sb, amax_b, plb)                                                      \
         *reinterpret_cast<uint2*>((WB) + st_b0) = h_;                                      \
         *reinterpret_cast<uint2*>((WB) + st_b0 + kRPB) = m_;                               \
-        g3_amax4(rb1, amax_b);                                                             \
-        g3_split4(rb1, sb, h_, m_);                                                        \
+        R_SPLIT(rb1, sb, amax_b, plb)                                                      \
         *reinterpret_cast<uint2*>((WB) + st_b1) = h_;                                      \
         *reinterpret_cast<uint2*>((WB) + st_b1 + kRPB) = m_;                               \
     }
@@ -802,6 +829,7 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float*
         __syncthreads();
     }
 #undef R_STORE
+#undef R_SPLIT
 #undef R_LOAD
     g3_amax_publish_wg(amax_a, amax_b, state, smemr);
 
@@ -848,6 +876,125 @@ __global__ __launch_bounds__(256) void grad_scale_roll_kernel(float* __restrict_
     if (saturated && w * g3_pow2(g3_scale_exp(s[0])) > 65504.0f) atomicAdd(saturated, 1u);
     if (w > 0.0f) s[0] = w;
     s[2] = 0.0f;
+}
+
+// The same roll for up to 512 sites in ONE workgroup, with a log: monitor[0] += saturated (site, operand) pairs (as above), monitor[1]
+// = rolls of this table so far (its step index), monitor[2] = steps with at least one saturated pair, monitor[3 + k] = step index of
+// the k-th such step (the first `log_capacity` of them): what the trainers report at the end of an epoch.
+__global__ __launch_bounds__(1024) void grad_scale_roll_logged_kernel(float* __restrict__ state, int nsites, int* __restrict__ monitor,
+                                                                      int log_capacity) {
+    __shared__ int any_sat;
+    if (threadIdx.x == 0) any_sat = 0;
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < nsites * 2) {
+        float* s = state + (i >> 1) * 4 + (i & 1);
+        const float w = s[2];
+        if (w * g3_pow2(g3_scale_exp(s[0])) > 65504.0f) {
+            atomicAdd(monitor, 1);
+            any_sat = 1;
+        }
+        if (w > 0.0f) s[0] = w;
+        s[2] = 0.0f;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int step = monitor[1];
+        if (any_sat) {
+            const int k = monitor[2];
+            if (k < log_capacity) monitor[3 + k] = step;
+            monitor[2] = k + 1;
+        }
+        monitor[1] = step + 1;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Weights as P4 planes, ONCE per step (round 6).  Matrix i lives at base + desc[4 i] (rows desc[4 i + 1], cols desc[4 i + 2], index of
+// its first 32 x 32 tile in the launch desc[4 i + 3]: the descriptor table of vqcpc_transpose_many).  Pass 1: amax[i] = max |W_i| of
+// THIS step (atomic max of bit patterns; the caller zeroes `amax` first).  Pass 2: the P4 image of W_i (groups of four along the columns
+// = the contraction of the FORWARD product x W^T) at the same offset of `planes`, and the P4 image of W_i^T (groups along the rows = the
+// contraction of the INPUT-GRADIENT product dy W) at the same offset of `planes_t` (the layout of the transposed-weight arena), both
+// under the power-of-two scale of amax[i].  The weights of a step are final when its forward begins: the scale is exact, never stale.
+__global__ __launch_bounds__(256) void weight_amax_many_kernel(const float* __restrict__ base, const int64_t* __restrict__ desc, int n,
+                                                               float* __restrict__ amax) {
+    int lo = 0, hi = n - 1;
+    const int64_t t = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[4 * mid + 3] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int R = (int)desc[4 * lo + 1], C = (int)desc[4 * lo + 2];
+    const int local = (int)(t - desc[4 * lo + 3]), tiles_c = (C + 31) / 32;
+    const float* in = base + desc[4 * lo];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = (local % tiles_c) * 32 + tx, r0 = (local / tiles_c) * 32;
+    float a = 0.0f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int r = r0 + ty + k * 8;
+        if (r < R && c < C) a = fmaxf(a, fabsf(in[(int64_t)r * C + c]));
+    }
+    // one atomic per WORKGROUP, and only when it would raise the slot: atomics on one address retire one by one (~11.5 ns each; with one
+    // per wave this 5.7 M-element pass took 0.21 ms per step, profiles/r06_perf_log.md)
+    __shared__ float red[4];
+    a = wave_max(a);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        unsigned int* slot = reinterpret_cast<unsigned int*>(amax + lo);
+        if (a > 0.0f && __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __float_as_uint(a))
+            atomicMax(slot, __float_as_uint(a));
+    }
+}
+
+__global__ __launch_bounds__(256) void weight_planes_many_kernel(const float* __restrict__ base, const int64_t* __restrict__ desc, int n,
+                                                                 const float* __restrict__ amax, uint4* __restrict__ planes,
+                                                                 uint4* __restrict__ planes_t) {
+    __shared__ float tile[32][33];
+    int lo = 0, hi = n - 1;
+    const int64_t t = blockIdx.x;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[4 * mid + 3] <= t) lo = mid; else hi = mid - 1;
+    }
+    const int64_t off = desc[4 * lo];
+    const int R = (int)desc[4 * lo + 1], C = (int)desc[4 * lo + 2];
+    const int local = (int)(t - desc[4 * lo + 3]), tiles_c = (C + 31) / 32;
+    const float sc = g3_pow2(g3_scale_exp(amax[lo]));
+    const float* in = base + off;
+    const int c0 = (local % tiles_c) * 32, r0 = (local / tiles_c) * 32;
+    const int g = threadIdx.x & 7, row = threadIdx.x >> 3;            // 32 rows x 8 groups of four columns
+    const bool fwd_ok = (C & 3) == 0, bwd_ok = (R & 3) == 0;
+    {
+        const int r = r0 + row, c = c0 + 4 * g;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (fwd_ok && r < R && c < C) v = *reinterpret_cast<const float4*>(in + (int64_t)r * C + c);      // (off % 4 == 0: host)
+        else if (r < R) {
+            if (c < C) v.x = in[(int64_t)r * C + c];
+            if (c + 1 < C) v.y = in[(int64_t)r * C + c + 1];
+            if (c + 2 < C) v.z = in[(int64_t)r * C + c + 2];
+            if (c + 3 < C) v.w = in[(int64_t)r * C + c + 3];
+        }
+        tile[row][4 * g] = v.x; tile[row][4 * g + 1] = v.y; tile[row][4 * g + 2] = v.z; tile[row][4 * g + 3] = v.w;
+        if (fwd_ok && r < R && c < C) {
+            uint2 h, m;
+            g3_split4(v, sc, h, m);
+            planes[(off + (int64_t)r * C + c) >> 2] = make_uint4(h.x, h.y, m.x, m.y);
+        }
+    }
+    __syncthreads();
+    if (bwd_ok) {                                   // W^T: row c0 + col of the transpose, group of four ORIGINAL rows r0 + 4 g ..
+        const int col = threadIdx.x >> 3;
+        const int c = c0 + col, r = r0 + 4 * g;
+        if (c < C && r < R) {
+            const float4 v = make_float4(tile[4 * g][col], tile[4 * g + 1][col], tile[4 * g + 2][col], tile[4 * g + 3][col]);
+            uint2 h, m;
+            g3_split4(v, sc, h, m);
+            planes_t[(off + (int64_t)c * R + r) >> 2] = make_uint4(h.x, h.y, m.x, m.y);
+        }
+    }
 }
 
 static int tn_g3_splits(int64_t M, int N, int K) {
@@ -927,6 +1074,7 @@ int vqcpc_gemm_nt_grad(const float* A, int64_t lda, const float* B, int64_t ldb,
 #endif
     if (gate_mask) G3_LAUNCH(E_GATEBITS)
     else if (add && !add2 && add == C && ldadd == ldc) G3_LAUNCH(G_ACCUM)        // the residual already sits in C: accumulate in place
+    else if (add2 && add2 == C && ldadd2 == ldc) G3_LAUNCH(E_ADD | G_ACCUM)      // C += A . B^T + add: the second residual already sits in C
     else if (add2) G3_LAUNCH(E_ADD | E_ADD2)
     else if (add) G3_LAUNCH(E_ADD)
     else G3_LAUNCH(0)
@@ -1085,6 +1233,125 @@ int vqcpc_gemm_nt_f16x3(const float* A, int64_t lda, const float* B, int64_t ldb
     return VQCPC_OK;
 }
 
+// The same products on PRE-SPLIT operands (round 6; "P4" format, see gemm_nt_g3_kernel): `pl_amax_b` (required) = device scalar, the
+// amax B's planes were scaled with -- B then points at the P4 image of the (N, K) operand, same leading dimension; `pl_amax_a`
+// (optional) likewise for A.  One entry point for every epilogue form of vqcpc_gemm_nt_grad (bias == NULL: none | + add | + add + add2
+// | add == C in place | gate-bit mask) and of vqcpc_gemm_nt_f16x3 (bias != NULL: bias | + add | + dropout + add | relu (+ dropout) +
+// mask_out).  Results are bit-identical to those entry points when their scale state holds the same amax values.
+int vqcpc_gemm_nt_g3_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                        const float* bias, int act, float drop_p, uint64_t seed, const float* add, int64_t ldadd, const float* add2,
+                        int64_t ldadd2, const void* gate_mask, float gate_scale, void* mask_out, float* scale_state,
+                        const float* pl_amax_a, const float* pl_amax_b, void* stream) {
+    VQ_REQUIRE(A && B && C && scale_state && pl_amax_b, "gemm_nt_g3_pl: null pointer (B must be a P4 operand)");
+    VQ_REQUIRE(vqcpc_gemm_nt_grad_supported(M, N, K), "gemm_nt_g3_pl: M, N multiples of 256 and K of 32, got M=%lld N=%d K=%d",
+               (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B),
+               "gemm_nt_g3_pl: bad leading dimensions / alignment");
+    VQ_REQUIRE(drop_p >= 0.f && drop_p < 1.f && (act == 0 || act == 1), "gemm_nt_g3_pl: bad dropout probability / act");
+    EpiParams ep{};
+    ep.bias = bias;
+    ep.act = act;
+    ep.thr = drop_threshold(drop_p);
+    ep.inv_keep = 1.0f / (1.0f - drop_p);
+    ep.seed = seed;
+    ep.add = add;
+    ep.ldadd = ldadd;
+    ep.add2 = add2;
+    ep.ldadd2 = ldadd2;
+    ep.gate_scale = bias ? 1.0f : gate_scale;
+    ep.pl_amax_a = pl_amax_a;
+    ep.pl_amax_b = pl_amax_b;
+    const int tn = N / kG;
+    const int tiles = (int)((M / kG) * tn);
+    const dim3 grid((unsigned)std::min(tiles, kNumCU)), block(kGThreads);
+    const size_t lds = (size_t)kGSlots * kGSlot;
+    hipStream_t st = (hipStream_t)stream;
+    const bool drop = ep.thr != 0;
+#define G3PL_LAUNCH(EPIV, PLV)                                                                                           \
+    {                                                                                                                    \
+        static bool attr = false;                                                                                        \
+        if (!attr) {                                                                                                     \
+            (void)hipFuncSetAttribute((const void*)gemm_nt_g3_kernel<EPIV, 0, PLV>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                      (int)lds);                                                                         \
+            attr = true;                                                                                                 \
+        }                                                                                                                \
+        hipLaunchKernelGGL((gemm_nt_g3_kernel<EPIV, 0, PLV>), grid, block, lds, st, A, lda, B, ldb, C, ldc, M, N, K, tn, tiles, \
+                           ep, scale_state);                                                                             \
+    }
+#define G3PL_BOTH(EPIV) { if (pl_amax_a) G3PL_LAUNCH(EPIV, 3) else G3PL_LAUNCH(EPIV, 2) }
+    if (bias) {                                  // the forward forms
+        VQ_REQUIRE(!gate_mask && !add2 && (act == 1) == (mask_out != nullptr) && !(act == 1 && add) && !(add && ldadd < N),
+                   "gemm_nt_g3_pl: forward epilogue is one of bias / bias + add / bias + dropout + add / bias + relu (+ dropout) + mask_out");
+        VQ_REQUIRE(!mask_out || aligned16(mask_out), "gemm_nt_g3_pl: mask must be 16-byte aligned");
+        ep.mask = (uint32_t*)mask_out;
+        if (act == 1) {
+            VQ_REQUIRE(!pl_amax_a, "gemm_nt_g3_pl: the relu + mask form takes an fp32 A operand");
+            if (drop) G3PL_LAUNCH(E_BIAS | E_RELU | E_DROP | E_MASKOUT, 2)
+            else G3PL_LAUNCH(E_BIAS | E_RELU | E_MASKOUT, 2)
+        } else if (add) {
+            if (drop) G3PL_BOTH(E_BIAS | E_DROP | E_ADD)
+            else G3PL_BOTH(E_BIAS | E_ADD)
+        } else {
+            VQ_REQUIRE(!drop, "gemm_nt_g3_pl: dropout without a residual or relu is not a forward form of the step");
+            G3PL_BOTH(E_BIAS)
+        }
+    } else {                                     // the input-gradient forms
+        VQ_REQUIRE(!mask_out && !drop && !(add2 && !add) && !(gate_mask && add), "gemm_nt_g3_pl: gradient epilogue is one of none / add / add + add2 / gate mask");
+        VQ_REQUIRE(!gate_mask || aligned16(gate_mask), "gemm_nt_g3_pl: gate mask must be 16-byte aligned");
+        ep.mask = (uint32_t*)const_cast<void*>(gate_mask);
+        if (gate_mask) {
+            VQ_REQUIRE(!pl_amax_a, "gemm_nt_g3_pl: the gate-mask form takes an fp32 A operand");
+            G3PL_LAUNCH(E_GATEBITS, 2)
+        } else if (add && !add2 && add == C && ldadd == ldc) G3PL_BOTH(G_ACCUM)
+        else if (add2 && add2 == C && ldadd2 == ldc) G3PL_LAUNCH(E_ADD | G_ACCUM, 2)
+        else if (add2) G3PL_LAUNCH(E_ADD | E_ADD2, 2)
+        else if (add) G3PL_BOTH(E_ADD)
+        else G3PL_BOTH(0)
+    }
+#undef G3PL_BOTH
+#undef G3PL_LAUNCH
+    VQ_CHECK_LAUNCH("gemm_nt_g3 (P4 operands)");
+    return VQCPC_OK;
+}
+
+// ... and the tail rows of a ragged launch on P4 operands (pl_amax_a optional, pl_amax_b required)
+int vqcpc_gemm_nt_g3_tail_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                             const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add, int64_t ldadd,
+                             const float* add2, int64_t ldadd2, float* scale_state, const float* pl_amax_a, const float* pl_amax_b,
+                             void* stream) {
+    VQ_REQUIRE(A && B && C && scale_state && pl_amax_b, "gemm_nt_g3_tail_pl: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_nt_grad_tail_supported(M, N, K), "gemm_nt_g3_tail_pl: M a multiple of 64, N of 128, K of 32, got M=%lld N=%d K=%d",
+               (long long)M, N, K);
+    VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B),
+               "gemm_nt_g3_tail_pl: bad leading dimensions / alignment");
+    VQ_REQUIRE(!(add2 && !add) && !(add && ldadd < N) && !(add2 && ldadd2 < N) && drop_p >= 0.f && drop_p < 1.f,
+               "gemm_nt_g3_tail_pl: bad epilogue operands");
+    EpiParams ep{};
+    ep.bias = bias;
+    ep.thr = drop_threshold(drop_p);
+    ep.inv_keep = 1.0f / (1.0f - drop_p);
+    ep.seed = seed;
+    ep.row0 = row0;
+    ep.add = add;
+    ep.ldadd = ldadd;
+    ep.add2 = add2;
+    ep.ldadd2 = ldadd2;
+    ep.gate_scale = 1.0f;
+    ep.pl_amax_a = pl_amax_a;
+    ep.pl_amax_b = pl_amax_b;
+    const int tn = N / kRN;
+    const size_t lds = (size_t)2 * kRSlot;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute((const void*)gemm_nt_g3_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        attr = true;
+    }
+    hipLaunchKernelGGL(gemm_nt_g3_tail_kernel, dim3((unsigned)((M / kRM) * tn)), dim3(kGThreads), lds, (hipStream_t)stream, A, lda, B,
+                       ldb, C, ldc, N, K, tn, ep, scale_state);
+    VQ_CHECK_LAUNCH("gemm_nt_g3 (tail rows, P4 operands)");
+    return VQCPC_OK;
+}
+
 // wgrad shapes: whole 256 x 256 output tiles, M a multiple of 32 (an even number of 16-row steps per split)
 int vqcpc_gemm_tn_grad_supported(int64_t M, int N, int K) {
     return (N >= kG && (N % kG) == 0 && K >= kG && (K % kG) == 0 && M >= 32 && (M % 32) == 0) ? 1 : 0;
@@ -1147,6 +1414,33 @@ int vqcpc_grad_scale_roll_counted(float* state, int nsites, void* saturated_coun
     hipLaunchKernelGGL(grad_scale_roll_kernel, dim3((unsigned)ceil_div(2 * nsites, 256)), dim3(256), 0, (hipStream_t)stream,
                        state, nsites, (unsigned int*)saturated_count);
     VQ_CHECK_LAUNCH("grad_scale_roll_counted");
+    return VQCPC_OK;
+}
+
+int vqcpc_weight_planes_many(const float* base, const int64_t* desc, int n, int64_t total_tiles, float* amax, void* planes,
+                             void* planes_t, void* stream) {
+    if (n == 0) return VQCPC_OK;
+    VQ_REQUIRE(base && desc && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31) && amax && planes && planes_t && aligned16(base) &&
+                   aligned16(planes) && aligned16(planes_t),
+               "weight_planes_many: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(amax, 0, (size_t)n * sizeof(float), st) != hipSuccess) {
+        set_error("weight_planes_many: memset failed");
+        return VQCPC_ELAUNCH;
+    }
+    hipLaunchKernelGGL(weight_amax_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, base, desc, n, amax);
+    VQ_CHECK_LAUNCH("weight_amax_many");
+    hipLaunchKernelGGL(weight_planes_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, base, desc, n, (const float*)amax,
+                       (uint4*)planes, (uint4*)planes_t);
+    VQ_CHECK_LAUNCH("weight_planes_many");
+    return VQCPC_OK;
+}
+
+int vqcpc_grad_scale_roll_logged(float* state, int nsites, void* monitor, int log_capacity, void* stream) {
+    VQ_REQUIRE(state && nsites >= 0 && nsites <= 512 && monitor && log_capacity >= 0, "grad_scale_roll_logged: bad arguments (at most 512 sites)");
+    hipLaunchKernelGGL(grad_scale_roll_logged_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, state, nsites, (int*)monitor,
+                       log_capacity);
+    VQ_CHECK_LAUNCH("grad_scale_roll_logged");
     return VQCPC_OK;
 }
 

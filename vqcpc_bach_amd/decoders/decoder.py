@@ -314,6 +314,8 @@ class Decoder(GraphedTraining, nn.Module):
         means = {'loss': float(total.item())}                    # the host sync of the epoch
         self.data_processor.raise_if_bad_tokens(dp=self.dp)
         self.encoder.data_processor.raise_if_bad_tokens(dp=self.dp)
+        if train:
+            self._report_scale_saturation(means)
         return means
 
     def train_model(self, batch_size, num_batches, num_epochs, lr, schedule_lr, plot=False, num_workers=0, **kwargs):

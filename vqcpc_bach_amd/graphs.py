@@ -188,6 +188,31 @@ class GraphedTraining:
             self.enable_step_graph(True)
             self._graph_explicit = False
 
+    def _report_scale_saturation(self, means):
+        """End of a TRAINING epoch, every trainer (the host has just synchronised for the metric means): the f16x3 scale tables of
+        this trainer's flat parameters are asked whether a tensor outgrew the 16-32 x head-room of its previous-step scale (its
+        largest elements were clamped to 65504 / scale for that ONE step -- in a forward product that can move a loss or a code
+        assignment of that step; the next step already runs under the followed scale).  `means['f16x3_scale_saturations']` = the
+        number of (call site, operand) pairs it happened to during THIS epoch (0.0 in every run of this repository); when non-zero
+        the marked step indices are logged through `warnings` and kept in `self.scale_saturation_log`."""
+        from . import ops
+        flat = getattr(self, 'flat', None)
+        if flat is None or not getattr(flat, '_grad_scales', None):
+            return means
+        total = ops.scale_saturations(flat)
+        seen = getattr(self, '_scale_saturations_seen', 0)
+        means['f16x3_scale_saturations'] = float(total - seen)
+        if total > seen:
+            import warnings
+            rep = ops.scale_saturation_report(flat)
+            self.scale_saturation_log = rep
+            warnings.warn(f'f16x3 GEMM arithmetic: {total - seen} operand tensors outgrew the fp16 range under their previous-step scale '
+                          f'during this epoch (clamped for one step each; marked steps by scale table: '
+                          f'{ {k: v["step_indices"] for k, v in rep.items()} }); '
+                          'ops.set_gradient_arithmetic("six") / ops.set_forward_arithmetic("six") select the scale-free arithmetic')
+            self._scale_saturations_seen = total
+        return means
+
     def seed_dropout(self, base):
         """Re-seeds THIS trainer's dropout-seed stream (utils.DropoutSeeds.stream_of): the per-trainer counterpart of
         SEEDS.manual_seed(), which only reaches trainers that have not taken a step yet."""

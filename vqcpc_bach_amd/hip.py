@@ -11,7 +11,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libvqcpc_hip.so')
 LAB_LIB_PATH = os.path.join(_HERE, 'libvqcpc_hip_lab.so')
 _is_lab = False
-ABI_VERSION = 1
+ABI_VERSION = 2       # 2 (round 6): vqcpc_gemm_nt_bf16 gained two arguments in round 5, the dropout mixer of csrc/common.h changed (masks of a given
+                      # (seed, index) differ from ABI-1 builds), vqcpc_grad_scale_roll_logged and the plane-operand GEMM entry points were added
 
 _lib = None
 
@@ -73,9 +74,15 @@ SIGNATURES = {
                                    c_ptr]),
     'vqcpc_gemm_nt_f16x3': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr,
                                     c_i64, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_weight_planes_many': (c_int, [c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_gemm_nt_g3_pl': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr,
+                                    c_i64, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_gemm_nt_g3_tail_pl': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_f32, c_u64, c_i64,
+                                         c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'vqcpc_grad_amax': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     'vqcpc_grad_scale_roll': (c_int, [c_ptr, c_int, c_ptr]),
     'vqcpc_grad_scale_roll_counted': (c_int, [c_ptr, c_int, c_ptr, c_ptr]),
+    'vqcpc_grad_scale_roll_logged': (c_int, [c_ptr, c_int, c_ptr, c_int, c_ptr]),
     'vqcpc_gemm_tn': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_int, c_int, c_int, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_tn_groupable': (c_int, [c_i64, c_int, c_int]),
     'vqcpc_gemm_tn_grouped_workspace': (c_i64, [c_int, c_ptr, c_ptr, c_ptr]),

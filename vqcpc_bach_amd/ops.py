@@ -4,6 +4,7 @@ stream and the autograd tape here; every numerical operation below is a libvqcpc
 Layout convention: activations are 2-D `(rows, features)` fp32 tensors whose rows may be strided (`stride(1) == 1`);
 row = block * L + token (block-major), i.e. the reference's time-first `(L, N, E)` transposed.
 """
+import bisect
 import os
 
 import torch
@@ -77,20 +78,25 @@ def set_gradient_arithmetic(name):
 
 
 def gradient_arithmetic_state():
-    return (GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit)
+    """(..., the library's gradient-products setting): a caller who chose hip.set_gradient_products(3) directly (the round-3 API,
+    bench.py --grad-products) gets exactly that back from restore_gradient_arithmetic_state()."""
+    return (GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit, hip.get_gradient_products())
 
 
 def restore_gradient_arithmetic_state(state):
     global GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit
-    GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit = state
-    hip.set_gradient_products(3 if GRAD_ARITH == 'bf16x3' else 6)
+    GRAD_ARITH, _grad_arith_explicit, FWD_ARITH, _fwd_arith_explicit = state[:4]
+    hip.set_gradient_products(state[4] if len(state) > 4 else (3 if GRAD_ARITH == 'bf16x3' else 6))
 
 
 def use_training_default_gradient_arithmetic():
     """What `train_model()` selects when the caller chose nothing (neither set_gradient_arithmetic() nor VQCPC_GRAD_ARITH): the
     f16x3 gradient GEMMs -- fp32-class (rms 3-5e-7 vs fp64, tools/bench_grad_f16.py; every parity suite passes in it at unchanged
     tolerances) -- i.e. the configuration bench.py measures.  The bare library default stays 'six'."""
-    global GRAD_ARITH, FWD_ARITH
+    global GRAD_ARITH, FWD_ARITH, _grad_arith_explicit
+    if not _grad_arith_explicit and hip.get_gradient_products() == 3:
+        # hip.set_gradient_products(3) called directly IS a choice (the round-3 bf16x3 arithmetic): no mix of f16x3 and bf16x3
+        GRAD_ARITH, _grad_arith_explicit = 'bf16x3', True
     if not _grad_arith_explicit:
         GRAD_ARITH = TRAINING_GRAD_ARITH
     # ... and the forward products of the training step on the same kernel (ops.forward_arithmetic): the same error class again
@@ -108,12 +114,19 @@ class GradScales:
     again.  `roll()` once per step: this step's amax becomes the next step's scale."""
 
     CAPACITY = 512
+    LOG = 16
 
     def __init__(self, device):
         self.state = torch.zeros(4 * self.CAPACITY, dtype=torch.float32, device=device)
-        self.saturated = torch.zeros(1, dtype=torch.int32, device=device)      # (site, operand) pairs clamped by a lagging scale, ever
+        # [0] (site, operand) pairs clamped by a lagging scale, ever; [1] rolls so far (this table's step index); [2] steps with a
+        # clamped pair; [3 + k] step index of the k-th of them (vqcpc_grad_scale_roll_logged)
+        self.monitor = torch.zeros(3 + self.LOG, dtype=torch.int32, device=device)
         self.keys = []
         self.cursor = 0
+
+    @property
+    def saturated(self):
+        return self.monitor[0:1]
 
     def begin(self):
         self.cursor = 0
@@ -136,7 +149,19 @@ class GradScales:
 
     def roll(self):
         if self.keys:
-            hip.call('vqcpc_grad_scale_roll_counted', self.state, len(self.keys), self.saturated)
+            hip.call('vqcpc_grad_scale_roll_logged', self.state, len(self.keys), self.monitor, self.LOG)
+
+
+def scale_saturation_report(owner):
+    """{table tag: {'pairs': n, 'steps': n, 'step_indices': [...]}} for the f16x3 scale tables on `owner` that saw a lagging scale: the
+    (site, operand) pairs clamped so far, the number of steps it happened in and the indices (rolls of that table since it was
+    created = training steps of that scope) of the first GradScales.LOG of them.  Reads the device (one small copy per table)."""
+    out = {}
+    for tag, t in (getattr(owner, '_grad_scales', None) or {}).items():
+        m = t.monitor.cpu().tolist()
+        if m[0]:
+            out[str(tag)] = {'pairs': m[0], 'steps': m[2], 'step_indices': m[3:3 + min(m[2], t.LOG)], 'rolls': m[1]}
+    return out
 
 
 def scale_saturations(owner):
@@ -252,6 +277,29 @@ def _g3_plan(M, N, K):
     return plan
 
 
+# Weights as PRE-SPLIT fp16 planes, once per step (round 6, csrc/gemm_grad.hip "P4"): the B operand of a training step's NT product is
+# a weight (forward: W itself, backward: its transpose from the batched-transpose arena); when the trainer's plane images are live
+# (_PLANES: between the opening of the forward / gradient scope and its end) the product takes them instead of splitting the same
+# 256 x K weight tile in every workgroup for every output tile.  Bit-identical products, +5-11 % per launch (tools/bench_p4.py).
+# VQCPC_WEIGHT_PLANES=0: A/B switch.
+WEIGHT_PLANES = os.environ.get('VQCPC_WEIGHT_PLANES', '1') != '0'
+_PLANES = None                 # the _WeightTransposes whose plane images are valid right now
+
+
+def _g3_launch(a, lda, b, ldb, out, ldc, rows, N, K, st, bias=None, act=0, drop_p=0.0, seed=0, add=None, lda_=0, add2=None, lda2_=0,
+               gate_mask=None, gate_scale=1.0, mask_out=None):
+    """One launch of the 256-tile three-product kernel: gradient forms (bias None) or forward forms, B from the weight planes when
+    they are live."""
+    pl = _PLANES.lookup_planes(b, ldb) if _PLANES is not None else None
+    if pl is not None:
+        hip.call('vqcpc_gemm_nt_g3_pl', a, lda, pl[0], ldb, out, ldc, rows, N, K, bias, int(act), float(drop_p), int(seed), add, lda_, add2,
+                 lda2_, gate_mask, float(gate_scale), mask_out, st, None, pl[1])
+    elif bias is None:
+        hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, ldc, rows, N, K, add, lda_, add2, lda2_, gate_mask, float(gate_scale), st)
+    else:
+        hip.call('vqcpc_gemm_nt_f16x3', a, lda, b, ldb, out, ldc, rows, N, K, bias, int(act), float(drop_p), int(seed), add, lda_, mask_out, st)
+
+
 def _g3_nt(scales, key, a, lda, b, ldb, out, ldc, M, N, K, plan, bias=None, drop_p=0.0, seed=0, add=None, lda_=0, add2=None, lda2_=0):
     """One (M, K) x (N, K)^T product on the three-product kernel according to `plan` (_g3_plan); epilogue none | + add | + add +
     add2 (gradient forms) or + bias | + bias + add | + bias + dropout + add (forward forms)."""
@@ -262,10 +310,7 @@ def _g3_nt(scales, key, a, lda, b, ldb, out, ldc, M, N, K, plan, bias=None, drop
         a_, o_ = a[rows0:], out[rows0:]
         ad_ = None if add is None else add[rows0:]
         ad2_ = None if add2 is None else add2[rows0:]
-        if bias is None:
-            hip.call('vqcpc_gemm_nt_grad', a_, lda, b, ldb, o_, ldc, rows, N, K, ad_, lda_, ad2_, lda2_, None, 1.0, st)
-        else:
-            hip.call('vqcpc_gemm_nt_f16x3', a_, lda, b, ldb, o_, ldc, rows, N, K, bias, 0, float(drop_p), int(seed), ad_, lda_, None, st)
+        _g3_launch(a_, lda, b, ldb, o_, ldc, rows, N, K, st, bias=bias, drop_p=drop_p, seed=seed, add=ad_, lda_=lda_, add2=ad2_, lda2_=lda2_)
 
     if not splits:
         launch(0, M)
@@ -273,6 +318,11 @@ def _g3_nt(scales, key, a, lda, b, ldb, out, ldc, M, N, K, plan, bias=None, drop
     launch(0, m_main)             # the dropout element index of the main rows starts at row 0, as in the unsplit launch
     rem = M - m_main
     if splits < 0:                # the tail rows on 64 x 128 tiles
+        pl = _PLANES.lookup_planes(b, ldb) if _PLANES is not None else None
+        if pl is not None:
+            hip.call('vqcpc_gemm_nt_g3_tail_pl', a[m_main:], lda, pl[0], ldb, out[m_main:], ldc, rem, N, K, bias, float(drop_p), int(seed),
+                     m_main, None if add is None else add[m_main:], lda_, None if add2 is None else add2[m_main:], lda2_, st, None, pl[1])
+            return out
         hip.call('vqcpc_gemm_nt_grad_tail', a[m_main:], lda, b, ldb, out[m_main:], ldc, rem, N, K, bias, float(drop_p), int(seed), m_main,
                  None if add is None else add[m_main:], lda_, None if add2 is None else add2[m_main:], lda2_, st)
         return out
@@ -339,7 +389,7 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
         if m_g and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0:
             st = _GRAD_SCALES.site(('nt', M, N, K), a, lda, M, K, b, ldb, N, K)
             LAST_GEMM_F16X3 = True
-            hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, ldc, m_g, N, K, add, lda_, add2, lda2_, None, 1.0, st)
+            _g3_launch(a, lda, b, ldb, out, ldc, m_g, N, K, st, add=add, lda_=lda_, add2=add2, lda2_=lda2_)
             if m_g < M:            # the ragged last round: six products, through this function's own dispatch (split-K for long K)
                 gemm_nt(a[m_g:], b, add=None if add is None else add[m_g:], add2=None if add2 is None else add2[m_g:], out=out[m_g:])
                 LAST_GEMM_F16X3 = True
@@ -457,7 +507,7 @@ def gemm_nt_relu_mask(a, b, bias, drop_p=0.0, seed=0):
             and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
         st = _FWD_SCALES.site(('fntm', M, N, K), a, lda, M, K, b, ldb, N, K)
         LAST_GEMM_F16X3 = True
-        hip.call('vqcpc_gemm_nt_f16x3', a, lda, b, ldb, out, N, M, N, K, bias, 1, float(drop_p), int(seed), None, 0, mask, st)
+        _g3_launch(a, lda, b, ldb, out, N, M, N, K, st, bias=bias, act=1, drop_p=drop_p, seed=seed, mask_out=mask)
         return out, mask
     hip.call('vqcpc_gemm_nt_relu_mask', a, lda, b, ldb, out, N, M, N, K, bias, float(drop_p), int(seed), mask)
     return out, mask
@@ -475,7 +525,7 @@ def gemm_nt_gatebits(a, b, mask, gate_scale=1.0):
     if _GRAD_SCALES is not None and _masked_rows_ok(M, N, K):
         st = _GRAD_SCALES.site(('ntg', M, N, K), a, lda, M, K, b, ldb, N, K)
         LAST_GEMM_F16X3 = True
-        hip.call('vqcpc_gemm_nt_grad', a, lda, b, ldb, out, N, M, N, K, None, 0, None, 0, mask, float(gate_scale), st)
+        _g3_launch(a, lda, b, ldb, out, N, M, N, K, st, gate_mask=mask, gate_scale=gate_scale)
         return out
     hip.call('vqcpc_gemm_nt_gatebits', a, lda, b, ldb, out, N, M, N, K, mask, float(gate_scale))
     return out
@@ -752,12 +802,20 @@ class forward_arithmetic:
                 and torch.is_grad_enabled()):
             self.mine = _FWD_SCALES = _grad_scales_of(self.flat, ('fwd', self.tag))
             self.mine.begin()
+            if WEIGHT_PLANES:                  # the weights of this step are final: their fp16 planes, once, for forward and backward
+                global _PLANES
+                self.planes = _PLANES = WEIGHT_T.instance(self.flat)
+                self.planes.refresh_planes()
         return self
 
     def __exit__(self, *exc):
-        global _FWD_SCALES
+        global _FWD_SCALES, _PLANES
         if self.mine is not None:
             _FWD_SCALES = self.prev
+            if getattr(self, 'planes', None) is not None:
+                _PLANES = None
+                self.planes.planes_paired = exc[0] is None      # the gradient scope that follows uses them as they are
+                self.planes = None
             if exc[0] is None:
                 self.mine.roll()
         return False
@@ -787,6 +845,13 @@ class direct_weight_gradients:
             _GRAD_SCALES.begin()
         if self.flat is not None and BATCHED_TRANSPOSES:
             WEIGHT_T.begin(self.flat)
+            if WEIGHT_PLANES and _GRAD_SCALES is not None:
+                global _PLANES
+                inst = WEIGHT_T.current
+                if not inst.planes_paired:         # no forward scope made them for this step
+                    inst.refresh_planes()
+                inst.planes_paired = False
+                _PLANES = inst
         return self
 
     def __exit__(self, *exc):
@@ -805,7 +870,9 @@ class direct_weight_gradients:
                 _PENDING_REDUCTIONS.clear()
                 _PENDING_VEC_REDUCTIONS.clear()
         finally:
+            global _PLANES
             _GRAD_SCALES = None
+            _PLANES = None
             hip.gradient_scope(False)
             WEIGHT_T.end()
         return False
@@ -943,8 +1010,20 @@ class _WeightTransposes:
         self.desc = None
         self.retired = []          # earlier descriptor tables: captured graphs may still read them
         self.total_tiles = 0
+        # round 6: the same matrices as fp16 plane pairs ("P4", csrc/gemm_grad.hip), made once per step: `planes` mirrors the flat
+        # buffer (B operand of the forward products), `planes_t` the arena (B operand of the input-gradient products), amax[i] = the
+        # amax matrix i (in descriptor order) was scaled with.  Same lifetime rules as the arena: never freed, never moved.
+        self.planes = torch.empty_like(flat)
+        self.planes_t = torch.empty_like(flat)
+        self.amax = torch.zeros(self.MAX_MATRICES, dtype=torch.float32, device=flat.device)
+        self.planes_paired = False      # a forward scope made the planes of this step: the gradient scope uses them as they are
+        self.planes_live = False        # the plane images describe the current `uploaded` set
+        self._plane_hits = {}           # (ptr, rows, cols, ld) -> (plane tensor, amax slot) | None
+        self._sorted = []               # (offset, rows, cols, index) of the uploaded set, ascending
 
-    def refresh(self):
+    MAX_MATRICES = 4096
+
+    def _upload(self):
         if len(self.entries) != len(self.uploaded) and not torch.cuda.is_current_stream_capturing():
             rows, tiles = [], 0
             for key, (off, r, c) in sorted(self.entries.items(), key=lambda kv: kv[1][0]):
@@ -954,6 +1033,50 @@ class _WeightTransposes:
                 self.retired.append(self.desc)
             self.desc = torch.tensor(rows, dtype=torch.int64).to(self.flat.device)
             self.total_tiles, self.uploaded = tiles, dict(self.entries)
+            self._sorted = [(off, r, c, i) for i, (off, r, c, _) in enumerate(rows)]
+            self._plane_hits = {}
+            self.planes_live = False
+
+    def refresh_planes(self):
+        """The P4 images of every uploaded matrix and of its transpose under this step's own amax: three small launches."""
+        self._upload()
+        n = len(self.uploaded)
+        if n and n <= self.MAX_MATRICES:
+            hip.call('vqcpc_weight_planes_many', self.flat, self.desc, n, self.total_tiles, self.amax, self.planes, self.planes_t)
+            self.planes_live = True
+
+    def lookup_planes(self, b, ldb):
+        """(P4 image at b's address, amax slot) when the 2-D operand `b` (unit inner stride, leading dimension ldb) is a registered
+        weight -- or a row / column block of one -- inside the flat buffer, or of its transpose inside the arena; else None."""
+        if not self.planes_live:
+            return None
+        key = (b.data_ptr(), b.shape[0], b.shape[1], ldb)
+        hit = self._plane_hits.get(key, 0)
+        if hit != 0:
+            return hit
+        res = None
+        ptr = key[0]
+        for base_t, img, transposed in ((self.flat, self.planes, False), (self.arena, self.planes_t, True)):
+            base = base_t.data_ptr()
+            off = (ptr - base) // 4
+            if not (base <= ptr and off < base_t.numel() and (ptr - base) % 16 == 0):
+                continue
+            i = bisect.bisect_right(self._sorted, (off, 1 << 62, 0, 0)) - 1
+            if i < 0:
+                continue
+            o, r, c, idx = self._sorted[i]
+            ld = r if transposed else c                     # leading dimension of the (possibly transposed) registered matrix
+            rows_all = c if transposed else r
+            if (off < o + r * c and ldb == ld and ld % 4 == 0 and b.shape[1] % 4 == 0
+                    and (off - o) % ld + b.shape[1] <= ld and (off - o) // ld + b.shape[0] <= rows_all):
+                span = (b.shape[0] - 1) * ld + b.shape[1]
+                res = (img[off:off + span], self.amax[idx:idx + 1])
+            break
+        self._plane_hits[key] = res
+        return res
+
+    def refresh(self):
+        self._upload()
         if self.uploaded:
             hip.call('vqcpc_transpose_many', self.flat, self.arena, self.desc, len(self.uploaded), self.total_tiles)
 
@@ -980,12 +1103,16 @@ class _WeightTransposeRegistry:
     def __init__(self):
         self.current = None
 
-    def begin(self, owner):
+    def instance(self, owner):
         flat = owner if torch.is_tensor(owner) else owner.flat
         inst = getattr(owner, '_vqcpc_weight_t', None)
         if inst is None or inst.flat.data_ptr() != flat.data_ptr() or inst.flat.numel() != flat.numel():
             inst = _WeightTransposes(flat)
             owner._vqcpc_weight_t = inst
+        return inst
+
+    def begin(self, owner):
+        inst = self.instance(owner)
         inst.refresh()
         self.current = inst
 

@@ -376,4 +376,6 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         means = dict(zip(self.KEYS, sums.cpu().tolist()))     # the host sync of the epoch
         self.teacher.data_processor.raise_if_bad_tokens(dp=self.dp)
         self.encoder.data_processor.raise_if_bad_tokens(dp=self.dp)
+        if train:
+            self._report_scale_saturation(means)
         return means

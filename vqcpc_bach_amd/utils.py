@@ -21,8 +21,13 @@ class _StepLock:
     def __enter__(self):
         self._lock.acquire()
         self._depth += 1
-        if self._depth == 1 and self._event is not None:
-            torch.cuda.current_stream().wait_event(self._event)
+        try:
+            if self._depth == 1 and self._event is not None:
+                torch.cuda.current_stream().wait_event(self._event)
+        except BaseException:                    # __exit__ is not called when __enter__ raises: give the lock back here
+            self._depth -= 1
+            self._lock.release()
+            raise
         return self
 
     def __exit__(self, *exc):
@@ -82,16 +87,21 @@ class _OwnedStream:
 
     def __enter__(self):
         STEP_LOCK.__enter__()                    # one training step at a time, process-wide (see _StepLock)
-        s, st = self.seeds, getattr(self.owner, '_dropout_stream', None)
-        self.outer = (s.base, s.counter)
-        if st is not None and len(st) > 2 and st[2] != s.generation and not getattr(self.owner, '_dropout_reseed_warned', False):
-            import warnings
-            self.owner._dropout_reseed_warned = True
-            warnings.warn('SEEDS.manual_seed() was called after this trainer took its first step: the trainer keeps its own '
-                          'dropout-seed stream (call trainer.seed_dropout(base) to re-seed it)', stacklevel=3)
-        self._gen = st[2] if (st is not None and len(st) > 2) else s.generation     # the generation this stream belongs to
-        if st is None:
-            st = (s.base, s.counter)
+        try:
+            s, st = self.seeds, getattr(self.owner, '_dropout_stream', None)
+            outer = (s.base, s.counter)
+            if st is not None and len(st) > 2 and st[2] != s.generation and not getattr(self.owner, '_dropout_reseed_warned', False):
+                import warnings
+                self.owner._dropout_reseed_warned = True
+                warnings.warn('SEEDS.manual_seed() was called after this trainer took its first step: the trainer keeps its own '
+                              'dropout-seed stream (call trainer.seed_dropout(base) to re-seed it)', stacklevel=3)
+            self._gen = st[2] if (st is not None and len(st) > 2) else s.generation     # the generation this stream belongs to
+            if st is None:
+                st = (s.base, s.counter)
+        except BaseException:                    # (warnings as errors, a broken owner): no __exit__ will follow -- release the lock
+            STEP_LOCK.__exit__(None, None, None)
+            raise
+        self.outer = outer
         s.base, s.counter = st[0], st[1]
         return s
 

@@ -295,16 +295,5 @@ class VQCPCEncoderTrainer(GraphedTraining, EncoderTrainer):
                      num_codewords=host[3], num_codewords_negative=host[4])
         means['loss_monitor'] = -sum(means['accuracy']) / len(means['accuracy'])
         if train:
-            self._warn_on_scale_saturation()
+            self._report_scale_saturation(means)      # graphs.GraphedTraining: means['f16x3_scale_saturations'] + marked steps
         return means
-
-    def _warn_on_scale_saturation(self):
-        """f16x3 arithmetic: a tensor that grew by more than the 16-32 x head-room of its previous-step scale had its largest elements
-        clamped for one step (csrc/gemm_grad.hip).  That never happened in the runs of this repository; if it does, say so."""
-        n = ops.scale_saturations(self.flat)
-        if n > getattr(self, '_scale_saturations_seen', 0):
-            import warnings
-            warnings.warn(f'f16x3 GEMM arithmetic: {n - getattr(self, "_scale_saturations_seen", 0)} operand tensors outgrew the fp16 range '
-                          'under their previous-step scale during this epoch (clamped for one step each); '
-                          'ops.set_gradient_arithmetic("six") / ops.FWD_ARITH = "six" select the scale-free arithmetic')
-            self._scale_saturations_seen = n

@@ -220,7 +220,7 @@ int vqcpc_gemm_nt_f16x3(const float* A, int64_t lda, const float* B, int64_t ldb
  *   fp32 A): same loads, same LDS image, same products in the same order -- bit-identical to the fp32-operand entry points whenever
  *   those run under the same amax (tests/test_kernels_gpu.py::test_p4_*).  scale_state still receives the amax of an fp32 A. */
 int vqcpc_weight_planes_many(const float* base, const int64_t* desc, int n, int64_t total_tiles, float* amax, void* planes,
-                             void* planes_t, void* stream);
+                             void* planes_t, void* workspace, int64_t workspace_bytes, void* stream);     /* workspace: total_tiles floats */
 int vqcpc_gemm_nt_g3_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                         const float* bias, int act, float drop_p, uint64_t seed, const float* add, int64_t ldadd, const float* add2,
                         int64_t ldadd2, const void* gate_mask, float gate_scale, void* mask_out, float* scale_state,

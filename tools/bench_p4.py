@@ -24,7 +24,8 @@ def planes_of(mats):
     desc = torch.tensor(rows, dtype=torch.int64).cuda()
     planes, planes_t = torch.empty_like(flat), torch.empty_like(flat)
     amax = torch.zeros(len(mats), device='cuda')
-    hip.call('vqcpc_weight_planes_many', flat, desc, len(mats), tiles, amax, planes, planes_t)
+    ws = torch.empty(tiles, device='cuda')
+    hip.call('vqcpc_weight_planes_many', flat, desc, len(mats), tiles, amax, planes, planes_t, ws, 4 * tiles)
     return flat, planes, planes_t, amax, offs
 
 

@@ -917,7 +917,7 @@ __global__ __launch_bounds__(1024) void grad_scale_roll_logged_kernel(float* __r
 // contraction of the INPUT-GRADIENT product dy W) at the same offset of `planes_t` (the layout of the transposed-weight arena), both
 // under the power-of-two scale of amax[i].  The weights of a step are final when its forward begins: the scale is exact, never stale.
 __global__ __launch_bounds__(256) void weight_amax_many_kernel(const float* __restrict__ base, const int64_t* __restrict__ desc, int n,
-                                                               float* __restrict__ amax) {
+                                                               float* __restrict__ tile_max) {
     int lo = 0, hi = n - 1;
     const int64_t t = blockIdx.x;
     while (lo < hi) {
@@ -935,24 +935,21 @@ __global__ __launch_bounds__(256) void weight_amax_many_kernel(const float* __re
         const int r = r0 + ty + k * 8;
         if (r < R && c < C) a = fmaxf(a, fabsf(in[(int64_t)r * C + c]));
     }
-    // one atomic per WORKGROUP, and only when it would raise the slot: atomics on one address retire one by one (~11.5 ns each; with one
-    // per wave this 5.7 M-element pass took 0.21 ms per step, profiles/r06_perf_log.md)
+    // no atomics: one value per 32 x 32 tile; the plane pass reduces its matrix's tiles itself (an atomic max per workgroup on one
+    // address per matrix took 67-210 us per step here: atomics on one address retire one by one, profiles/r06_perf_log.md)
     __shared__ float red[4];
     a = wave_max(a);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        a = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
-        unsigned int* slot = reinterpret_cast<unsigned int*>(amax + lo);
-        if (a > 0.0f && __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < __float_as_uint(a))
-            atomicMax(slot, __float_as_uint(a));
-    }
+    if (threadIdx.x == 0) tile_max[t] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
 __global__ __launch_bounds__(256) void weight_planes_many_kernel(const float* __restrict__ base, const int64_t* __restrict__ desc, int n,
-                                                                 const float* __restrict__ amax, uint4* __restrict__ planes,
+                                                                 const float* __restrict__ tile_max, int64_t total_tiles,
+                                                                 float* __restrict__ amax, uint4* __restrict__ planes,
                                                                  uint4* __restrict__ planes_t) {
     __shared__ float tile[32][33];
+    __shared__ float red[4];
     int lo = 0, hi = n - 1;
     const int64_t t = blockIdx.x;
     while (lo < hi) {
@@ -962,7 +959,18 @@ __global__ __launch_bounds__(256) void weight_planes_many_kernel(const float* __
     const int64_t off = desc[4 * lo];
     const int R = (int)desc[4 * lo + 1], C = (int)desc[4 * lo + 2];
     const int local = (int)(t - desc[4 * lo + 3]), tiles_c = (C + 31) / 32;
-    const float sc = g3_pow2(g3_scale_exp(amax[lo]));
+    // amax of the matrix = max over its tiles' maxima (the previous pass), the same value in every workgroup of the matrix
+    float am = 0.0f;
+    {
+        const int64_t t0 = desc[4 * lo + 3], t1 = (lo + 1 < n) ? desc[4 * (lo + 1) + 3] : total_tiles;
+        for (int64_t i = t0 + threadIdx.x; i < t1; i += 256) am = fmaxf(am, tile_max[i]);
+        am = wave_max(am);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = am;
+        __syncthreads();
+        am = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        if (local == 0 && threadIdx.x == 0) amax[lo] = am;              // what the GEMM kernels derive the same scale from
+    }
+    const float sc = g3_pow2(g3_scale_exp(am));
     const float* in = base + off;
     const int c0 = (local % tiles_c) * 32, r0 = (local / tiles_c) * 32;
     const int g = threadIdx.x & 7, row = threadIdx.x >> 3;            // 32 rows x 8 groups of four columns
@@ -1418,20 +1426,20 @@ int vqcpc_grad_scale_roll_counted(float* state, int nsites, void* saturated_coun
 }
 
 int vqcpc_weight_planes_many(const float* base, const int64_t* desc, int n, int64_t total_tiles, float* amax, void* planes,
-                             void* planes_t, void* stream) {
+                             void* planes_t, void* workspace, int64_t workspace_bytes, void* stream) {
     if (n == 0) return VQCPC_OK;
-    VQ_REQUIRE(base && desc && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31) && amax && planes && planes_t && aligned16(base) &&
-                   aligned16(planes) && aligned16(planes_t),
+    VQ_REQUIRE(base && desc && n > 0 && total_tiles > 0 && total_tiles < (1ll << 31) && amax && planes && planes_t && workspace &&
+                   aligned16(base) && aligned16(planes) && aligned16(planes_t),
                "weight_planes_many: bad arguments");
-    hipStream_t st = (hipStream_t)stream;
-    if (hipMemsetAsync(amax, 0, (size_t)n * sizeof(float), st) != hipSuccess) {
-        set_error("weight_planes_many: memset failed");
-        return VQCPC_ELAUNCH;
+    if (workspace_bytes < total_tiles * (int64_t)sizeof(float)) {
+        set_error("weight_planes_many: workspace too small (one float per 32 x 32 tile)");
+        return VQCPC_EWORKSPACE;
     }
-    hipLaunchKernelGGL(weight_amax_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, base, desc, n, amax);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(weight_amax_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, base, desc, n, (float*)workspace);
     VQ_CHECK_LAUNCH("weight_amax_many");
-    hipLaunchKernelGGL(weight_planes_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, base, desc, n, (const float*)amax,
-                       (uint4*)planes, (uint4*)planes_t);
+    hipLaunchKernelGGL(weight_planes_many_kernel, dim3((unsigned)total_tiles), dim3(256), 0, st, base, desc, n, (const float*)workspace,
+                       total_tiles, amax, (uint4*)planes, (uint4*)planes_t);
     VQ_CHECK_LAUNCH("weight_planes_many");
     return VQCPC_OK;
 }

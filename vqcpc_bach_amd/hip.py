@@ -74,7 +74,7 @@ SIGNATURES = {
                                    c_ptr]),
     'vqcpc_gemm_nt_f16x3': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr,
                                     c_i64, c_ptr, c_ptr, c_ptr]),
-    'vqcpc_weight_planes_many': (c_int, [c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_weight_planes_many': (c_int, [c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_nt_g3_pl': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr,
                                     c_i64, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     'vqcpc_gemm_nt_g3_tail_pl': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_f32, c_u64, c_i64,

@@ -1016,6 +1016,8 @@ class _WeightTransposes:
         self.planes = torch.empty_like(flat)
         self.planes_t = torch.empty_like(flat)
         self.amax = torch.zeros(self.MAX_MATRICES, dtype=torch.float32, device=flat.device)
+        # one float per 32 x 32 tile of every registered matrix (their maxima, reduced per matrix by the plane pass: no atomics)
+        self.tile_max = torch.zeros(flat.numel() // 256 + 4 * self.MAX_MATRICES + 64, dtype=torch.float32, device=flat.device)
         self.planes_paired = False      # a forward scope made the planes of this step: the gradient scope uses them as they are
         self.planes_live = False        # the plane images describe the current `uploaded` set
         self._plane_hits = {}           # (ptr, rows, cols, ld) -> (plane tensor, amax slot) | None
@@ -1041,8 +1043,9 @@ class _WeightTransposes:
         """The P4 images of every uploaded matrix and of its transpose under this step's own amax: three small launches."""
         self._upload()
         n = len(self.uploaded)
-        if n and n <= self.MAX_MATRICES:
-            hip.call('vqcpc_weight_planes_many', self.flat, self.desc, n, self.total_tiles, self.amax, self.planes, self.planes_t)
+        if n and n <= self.MAX_MATRICES and self.total_tiles <= self.tile_max.numel():
+            hip.call('vqcpc_weight_planes_many', self.flat, self.desc, n, self.total_tiles, self.amax, self.planes, self.planes_t,
+                     self.tile_max, 4 * self.tile_max.numel())
             self.planes_live = True
 
     def lookup_planes(self, b, ldb):

@@ -215,20 +215,24 @@ int vqcpc_gemm_nt_f16x3(const float* A, int64_t lda, const float* B, int64_t ldb
  *   P4 of W_i at the same offset (groups along the columns: B operand of the forward x W^T; needs cols % 4 == 0), `planes_t` = P4 of
  *   W_i^T at the same offset of the transposed-weight arena (groups along the rows: B operand of dy W; needs rows % 4 == 0).
  *   Replaces the split of the same 256 x K weight tile by every workgroup for every output tile (2 176 times per 557 056-row launch).
- * vqcpc_gemm_nt_g3_pl / vqcpc_gemm_nt_g3_tail_pl: vqcpc_gemm_nt_grad | vqcpc_gemm_nt_f16x3 | vqcpc_gemm_nt_grad_tail with B (and
- *   optionally A) given as P4 images + the device scalar their planes were scaled with (pl_amax_b required, pl_amax_a NULL for an
- *   fp32 A): same loads, same LDS image, same products in the same order -- bit-identical to the fp32-operand entry points whenever
- *   those run under the same amax (tests/test_kernels_gpu.py::test_p4_*).  scale_state still receives the amax of an fp32 A. */
+ * vqcpc_gemm_nt_g3_pl: vqcpc_gemm_nt_grad | vqcpc_gemm_nt_f16x3 with B (and optionally A) given as P4 images + the device scalar
+ *   their planes were scaled with (pl_amax_b required, pl_amax_a NULL for an fp32 A): same loads, same LDS image, same products in
+ *   the same order -- bit-identical to the fp32-operand entry points whenever those run under the same amax
+ *   (tests/test_kernels_gpu.py::test_p4_*).  scale_state still receives the amax of an fp32 A.
+ * vqcpc_gemm_nt_g3_small: the 64 x 128-tile kernel of vqcpc_gemm_nt_grad_tail as a general entry point -- tail rows of ragged
+ *   launches on P4 operands AND whole products too small for 256-tiles (M % 64 == 0, N % 128 == 0, K % 32 == 0: the 3 072 - 12 288-row
+ *   products of the student / decoder steps); operands fp32 or P4 (pl_amax_* NULL: fp32); epilogue in the order of vqcpc_gemm_nt:
+ *   + bias, relu (act == 1), dropout, * (gate > 0 ? gate_scale : 0), + add (may be C), + add2. */
 int vqcpc_weight_planes_many(const float* base, const int64_t* desc, int n, int64_t total_tiles, float* amax, void* planes,
                              void* planes_t, void* workspace, int64_t workspace_bytes, void* stream);     /* workspace: total_tiles floats */
 int vqcpc_gemm_nt_g3_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
                         const float* bias, int act, float drop_p, uint64_t seed, const float* add, int64_t ldadd, const float* add2,
                         int64_t ldadd2, const void* gate_mask, float gate_scale, void* mask_out, float* scale_state,
                         const float* pl_amax_a, const float* pl_amax_b, void* stream);
-int vqcpc_gemm_nt_g3_tail_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
-                             const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add, int64_t ldadd,
-                             const float* add2, int64_t ldadd2, float* scale_state, const float* pl_amax_a, const float* pl_amax_b,
-                             void* stream);
+int vqcpc_gemm_nt_g3_small(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                           const float* bias, int act, float drop_p, uint64_t seed, int64_t row0, const float* gate, int64_t ldgate,
+                           float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, float* scale_state,
+                           const float* pl_amax_a, const float* pl_amax_b, void* stream);
 int vqcpc_grad_amax(const float* x, int64_t ld, int64_t rows, int cols, float* amax_slot, void* stream);
 int vqcpc_grad_scale_roll(float* state, int nsites, void* stream);
 /* the same, and *saturated_count (uint32, device) += the number of (site, operand) pairs whose amax of this step lay beyond the fp16

@@ -70,7 +70,7 @@ class _CallLog:
 
         def rec(name, *args):
             self.names.append(name)
-            if name in ('vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad_tail', 'vqcpc_gemm_nt_g3_pl', 'vqcpc_gemm_nt_g3_tail_pl'):
+            if name in ('vqcpc_gemm_nt_grad', 'vqcpc_gemm_nt_f16x3', 'vqcpc_gemm_nt_grad_tail', 'vqcpc_gemm_nt_g3_pl', 'vqcpc_gemm_nt_g3_small'):
                 M, N, K = args[6:9]
                 in_place = False
                 if name == 'vqcpc_gemm_nt_grad' and args[9] is not None:
@@ -181,12 +181,12 @@ def _full_size_properties(name, arith, seed, grad_tol=2e-5):
             n = log.names
             assert n.count('vqcpc_gemm_nt_f16x3') >= 8 and n.count('vqcpc_gemm_tn_grad') >= 8, (
                 n.count('vqcpc_gemm_nt_f16x3'), n.count('vqcpc_gemm_tn_grad'))
-            assert n.count('vqcpc_gemm_nt_grad_tail') + n.count('vqcpc_gemm_nt_g3_tail_pl') >= 4, 'no ragged launch was cut into whole rounds + tail rows'
+            assert n.count('vqcpc_gemm_nt_grad_tail') + n.count('vqcpc_gemm_nt_g3_small') >= 4, 'no ragged launch was cut into whole rounds + tail rows'
             assert any(e[4] for e in log.nt), 'the in-place (add == C) accumulate form of vqcpc_gemm_nt_grad did not run'
             under = [e for e in log.nt if 'tail' not in e[0] and (e[1] // 256) * (e[2] // 256) < 256]
             # round 6: from the second step on the B operands are the weights' fp16 planes, made once per step
-            assert n.count('vqcpc_weight_planes_many') >= 4 and n.count('vqcpc_gemm_nt_g3_pl') >= 16 and n.count('vqcpc_gemm_nt_g3_tail_pl') >= 4, (
-                n.count('vqcpc_weight_planes_many'), n.count('vqcpc_gemm_nt_g3_pl'), n.count('vqcpc_gemm_nt_g3_tail_pl'))
+            assert n.count('vqcpc_weight_planes_many') >= 4 and n.count('vqcpc_gemm_nt_g3_pl') >= 16 and n.count('vqcpc_gemm_nt_g3_small') >= 4, (
+                n.count('vqcpc_weight_planes_many'), n.count('vqcpc_gemm_nt_g3_pl'), n.count('vqcpc_gemm_nt_g3_small'))
             if name == 'C1':             # (C4's smallest 256-tile products still fill a round)
                 assert under, 'no under-filled round (fewer 256-tiles than CUs) ran on the three-product kernel'
         else:

@@ -525,6 +525,64 @@ def test_decoder_full_config_through_getters_vs_oracle(gemm_mode):
     assert a == b
 
 
+def test_decoder_full_config_with_f16x3_small_tile_products(gemm_mode):
+    """Round 6: the decoder step the way train_model() runs it -- forward inside ops.forward_arithmetic, backward inside the gradient
+    scope, the 64 x 128-tile three-product kernel for its 1 536-row products (batch 4 x 384 tokens) -- against the oracle at the
+    tolerances of the test above."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('an arithmetic of the bf16x6 mode')
+    from vqcpc_bach_amd import configs, getters, hip, ops
+    config = configs.make_config('DEC', dropout=0.0)
+    torch.manual_seed(5)
+    dlg = getters.get_dataloader_generator(config['dataset'], config['training_method'],
+                                           dict(config['dataloader_generator_kwargs'], seed=7, device='cuda'))
+    enc_cfg = config['config_encoder']
+    enc_cfg['downscaler_kwargs']['dropout'] = 0.0
+    enc_dlg = getters.get_dataloader_generator(enc_cfg['dataset'], enc_cfg['training_method'],
+                                               dict(enc_cfg['dataloader_generator_kwargs'], seed=7, device='cuda'))
+    encoder = getters.get_encoder('/tmp/vqcpc_test_decoder_full3', enc_dlg, enc_cfg)
+    dp = getters.get_data_processor(dlg, config['data_processor_type'], config['data_processor_kwargs'])
+    dec = getters.get_decoder('/tmp/vqcpc_test_decoder_full3', dlg, dp, encoder, config['decoder_type'], config['decoder_kwargs'])
+    dec.cuda()
+    dec.init_optimizers(lr=config['lr'], schedule_lr=config['schedule_lr'])
+    sd = {k: v.detach().cpu().clone() for k, v in dec.state_dict().items()}
+    cfg = D.make_cfg('DEC', vocab=list(dlg.vocab), B=4)
+    x = next(dlg.dataloaders(batch_size=4)[0])['x']
+    oracle = D.DecoderOracleTrainer(cfg, sd, lr=config['lr'])
+    ref = oracle.step({'x': x.cpu()}, train=True)
+    dec.eval()
+    codes = dec.encode(x)
+    assert torch.equal(codes.cpu(), ref['codes'])
+    dec.train()
+    prev = ops.set_gradient_arithmetic('f16x3')
+    saved = ops.FWD_ARITH, ops.SMALL_F16X3_MIN_TILES
+    ops.FWD_ARITH, ops.SMALL_F16X3_MIN_TILES = 'f16x3', 0
+    calls, raw = [], hip.call
+    hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+    try:
+        with ops.forward_arithmetic(dec.flat):
+            loss, logits, _, _ = dec.compute_loss(codes, dec.data_processor.preprocess(x))
+        dec.flat.zero_grad()
+        with ops.direct_weight_gradients(dec.flat):
+            loss.backward()
+    finally:
+        hip.call = raw
+        ops.FWD_ARITH, ops.SMALL_F16X3_MIN_TILES = saved
+        ops.set_gradient_arithmetic(prev)
+    assert calls.count('vqcpc_gemm_nt_g3_small') >= 30, calls.count('vqcpc_gemm_nt_g3_small')
+    assert abs(float(loss.detach()) - float(ref['loss'].detach())) < FWD_TOL * float(ref['loss'].detach())
+    for c in range(4):
+        assert rel_err(logits[c].cpu(), ref['logits'][c]) < 2 * FWD_TOL
+    for k, p in dec.named_parameters():
+        if k.startswith('encoder.'):
+            continue
+        r = oracle.last_grads[k]
+        if float(r.abs().max()) == 0.0:
+            assert float(p.grad.abs().max()) == 0.0, k
+        else:
+            assert rel_err(p.grad.cpu(), r) < 2 * GRAD_TOL, k
+
+
 @pytest.mark.parametrize('name', ['mha_self_causal_T24', 'mha_self_full_T16', 'mha_cross_anticausal_S6_T12'])
 def test_multihead_attention_forward_api_against_the_reference(name, gemm_mode):
     """`MultiheadAttentionCustom.forward(query, key, value, attn_mask=...)` -- the reference's own signature

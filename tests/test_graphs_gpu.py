@@ -76,7 +76,7 @@ def test_graph_replay_is_the_eager_step_under_the_f16x3_arithmetic():
     hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
     try:
         l_e, p_e, r_e, tr_e = _run(cfg, sd, batches, graph=False)
-        n_eager = calls.count('vqcpc_gemm_nt_f16x3') + sum(1 for c in calls if c in ('vqcpc_gemm_nt_g3_pl', 'vqcpc_gemm_nt_g3_tail_pl'))
+        n_eager = calls.count('vqcpc_gemm_nt_f16x3') + sum(1 for c in calls if c in ('vqcpc_gemm_nt_g3_pl', 'vqcpc_gemm_nt_g3_small'))
         assert 'vqcpc_weight_planes_many' in calls     # round 6: from the second step on B comes from the weights' fp16 planes
         l_g, p_g, r_g, tr = _run(cfg, sd, batches, graph=True)
     finally:

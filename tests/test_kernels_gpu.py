@@ -2552,6 +2552,6 @@ def test_p4_products_are_bit_identical_to_the_fp32_operand_kernels(ops, bf16x6, 
     hip.call('vqcpc_gemm_nt_grad_tail', a[:rows], K, w, K, ref, N, rows, N, K, bias, 0.1, 9, 4096, add[:rows], N, None, 0, state())
     for a_, am in ((a, None), (ap, amax[1:2])):
         out = torch.empty(rows, N, device='cuda')
-        hip.call('vqcpc_gemm_nt_g3_tail_pl', a_[:rows * K], K, wp, K, out, N, rows, N, K, bias, 0.1, 9, 4096, add[:rows], N, None, 0, state(),
-                 am, amax[0:1])
+        hip.call('vqcpc_gemm_nt_g3_small', a_[:rows * K], K, wp, K, out, N, rows, N, K, bias, 0, 0.1, 9, 4096, None, 0, 1.0, add[:rows], N,
+                 None, 0, state(), am, amax[0:1])
         assert torch.equal(out, ref), am is not None

@@ -278,3 +278,61 @@ def test_student_c3_model_dimensions_vs_oracle(gemm_mode):
         worst = max(worst, e)
         assert e < GRAD_TOL, (n, e)
     print(f'worst relative gradient error {worst:.2e}')
+
+
+def test_student_c3_model_dimensions_with_f16x3_small_tile_products(gemm_mode):
+    """Round 6: what train_model() selects for the student step -- the forward inside ops.forward_arithmetic, the backward inside the
+    gradient scope, every product the 64 x 128-tile three-product kernel takes (vqcpc_gemm_nt_g3_small) forced through it -- at the
+    C3 model dimensions against the oracle, UNCHANGED tolerances: indices bit-exact, the four losses within 5e-5, every gradient
+    within 5e-4.  A second step then runs the same products on the weights' fp16 planes."""
+    if gemm_mode != 'bf16x6':
+        pytest.skip('an arithmetic of the bf16x6 mode')
+    from vqcpc_bach_amd import hip, ops
+    cfg = S.make_cfg('C3', B=2)
+    sd = S.init_state(cfg, seed=5)
+    batch = S.synthetic_batch(cfg, seed=6)
+    m = 37
+    with torch.no_grad():
+        z = S.encoder_forward(batch['x'], sd, cfg)[3].reshape(-1, cfg['D'])
+        sd['encoder.quantizer.embeddings.0'] = z[:cfg['K']].clone() + 0.01
+    _condition_student_relu_gates(cfg, sd, batch['x'], m)
+    otr = S.StudentOracleTrainer(cfg, sd, lr=1e-4)
+    ref = otr.step(batch, train=True, masked_event_index=m)
+    tr = build_student(cfg, sd, lr=1e-4)
+    tr.train()
+    prev = ops.set_gradient_arithmetic('f16x3')
+    saved = ops.FWD_ARITH, ops.SMALL_F16X3_MIN_TILES
+    ops.FWD_ARITH, ops.SMALL_F16X3_MIN_TILES = 'f16x3', 0
+    calls, raw = [], hip.call
+    hip.call = lambda name, *args: (calls.append(name), raw(name, *args))[1]
+    try:
+        with ops.forward_arithmetic(tr.flat):
+            lt, le, out = tr.compute_losses(batch, masked_event_index=m)
+        n_fwd = calls.count('vqcpc_gemm_nt_g3_small')
+        tr.flat.zero_grad()
+        with ops.direct_weight_gradients(tr.flat):
+            (lt + le).backward()
+        n_all = calls.count('vqcpc_gemm_nt_g3_small')
+        assert torch.equal(out['encoding_indices'].cpu(), ref['idx'])
+        for k in ('loss_teacher', 'loss_encdec', 'loss_quantization', 'loss_reconstruction'):
+            assert abs(float(out[k]) - float(ref[k])) < FWD_TOL * max(1.0, abs(float(ref[k]))), k
+        worst = 0.0
+        for n, p in named_params(tr):
+            e = rel_err(p.grad.cpu(), otr.last_grads[n])
+            worst = max(worst, e)
+            assert e < GRAD_TOL, (n, e)
+        print(f'{n_fwd} forward + {n_all - n_fwd} backward launches on the 64 x 128-tile three-product kernel; worst relative gradient error {worst:.2e}')
+        assert n_fwd >= 40 and n_all - n_fwd >= 40, (n_fwd, n_all)
+        # second pass of the same step (no optimiser update in between): B operands from the weight planes, same results to rounding
+        del lt, le
+        g1 = tr.flat.flat_grad.clone()
+        del calls[:]
+        out2 = tr._step_compute(batch, masked_event_index=m)
+        assert 'vqcpc_weight_planes_many' in calls and calls.count('vqcpc_gemm_nt_g3_small') >= 80
+        assert torch.equal(out2['encoding_indices'].cpu(), ref['idx'])
+        assert float((tr.flat.flat_grad - g1).abs().max() / g1.abs().max()) < 1e-5
+        assert ops.scale_saturations(tr.flat) == 0
+    finally:
+        hip.call = raw
+        ops.FWD_ARITH, ops.SMALL_F16X3_MIN_TILES = saved
+        ops.set_gradient_arithmetic(prev)

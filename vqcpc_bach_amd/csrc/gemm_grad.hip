@@ -842,7 +842,9 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float*
         const int64_t row = row_base + (r & 3) + 8 * (r >> 2);
         float v = acc[r] * inv;                          // exact: a power of two
         if (ep.bias) v += bv;
+        if (ep.act == 1) v = fmaxf(v, 0.0f);             // (round 6: the epilogue order of gemm_nt_kernel, gemm.hip)
         if (ep.thr) v *= drop_scale(ep.seed, (uint64_t)(row + ep.row0) * (uint64_t)N + (uint64_t)col, ep.thr, ep.inv_keep);
+        if (ep.gate) v *= (ep.gate[row * ep.ldgate + col] > 0.0f ? ep.gate_scale : 0.0f);
         if (ep.add) v += ep.add[row * ep.ldadd + col];   // may be C itself (in place): read and written by this lane only
         if (ep.add2) v += ep.add2[row * ep.ldadd2 + col];
         C[row * ldc + col] = v;
@@ -1322,29 +1324,37 @@ int vqcpc_gemm_nt_g3_pl(const float* A, int64_t lda, const float* B, int64_t ldb
     return VQCPC_OK;
 }
 
-// ... and the tail rows of a ragged launch on P4 operands (pl_amax_a optional, pl_amax_b required)
-int vqcpc_gemm_nt_g3_tail_pl(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
-                             const float* bias, float drop_p, uint64_t seed, int64_t row0, const float* add, int64_t ldadd,
-                             const float* add2, int64_t ldadd2, float* scale_state, const float* pl_amax_a, const float* pl_amax_b,
-                             void* stream) {
-    VQ_REQUIRE(A && B && C && scale_state && pl_amax_b, "gemm_nt_g3_tail_pl: null pointer");
-    VQ_REQUIRE(vqcpc_gemm_nt_grad_tail_supported(M, N, K), "gemm_nt_g3_tail_pl: M a multiple of 64, N of 128, K of 32, got M=%lld N=%d K=%d",
+// The 64 x 128-tile kernel as a GENERAL entry point (round 6): the tail rows of a ragged launch on P4 operands, and whole products
+// whose 256-tiles would not fill the chip (the 3 072 - 12 288-row products of the student / decoder steps: x 1.1-1.36 the six-product
+// 128-tile / split-K path, tools/bench_small_f16x3.py).  Operands fp32 or P4 (pl_amax_a / pl_amax_b NULL: fp32, split in the kernel).
+// Epilogue, in the order of vqcpc_gemm_nt: + bias, relu (act == 1), dropout (element index (row0 + row) * N + col), * (gate > 0 ?
+// gate_scale : 0), + add (may be C), + add2.
+int vqcpc_gemm_nt_g3_small(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K,
+                           const float* bias, int act, float drop_p, uint64_t seed, int64_t row0, const float* gate, int64_t ldgate,
+                           float gate_scale, const float* add, int64_t ldadd, const float* add2, int64_t ldadd2, float* scale_state,
+                           const float* pl_amax_a, const float* pl_amax_b, void* stream) {
+    VQ_REQUIRE(A && B && C && scale_state, "gemm_nt_g3_small: null pointer");
+    VQ_REQUIRE(vqcpc_gemm_nt_grad_tail_supported(M, N, K), "gemm_nt_g3_small: M a multiple of 64, N of 128, K of 32, got M=%lld N=%d K=%d",
                (long long)M, N, K);
     VQ_REQUIRE(lda % 4 == 0 && ldb % 4 == 0 && lda >= K && ldb >= K && ldc >= N && aligned16(A) && aligned16(B),
-               "gemm_nt_g3_tail_pl: bad leading dimensions / alignment");
-    VQ_REQUIRE(!(add2 && !add) && !(add && ldadd < N) && !(add2 && ldadd2 < N) && drop_p >= 0.f && drop_p < 1.f,
-               "gemm_nt_g3_tail_pl: bad epilogue operands");
+               "gemm_nt_g3_small: bad leading dimensions / alignment");
+    VQ_REQUIRE(!(add2 && !add) && !(add && ldadd < N) && !(add2 && ldadd2 < N) && !(gate && ldgate < N) && drop_p >= 0.f && drop_p < 1.f &&
+                   (act == 0 || act == 1),
+               "gemm_nt_g3_small: bad epilogue operands");
     EpiParams ep{};
     ep.bias = bias;
+    ep.act = act;
     ep.thr = drop_threshold(drop_p);
     ep.inv_keep = 1.0f / (1.0f - drop_p);
     ep.seed = seed;
     ep.row0 = row0;
+    ep.gate = gate;
+    ep.ldgate = ldgate;
+    ep.gate_scale = gate_scale;
     ep.add = add;
     ep.ldadd = ldadd;
     ep.add2 = add2;
     ep.ldadd2 = ldadd2;
-    ep.gate_scale = 1.0f;
     ep.pl_amax_a = pl_amax_a;
     ep.pl_amax_b = pl_amax_b;
     const int tn = N / kRN;
@@ -1356,7 +1366,7 @@ int vqcpc_gemm_nt_g3_tail_pl(const float* A, int64_t lda, const float* B, int64_
     }
     hipLaunchKernelGGL(gemm_nt_g3_tail_kernel, dim3((unsigned)((M / kRM) * tn)), dim3(kGThreads), lds, (hipStream_t)stream, A, lda, B,
                        ldb, C, ldc, N, K, tn, ep, scale_state);
-    VQ_CHECK_LAUNCH("gemm_nt_g3 (tail rows, P4 operands)");
+    VQ_CHECK_LAUNCH("gemm_nt_g3 (64 x 128 tiles)");
     return VQCPC_OK;
 }
 

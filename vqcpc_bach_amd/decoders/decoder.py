@@ -266,7 +266,9 @@ class Decoder(GraphedTraining, nn.Module):
     def _step_compute(self, tensor_dict):
         x = self.data_processor.checked(self.data_processor.preprocess(tensor_dict['x']))
         codes = self.encode(tensor_dict['x'])
-        with torch.enable_grad():              # whatever the caller's ambient grad mode: this IS the training step
+        # (round 6: the decoder's forward products inside ops.forward_arithmetic -- f16x3 scale table + the weights' fp16 planes of this
+        # step; the frozen encoder above is inference and stays outside, on six products)
+        with torch.enable_grad(), ops.forward_arithmetic(self.flat):      # whatever the caller's ambient grad mode: this IS the training step
             loss, _, _, _ = self.compute_loss(codes, x)
         self.flat.zero_grad()
         with ops.direct_weight_gradients(self.flat):

@@ -77,8 +77,8 @@ SIGNATURES = {
     'vqcpc_weight_planes_many': (c_int, [c_ptr, c_ptr, c_int, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr]),
     'vqcpc_gemm_nt_g3_pl': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_ptr,
                                     c_i64, c_ptr, c_i64, c_ptr, c_f32, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
-    'vqcpc_gemm_nt_g3_tail_pl': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_f32, c_u64, c_i64,
-                                         c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    'vqcpc_gemm_nt_g3_small': (c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i64, c_int, c_int, c_ptr, c_int, c_f32, c_u64, c_i64,
+                                       c_ptr, c_i64, c_f32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
     'vqcpc_grad_amax': (c_int, [c_ptr, c_i64, c_i64, c_int, c_ptr, c_ptr]),
     'vqcpc_grad_scale_roll': (c_int, [c_ptr, c_int, c_ptr]),
     'vqcpc_grad_scale_roll_counted': (c_int, [c_ptr, c_int, c_ptr, c_ptr]),

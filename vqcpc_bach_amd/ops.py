@@ -320,8 +320,9 @@ def _g3_nt(scales, key, a, lda, b, ldb, out, ldc, M, N, K, plan, bias=None, drop
     if splits < 0:                # the tail rows on 64 x 128 tiles
         pl = _PLANES.lookup_planes(b, ldb) if _PLANES is not None else None
         if pl is not None:
-            hip.call('vqcpc_gemm_nt_g3_tail_pl', a[m_main:], lda, pl[0], ldb, out[m_main:], ldc, rem, N, K, bias, float(drop_p), int(seed),
-                     m_main, None if add is None else add[m_main:], lda_, None if add2 is None else add2[m_main:], lda2_, st, None, pl[1])
+            hip.call('vqcpc_gemm_nt_g3_small', a[m_main:], lda, pl[0], ldb, out[m_main:], ldc, rem, N, K, bias, 0, float(drop_p), int(seed),
+                     m_main, None, 0, 1.0, None if add is None else add[m_main:], lda_, None if add2 is None else add2[m_main:], lda2_, st,
+                     None, pl[1])
             return out
         hip.call('vqcpc_gemm_nt_grad_tail', a[m_main:], lda, b, ldb, out[m_main:], ldc, rem, N, K, bias, float(drop_p), int(seed), m_main,
                  None if add is None else add[m_main:], lda_, None if add2 is None else add2[m_main:], lda2_, st)
@@ -394,6 +395,18 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
                 gemm_nt(a[m_g:], b, add=None if add is None else add[m_g:], add2=None if add2 is None else add2[m_g:], out=out[m_g:])
                 LAST_GEMM_F16X3 = True
             return out
+    if ((_FWD_SCALES is not None or _GRAD_SCALES is not None) and SMALL_F16X3 and hip.get_gemm_mode() == 1 and _small_f16x3_ok(M, N, K)
+            and act in (0, 1) and not (act and gate is not None) and (add2 is None or add is not None)
+            and lda % 4 == 0 and ldb % 4 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0):
+        # a product of a training step too small for 256-tiles (the 3 072 - 12 288-row products of the student / decoder steps): the
+        # three-product kernel on 64 x 128 tiles instead of the six-product 128-tile / split-K path, B from the weight planes
+        scales = _GRAD_SCALES if _GRAD_SCALES is not None else _FWD_SCALES
+        st = scales.site(('snt', M, N, K), a, lda, M, K, b, ldb, N, K)
+        pl = _PLANES.lookup_planes(b, ldb) if _PLANES is not None else None
+        LAST_GEMM_F16X3 = True
+        hip.call('vqcpc_gemm_nt_g3_small', a, lda, b if pl is None else pl[0], ldb, out, ldc, M, N, K, bias, int(act), float(drop_p),
+                 int(seed), 0, gate, ldg, float(gate_scale), add, lda_, add2, lda2_, st, None, None if pl is None else pl[1])
+        return out
     if (SPLIT_K and M <= _SPLITK_MAX_ROWS and K >= 512 and not act and not drop_p and gate is None and add2 is None
             and hip.get_gemm_mode() == 1):
         # few output tiles, long K (student / decoder steps): K cut over partial planes, see include/vqcpc.h
@@ -425,6 +438,19 @@ def gemm_nt(a, b, bias=None, act=0, drop_p=0.0, seed=0, gate=None, gate_scale=1.
     hip.call('vqcpc_gemm_nt', a, lda, b, ldb, out, ldc, M, N, K, bias, int(act), float(drop_p), int(seed), gate, ldg,
              float(gate_scale), add, lda_, add2, lda2_)
     return out
+
+
+# sub-256-tile products of a training step on the 64 x 128-tile three-product kernel (vqcpc_gemm_nt_g3_small; VQCPC_SMALL_F16X3=0: A/B
+# switch): from 128 tiles on (768 x 512 x 512 = 48 tiles: 0.95 x the six-product path, 768 x 2048 x 512 = 192 tiles: 1.19 x, 3 072-row
+# shapes 1.12-1.36 x, tools/bench_small_f16x3.py), up to the row count where the split-K / 128-tile paths end
+SMALL_F16X3 = os.environ.get('VQCPC_SMALL_F16X3', '1') != '0'
+SMALL_F16X3_MIN_TILES = 128
+SMALL_F16X3_MIN_K = 256
+
+
+def _small_f16x3_ok(M, N, K):
+    return (M % 64 == 0 and N % 128 == 0 and K % 32 == 0 and K >= SMALL_F16X3_MIN_K and 512 <= M <= _SPLITK_MAX_ROWS
+            and (M // 64) * (N // 128) >= SMALL_F16X3_MIN_TILES)
 
 
 def _splitk_operands_ok(plan, out, ldc, add, lda_, add2, lda2_, bias):

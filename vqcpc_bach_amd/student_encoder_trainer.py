@@ -222,7 +222,9 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
 
     def _step_compute(self, tensor_dict, masked_event_index=None):
         m = self._graph_m if masked_event_index is None else masked_event_index
-        with torch.enable_grad():              # whatever the caller's ambient grad mode: this IS the training step
+        # (round 6: the forward products of the step inside ops.forward_arithmetic, as in the CPC trainer -- their f16x3 scale table
+        # and the weights' fp16 planes for this step; the masked event index selects rows, not shapes: one table serves every index)
+        with torch.enable_grad(), ops.forward_arithmetic(self.flat):      # whatever the caller's ambient grad mode: this IS the training step
             loss_teacher, loss_encdec, out = self.compute_losses(tensor_dict, m)
         self.flat.zero_grad()
         with ops.direct_weight_gradients(self.flat):
@@ -276,7 +278,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
         x = self.teacher.data_processor.checked(self.teacher.data_processor.preprocess(tensor_dict['x']))
         m = self.draw_masked_event(x.shape[1]) if m is None else int(m)
         self.flat.zero_grad()
-        with torch.enable_grad():
+        with torch.enable_grad(), ops.forward_arithmetic(self.flat, tag='teacher'):
             t = self.forward_teacher(x, m)
         with ops.direct_weight_gradients(self.flat, tag='teacher'):       # own f16x3 scale table: two backward passes per step
             t['loss'].backward()
@@ -284,7 +286,7 @@ class StudentEncoderTrainer(GraphedTraining, EncoderTrainer):
                     monitored=dict(t['monitored_quantities']))
 
     def _step_compute_encdec(self, st):
-        with torch.enable_grad():
+        with torch.enable_grad(), ops.forward_arithmetic(self.flat, tag='encdec'):
             e = self._encdec_losses(*self._encode_decode(st['x'], st['m']), st['teacher_logits'])
         with ops.direct_weight_gradients(self.flat, tag='encdec'):
             e['loss'].backward()

@@ -1,10 +1,14 @@
 """profiles/rNN_roofline_table.md from a kernel-stats CSV of the C1 step (tools/rocpd_stats.py output):
-    python tools/roofline_table.py profiles/r03_c1_step_kernel_stats.csv > profiles/r03_roofline_table.md
+    python tools/roofline_table.py profiles/r06_c1_step_kernel_stats.csv > profiles/r06_roofline_table.md
 Work per step = algorithmic FLOPs / bytes of the C1 configuration (each operand once), peaks from
-MI355X_MICROARCH.md (HBM 8 TB/s, bf16x6 algorithmic MFMA ceiling 2500 / 6 = 416.7 TFLOP/s)."""
+MI355X_MICROARCH.md (HBM 8 TB/s, bf16x6 algorithmic MFMA ceiling 2500 / 6 = 416.7 TFLOP/s, f16x3 2500 / 3 = 833.3).
+Round 6: TWO ceilings for the GEMM families -- t_mfma = FLOPs / MFMA peak of the arithmetic, t_hbm = algorithmic bytes (A, B, C and
+every epilogue operand once, summed over the step's launches by bench.py: roofline.hbm.floor_ms_per_step x 8 TB/s) / 8 TB/s; the
+binding ceiling is the larger, "of binding" = max(t_mfma, t_hbm) / measured (bench.py reports the same per launch family)."""
 import csv, sys
 
 ROWS_LN = 2 * (557056 + 139264 + 139264 + 34816)           # LayerNorm rows per step (8 instances), d = 256
+GEMM_BYTES = {'gemm_nt_g3': 31.4e9, 'gemm_tn_g3': 13.9e9}     # algorithmic HBM bytes per step of the f16x3 NT / TN launches (bench.py, r06)
 FAMILIES = [   # (label, match substrings, algorithmic work per step, unit, peak, note)
     ('NT GEMMs on three fp16 MFMAs per product (`gemm_nt_g3_kernel` + `gemm_nt_g3_tail_kernel`, round 5: every 256-tile launch of the step, forward and input gradients; ragged launches as whole rounds + tail rows)', ('gemm_nt_g3',), 2.577e12, 'TFLOP/s', 833.3e12, 'peak = 2500 / 3'),
     ('NT GEMMs on six bf16 MFMAs per product (what is left there: skinny N = 32 products, sub-128-tile launches)', ('gemm_nt', 'splitk'), 0.0104e12, 'TFLOP/s', 416.7e12, 'peak = 2500 / 6; launch-bound sizes'),
@@ -46,6 +50,11 @@ def main(path):
             rate = work / (per * 1e-3)
             ach = f'{work / 1e12:.2f} TFLOP -> {rate / 1e12:.0f} TFLOP/s' if unit == 'TFLOP/s' else f'{work / 1e9:.2f} GB -> {rate / 1e12:.1f} TB/s'
             frac = f'{rate / peak:.2f}'
+            gb = next((v for k, v in GEMM_BYTES.items() if k in match), None)
+            if gb:       # two ceilings: the binding one is the larger floor
+                t_m, t_h = work / peak * 1e3, gb / 8e12 * 1e3
+                note = (f'{note}; MFMA floor {t_m:.2f} ms, HBM floor {t_h:.2f} ms ({gb / 1e9:.1f} GB algorithmic, {gb / (per * 1e-3) / 1e12:.2f} TB/s achieved) '
+                        f'-> bound: {"hbm" if t_h >= t_m else "mfma"}, **{max(t_m, t_h) / per:.2f} of the binding ceiling**')
         else:
             ach, frac = note or '-', '-'
         out.append((label, n / steps, per, ach, frac, note if work else ''))

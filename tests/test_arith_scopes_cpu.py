@@ -173,3 +173,45 @@ def test_training_defaults_select_both_arithmetics_unless_the_caller_chose(rec):
     ops.set_gradient_arithmetic('six')
     ops.use_training_default_gradient_arithmetic()
     assert (ops.GRAD_ARITH, ops.FWD_ARITH) == ('six', 'f16x3')
+
+
+def test_weight_planes_are_made_once_per_step_and_found_by_address(rec):
+    """Round 6 (ops._WeightTransposes.refresh_planes / lookup_planes): the fp16 planes of the registered weights are made when the
+    forward scope opens, the gradient scope of the SAME step uses them as they are, a gradient scope after an optimiser step (or
+    without a forward scope) makes them again; a weight -- or a row block of it, or a column block of its transpose in the arena --
+    is found by its address, anything else is not."""
+    from vqcpc_bach_amd import ops
+    ops.set_forward_arithmetic('f16x3')
+    ops.set_gradient_arithmetic('f16x3')
+
+    class Owner:
+        pass
+    owner = Owner()
+    owner.flat = torch.zeros(2 * 768 * 256 + 64)
+    w = owner.flat[64:64 + 768 * 256].view(768, 256)            # in_proj-like weight at a 16-byte aligned offset
+    inst = ops.WEIGHT_T.instance(owner)
+    inst.entries[w.data_ptr()] = (64, 768, 256)                 # what ops.transpose(w) registers during a backward pass
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        assert _names(rec).count('vqcpc_weight_planes_many') == 1
+        hit = ops._PLANES.lookup_planes(w, 256)
+        assert hit is not None and hit[0].data_ptr() - inst.planes.data_ptr() == 64 * 4 and hit[1].data_ptr() == inst.amax.data_ptr()
+        rows = ops._PLANES.lookup_planes(w[256:], 256)          # k | v rows of in_proj
+        assert rows is not None and rows[0].data_ptr() - inst.planes.data_ptr() == (64 + 256 * 256) * 4
+        assert ops._PLANES.lookup_planes(torch.zeros(768, 256), 256) is None            # not a registered weight
+        assert ops._PLANES.lookup_planes(owner.flat[:64 * 4].view(16, 16), 16) is None  # inside the buffer, before the weight
+    assert ops._PLANES is None
+    with ops.direct_weight_gradients(owner):
+        assert _names(rec).count('vqcpc_weight_planes_many') == 1          # the forward scope's planes, as they are
+        wt = ops.transpose(w)                                              # (256, 768) view of the arena
+        assert wt.data_ptr() - inst.arena.data_ptr() == 64 * 4
+        hit = ops._PLANES.lookup_planes(wt, 768)
+        assert hit is not None and hit[0].data_ptr() - inst.planes_t.data_ptr() == 64 * 4
+        cols = ops._PLANES.lookup_planes(wt[:, 256:], 768)                 # k | v columns of W^T (row stride 768)
+        assert cols is not None and cols[0].data_ptr() - inst.planes_t.data_ptr() == (64 + 256) * 4
+    with ops.direct_weight_gradients(owner):                               # no forward scope for this pass: made again
+        assert _names(rec).count('vqcpc_weight_planes_many') == 2
+    with torch.enable_grad(), ops.forward_arithmetic(owner):
+        pass
+    ops._PARAM_STEPS += 1                                                  # an optimiser step between the forward and the backward
+    with ops.direct_weight_gradients(owner):
+        assert _names(rec).count('vqcpc_weight_planes_many') == 4

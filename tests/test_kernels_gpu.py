@@ -2326,7 +2326,7 @@ def test_f16x3_arithmetic_is_taken_inside_a_backward_scope_only(ops, bf16x6):
             assert tab.keys == [('nt', M, N, K), ('tn', 4096, 256, 512)]
             assert calls.count('vqcpc_gemm_nt_grad') == 1 and calls.count('vqcpc_gemm_tn_grad') == 1
             assert calls.count('vqcpc_grad_amax') == (4 if step == 0 else 0), 'primed once'
-            assert calls.count('vqcpc_grad_scale_roll_counted') == 1
+            assert calls.count('vqcpc_grad_scale_roll_logged') == 1
             assert calls.count('vqcpc_gemm_nt') == 2, 'the 128 ragged rows + the bias GEMM'
             assert torch.equal(fwd_like, six)
             assert not torch.equal(g3, six) and float((g3 - six).abs().max() / six.abs().max()) < 3e-6

@@ -177,7 +177,7 @@ def test_student_step_bucketed_all_reduce_two_ranks_share_this_gpu(tmp_path):
         assert x['world'] == 2 and x['rank'] == k
         assert x['grads_equal'], ('bucketed vs single-call all-reduce', x['grad_rel'])
         assert x['stages'] == 3 and x['replays'] == 5, (x['stages'], x['replays'])
-        assert x['graph_vs_eager'] < tol, x['graph_vs_eager']
+        assert x['graph_vs_eager'] < 2e-6, x['graph_vs_eager']
         assert x['single_vs_bucketed'] < 2e-6, x['single_vs_bucketed']       # same gradients, other launch order
     assert res[0]['digest_bucketed'] == res[1]['digest_bucketed'], 'replicas must stay bit-identical (eager)'
     assert res[0]['digest_graph'] == res[1]['digest_graph'], 'replicas must stay bit-identical (graph replays)'

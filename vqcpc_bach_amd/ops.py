@@ -284,6 +284,7 @@ def _g3_plan(M, N, K):
 # VQCPC_WEIGHT_PLANES=0: A/B switch.
 WEIGHT_PLANES = os.environ.get('VQCPC_WEIGHT_PLANES', '1') != '0'
 _PLANES = None                 # the _WeightTransposes whose plane images are valid right now
+_PARAM_STEPS = 0               # bumped by every FlatAdam.step(): planes made before an optimiser step are never paired with a later backward
 
 
 def _g3_launch(a, lda, b, ldb, out, ldc, rows, N, K, st, bias=None, act=0, drop_p=0.0, seed=0, add=None, lda_=0, add2=None, lda2_=0,
@@ -840,7 +841,8 @@ class forward_arithmetic:
             _FWD_SCALES = self.prev
             if getattr(self, 'planes', None) is not None:
                 _PLANES = None
-                self.planes.planes_paired = exc[0] is None      # the gradient scope that follows uses them as they are
+                # the gradient scope that follows uses them as they are -- unless an optimiser step comes in between
+                self.planes.planes_paired = _PARAM_STEPS if exc[0] is None else None
                 self.planes = None
             if exc[0] is None:
                 self.mine.roll()
@@ -874,9 +876,9 @@ class direct_weight_gradients:
             if WEIGHT_PLANES and _GRAD_SCALES is not None:
                 global _PLANES
                 inst = WEIGHT_T.current
-                if not inst.planes_paired:         # no forward scope made them for this step
+                if inst.planes_paired is None or inst.planes_paired != _PARAM_STEPS:     # no forward scope made them for THIS step
                     inst.refresh_planes()
-                inst.planes_paired = False
+                inst.planes_paired = None
                 _PLANES = inst
         return self
 
@@ -1044,7 +1046,7 @@ class _WeightTransposes:
         self.amax = torch.zeros(self.MAX_MATRICES, dtype=torch.float32, device=flat.device)
         # one float per 32 x 32 tile of every registered matrix (their maxima, reduced per matrix by the plane pass: no atomics)
         self.tile_max = torch.zeros(flat.numel() // 256 + 4 * self.MAX_MATRICES + 64, dtype=torch.float32, device=flat.device)
-        self.planes_paired = False      # a forward scope made the planes of this step: the gradient scope uses them as they are
+        self.planes_paired = None       # _PARAM_STEPS at which a forward scope made the planes: the gradient scope of the same step uses them as they are
         self.planes_live = False        # the plane images describe the current `uploaded` set
         self._plane_hits = {}           # (ptr, rows, cols, ld) -> (plane tensor, amax slot) | None
         self._sorted = []               # (offset, rows, cols, index) of the uploaded set, ascending
@@ -1052,7 +1054,7 @@ class _WeightTransposes:
     MAX_MATRICES = 4096
 
     def _upload(self):
-        if len(self.entries) != len(self.uploaded) and not torch.cuda.is_current_stream_capturing():
+        if len(self.entries) != len(self.uploaded) and not (self.flat.is_cuda and torch.cuda.is_current_stream_capturing()):
             rows, tiles = [], 0
             for key, (off, r, c) in sorted(self.entries.items(), key=lambda kv: kv[1][0]):
                 rows.append((off, r, c, tiles))
@@ -2154,6 +2156,8 @@ class FlatAdam:
         self._dev = (lr_dev, step_dev) if lr_dev is not None else None
 
     def step(self, lr=None, grad_scale=1.0):
+        global _PARAM_STEPS
+        _PARAM_STEPS += 1
         self.step_count += 1
         n = self.p.numel()
         hip.call('vqcpc_sumsq', self.g, n, float(grad_scale), self.sumsq, self._ws, self._ws_bytes)

@@ -9,7 +9,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-COMMON="--no-cpu-baseline --no-kernel-timing --no-live-pmc --no-extras --no-secondary"
+COMMON="--no-cpu-baseline --no-kernel-timing --no-live-pmc --no-extras --no-secondary --no-long"
 run_trace() {   # name, bench args
     local name=$1; shift
     rm -rf /tmp/prof_$name

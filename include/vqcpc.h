@@ -60,6 +60,10 @@ extern "C" {
  * ------------------------------------------------------------------------------------------------------------------ */
 int vqcpc_abi_version(void);
 const char* vqcpc_last_error(void);
+/* returns and clears the HIP runtime's last (non-sticky) error of the calling thread: every launch of this library is checked with
+ * hipGetLastError(), which would otherwise attribute an earlier failure of SOMEBODY ELSE's runtime call (a rejected stream capture)
+ * to the next kernel launched here */
+int vqcpc_clear_runtime_error(void);
 
 /* ------------------------------------------------------------------------------------------------------------------
  * Dropout RNG shared by all kernels: keep(seed, i) = (u24(mix32((uint32)i * 0x9E3779B1 + lo(seed) ^ hi(seed))) >= p * 2^24)

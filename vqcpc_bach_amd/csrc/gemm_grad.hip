@@ -764,12 +764,16 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float*
     const int st_half = (q >> 2) * kRHalf;
     const int o_a = s_row * 32 + ((((c4 >> 3) ^ (s_row >> 3)) & 1) << 4) + (c4 & 7) * 2;      // rows s_row and s_row + 64: same swizzle bit
     const int st_a = st_half + o_a, st_b0 = st_half + 2 * kRPA + o_a, st_b1 = st_b0 + 64 * 32;
-    float4 ra, rb0, rb1;
-#define R_LOAD(KT)                                                                         \
+    // raw operand registers: a ring of THREE sets, requested three steps ahead (round 6).  A launch of this kernel has one to three
+    // workgroups per CU (3 072 x 512: 192 tiles on 256 CUs): with the one-step run-ahead of round 5 every K step waited out most of
+    // an HBM round trip (0.75 us per step for 192 cycles of matrix work per wave, tools/bench_small_f16x3.py).
+    struct Raw { float4 a, b0, b1; };
+    Raw r0, r1, r2;
+#define R_LOAD(S, KT)                                                                      \
     {                                                                                      \
-        ra = *reinterpret_cast<const float4*>(a_src + (int64_t)(KT) * kRBK);               \
-        rb0 = *reinterpret_cast<const float4*>(b_src + (int64_t)(KT) * kRBK);              \
-        rb1 = *reinterpret_cast<const float4*>(b_src + b_src1 + (int64_t)(KT) * kRBK);     \
+        S.a = *reinterpret_cast<const float4*>(a_src + (int64_t)(KT) * kRBK);              \
+        S.b0 = *reinterpret_cast<const float4*>(b_src + (int64_t)(KT) * kRBK);             \
+        S.b1 = *reinterpret_cast<const float4*>(b_src + b_src1 + (int64_t)(KT) * kRBK);    \
     }
 #define R_SPLIT(R, SC, AM, ISPL)                                                           \
     if (ISPL) {                                                                            \
@@ -779,16 +783,16 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float*
         g3_amax4(R, AM);                                                                   \
         g3_split4(R, SC, h_, m_);                                                          \
     }
-#define R_STORE(WB)                                                                        \
+#define R_STORE(WB, S)                                                                     \
     {                                                                                      \
         uint2 h_, m_;                                                                      \
-        R_SPLIT(ra, sa, amax_a, pla)                                                       \
+        R_SPLIT(S.a, sa, amax_a, pla)                                                      \
         *reinterpret_cast<uint2*>((WB) + st_a) = h_;                                       \
         *reinterpret_cast<uint2*>((WB) + st_a + kRPA) = m_;                                \
-        R_SPLIT(rb0, sb, amax_b, plb)                                                      \
+        R_SPLIT(S.b0, sb, amax_b, plb)                                                     \
         *reinterpret_cast<uint2*>((WB) + st_b0) = h_;                                      \
         *reinterpret_cast<uint2*>((WB) + st_b0 + kRPB) = m_;                               \
-        R_SPLIT(rb1, sb, amax_b, plb)                                                      \
+        R_SPLIT(S.b1, sb, amax_b, plb)                                                     \
         *reinterpret_cast<uint2*>((WB) + st_b1) = h_;                                      \
         *reinterpret_cast<uint2*>((WB) + st_b1 + kRPB) = m_;                               \
     }
@@ -800,34 +804,44 @@ __global__ __launch_bounds__(kGThreads) void gemm_nt_g3_tail_kernel(const float*
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
 
-    R_LOAD(0)
-    R_STORE(smemr)
-    if (T > 1) R_LOAD(1)
+    // step s lives in register set s % 3: step J multiplies slot J & 1, splits + stores step J + 1 (set SN) into the other slot and
+    // re-requests step J + 4 into the same set
+#define R_STEP(J, SN)                                                                      \
+    {                                                                                      \
+        const unsigned char* cur = smemr + ((J) & 1) * kRSlot;                             \
+        unsigned char* nxt = smemr + (((J) + 1) & 1) * kRSlot;                             \
+        half8 fa[2][2], fb[2][2];                        /* [half][h | m] */               \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {                                 \
+            fa[hf][0] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fa_off);       \
+            fa[hf][1] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fa_off + kRPA); \
+            fb[hf][0] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fb_off);       \
+            fb[hf][1] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fb_off + kRPB); \
+        }                                                                                  \
+        if ((J) + 1 < T) {                                                                 \
+            R_STORE(nxt, SN)                                                               \
+            if ((J) + 4 < T) R_LOAD(SN, (J) + 4)                                           \
+        }                                                                                  \
+        _Pragma("unroll") for (int hf = 0; hf < 2; ++hf) {   /* m.h, h.m, h.h: the order of gemm_nt_g3_kernel */ \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][1], fb[hf][0], acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][0], fb[hf][1], acc, 0, 0, 0); \
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][0], fb[hf][0], acc, 0, 0, 0); \
+        }                                                                                  \
+        __syncthreads();                                                                   \
+    }
+
+    R_LOAD(r0, 0)
+    if (T > 1) R_LOAD(r1, 1)
+    if (T > 2) R_LOAD(r2, 2)
+    R_STORE(smemr, r0)
+    if (T > 3) R_LOAD(r0, 3)
     __syncthreads();
 #pragma unroll 1
-    for (int j = 0; j < T; ++j) {
-        const unsigned char* cur = smemr + (j & 1) * kRSlot;
-        unsigned char* nxt = smemr + ((j + 1) & 1) * kRSlot;
-        half8 fa[2][2], fb[2][2];                        // [half][h | m]
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            fa[hf][0] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fa_off);
-            fa[hf][1] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fa_off + kRPA);
-            fb[hf][0] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fb_off);
-            fb[hf][1] = *reinterpret_cast<const half8*>(cur + hf * kRHalf + fb_off + kRPB);
-        }
-        if (j + 1 < T) {
-            R_STORE(nxt)
-            if (j + 2 < T) R_LOAD(j + 2)
-        }
-#pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {                 // m.h, h.m, h.h: the order of gemm_nt_g3_kernel
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][1], fb[hf][0], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][0], fb[hf][1], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[hf][0], fb[hf][0], acc, 0, 0, 0);
-        }
-        __syncthreads();
+    for (int j = 0; j < T; j += 3) {
+        R_STEP(j, r1)
+        if (j + 1 < T) R_STEP(j + 1, r2)
+        if (j + 2 < T) R_STEP(j + 2, r0)
     }
+#undef R_STEP
 #undef R_STORE
 #undef R_SPLIT
 #undef R_LOAD

@@ -532,6 +532,7 @@ extern "C" {
 
 int vqcpc_abi_version(void) { return VQCPC_ABI_VERSION; }
 const char* vqcpc_last_error(void) { return vq::g_err; }
+int vqcpc_clear_runtime_error(void) { return (int)hipGetLastError(); }
 
 int vqcpc_dropout_mask(float* mask, int64_t n, float p, uint64_t seed, void* stream) {
     if (n == 0) return VQCPC_OK;

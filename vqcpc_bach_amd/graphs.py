@@ -113,9 +113,11 @@ class StepGraph:
         graph = torch.cuda.CUDAGraph()
         counts = [opt.step_count for opt in self.optimizers]
         torch.cuda.synchronize()
-        # with a process group alive its watchdog thread polls events while we capture: only calls of THIS thread may
-        # invalidate the capture
-        mode = 'thread_local' if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 'global'
+        # only calls of THIS thread may invalidate the capture: with a process group alive its watchdog thread polls events while we
+        # capture, and a second trainer stepped from another Python thread (utils.STEP_LOCK keeps its STEPS out of this capture)
+        # still synchronises its own stream and copies its batches between its steps -- under the 'global' mode such a call, landing
+        # inside this thread's capture window, invalidated the capture (round 6: one run in three of the two-threads test)
+        mode = 'thread_local'
         graphs = [graph]
         try:
             with torch.cuda.graph(graph, pool=self.pool, capture_error_mode=mode):
@@ -279,6 +281,7 @@ class GraphedTraining:
             import warnings
             warnings.warn(f'step-graph capture failed ({str(e)[:200]}); continuing with eager steps')
             torch.cuda.synchronize()
+            hip.clear_runtime_error()       # the failed capture's HIP error must not be reported by the next kernel launch check
             self._graph_on = False
             self._graph.release()
             self._graph = None

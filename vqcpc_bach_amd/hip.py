@@ -22,6 +22,7 @@ c_i64, c_int, c_f32, c_u64, c_ptr = ctypes.c_int64, ctypes.c_int, ctypes.c_float
 SIGNATURES = {
     'vqcpc_abi_version': (c_int, []),
     'vqcpc_last_error': (ctypes.c_char_p, []),
+    'vqcpc_clear_runtime_error': (c_int, []),
     'vqcpc_dropout_mask': (c_int, [c_ptr, c_i64, c_f32, c_u64, c_ptr]),
     'vqcpc_check_tokens': (c_int, [c_ptr, c_i64, c_int, c_ptr, c_ptr, c_ptr, c_ptr]),
     'vqcpc_embed_pos_fwd': (c_int, [c_ptr, c_i64, c_int, c_int, c_ptr, c_int, c_int, c_ptr, c_ptr, c_int, c_ptr, c_ptr]),
@@ -227,6 +228,11 @@ def load(path=None):
         raise VqcpcHipError(f'ABI version mismatch: library {lib.vqcpc_abi_version()} != binding {ABI_VERSION}')
     _lib = lib
     return lib
+
+
+def clear_runtime_error():
+    """Returns and clears the HIP runtime's pending (non-sticky) error of this thread (include/vqcpc.h)."""
+    return int(load().vqcpc_clear_runtime_error())
 
 
 def is_lab():

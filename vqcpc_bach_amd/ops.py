@@ -123,6 +123,9 @@ class GradScales:
         self.monitor = torch.zeros(3 + self.LOG, dtype=torch.int32, device=device)
         self.keys = []
         self.cursor = 0
+        self.reprimed = 0
+
+    REPRIME_WARN = 64
 
     @property
     def saturated(self):
@@ -141,8 +144,17 @@ class GradScales:
             if i == len(self.keys):
                 self.keys.append(key)
             else:
+                # another product took the site's place: correct (the scale is primed from the operands themselves) but it costs two
+                # amax passes per re-primed site and step -- a forward whose GEMM sequence changes from step to step (a data-dependent
+                # branch, alternating batch shapes) should use one scope tag per variant.  Said once per table, not silently.
                 self.keys[i] = key
                 st.zero_()
+                self.reprimed += 1
+                if self.reprimed == self.REPRIME_WARN:
+                    import warnings
+                    warnings.warn(f'f16x3 scale table: {self.reprimed} call sites were re-primed because the sequence of GEMM shapes '
+                                  'inside the arithmetic scope changed between steps (correct, but two extra passes over the operands '
+                                  'per site and step); give each variant of the step its own tag: ops.forward_arithmetic(flat, tag=...)')
             hip.call('vqcpc_grad_amax', a, lda, rows_a, cols_a, st[0:1])
             hip.call('vqcpc_grad_amax', b, ldb, rows_b, cols_b, st[1:2])
         return st
